@@ -1,0 +1,119 @@
+/*
+ * kosk_mi355x.h -- C ABI of the MI355X-native KOSK prover/verifier.
+ *
+ * Drop-in boundary for the reference's hot path (ZGC-SP/mpcith_kyber_kosk).
+ * Every entry point names the reference interface it replaces (file:line
+ * relative to the reference root).  Plain pointers and sizes only; the library
+ * owns all device memory.  All functions return 0 on success and a negative
+ * value on error (kosk_last_error() gives the text) unless stated otherwise.
+ * There is no CPU fallback: kosk_create() fails when no HIP device is present.
+ *
+ * Parameter sets: kyber_k in {2,3,4} is a run-time argument here; in the
+ * reference it is the compile-time macro KYBER_K (params.hpp:8-10).
+ */
+#ifndef KOSK_MI355X_H
+#define KOSK_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kosk_ctx kosk_ctx;
+
+/* Replaces the link-time symbol randombytes() (kyber/randombytes.h:7).  The
+ * library calls it in exactly the reference's order and lengths for each
+ * proof: 64, M x 32, then 302-byte draws. */
+typedef void (*kosk_randombytes_fn)(void *user, uint8_t *out, size_t len);
+
+/* sizes: KYBER_PUBLICKEYBYTES / KYBER_SECRETKEYBYTES (kyber/params.h:49-52),
+ * MPCITH_PROOF_SIZE (mlwe_prover.hpp:30), randomness per verifiable keygen */
+size_t kosk_pk_bytes(int kyber_k);
+size_t kosk_sk_bytes(int kyber_k);
+size_t kosk_proof_bytes(int kyber_k);
+size_t kosk_tape_bytes(int kyber_k);
+/* byte offset / size of field `idx` (0..23, declaration order of mpcith_proof,
+ * mlwe_prover.hpp:57-75) inside the proof image; returns 0 on success */
+int kosk_proof_field(int kyber_k, int idx, size_t *offset, size_t *size);
+
+int kosk_create(kosk_ctx **ctx, int device, int kyber_k, int max_batch);
+void kosk_destroy(kosk_ctx *ctx);
+const char *kosk_last_error(const kosk_ctx *ctx); /* ctx may be NULL: error of the last failed kosk_create */
+int kosk_set_randombytes(kosk_ctx *ctx, kosk_randombytes_fn fn, void *user); /* NULL: OS entropy */
+
+/* void kyber_verifiable_keygen(kyber_keypair *keypair, uint8_t *pi)   kosk.hpp:20-21, kosk.cpp:72-86
+ * n independent instances; pk/sk/pi are n consecutive records of kosk_*_bytes().
+ * `tapes` == NULL draws randomness through the randombytes callback; otherwise
+ * proof b consumes tapes[b*tape_stride ..] (kosk_tape_bytes() bytes each). */
+int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride,
+                                 uint8_t *pk, uint8_t *sk, uint8_t *pi);
+
+/* bool kyber_kosk_verify(const uint8_t *pi, const uint8_t *pk)       kosk.hpp:23-24, kosk.cpp:88-117
+ * ok[b] = 1 accept / 0 reject.  The reference prints a diagnostic and returns
+ * false (mlwe_verifier.cpp:120 etc.); here kosk_verify_fail_masks() reports
+ * which checks failed (bit i = check i of DESIGN.md's verifier table). */
+int kosk_verify_batch(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk, uint8_t *ok);
+int kosk_verify_fail_masks(const kosk_ctx *ctx, uint32_t *masks, int n);
+
+/* Device-resident split of the two calls above, for callers that keep inputs
+ * and proofs in HBM (and for bench.py: the timed region is *_resident only). */
+int kosk_stage_prover_inputs(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk);
+int kosk_prove_resident(kosk_ctx *ctx, int n);
+int kosk_fetch_proofs(kosk_ctx *ctx, int n, uint8_t *pi);
+int kosk_stage_verifier_inputs(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk);
+int kosk_verify_resident(kosk_ctx *ctx, int n, uint8_t *ok);
+/* wall seconds of the phases of the last prove (7 values) */
+int kosk_phase_seconds(const kosk_ctx *ctx, double *out, int n);
+
+/* ---- kernel-level entry points on DEVICE pointers (stream 0 of the ctx) ----
+ * Used by the parity tests and by bench.py's roofline leg. */
+
+/* sha3_256(h, in, inlen) for n equal-length messages        kyber/fips202.c:745-754
+ * message-major layout: message i at in + i*in_stride; digest i at out + 32*i */
+int kosk_sha3_256_batch(kosk_ctx *ctx, const uint8_t *d_in, size_t in_stride, size_t inlen, uint8_t *d_out, int n);
+/* shake256(out, outlen, in, inlen)                           kyber/fips202.c:723-734 */
+int kosk_shake256_batch(kosk_ctx *ctx, const uint8_t *d_in, size_t in_stride, size_t inlen,
+                        uint8_t *d_out, size_t outlen, int n);
+/* The view-commitment kernel on its native column layout: lane l hashes
+ * [prefix32(l)] || rows[r][l], r < words, rows being u16 arrays `row_stride`
+ * elements apart (mlwe_prover.cpp:116-127 when with_prefix == 0, :397-444 when 1).
+ * words must equal the Tcomm / view word count of kyber_k. */
+int kosk_commit_hash_lanes(kosk_ctx *ctx, const uint16_t *d_rows, size_t row_stride, int n_lanes,
+                           const uint8_t *d_prefix, int with_prefix, uint8_t *d_out);
+/* poly_ntt(r) on n polynomials of 256 int16                  kyber/poly.c:261-265 (ntt.c:80-95 + Barrett) */
+int kosk_ntt256_batch(kosk_ctx *ctx, const int16_t *d_in, int16_t *d_out, int n);
+/* share values of all 1454 parties from the 407 values at points 0..406
+ * (recompute_share_secrets_ddeg, ss.cpp:76-99): in  n x 407 u16, out n x 1454 u16 */
+int kosk_lagrange_expand(kosk_ctx *ctx, const uint16_t *d_y407, uint16_t *d_shares, int n);
+/* recon_secrets_ddeg / recon_secrets_2ddeg (ss.cpp:37-73): in n x 1454 u16, out n x 256 u16 */
+int kosk_recon_secrets(kosk_ctx *ctx, const uint16_t *d_shares, uint16_t *d_secrets, int n, int two_d);
+int kosk_device_synchronize(kosk_ctx *ctx);
+/* device pointer / stride of the resident proof images, for callers chaining work in HBM */
+int kosk_resident_proofs(kosk_ctx *ctx, void **d_proofs, size_t *stride);
+
+/* ---- host-only pieces of the path (no device needed) ------------------------ */
+
+/* void kyber_keygen(kyber_keypair *keypair, mlwe_inst *raw_key)      kosk.hpp:18-19, kosk.cpp:4-70
+ * seed64 = the 64 bytes the reference draws with randombytes (kosk.cpp:12).
+ * Raw key (mlwe_inst, mlwe_prover.hpp:34-37): A [K][K][256] NTT domain in [0,q),
+ * s,e [K][256] small signed, t [K][256] NTT domain centred.  Any of A/s/e/t may be NULL. */
+int kosk_keygen(int kyber_k, const uint8_t seed64[64], uint8_t *pk, uint8_t *sk,
+                int16_t *A, int16_t *s, int16_t *e, int16_t *t);
+/* alpha challenge from the 1454 Tcomm digests (mlwe_prover.cpp:130-142); alpha has 70+2K entries */
+int kosk_fs_alpha(int kyber_k, const uint8_t *tcomm_all, uint16_t *alpha);
+/* opened set I[150] and its ascending complement rest[1304] from the 1454 view digests
+ * (mlwe_prover.cpp:445-490) */
+int kosk_fs_opened(const uint8_t *digests_all, uint16_t *I, uint16_t *rest);
+/* host sha3_256 / shake256 used by the two functions above (kyber/fips202.c:745-754, :723-734) */
+void kosk_host_sha3_256(uint8_t out[32], const uint8_t *in, size_t inlen);
+void kosk_host_shake256(uint8_t *out, size_t outlen, const uint8_t *in, size_t inlen);
+/* Lagrange coefficient tables the reference reads through utils/precomputed_kyber.h:10-13:
+ * which = 0: share_coeff_ddeg [1303][407], 1: recon_coeff_ddeg [256][407], 2: recon_coeff_2ddeg [256][813] */
+int kosk_lagrange_table(int which, uint16_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KOSK_MI355X_H */

@@ -1,0 +1,246 @@
+"""ctypes binding of libkosk_mi355x.so -- the host-side mirror of the reference
+API (kosk.hpp:18-24) plus the kernel-level entry points used by tests/bench.
+
+There is NO CPU fallback: constructing :class:`Kosk` without a usable HIP device
+raises, and importing this module without the built library raises.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkosk_mi355x.so")
+
+
+class KoskError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        _build.build()
+    lib = C.CDLL(LIB_PATH)
+    u8p, u16p, i16p, sz, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), C.POINTER(C.c_int16), C.c_size_t, C.c_void_p
+    sig = {
+        "kosk_pk_bytes": (sz, [C.c_int]), "kosk_sk_bytes": (sz, [C.c_int]),
+        "kosk_proof_bytes": (sz, [C.c_int]), "kosk_tape_bytes": (sz, [C.c_int]),
+        "kosk_proof_field": (C.c_int, [C.c_int, C.c_int, C.POINTER(sz), C.POINTER(sz)]),
+        "kosk_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int]),
+        "kosk_destroy": (None, [vp]),
+        "kosk_last_error": (C.c_char_p, [vp]),
+        "kosk_set_randombytes": (C.c_int, [vp, vp, vp]),
+        "kosk_verifiable_keygen_batch": (C.c_int, [vp, C.c_int, vp, sz, vp, vp, vp]),
+        "kosk_verify_batch": (C.c_int, [vp, C.c_int, vp, vp, vp]),
+        "kosk_verify_fail_masks": (C.c_int, [vp, vp, C.c_int]),
+        "kosk_stage_prover_inputs": (C.c_int, [vp, C.c_int, vp, sz, vp, vp]),
+        "kosk_prove_resident": (C.c_int, [vp, C.c_int]),
+        "kosk_fetch_proofs": (C.c_int, [vp, C.c_int, vp]),
+        "kosk_stage_verifier_inputs": (C.c_int, [vp, C.c_int, vp, vp]),
+        "kosk_verify_resident": (C.c_int, [vp, C.c_int, vp]),
+        "kosk_phase_seconds": (C.c_int, [vp, C.POINTER(C.c_double), C.c_int]),
+        "kosk_sha3_256_batch": (C.c_int, [vp, vp, sz, sz, vp, C.c_int]),
+        "kosk_shake256_batch": (C.c_int, [vp, vp, sz, sz, vp, sz, C.c_int]),
+        "kosk_commit_hash_lanes": (C.c_int, [vp, vp, sz, C.c_int, vp, C.c_int, vp]),
+        "kosk_ntt256_batch": (C.c_int, [vp, vp, vp, C.c_int]),
+        "kosk_lagrange_expand": (C.c_int, [vp, vp, vp, C.c_int]),
+        "kosk_recon_secrets": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
+        "kosk_device_synchronize": (C.c_int, [vp]),
+        "kosk_resident_proofs": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
+        "kosk_keygen": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+        "kosk_fs_alpha": (C.c_int, [C.c_int, vp, vp]),
+        "kosk_fs_opened": (C.c_int, [vp, vp, vp]),
+        "kosk_host_sha3_256": (None, [vp, vp, sz]),
+        "kosk_host_shake256": (None, [vp, sz, vp, sz]),
+        "kosk_lagrange_table": (C.c_int, [C.c_int, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library ever disagree
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+EXPORTS = ["kosk_pk_bytes", "kosk_sk_bytes", "kosk_proof_bytes", "kosk_tape_bytes", "kosk_proof_field", "kosk_create",
+           "kosk_destroy", "kosk_last_error", "kosk_set_randombytes", "kosk_verifiable_keygen_batch", "kosk_verify_batch",
+           "kosk_verify_fail_masks", "kosk_stage_prover_inputs", "kosk_prove_resident", "kosk_fetch_proofs",
+           "kosk_stage_verifier_inputs", "kosk_verify_resident", "kosk_phase_seconds", "kosk_sha3_256_batch",
+           "kosk_shake256_batch", "kosk_commit_hash_lanes", "kosk_ntt256_batch", "kosk_lagrange_expand",
+           "kosk_recon_secrets", "kosk_device_synchronize", "kosk_resident_proofs", "kosk_keygen", "kosk_fs_alpha",
+           "kosk_fs_opened", "kosk_host_sha3_256", "kosk_host_shake256", "kosk_lagrange_table"]
+
+
+def pk_bytes(k): return lib.kosk_pk_bytes(k)
+def sk_bytes(k): return lib.kosk_sk_bytes(k)
+def proof_bytes(k): return lib.kosk_proof_bytes(k)
+def tape_bytes(k): return lib.kosk_tape_bytes(k)
+
+
+def proof_field(k, idx):
+    off, size = C.c_size_t(), C.c_size_t()
+    if lib.kosk_proof_field(k, idx, C.byref(off), C.byref(size)):
+        raise KoskError("bad field")
+    return off.value, size.value
+
+
+def _buf(b):
+    """bytes-like -> (ctypes pointer value, keepalive)"""
+    if isinstance(b, (bytes, bytearray)):
+        arr = (C.c_uint8 * len(b)).from_buffer_copy(b) if isinstance(b, bytes) else (C.c_uint8 * len(b)).from_buffer(b)
+        return C.cast(arr, C.c_void_p), arr
+    raise TypeError(type(b))
+
+
+def host_keygen(k, seed64):
+    """kyber_keygen (kosk.cpp:4-70) on the host; returns pk, sk, A, s, e, t (lists of int)."""
+    import numpy as np
+    pk = C.create_string_buffer(pk_bytes(k)); sk = C.create_string_buffer(sk_bytes(k))
+    A = np.zeros(k * k * 256, np.int16); s = np.zeros(k * 256, np.int16); e = np.zeros(k * 256, np.int16); t = np.zeros(k * 256, np.int16)
+    r = lib.kosk_keygen(k, C.c_char_p(bytes(seed64)), pk, sk, A.ctypes.data, s.ctypes.data, e.ctypes.data, t.ctypes.data)
+    if r:
+        raise KoskError("kosk_keygen failed")
+    return pk.raw, sk.raw, A, s, e, t
+
+
+def host_sha3_256(data):
+    out = C.create_string_buffer(32)
+    lib.kosk_host_sha3_256(out, C.c_char_p(bytes(data)), len(data))
+    return out.raw
+
+
+def host_shake256(data, outlen):
+    out = C.create_string_buffer(outlen)
+    lib.kosk_host_shake256(out, outlen, C.c_char_p(bytes(data)), len(data))
+    return out.raw
+
+
+class Kosk:
+    """One library context = one GPU, one parameter set, up to max_batch proofs in flight.
+
+    Mirrors the reference's top-level API (kosk.hpp):
+      verifiable_keygen(tapes) -> (pk, sk, pi) lists      kyber_verifiable_keygen
+      verify(pi, pk) -> list[bool]                         kyber_kosk_verify
+    """
+
+    def __init__(self, kyber_k=2, max_batch=1, device=0):
+        self.k = kyber_k
+        self.max_batch = max_batch
+        self._h = C.c_void_p()
+        if lib.kosk_create(C.byref(self._h), device, kyber_k, max_batch):
+            raise KoskError("kosk_create: " + lib.kosk_last_error(None).decode())
+        self.pk_bytes, self.sk_bytes = pk_bytes(kyber_k), sk_bytes(kyber_k)
+        self.proof_bytes, self.tape_bytes = proof_bytes(kyber_k), tape_bytes(kyber_k)
+        self._cb = None
+
+    def close(self):
+        if self._h:
+            lib.kosk_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, r, what):
+        if r:
+            raise KoskError(what + ": " + lib.kosk_last_error(self._h).decode())
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_randombytes(self, fn):
+        """fn(nbytes) -> bytes, called in the reference's randombytes order."""
+        if fn is None:
+            self._cb = None
+            self._chk(lib.kosk_set_randombytes(self._h, None, None), "set_randombytes")
+            return
+        CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
+
+        def tramp(_user, out, n):
+            data = fn(n)
+            C.memmove(out, data, n)
+        self._cb = CB(tramp)
+        self._chk(lib.kosk_set_randombytes(self._h, C.cast(self._cb, C.c_void_p), None), "set_randombytes")
+
+    def verifiable_keygen(self, tapes=None, n=None):
+        """tapes: list of bytes (one randomness tape per instance) or None (callback / OS entropy)."""
+        if tapes is not None:
+            n = len(tapes)
+            stride = self.tape_bytes
+            blob = b"".join(t[:stride].ljust(stride, b"\0") for t in tapes)
+            for t in tapes:
+                if len(t) < stride:
+                    raise KoskError("tape shorter than kosk_tape_bytes")
+            tp = C.c_char_p(blob)
+        else:
+            if n is None:
+                n = 1
+            stride, tp = 0, None
+        pk = C.create_string_buffer(self.pk_bytes * n); sk = C.create_string_buffer(self.sk_bytes * n)
+        pi = C.create_string_buffer(self.proof_bytes * n)
+        self._chk(lib.kosk_verifiable_keygen_batch(self._h, n, tp, stride, pk, sk, pi), "verifiable_keygen")
+        cut = lambda b, s: [b.raw[i * s:(i + 1) * s] for i in range(n)]
+        return cut(pk, self.pk_bytes), cut(sk, self.sk_bytes), cut(pi, self.proof_bytes)
+
+    def verify(self, pis, pks):
+        n = len(pis)
+        ok = C.create_string_buffer(n)
+        self._chk(lib.kosk_verify_batch(self._h, n, C.c_char_p(b"".join(pis)), C.c_char_p(b"".join(pks)), ok), "verify")
+        return [b == 1 for b in ok.raw]
+
+    def fail_masks(self, n):
+        m = (C.c_uint32 * n)()
+        self._chk(lib.kosk_verify_fail_masks(self._h, m, n), "fail_masks")
+        return list(m)
+
+    # resident split (bench)
+    def stage_prover_inputs(self, tapes):
+        n = len(tapes)
+        blob = b"".join(t[:self.tape_bytes] for t in tapes)
+        self._pk = C.create_string_buffer(self.pk_bytes * n); self._sk = C.create_string_buffer(self.sk_bytes * n)
+        self._chk(lib.kosk_stage_prover_inputs(self._h, n, C.c_char_p(blob), self.tape_bytes, self._pk, self._sk), "stage_prover_inputs")
+        return n
+
+    def prove_resident(self, n):
+        self._chk(lib.kosk_prove_resident(self._h, n), "prove_resident")
+
+    def verify_resident(self, n):
+        ok = C.create_string_buffer(n)
+        self._chk(lib.kosk_verify_resident(self._h, n, ok), "verify_resident")
+        return [b == 1 for b in ok.raw]
+
+    def fetch_proofs(self, n):
+        pi = C.create_string_buffer(self.proof_bytes * n)
+        self._chk(lib.kosk_fetch_proofs(self._h, n, pi), "fetch_proofs")
+        return [pi.raw[i * self.proof_bytes:(i + 1) * self.proof_bytes] for i in range(n)]
+
+    def phase_seconds(self):
+        out = (C.c_double * 7)()
+        lib.kosk_phase_seconds(self._h, out, 7)
+        return list(out)
+
+    def synchronize(self):
+        self._chk(lib.kosk_device_synchronize(self._h), "synchronize")
+
+    # kernel-level (device pointers as ints, e.g. torch tensor .data_ptr())
+    def sha3_256_batch(self, d_in, in_stride, inlen, d_out, n):
+        self._chk(lib.kosk_sha3_256_batch(self._h, d_in, in_stride, inlen, d_out, n), "sha3_256_batch")
+
+    def shake256_batch(self, d_in, in_stride, inlen, d_out, outlen, n):
+        self._chk(lib.kosk_shake256_batch(self._h, d_in, in_stride, inlen, d_out, outlen, n), "shake256_batch")
+
+    def commit_hash_lanes(self, d_rows, row_stride, n_lanes, d_prefix, with_prefix, d_out):
+        self._chk(lib.kosk_commit_hash_lanes(self._h, d_rows, row_stride, n_lanes, d_prefix, int(with_prefix), d_out), "commit_hash_lanes")
+
+    def ntt256_batch(self, d_in, d_out, n):
+        self._chk(lib.kosk_ntt256_batch(self._h, d_in, d_out, n), "ntt256_batch")
+
+    def lagrange_expand(self, d_y407, d_shares, n):
+        self._chk(lib.kosk_lagrange_expand(self._h, d_y407, d_shares, n), "lagrange_expand")
+
+    def recon_secrets(self, d_shares, d_secrets, n, two_d=False):
+        self._chk(lib.kosk_recon_secrets(self._h, d_shares, d_secrets, n, int(two_d)), "recon_secrets")

@@ -1,0 +1,276 @@
+// extern "C" boundary (include/kosk_mi355x.h) over kosk::Ctx.
+#include "../../include/kosk_mi355x.h"
+
+#include <cstring>
+#include <string>
+
+#include "kosk_ctx.hpp"
+
+using namespace kosk;
+
+struct kosk_ctx {
+    Ctx *c;
+};
+
+static std::string g_create_err;
+
+#define HIPCHK_C(x)                                                        \
+    do {                                                                   \
+        hipError_t e_ = (x);                                               \
+        if (e_ != hipSuccess) {                                            \
+            c.err = std::string(#x) + ": " + hipGetErrorString(e_);        \
+            return -1;                                                     \
+        }                                                                  \
+    } while (0)
+
+extern "C" {
+
+size_t kosk_pk_bytes(int k) { Params p; return make_params(k, p) ? p.pk_bytes : 0; }
+size_t kosk_sk_bytes(int k) { Params p; return make_params(k, p) ? p.sk_bytes : 0; }
+size_t kosk_proof_bytes(int k) { Params p; return make_params(k, p) ? p.proof_bytes : 0; }
+size_t kosk_tape_bytes(int k) { Params p; return make_params(k, p) ? p.tape_bytes : 0; }
+int kosk_proof_field(int k, int idx, size_t *offset, size_t *size)
+{
+    Params p;
+    if (!make_params(k, p) || idx < 0 || idx >= NFIELDS) return -1;
+    if (offset) *offset = p.off[idx];
+    if (size) *size = p.size[idx];
+    return 0;
+}
+
+int kosk_create(kosk_ctx **ctx, int device, int kyber_k, int max_batch)
+{
+    if (!ctx) return -1;
+    Ctx *c = nullptr;
+    if (ctx_create(&c, device, kyber_k, max_batch, g_create_err)) return -1;
+    *ctx = new kosk_ctx{c};
+    return 0;
+}
+void kosk_destroy(kosk_ctx *ctx)
+{
+    if (!ctx) return;
+    delete ctx->c;
+    delete ctx;
+}
+const char *kosk_last_error(const kosk_ctx *ctx) { return ctx ? ctx->c->err.c_str() : g_create_err.c_str(); }
+int kosk_set_randombytes(kosk_ctx *ctx, kosk_randombytes_fn fn, void *user)
+{
+    if (!ctx) return -1;
+    ctx->c->rb = fn;
+    ctx->c->rb_user = user;
+    return 0;
+}
+
+int kosk_stage_prover_inputs(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk)
+{
+    return ctx ? stage_prover_inputs(*ctx->c, n, tapes, tape_stride, pk, sk) : -1;
+}
+int kosk_prove_resident(kosk_ctx *ctx, int n) { return ctx ? prove_resident(*ctx->c, n) : -1; }
+int kosk_fetch_proofs(kosk_ctx *ctx, int n, uint8_t *pi) { return ctx ? fetch_proofs(*ctx->c, n, pi) : -1; }
+int kosk_stage_verifier_inputs(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk)
+{
+    return ctx ? stage_verifier_inputs(*ctx->c, n, pi, pk) : -1;
+}
+int kosk_verify_resident(kosk_ctx *ctx, int n, uint8_t *ok) { return ctx ? verify_resident(*ctx->c, n, ok) : -1; }
+
+int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride,
+                                 uint8_t *pk, uint8_t *sk, uint8_t *pi)
+{
+    if (!ctx || n < 0) return -1;
+    Ctx &c = *ctx->c;
+    const Params &P = c.P;
+    for (int done = 0; done < n;) {
+        const int m = (n - done) < c.max_batch ? (n - done) : c.max_batch;
+        const uint8_t *tp = tapes ? tapes + (size_t)done * tape_stride : nullptr;
+        if (stage_prover_inputs(c, m, tp, tape_stride, pk + (size_t)done * P.pk_bytes, sk + (size_t)done * P.sk_bytes)) return -1;
+        if (prove_resident(c, m)) return -1;
+        if (fetch_proofs(c, m, pi + (size_t)done * P.proof_bytes)) return -1;
+        done += m;
+    }
+    return 0;
+}
+
+int kosk_verify_batch(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk, uint8_t *ok)
+{
+    if (!ctx || n < 0) return -1;
+    Ctx &c = *ctx->c;
+    const Params &P = c.P;
+    for (int done = 0; done < n;) {
+        const int m = (n - done) < c.max_batch ? (n - done) : c.max_batch;
+        if (stage_verifier_inputs(c, m, pi + (size_t)done * P.proof_bytes, pk + (size_t)done * P.pk_bytes)) return -1;
+        if (verify_resident(c, m, ok + done)) return -1;
+        done += m;
+    }
+    return 0;
+}
+
+int kosk_verify_fail_masks(const kosk_ctx *ctx, uint32_t *masks, int n)
+{
+    if (!ctx || n < 0 || n > ctx->c->max_batch) return -1;
+    memcpy(masks, ctx->c->h_fail, sizeof(uint32_t) * (size_t)n);
+    return 0;
+}
+
+int kosk_phase_seconds(const kosk_ctx *ctx, double *out, int n)
+{
+    if (!ctx) return -1;
+    for (int i = 0; i < n && i < PH_COUNT; i++) out[i] = ctx->c->phase_sec[i];
+    return 0;
+}
+
+int kosk_device_synchronize(kosk_ctx *ctx)
+{
+    if (!ctx) return -1;
+    Ctx &c = *ctx->c;
+    HIPCHK_C(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+int kosk_resident_proofs(kosk_ctx *ctx, void **d_proofs, size_t *stride)
+{
+    if (!ctx) return -1;
+    if (d_proofs) *d_proofs = ctx->c->d_proof;
+    if (stride) *stride = ctx->c->image_stride;
+    return 0;
+}
+
+// ---- kernel-level entry points -------------------------------------------------
+
+int kosk_sha3_256_batch(kosk_ctx *ctx, const uint8_t *d_in, size_t in_stride, size_t inlen, uint8_t *d_out, int n)
+{
+    if (!ctx) return -1;
+    Ctx &c = *ctx->c;
+    HIPCHK_C(launch_sha3_msgs(d_in, in_stride, (int)inlen, d_out, 32, 32, n, 0x06, c.stream));
+    return 0;
+}
+int kosk_shake256_batch(kosk_ctx *ctx, const uint8_t *d_in, size_t in_stride, size_t inlen, uint8_t *d_out, size_t outlen, int n)
+{
+    if (!ctx) return -1;
+    Ctx &c = *ctx->c;
+    HIPCHK_C(launch_sha3_msgs(d_in, in_stride, (int)inlen, d_out, outlen, (int)outlen, n, 0x1F, c.stream));
+    return 0;
+}
+
+int kosk_commit_hash_lanes(kosk_ctx *ctx, const uint16_t *d_rows, size_t row_stride, int n_lanes,
+                           const uint8_t *d_prefix, int with_prefix, uint8_t *d_out)
+{
+    if (!ctx) return -1;
+    Ctx &c = *ctx->c;
+    HashArgs ha{};
+    ha.rows = d_rows;
+    ha.group_stride = 0;
+    ha.row_stride = (int)row_stride;
+    ha.col_off = 0;
+    ha.lanes_per_group = n_lanes;
+    ha.lane_map = nullptr;
+    ha.prefix = d_prefix;
+    ha.out = d_out;
+    ha.out_lanes_per_group = n_lanes;
+    HIPCHK_C(launch_commit_hash(ha, 1, c.P.K, with_prefix != 0, c.stream));
+    return 0;
+}
+
+int kosk_ntt256_batch(kosk_ctx *ctx, const int16_t *d_in, int16_t *d_out, int n)
+{
+    if (!ctx) return -1;
+    Ctx &c = *ctx->c;
+    NttArgs na{};
+    na.in = d_in;
+    na.out = d_out;
+    na.npg = n;
+    na.npoly = n;
+    na.out_canonical = 0;
+    HIPCHK_C(launch_ntt(na, c.stream));
+    return 0;
+}
+
+int kosk_lagrange_expand(kosk_ctx *ctx, const uint16_t *d_y407, uint16_t *d_shares, int n)
+{
+    if (!ctx) return -1;
+    Ctx &c = *ctx->c;
+    const int cap = c.max_batch * c.rm.nrows; // the row matrix doubles as scratch
+    for (int done = 0; done < n;) {
+        const int m = (n - done) < cap ? (n - done) : cap;
+        HIPCHK_C(launch_rows_copy(d_y407 + (size_t)done * XLEN, XLEN, c.d_P, RS, XLEN, m, c.stream));
+        GemmArgs ga{};
+        ga.A = c.t_expand.d; ga.Mpad = c.t_expand.Mpad; ga.M = c.t_expand.M; ga.KP = c.t_expand.KP;
+        ga.B = c.d_P; ga.b_gstride = 0; ga.b_rows = nullptr; ga.b_koff = 0;
+        ga.C = c.d_P; ga.c_gstride = 0; ga.c_rows = nullptr; ga.c_rstride = RS; ga.c_off = EXP_OFF;
+        ga.npg = m; ga.ngroups = 1; ga.grouped = 0;
+        HIPCHK_C(launch_gemm(ga, c.stream));
+        HIPCHK_C(launch_rows_copy(c.d_P + NSEC, RS, d_shares + (size_t)done * NPARTY, NPARTY, NPARTY, m, c.stream));
+        done += m;
+    }
+    return 0;
+}
+
+int kosk_recon_secrets(kosk_ctx *ctx, const uint16_t *d_shares, uint16_t *d_secrets, int n, int two_d)
+{
+    if (!ctx) return -1;
+    Ctx &c = *ctx->c;
+    const GemmTable &t = two_d ? c.t_recon_2d : c.t_recon_d;
+    const int cap = c.max_batch * c.rm.nrows;
+    for (int done = 0; done < n;) {
+        const int m = (n - done) < cap ? (n - done) : cap;
+        HIPCHK_C(launch_rows_copy(d_shares + (size_t)done * NPARTY, NPARTY, c.d_P + NSEC, RS, NPARTY, m, c.stream));
+        GemmArgs ga{};
+        ga.A = t.d; ga.Mpad = t.Mpad; ga.M = t.M; ga.KP = t.KP;
+        ga.B = c.d_P; ga.b_gstride = 0; ga.b_rows = nullptr; ga.b_koff = NSEC;
+        ga.C = c.d_P; ga.c_gstride = 0; ga.c_rows = nullptr; ga.c_rstride = RS; ga.c_off = 0;
+        ga.npg = m; ga.ngroups = 1; ga.grouped = 0;
+        HIPCHK_C(launch_gemm(ga, c.stream));
+        HIPCHK_C(launch_rows_copy(c.d_P, RS, d_secrets + (size_t)done * NSEC, NSEC, NSEC, m, c.stream));
+        done += m;
+    }
+    return 0;
+}
+
+// ---- host-only entry points -----------------------------------------------------
+
+int kosk_keygen(int kyber_k, const uint8_t seed64[64], uint8_t *pk, uint8_t *sk, int16_t *A, int16_t *s, int16_t *e, int16_t *t)
+{
+    Params P;
+    if (!make_params(kyber_k, P) || !seed64 || !pk || !sk) return -1;
+    HostKey *key = new HostKey();
+    host_keygen(P, seed64, pk, sk, *key);
+    const int K = P.K;
+    if (A) memcpy(A, key->A, sizeof(int16_t) * K * K * 256);
+    if (s) memcpy(s, key->se, sizeof(int16_t) * K * 256);
+    if (e) memcpy(e, key->se + K * 256, sizeof(int16_t) * K * 256);
+    if (t) memcpy(t, key->t, sizeof(int16_t) * K * 256);
+    delete key;
+    return 0;
+}
+
+int kosk_fs_alpha(int kyber_k, const uint8_t *tcomm_all, uint16_t *alpha)
+{
+    Params P;
+    if (!make_params(kyber_k, P)) return -1;
+    fs_alpha(P, tcomm_all, alpha);
+    return 0;
+}
+
+int kosk_fs_opened(const uint8_t *digests_all, uint16_t *I, uint16_t *rest)
+{
+    fs_opened(digests_all, I, rest);
+    return 0;
+}
+
+void kosk_host_sha3_256(uint8_t out[32], const uint8_t *in, size_t inlen) { sha3_256(out, in, inlen); }
+void kosk_host_shake256(uint8_t *out, size_t outlen, const uint8_t *in, size_t inlen) { shake256(out, outlen, in, inlen); }
+
+int kosk_lagrange_table(int which, uint16_t *out)
+{
+    if (which == 0) {
+        for (int x = 0; x < NPARTY - NOPEN - 1; x++) lagrange_row(out + (size_t)x * XLEN, XLEN, 0, XLEN + x);
+    } else if (which == 1) {
+        for (int i = 0; i < NSEC; i++) lagrange_row(out + (size_t)i * XLEN, XLEN, NSEC, i);
+    } else if (which == 2) {
+        for (int i = 0; i < NSEC; i++) lagrange_row(out + (size_t)i * (DEG2 + 1), DEG2 + 1, NSEC, i);
+    } else {
+        return -1;
+    }
+    return 0;
+}
+
+} // extern "C"

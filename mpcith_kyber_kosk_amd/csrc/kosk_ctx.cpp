@@ -1,0 +1,437 @@
+// Context construction and the batched prover pipeline.
+//
+// Stage map (reference prove(), mlwe_prover.cpp:81-538):
+//   stage_prover_inputs : tape upload + host keygen (kosk.cpp:4-70)
+//   prove_resident      : [GPU] prepare_randomness / prepare_range_proof / P1 as
+//                         ONE Lagrange-expansion GEMM over every fresh sharing,
+//                         gates P13-P15, Tcomm P3 -> [host] alpha P4 -> [GPU] P5-P12
+//                         -> view hash P16 -> [host] I P17 -> [GPU] wire image P18.
+// All linear steps act on whole evaluation-point rows (secrets included), so the
+// values the reference obtains by recon_secrets_ddeg/2ddeg are simply the x < 256
+// part of the same rows.
+#include "kosk_ctx.hpp"
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+
+#include "kosk_math.hpp"
+
+namespace kosk {
+
+#define HIPCHK(x)                                                                       \
+    do {                                                                                \
+        hipError_t e_ = (x);                                                            \
+        if (e_ != hipSuccess) {                                                         \
+            c.err = std::string(#x) + ": " + hipGetErrorString(e_);                     \
+            return -1;                                                                  \
+        }                                                                               \
+    } while (0)
+
+static double now_sec()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <typename T>
+static hipError_t dalloc(T **p, size_t n)
+{
+    return hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T));
+}
+template <typename T>
+static hipError_t halloc(T **p, size_t n)
+{
+    return hipHostMalloc(reinterpret_cast<void **>(p), n * sizeof(T), hipHostMallocDefault);
+}
+
+Ctx::~Ctx()
+{
+    void *dev[] = {t_expand.d, t_recon_d.d, t_recon_2d.d, d_fresh_rows, d_gemm1_rows, d_gemm2_rows, d_off, d_fields,
+                   d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_poly, d_t, d_alpha, d_I, d_rest, d_pwT,
+                   d_gather, d_gather2, d_W, d_W2, d_wtmp, d_sec, d_fail, d_vrows};
+    for (void *p : dev)
+        if (p) (void)hipFree(p);
+    void *host[] = {h_tape, h_dig, h_proof, h_A, h_se, h_t, h_alpha, h_I, h_rest, h_fail};
+    for (void *p : host)
+        if (p) (void)hipHostFree(p);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+static int upload_table(Ctx &c, GemmTable &t, const std::vector<uint16_t> &A, int M, int Kdim)
+{
+    t.M = M;
+    t.Mpad = (M + 127) / 128 * 128;
+    t.KP = ((Kdim + 31) / 32 * 32) / 2;
+    std::vector<uint32_t> pk;
+    pack_gemm_table(A, M, Kdim, t.Mpad, t.KP, pk);
+    HIPCHK(dalloc(&t.d, pk.size()));
+    HIPCHK(hipMemcpy(t.d, pk.data(), pk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return 0;
+}
+
+template <typename T>
+static int upload_vec(Ctx &c, T **d, const std::vector<T> &v)
+{
+    HIPCHK(dalloc(d, v.size() ? v.size() : 1));
+    if (!v.empty()) HIPCHK(hipMemcpy(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int build_tables(Ctx &c)
+{
+    const Params &P = c.P;
+    const RowMap &rm = c.rm;
+    const int K = P.K, M = P.M, E = P.E, Z = P.Z;
+
+    { // Lagrange expansion operator for the points EXP_OFF..RS-1 from the 407 values at 0..406
+        std::vector<uint16_t> A((size_t)EXP_M * XLEN, 0);
+        for (int m = 0; m < EXP_M; m++) {
+            const int x = EXP_OFF + m;
+            if (x < XLEN) A[(size_t)m * XLEN + x] = 1;             // already an input: identity
+            else if (x < NPTS) lagrange_row(&A[(size_t)m * XLEN], XLEN, 0, x); // ss.cpp:26-27
+        }
+        if (upload_table(c, c.t_expand, A, EXP_M, XLEN)) return -1;
+    }
+    { // reconstruction of the packed secrets from parties 0..406 / 0..812   ss.cpp:47, :66
+        std::vector<uint16_t> A((size_t)NSEC * XLEN), A2((size_t)NSEC * (DEG2 + 1));
+        for (int i = 0; i < NSEC; i++) {
+            lagrange_row(&A[(size_t)i * XLEN], XLEN, NSEC, i);
+            lagrange_row(&A2[(size_t)i * (DEG2 + 1)], DEG2 + 1, NSEC, i);
+        }
+        if (upload_table(c, c.t_recon_d, A, NSEC, XLEN)) return -1;
+        if (upload_table(c, c.t_recon_2d, A2, NSEC, DEG2 + 1)) return -1;
+    }
+
+    // fresh sharings in randomness-tape order
+    std::vector<int16_t> fresh;
+    for (int i = 0; i < M; i++) { fresh.push_back((int16_t)(rm.f + i)); fresh.push_back((int16_t)(rm.tf + i)); }   // mlwe_prover.cpp:29-38
+    for (int i = 0; i < K; i++)
+        for (int j = 0; j < E; j++) { fresh.push_back((int16_t)(rm.seta + i * E + j)); fresh.push_back((int16_t)(rm.eeta + i * E + j)); } // :51-58
+    for (int i = 0; i < K; i++) { fresh.push_back((int16_t)(rm.s + i)); fresh.push_back((int16_t)(rm.e + i)); }    // :98-101
+    for (int i = 0; i < K; i++) fresh.push_back((int16_t)(rm.nttas + i));                                         // :316
+    for (int i = 0; i < K; i++)
+        for (int j = 0; j < Z; j++) { fresh.push_back((int16_t)rm.zs(i, j)); fresh.push_back((int16_t)rm.ze(i, j)); } // :369,:371
+    if ((int)fresh.size() != P.nfresh) { c.err = "internal: fresh row count"; return -1; }
+    if (upload_vec(c, &c.d_fresh_rows, fresh)) return -1;
+    if (upload_vec(c, &c.d_gemm1_rows, fresh)) return -1;
+    c.n_gemm1 = (int)fresh.size();
+    std::vector<int16_t> g2;
+    for (int i = 0; i < K; i++) { g2.push_back((int16_t)(rm.nttsr + i)); g2.push_back((int16_t)(rm.ntter + i)); g2.push_back((int16_t)(rm.nttasr + i)); }
+    if (upload_vec(c, &c.d_gemm2_rows, g2)) return -1;
+    c.n_gemm2 = (int)g2.size();
+
+    // NTT source / destination offsets (u16 units inside one proof group)
+    std::vector<int32_t> off;
+    auto push_rows = [&](int row0, int n) { int b = (int)off.size(); for (int i = 0; i < n; i++) off.push_back((row0 + i) * RS); return b; };
+    auto push_slots = [&](int s0, int n) { int b = (int)off.size(); for (int i = 0; i < n; i++) off.push_back((s0 + i) * 256); return b; };
+    c.off_f = push_rows(rm.f, M);
+    c.off_tf = push_rows(rm.tf, M);
+    c.off_s = push_rows(rm.s, K);
+    c.off_slot0 = push_slots(0, K);
+    c.off_sr_er = push_rows(rm.sr, 2 * K);        // sr rows then er rows (adjacent in the row map)
+    c.off_slotK = push_slots(K, 2 * K);
+    c.off_nttsr_er = push_rows(rm.nttsr, 2 * K);  // nttsr rows then ntter rows
+    if (rm.er != rm.sr + K || rm.ntter != rm.nttsr + K) { c.err = "internal: row map adjacency"; return -1; }
+    if (upload_vec(c, &c.d_off, off)) return -1;
+
+    // wire image fields (mlwe_prover.hpp:57-75): element e of a party's record <- row
+    auto add = [&](int fid, int sel, int width, auto rowfn) {
+        FieldDesc fd;
+        fd.off = (uint32_t)P.off[fid];
+        fd.sel = sel;
+        fd.width = width;
+        fd.rowtab_off = (int)c.h_rowtab.size();
+        for (int e = 0; e < width; e++) c.h_rowtab.push_back((int16_t)rowfn(e));
+        c.h_fields.push_back(fd);
+    };
+    add(F_F, 0, M, [&](int e) { return rm.f + e; });
+    add(F_NTTF, 0, M, [&](int e) { return rm.tf + e; });
+    add(F_BETA, 1, NCHK, [&](int e) { return rm.beta(e); });
+    add(F_GAMMA, 1, NCHK, [&](int e) { return rm.gamma(e); });
+    add(F_S, 0, K, [&](int e) { return rm.s + e; });
+    add(F_E, 0, K, [&](int e) { return rm.e + e; });
+    add(F_T, 1, K, [&](int e) { return rm.t + e; });
+    add(F_NTTS, 0, K, [&](int e) { return rm.ntts + e; });
+    add(F_NTTE, 0, K, [&](int e) { return rm.ntte + e; });
+    add(F_NTTAR, 0, K, [&](int e) { return rm.nttar + e; });
+    add(F_NTTAS, 0, K, [&](int e) { return rm.nttas + e; });
+    add(F_SR, 1, K, [&](int e) { return rm.sr + e; });
+    add(F_ER, 1, K, [&](int e) { return rm.er + e; });
+    add(F_SETA, 1, K * E, [&](int e) { return rm.seta + e; });
+    add(F_EETA, 1, K * E, [&](int e) { return rm.eeta + e; });
+    add(F_SSUB, 0, K * E, [&](int e) { return rm.ssub + e; });
+    add(F_ESUB, 0, K * E, [&](int e) { return rm.esub + e; });
+    add(F_ZS, 0, K * Z, [&](int e) { return rm.zs(e / Z, e % Z); });
+    add(F_ZE, 0, K * Z, [&](int e) { return rm.ze(e / Z, e % Z); });
+    add(F_US, 1, K * Z, [&](int e) { return rm.us(e / Z, e % Z); });
+    add(F_UE, 1, K * Z, [&](int e) { return rm.ue(e / Z, e % Z); });
+    c.nfields = (int)c.h_fields.size();
+    if (upload_vec(c, &c.d_fields, c.h_fields)) return -1;
+    if (upload_vec(c, &c.d_rowtab, c.h_rowtab)) return -1;
+    return 0;
+}
+
+int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &err)
+{
+    Ctx *cp = new Ctx();
+    Ctx &c = *cp;
+    auto fail = [&]() { err = c.err; delete cp; return -1; };
+    if (!make_params(kyber_k, c.P)) { c.err = "kyber_k must be 2, 3 or 4"; return fail(); }
+    if (max_batch < 1) { c.err = "max_batch must be >= 1"; return fail(); }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        c.err = "no HIP device available: the KOSK path has no CPU fallback";
+        return fail();
+    }
+    c.device = device;
+    c.max_batch = max_batch;
+    c.rm = make_rowmap(c.P);
+    unsigned hc = std::thread::hardware_concurrency();
+    c.nthreads = hc ? (int)(hc > 16 ? 16 : hc) : 1;
+    if (const char *e = getenv("KOSK_HOST_THREADS")) c.nthreads = atoi(e) > 0 ? atoi(e) : c.nthreads;
+
+    auto body = [&]() -> int {
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        if (build_tables(c)) return -1;
+        const Params &P = c.P;
+        const size_t B = (size_t)max_batch;
+        c.proof_stride = (size_t)c.rm.nrows * RS;
+        c.tape_stride = (P.tape_bytes + 63) / 64 * 64;
+        c.image_stride = (P.proof_bytes + 63) / 64 * 64;
+        c.key_stride = (size_t)P.K * P.K * 256;
+        c.se_stride = (size_t)2 * P.K * 256;
+        c.poly_stride = (size_t)3 * P.K * 256;
+        c.sel_stride = 1312;
+        HIPCHK(dalloc(&c.d_P, B * c.proof_stride));
+        HIPCHK(hipMemsetAsync(c.d_P, 0, B * c.proof_stride * 2, c.stream));
+        HIPCHK(dalloc(&c.d_tape, B * c.tape_stride));
+        HIPCHK(dalloc(&c.d_dig1, B * NPARTY * 32));
+        HIPCHK(dalloc(&c.d_dig2, B * NPARTY * 32));
+        HIPCHK(dalloc(&c.d_proof, B * c.image_stride));
+        HIPCHK(dalloc(&c.d_A, B * c.key_stride));
+        HIPCHK(dalloc(&c.d_se, B * c.se_stride));
+        HIPCHK(dalloc(&c.d_poly, B * c.poly_stride));
+        HIPCHK(dalloc(&c.d_t, B * P.K * 256));
+        HIPCHK(dalloc(&c.d_alpha, B * 80));
+        HIPCHK(dalloc(&c.d_I, B * c.sel_stride));
+        HIPCHK(dalloc(&c.d_rest, B * c.sel_stride));
+        HIPCHK(dalloc(&c.d_pwT, B * MAXM * 80));
+        HIPCHK(dalloc(&c.d_fail, B));
+        HIPCHK(halloc(&c.h_tape, B * c.tape_stride));
+        HIPCHK(halloc(&c.h_dig, B * NPARTY * 32));
+        HIPCHK(halloc(&c.h_proof, B * c.image_stride));
+        HIPCHK(halloc(&c.h_A, B * c.key_stride));
+        HIPCHK(halloc(&c.h_se, B * c.se_stride));
+        HIPCHK(halloc(&c.h_t, B * P.K * 256));
+        HIPCHK(halloc(&c.h_alpha, B * 80));
+        HIPCHK(halloc(&c.h_I, B * c.sel_stride));
+        HIPCHK(halloc(&c.h_rest, B * c.sel_stride));
+        HIPCHK(halloc(&c.h_fail, B));
+        memset(c.h_alpha, 0, B * 80 * sizeof(uint16_t));
+        HIPCHK(hipStreamSynchronize(c.stream));
+        return 0;
+    };
+    if (body()) return fail();
+    *out = cp;
+    return 0;
+}
+
+int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk)
+{
+    if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
+    HIPCHK(hipSetDevice(c.device));
+    const Params &P = c.P;
+    const double t0 = now_sec();
+    if (!tapes) {
+        // draw through the randombytes callback in the reference's call order and
+        // lengths (kosk.cpp:12, mlwe_prover.cpp:9, ss.cpp:5), proof after proof
+        for (int b = 0; b < n; b++) {
+            uint8_t *tp = c.h_tape + (size_t)b * c.tape_stride;
+            auto draw = [&](size_t len) {
+                if (c.rb) c.rb(c.rb_user, tp, len);
+                else os_randombytes(tp, len);
+                tp += len;
+            };
+            draw(64);
+            for (int i = 0; i < P.M; i++) draw(32);
+            for (int i = 0; i < P.nfresh; i++) draw(302);
+        }
+    }
+    parallel_for(n, c.nthreads, [&](int b) {
+        uint8_t *tp = c.h_tape + (size_t)b * c.tape_stride;
+        if (tapes) {
+            memcpy(tp, tapes + (size_t)b * tape_stride, P.tape_bytes);
+        }
+        HostKey key;
+        host_keygen(P, tp, pk + (size_t)b * P.pk_bytes, sk + (size_t)b * P.sk_bytes, key);
+        memcpy(c.h_A + (size_t)b * c.key_stride, key.A, c.key_stride * sizeof(int16_t));
+        memcpy(c.h_se + (size_t)b * c.se_stride, key.se, c.se_stride * sizeof(int16_t));
+        for (int i = 0; i < P.K * 256; i++) c.h_t[(size_t)b * P.K * 256 + i] = (uint16_t)gf_encode(key.t[i]);
+    });
+    HIPCHK(hipMemcpyAsync(c.d_tape, c.h_tape, (size_t)n * c.tape_stride, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipMemcpyAsync(c.d_A, c.h_A, (size_t)n * c.key_stride * 2, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipMemcpyAsync(c.d_se, c.h_se, (size_t)n * c.se_stride * 2, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipMemcpyAsync(c.d_t, c.h_t, (size_t)n * P.K * 256 * 2, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    c.phase_sec[PH_HOST_PRE] = now_sec() - t0;
+    return 0;
+}
+
+int prove_resident(Ctx &c, int n)
+{
+    if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
+    HIPCHK(hipSetDevice(c.device));
+    const Params &P = c.P;
+    const RowMap &rm = c.rm;
+    const int K = P.K;
+    hipStream_t st = c.stream;
+    double t0 = now_sec(), t1;
+
+    // ---- offline phase + witness sharing: secrets, randoms, one expansion GEMM
+    HIPCHK(launch_expand_f(c.d_tape, c.tape_stride, c.d_P, c.proof_stride, rm.f, P.M, n, st));
+    HIPCHK(launch_tape_randoms(c.d_tape, c.tape_stride, 64 + 32 * P.M, c.d_fresh_rows, P.nfresh, c.d_P, c.proof_stride, n, st));
+    HIPCHK(launch_witness_secrets(c.d_se, c.se_stride, c.d_P, c.proof_stride, rm, P.eta1, n, st));
+    NttArgs na{};
+    na.in = reinterpret_cast<const int16_t *>(c.d_P);
+    na.in_gstride = c.proof_stride;
+    na.src_off = c.d_off + c.off_f;            // NTT(f_i) -> Tf_i secrets   mlwe_prover.cpp:17-26
+    na.out = reinterpret_cast<int16_t *>(c.d_P);
+    na.out_gstride = c.proof_stride;
+    na.dst_off = c.d_off + c.off_tf;
+    na.npg = P.M;
+    na.npoly = P.M * n;
+    na.out_canonical = 1;
+    HIPCHK(launch_ntt(na, st));
+    na.src_off = c.d_off + c.off_s;            // NTT(s) -> poly slots 0..K-1   :256
+    na.out = c.d_poly;
+    na.out_gstride = c.poly_stride;
+    na.dst_off = c.d_off + c.off_slot0;
+    na.npg = K;
+    na.npoly = K * n;
+    na.out_canonical = 0;
+    HIPCHK(launch_ntt(na, st));
+    HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_poly, c.poly_stride, 0, c.d_P, c.proof_stride, rm.nttas, K, n, st)); // :284-285
+
+    GemmArgs ga{};
+    ga.A = c.t_expand.d;
+    ga.Mpad = c.t_expand.Mpad;
+    ga.M = c.t_expand.M;
+    ga.KP = c.t_expand.KP;
+    ga.B = c.d_P;
+    ga.b_gstride = c.proof_stride;
+    ga.b_rows = c.d_gemm1_rows;
+    ga.b_koff = 0;
+    ga.C = c.d_P;
+    ga.c_gstride = c.proof_stride;
+    ga.c_rows = c.d_gemm1_rows;
+    ga.c_rstride = RS;
+    ga.c_off = EXP_OFF;
+    ga.npg = c.n_gemm1;
+    ga.ngroups = n;
+    ga.grouped = 0;
+    HIPCHK(launch_gemm(ga, st));
+    HIPCHK(launch_post_gates(c.d_P, c.proof_stride, rm, n, st));
+
+    HashArgs ha{};
+    ha.rows = c.d_P;
+    ha.group_stride = c.proof_stride;
+    ha.row_stride = RS;
+    ha.col_off = NSEC;
+    ha.lanes_per_group = NPARTY;
+    ha.lane_map = nullptr;
+    ha.prefix = nullptr;
+    ha.out = c.d_dig1;
+    ha.out_lanes_per_group = NPARTY;
+    HIPCHK(launch_commit_hash(ha, n, K, false, st));
+    HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig1, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    t1 = now_sec(); c.phase_sec[PH_GPU_COMMIT] = t1 - t0; t0 = t1;
+
+    // ---- Fiat-Shamir round 1 on the host
+    parallel_for(n, c.nthreads, [&](int b) { fs_alpha(P, c.h_dig + (size_t)b * NPARTY * 32, c.h_alpha + (size_t)b * 80); });
+    t1 = now_sec(); c.phase_sec[PH_FS_ALPHA] = t1 - t0; t0 = t1;
+    HIPCHK(hipMemcpyAsync(c.d_alpha, c.h_alpha, (size_t)n * 80 * 2, hipMemcpyHostToDevice, st));
+
+    // ---- online relation phase
+    HIPCHK(launch_pow_table(c.d_alpha, P.J, P.M, c.d_pwT, n, st));
+    LincombArgs la{};
+    la.P = c.d_P;
+    la.proof_stride = c.proof_stride;
+    la.rm = rm;
+    la.J = P.J;
+    la.pwT = c.d_pwT;
+    la.ncols = NPTS;
+    la.col_map = nullptr;
+    HIPCHK(launch_lincomb(la, n, st));
+    HIPCHK(launch_post_open(c.d_P, c.proof_stride, rm, n, st));
+    na.in = reinterpret_cast<const int16_t *>(c.d_P);
+    na.in_gstride = c.proof_stride;
+    na.src_off = c.d_off + c.off_sr_er;        // NTT of the opened s+r, e+r     :260-277
+    na.npg = 2 * K;
+    na.npoly = 2 * K * n;
+    na.out = c.d_poly;
+    na.out_gstride = c.poly_stride;
+    na.dst_off = c.d_off + c.off_slotK;
+    na.out_canonical = 0;
+    HIPCHK(launch_ntt(na, st));
+    na.out = reinterpret_cast<int16_t *>(c.d_P);
+    na.out_gstride = c.proof_stride;
+    na.dst_off = c.d_off + c.off_nttsr_er;
+    na.out_canonical = 1;
+    HIPCHK(launch_ntt(na, st));
+    HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_poly, c.poly_stride, K, c.d_P, c.proof_stride, rm.nttasr, K, n, st)); // :287-288
+    HIPCHK(launch_copy_tails(c.d_P, c.proof_stride, rm, n, st));
+    ga.b_rows = c.d_gemm2_rows;
+    ga.c_rows = c.d_gemm2_rows;
+    ga.npg = c.n_gemm2;
+    HIPCHK(launch_gemm(ga, st));                // recompute_share_secrets_ddeg x 3K   :298-299,:315
+    HIPCHK(launch_post_relation(c.d_P, c.proof_stride, rm, n, st));
+    ha.prefix = c.d_dig1;
+    ha.out = c.d_dig2;
+    HIPCHK(launch_commit_hash(ha, n, K, true, st));
+    HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig2, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    t1 = now_sec(); c.phase_sec[PH_GPU_RELATION] = t1 - t0; t0 = t1;
+
+    // ---- Fiat-Shamir round 2 on the host
+    parallel_for(n, c.nthreads, [&](int b) {
+        fs_opened(c.h_dig + (size_t)b * NPARTY * 32, c.h_I + (size_t)b * c.sel_stride, c.h_rest + (size_t)b * c.sel_stride);
+    });
+    t1 = now_sec(); c.phase_sec[PH_FS_OPEN] = t1 - t0; t0 = t1;
+    HIPCHK(hipMemcpyAsync(c.d_I, c.h_I, (size_t)n * c.sel_stride * 2, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c.d_rest, c.h_rest, (size_t)n * c.sel_stride * 2, hipMemcpyHostToDevice, st));
+
+    // ---- wire image
+    AssembleArgs aa{};
+    aa.P = c.d_P;
+    aa.proof_stride = c.proof_stride;
+    aa.fields = c.d_fields;
+    aa.rowtab = c.d_rowtab;
+    aa.opened = c.d_I;
+    aa.rest = c.d_rest;
+    aa.sel_stride = c.sel_stride;
+    aa.dig1 = c.d_dig1;
+    aa.dig2 = c.d_dig2;
+    aa.proof = c.d_proof;
+    aa.image_stride = c.image_stride;
+    HIPCHK(launch_assemble(aa, c.nfields, P.off[F_TCOMM], P.off[F_COMM], P.off[F_I], n, st));
+    HIPCHK(hipStreamSynchronize(st));
+    t1 = now_sec(); c.phase_sec[PH_GPU_ASSEMBLE] = t1 - t0;
+    return 0;
+}
+
+int fetch_proofs(Ctx &c, int n, uint8_t *pi)
+{
+    if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
+    HIPCHK(hipSetDevice(c.device));
+    const double t0 = now_sec();
+    HIPCHK(hipMemcpyAsync(c.h_proof, c.d_proof, (size_t)n * c.image_stride, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    for (int b = 0; b < n; b++) memcpy(pi + (size_t)b * c.P.proof_bytes, c.h_proof + (size_t)b * c.image_stride, c.P.proof_bytes);
+    c.phase_sec[PH_D2H] = now_sec() - t0;
+    return 0;
+}
+
+} // namespace kosk

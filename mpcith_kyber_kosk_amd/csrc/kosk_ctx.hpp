@@ -1,0 +1,90 @@
+// Library context: constant tables + HBM workspace for up to max_batch proofs
+// in flight, and the batched prove / verify pipelines built on kosk_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "kosk_device.hpp"
+#include "kosk_host.hpp"
+#include "kosk_params.hpp"
+
+namespace kosk {
+
+typedef void (*randombytes_fn)(void *user, uint8_t *out, size_t len);
+
+enum Phase { PH_HOST_PRE = 0, PH_GPU_COMMIT, PH_FS_ALPHA, PH_GPU_RELATION, PH_FS_OPEN, PH_GPU_ASSEMBLE, PH_D2H, PH_COUNT };
+
+struct GemmTable {
+    uint32_t *d = nullptr;
+    int M = 0, Mpad = 0, KP = 0;
+};
+
+struct Ctx {
+    int device = 0;
+    Params P{};
+    RowMap rm{};
+    int max_batch = 0;
+    int nthreads = 1;
+    hipStream_t stream = nullptr;
+    std::string err;
+    randombytes_fn rb = nullptr;
+    void *rb_user = nullptr;
+
+    // constant tables (HBM, L2-resident while in use)
+    GemmTable t_expand, t_recon_d, t_recon_2d;
+    int16_t *d_fresh_rows = nullptr, *d_gemm1_rows = nullptr, *d_gemm2_rows = nullptr;
+    int n_gemm1 = 0, n_gemm2 = 0;
+    int32_t *d_off = nullptr; // NTT offset tables, see build_tables()
+    int off_f = 0, off_tf = 0, off_s = 0, off_slot0 = 0, off_sr_er = 0, off_slotK = 0, off_nttsr_er = 0;
+    FieldDesc *d_fields = nullptr;
+    int16_t *d_rowtab = nullptr;
+    int nfields = 0;
+    std::vector<FieldDesc> h_fields;
+    std::vector<int16_t> h_rowtab;
+
+    // per-batch workspace
+    size_t proof_stride = 0; // u16 per proof in the row matrix
+    size_t tape_stride = 0, image_stride = 0, key_stride = 0, se_stride = 0, poly_stride = 0;
+    int sel_stride = 0;
+    uint16_t *d_P = nullptr;
+    uint8_t *d_tape = nullptr, *d_dig1 = nullptr, *d_dig2 = nullptr, *d_proof = nullptr;
+    int16_t *d_A = nullptr, *d_se = nullptr, *d_poly = nullptr;
+    uint16_t *d_t = nullptr; // pk's t, canonical (verifier)
+    uint16_t *d_alpha = nullptr, *d_I = nullptr, *d_rest = nullptr;
+    int32_t *d_pwT = nullptr;
+    // verifier workspace
+    uint16_t *d_gather = nullptr;  // [proof][vrows][416] values at the first 407 unopened nodes
+    uint16_t *d_gather2 = nullptr; // [proof][urows][832] values at the first 813 unopened nodes
+    uint32_t *d_W = nullptr, *d_W2 = nullptr; // per-proof interpolation operators, GEMM layout
+    uint16_t *d_wtmp = nullptr;
+    uint16_t *d_sec = nullptr;     // [proof][secrows][256] reconstructed secrets
+    uint32_t *d_fail = nullptr;    // [proof] bit mask of failed checks
+    int16_t *d_vrows = nullptr;
+    int n_interp_d = 0, n_interp_2d = 0;
+
+    // pinned host staging
+    uint8_t *h_tape = nullptr, *h_dig = nullptr, *h_proof = nullptr;
+    int16_t *h_A = nullptr, *h_se = nullptr;
+    uint16_t *h_t = nullptr;
+    uint16_t *h_alpha = nullptr, *h_I = nullptr, *h_rest = nullptr;
+    uint32_t *h_fail = nullptr;
+
+    double phase_sec[PH_COUNT] = {0};
+
+    ~Ctx();
+};
+
+int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &err);
+
+// host tapes -> pk/sk on host, tape + key material resident in HBM
+int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk);
+// everything from resident inputs to resident proof images (two host Fiat-Shamir round trips)
+int prove_resident(Ctx &c, int n);
+int fetch_proofs(Ctx &c, int n, uint8_t *pi);
+
+int stage_verifier_inputs(Ctx &c, int n, const uint8_t *pi, const uint8_t *pk);
+int verify_resident(Ctx &c, int n, uint8_t *ok);
+
+} // namespace kosk

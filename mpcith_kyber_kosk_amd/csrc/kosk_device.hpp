@@ -1,0 +1,106 @@
+// Kernel argument blocks and launcher prototypes (kosk_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kosk_params.hpp"
+
+namespace kosk {
+
+// K4: lane `l` of group `g` hashes  [prefix(32 B)] || rows[g][r][col_off + col(l)], r = 0..NROWS-1
+struct HashArgs {
+    const uint16_t *rows;      // row 0 of group 0
+    size_t group_stride;       // u16 between groups
+    int row_stride;            // u16 between rows
+    int col_off;               // column of lane 0 (NSEC for party lanes)
+    int lanes_per_group;
+    const uint16_t *lane_map;  // optional: lane -> party (opened list), else identity
+    int lane_map_stride;
+    const uint8_t *prefix;     // [group][out_lanes_per_group][32], read at the output index
+    uint8_t *out;              // [group][out_lanes_per_group][32]
+    int out_lanes_per_group;
+};
+
+struct NttArgs {
+    const int16_t *in;
+    const int32_t *src_off; // per-polynomial offset (u16 units) inside a group, or null: i*256
+    size_t in_gstride;
+    int16_t *out;
+    const int32_t *dst_off;
+    size_t out_gstride;
+    int npg;   // polynomials per group
+    int npoly; // total
+    int out_canonical; // 1: [0,q) (encode_to_gf3329), 0: centred int16 (poly_ntt)
+};
+
+struct GemmArgs {
+    const uint32_t *A; // Apk[KP][Mpad] centred int16 pairs
+    size_t a_gstride;  // u32 between groups (grouped mode), else unused
+    int Mpad, M, KP;   // KP multiple of 16
+    const uint16_t *B;
+    size_t b_gstride;
+    const int16_t *b_rows; // row index per n (null: n itself)
+    int b_koff;
+    uint16_t *C;
+    size_t c_gstride;
+    const int16_t *c_rows;
+    int c_rstride;
+    int c_off;
+    int npg, ngroups;
+    int grouped; // 1: blockIdx.z = group (per-group A), 0: n flattened over groups
+};
+
+struct LincombArgs {
+    uint16_t *P;
+    size_t proof_stride;
+    RowMap rm;
+    int J;
+    const int32_t *pwT; // [proof][MAXM][80]
+    int ncols;
+    const uint16_t *col_map; // optional party list (verifier: opened parties)
+    int col_map_stride;
+};
+
+struct FieldDesc {
+    uint32_t off;
+    int sel;   // 0: opened parties in I order, 1: unopened ascending
+    int width; // u16 per party
+    int rowtab_off;
+};
+
+struct AssembleArgs {
+    const uint16_t *P;
+    size_t proof_stride;
+    const FieldDesc *fields;
+    const int16_t *rowtab;
+    const uint16_t *opened, *rest; // [proof][sel_stride]
+    int sel_stride;
+    const uint8_t *dig1, *dig2; // [proof][NPARTY][32]
+    uint8_t *proof;
+    size_t image_stride;
+};
+
+hipError_t launch_commit_hash(const HashArgs &a, int ngroups, int K, bool view, hipStream_t st);
+hipError_t launch_sha3_msgs(const uint8_t *in, size_t in_stride, int len, uint8_t *out, size_t out_stride,
+                            int outlen, int n, int domain, hipStream_t st);
+hipError_t launch_rows_copy(const uint16_t *src, size_t src_stride, uint16_t *dst, size_t dst_stride, int count,
+                            int nrows, hipStream_t st);
+hipError_t launch_expand_f(const uint8_t *tape, size_t tape_stride, uint16_t *P, size_t proof_stride, int row_f,
+                           int M, int nproofs, hipStream_t st);
+hipError_t launch_tape_randoms(const uint8_t *tape, size_t tape_stride, int slice0_off, const int16_t *fresh_rows,
+                               int nfresh, uint16_t *P, size_t proof_stride, int nproofs, hipStream_t st);
+hipError_t launch_witness_secrets(const int16_t *se, size_t se_stride, uint16_t *P, size_t proof_stride,
+                                  const RowMap &rm, int eta1, int nproofs, hipStream_t st);
+hipError_t launch_ntt(const NttArgs &a, hipStream_t st);
+hipError_t launch_matvec_ntt(const int16_t *A, size_t A_stride, const int16_t *v, size_t v_stride, int v_slot,
+                             uint16_t *P, size_t proof_stride, int row0, int K, int nproofs, hipStream_t st);
+hipError_t launch_gemm(const GemmArgs &a, hipStream_t st);
+hipError_t launch_pow_table(const uint16_t *alpha, int J, int M, int32_t *pwT, int nproofs, hipStream_t st);
+hipError_t launch_lincomb(const LincombArgs &a, int nproofs, hipStream_t st);
+hipError_t launch_post_gates(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st);
+hipError_t launch_post_open(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st);
+hipError_t launch_copy_tails(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st);
+hipError_t launch_post_relation(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st);
+hipError_t launch_assemble(const AssembleArgs &a, int nfields, size_t off_tcomm, size_t off_comm, size_t off_I,
+                           int nproofs, hipStream_t st);
+
+} // namespace kosk

@@ -1,0 +1,52 @@
+// Host-side pieces of the product path: the Fiat-Shamir hashing that stays on
+// the CPU by design (BASELINE.json north_star), Kyber key generation
+// (host for now), Lagrange table generation, and a small
+// thread pool.  None of this touches oracle/.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+#include <vector>
+
+#include "kosk_params.hpp"
+
+namespace kosk {
+
+// fips202.c:745-774, :723-734, symmetric-shake.c:43-51
+void sha3_256(uint8_t out[32], const uint8_t *in, size_t inlen);
+void sha3_512(uint8_t out[64], const uint8_t *in, size_t inlen);
+void shake128(uint8_t *out, size_t outlen, const uint8_t *in, size_t inlen);
+void shake256(uint8_t *out, size_t outlen, const uint8_t *in, size_t inlen);
+void shake256_prf(uint8_t *out, size_t outlen, const uint8_t key[32], uint8_t nonce);
+
+// kosk.cpp:4-70.  A is [K][K][256] canonical, s/e are [K][256] small signed,
+// t is [K][256] centred NTT-domain; pk/sk in Kyber wire format.
+struct HostKey {
+    int16_t A[MAXK * MAXK * 256];
+    int16_t se[2 * MAXK * 256]; // s polys then e polys
+    int16_t t[MAXK * 256];
+};
+void host_keygen(const Params &P, const uint8_t seed64[64], uint8_t *pk, uint8_t *sk, HostKey &key);
+// kosk.cpp:94-110: decode pk into A (canonical) and t (12-bit values as stored)
+void host_decode_pk(const Params &P, const uint8_t *pk, HostKey &key);
+
+// mlwe_prover.cpp:130-142: alpha_j = BE16(SHAKE256(sha3_256(Tcomm) || 1)) % q
+void fs_alpha(const Params &P, const uint8_t *tcomm_all /* [1454][32] */, uint16_t *alpha /* [J] */);
+// mlwe_prover.cpp:445-474: opened list I (with the linear-probing de-dup) and its complement
+void fs_opened(const uint8_t *digests_all /* [1454][32] */, uint16_t I[NOPEN], uint16_t rest[NREST]);
+
+// Lagrange basis over n consecutive integer nodes a..a+n-1 evaluated at t
+// (utils/precomputed_kyber.h:10-13; values by the call sites ss.cpp:26-27,:47,:66)
+void lagrange_row(uint16_t *row, int n, int a, int t);
+uint16_t gf_inv_host(uint16_t a);
+
+// pack A[m][k] (canonical) into the GEMM operand Apk[KP][Mpad] of centred int16 pairs
+void pack_gemm_table(const std::vector<uint16_t> &A, int M, int Kdim, int Mpad, int KP, std::vector<uint32_t> &out);
+
+// run fn(i) for i in [0,n) on up to nthreads host threads
+void parallel_for(int n, int nthreads, const std::function<void(int)> &fn);
+
+// OS entropy (kyber/randombytes.c:44-57, Linux branch)
+void os_randombytes(uint8_t *out, size_t len);
+
+} // namespace kosk

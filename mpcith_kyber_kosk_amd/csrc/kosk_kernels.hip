@@ -1,0 +1,775 @@
+// Hand-written gfx950 (CDNA4) kernels for the KOSK party-view simulation.
+//
+// Every kernel works on the row matrix described in kosk_params.hpp:
+//   P[proof][row][x]   canonical u16, x = evaluation point (0..1709), RS = 1728.
+// Kernel <-> reference loop map:
+//   k_commit_hash   K4   mlwe_prover.cpp:116-127, :397-444 ; mlwe_verifier.cpp:23-35, :585-632
+//   k_sha3_msgs          kyber/fips202.c:745-754 on message-major input (tests, generic ABI)
+//   k_expand_f           mlwe_prover.cpp:8-14 (SHAKE256 PRF, BE16 % q)
+//   k_tape_randoms       ss.cpp:5-11
+//   k_ntt256        K5   kyber/ntt.c:80-95 + poly.c:261-265
+//   k_matvec_ntt    K6   polyvec.c:202-214 + poly.c:307-313
+//   k_gemm_modq     K1/K2 ss.cpp:23-32, :44-51, :63-70, :88-97 (+ verifier interpolation apply)
+//   k_lincomb       K3   mlwe_prover.cpp:159-203 ; mlwe_verifier.cpp:68-89, :149-170
+//   k_witness_secrets, k_post_*  K7  ss.cpp:101-136 call sites in prove()
+//   k_assemble_*    K8   mlwe_prover.cpp:480-537
+#include <hip/hip_runtime.h>
+
+#include "kosk_device.hpp"
+#include "kosk_keccak_dev.hpp"
+#include "kosk_math.hpp"
+
+namespace kosk {
+
+// =========================================================================
+// K4  SHA3-256 view commitments: one party lane per thread, 25 x u64 state
+// in VGPRs (v_bitop3_b32 / v_alignbit_b32), message words gathered from the
+// row matrix with one coalesced 128-byte line per wave per row.
+// =========================================================================
+template <int PREFIX_WORDS, int NROWS>
+__global__ __launch_bounds__(64) void k_commit_hash(HashArgs a)
+{
+    const int lane = blockIdx.x * 64 + threadIdx.x;
+    const int g = blockIdx.y;
+    if (lane >= a.lanes_per_group) return;
+    const int col = a.lane_map ? (int)a.lane_map[(size_t)g * a.lane_map_stride + lane] : lane;
+    const uint16_t *__restrict__ base = a.rows + (size_t)g * a.group_stride + a.col_off + col;
+    const size_t dig = ((size_t)g * a.out_lanes_per_group + col) * 32;
+
+    constexpr int W = PREFIX_WORDS + NROWS; // u16 words in the message
+    constexpr int RATE_W = 68;              // 136-byte rate
+    constexpr int NBLK = W / RATE_W + 1;    // pad10*1 always adds to the last (possibly empty) block
+
+    KState s;
+    kstate_zero(s);
+
+#pragma unroll
+    for (int blk = 0; blk < NBLK; blk++) {
+#pragma unroll
+        for (int w = 0; w < RATE_W; w += 2) {
+            const int gw = blk * RATE_W + w; // first of two u16 words forming half a lane
+            if (gw >= W) continue;
+            uint32_t v = 0;
+            if (gw + 1 < PREFIX_WORDS) {
+                v = *reinterpret_cast<const uint32_t *>(a.prefix + dig + 2 * gw);
+            } else {
+                v = base[(size_t)(gw - PREFIX_WORDS) * a.row_stride];
+                if (gw + 1 < W) v |= (uint32_t)base[(size_t)(gw + 1 - PREFIX_WORDS) * a.row_stride] << 16;
+            }
+            if ((w & 2) == 0) s.lo[w / 4] ^= v;
+            else s.hi[w / 4] ^= v;
+        }
+        if (blk == NBLK - 1) {
+            constexpr int padbyte = 2 * W - (NBLK - 1) * 136;
+            constexpr uint32_t padv = 0x06u << (8 * (padbyte % 4));
+            if ((padbyte % 8) < 4) s.lo[padbyte / 8] ^= padv;
+            else s.hi[padbyte / 8] ^= padv;
+            s.hi[16] ^= 0x80000000u;
+        }
+        keccak_f1600_dev(s);
+    }
+    uint4 *o = reinterpret_cast<uint4 *>(a.out + dig);
+    o[0] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
+    o[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
+}
+
+// SHA3-256 / SHAKE256 of n byte messages of equal length stored message-major.
+__global__ __launch_bounds__(64) void k_sha3_msgs(const uint8_t *__restrict__ in, size_t in_stride, int len,
+                                                  uint8_t *__restrict__ out, size_t out_stride, int outlen,
+                                                  int n, int domain)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *m = in + (size_t)i * in_stride;
+    uint64_t s[25];
+#pragma unroll
+    for (int k = 0; k < 25; k++) s[k] = 0;
+    int pos = 0;
+    for (int b = 0; b < len; b++) {
+        const uint64_t v = (uint64_t)m[b] << (8 * (pos & 7));
+        const int w = pos >> 3;
+#pragma unroll
+        for (int k = 0; k < 17; k++)
+            if (k == w) s[k] ^= v;
+        if (++pos == 136) {
+            keccak_f1600(s);
+            pos = 0;
+        }
+    }
+    {
+        const uint64_t v = (uint64_t)domain << (8 * (pos & 7));
+        const int w = pos >> 3;
+#pragma unroll
+        for (int k = 0; k < 17; k++)
+            if (k == w) s[k] ^= v;
+        s[16] ^= 0x8000000000000000ULL;
+    }
+    uint8_t *o = out + (size_t)i * out_stride;
+    int produced = 0;
+    while (produced < outlen) {
+        keccak_f1600(s);
+        const int take = min(136, outlen - produced);
+        for (int b = 0; b < take; b++) {
+            uint64_t lanev = 0;
+            const int w = b >> 3;
+#pragma unroll
+            for (int k = 0; k < 17; k++)
+                if (k == w) lanev = s[k];
+            o[produced + b] = (uint8_t)(lanev >> (8 * (b & 7)));
+        }
+        produced += take;
+    }
+}
+
+// =========================================================================
+// preprocessing expansions from the randomness tape
+// =========================================================================
+
+// f_i = BE16(SHAKE256(seed_i || i)[2j..2j+1]) % q          mlwe_prover.cpp:8-14
+__global__ __launch_bounds__(64) void k_expand_f(const uint8_t *__restrict__ tape, size_t tape_stride,
+                                                 uint16_t *__restrict__ P, size_t proof_stride, int row_f,
+                                                 int M, int nproofs)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= M * nproofs) return;
+    const int b = t / M, i = t % M;
+    const uint64_t *seed = reinterpret_cast<const uint64_t *>(tape + (size_t)b * tape_stride + 64 + 32 * i);
+    KState s;
+    kstate_zero(s);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        s.lo[k] = (uint32_t)seed[k];
+        s.hi[k] = (uint32_t)(seed[k] >> 32);
+    }
+    s.lo[4] = (uint32_t)(uint8_t)i | (0x1Fu << 8);
+    s.hi[16] = 0x80000000u;
+    uint16_t *dst = P + (size_t)b * proof_stride + (size_t)(row_f + i) * RS;
+    // 512 bytes = 3 full 136-byte squeezes + 104 bytes
+#pragma unroll 1
+    for (int blk = 0; blk < 4; blk++) {
+        keccak_f1600_dev(s);
+#pragma unroll
+        for (int w = 0; w < 17; w++) {
+            if (blk == 3 && w >= 13) break;
+            uint32_t o[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                const uint32_t v = hf ? s.hi[w] : s.lo[w];
+                const uint32_t h0 = v & 0xFFFFu, h1 = v >> 16;
+                const uint32_t be0 = ((h0 & 0xFF) << 8) | (h0 >> 8), be1 = ((h1 & 0xFF) << 8) | (h1 >> 8);
+                o[hf] = (be0 % (uint32_t)Q) | ((be1 % (uint32_t)Q) << 16);
+            }
+            *reinterpret_cast<uint2 *>(dst + blk * 68 + w * 4) = make_uint2(o[0], o[1]);
+        }
+    }
+}
+
+// shares of parties 0..150 of every fresh sharing = BE16(tape) % q   ss.cpp:5-11
+__global__ __launch_bounds__(192) void k_tape_randoms(const uint8_t *__restrict__ tape, size_t tape_stride, int slice0_off,
+                                                     const int16_t *__restrict__ fresh_rows,
+                                                     uint16_t *__restrict__ P, size_t proof_stride)
+{
+    const int t = threadIdx.x;
+    if (t > NOPEN) return;
+    const int slice = blockIdx.x, b = blockIdx.y;
+    const uint8_t *src = tape + (size_t)b * tape_stride + slice0_off + 302 * slice + 2 * t;
+    const uint32_t v = (((uint32_t)src[0] << 8) | src[1]) % (uint32_t)Q;
+    P[(size_t)b * proof_stride + (size_t)fresh_rows[slice] * RS + NSEC + t] = (uint16_t)v;
+}
+
+// packed secrets that depend only on the witness: s, e, the range constants,
+// and the multiplication-gate chain prod_{m<=k+1} (s - eta_m)  (what the
+// reference obtains through recon_secrets_2ddeg, mlwe_prover.cpp:351-373).
+__global__ __launch_bounds__(256) void k_witness_secrets(const int16_t *__restrict__ se, size_t se_stride,
+                                                        uint16_t *__restrict__ P, size_t proof_stride, RowMap rm, int eta1)
+{
+    const int j = threadIdx.x, b = blockIdx.x;
+    uint16_t *Pb = P + (size_t)b * proof_stride;
+    const int16_t *sb = se + (size_t)b * se_stride;
+    for (int who = 0; who < 2; who++) {
+        for (int i = 0; i < rm.K; i++) {
+            const uint32_t v = gf_encode(sb[(who * rm.K + i) * 256 + j]);
+            Pb[(size_t)((who ? rm.e : rm.s) + i) * RS + j] = (uint16_t)v;
+            uint32_t z = 0;
+            for (int m = 0; m < rm.E; m++) {
+                const uint32_t c = gf_encode(m - eta1);
+                Pb[(size_t)((who ? rm.eeta : rm.seta) + i * rm.E + m) * RS + j] = (uint16_t)c;
+                const uint32_t x = gf_sub(v, c);
+                z = (m == 0) ? x : gf_mul(z, x);
+                if (m >= 1) Pb[(size_t)(who ? rm.ze(i, m - 1) : rm.zs(i, m - 1)) * RS + j] = (uint16_t)z;
+            }
+        }
+    }
+}
+
+// =========================================================================
+// K5  NTT-256: 16 lanes x 16 coefficients per polynomial, 4 polynomials per
+// wave, 16 per workgroup.  Layers len=128..16 run on the stride-16 register
+// layout, one LDS transpose, layers len=8..2 on the contiguous layout, then
+// Barrett.  Global traffic is 16-byte coalesced both ways.
+// =========================================================================
+__constant__ static const ZetaTable kZetasDev = ZetaTable();
+
+constexpr int NTT_PPB = 16;
+constexpr int NTT_LSTRIDE = 256 + 16; // int16 per polynomial in LDS (32-byte pad: conflict-free stride reads)
+
+#define KOSK_BFLY(lo, hi, z)                 \
+    {                                        \
+        const int32_t t_ = fqmul((z), (hi)); \
+        (hi) = (lo) - t_;                    \
+        (lo) = (lo) + t_;                    \
+    }
+
+__global__ __launch_bounds__(256) void k_ntt256(NttArgs a)
+{
+    __shared__ __attribute__((aligned(16))) int16_t lds[NTT_PPB * NTT_LSTRIDE];
+    const int tid = threadIdx.x;
+    const int p0 = blockIdx.x * NTT_PPB;
+
+    for (int c = tid; c < NTT_PPB * 32; c += 256) {
+        const int pl = c >> 5, ch = c & 31, p = p0 + pl;
+        if (p < a.npoly) {
+            const int g = p / a.npg, i = p - g * a.npg;
+            const size_t off = (size_t)g * a.in_gstride + (a.src_off ? (size_t)a.src_off[i] : (size_t)i * 256);
+            *reinterpret_cast<uint4 *>(lds + pl * NTT_LSTRIDE + ch * 8) =
+                *reinterpret_cast<const uint4 *>(a.in + off + ch * 8);
+        }
+    }
+    __syncthreads();
+
+    const int pl = tid >> 4, l = tid & 15;
+    int16_t *mine = lds + pl * NTT_LSTRIDE;
+    int32_t r[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) r[i] = mine[l + 16 * i];
+
+    // coefficient index j = l + 16 i : len = 128, 64, 32, 16 <-> register distance 8, 4, 2, 1
+#pragma unroll
+    for (int i = 0; i < 8; i++) KOSK_BFLY(r[i], r[i + 8], (int32_t)kZetasDev.z[1]);
+#pragma unroll
+    for (int blk = 0; blk < 2; blk++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) KOSK_BFLY(r[8 * blk + i], r[8 * blk + i + 4], (int32_t)kZetasDev.z[2 + blk]);
+#pragma unroll
+    for (int blk = 0; blk < 4; blk++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) KOSK_BFLY(r[4 * blk + i], r[4 * blk + i + 2], (int32_t)kZetasDev.z[4 + blk]);
+#pragma unroll
+    for (int blk = 0; blk < 8; blk++) KOSK_BFLY(r[2 * blk], r[2 * blk + 1], (int32_t)kZetasDev.z[8 + blk]);
+
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) mine[l + 16 * i] = (int16_t)r[i];
+    __syncthreads();
+    {
+        const uint4 v0 = *reinterpret_cast<const uint4 *>(mine + 16 * l);
+        const uint4 v1 = *reinterpret_cast<const uint4 *>(mine + 16 * l + 8);
+        const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            r[2 * q] = (int16_t)(w[q] & 0xFFFF);
+            r[2 * q + 1] = (int16_t)(w[q] >> 16);
+        }
+    }
+    // coefficient index j = 16 l + c : zeta index = 128/len + j/(2 len)
+    {
+        const int32_t z8 = kZetasDev.z[16 + l];
+#pragma unroll
+        for (int c = 0; c < 8; c++) KOSK_BFLY(r[c], r[c + 8], z8);
+        const int32_t z4a = kZetasDev.z[32 + 2 * l], z4b = kZetasDev.z[33 + 2 * l];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            KOSK_BFLY(r[c], r[c + 4], z4a);
+            KOSK_BFLY(r[8 + c], r[12 + c], z4b);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int32_t z2 = kZetasDev.z[64 + 4 * l + q];
+            KOSK_BFLY(r[4 * q], r[4 * q + 2], z2);
+            KOSK_BFLY(r[4 * q + 1], r[4 * q + 3], z2);
+        }
+    }
+    const int p = p0 + pl;
+    if (p < a.npoly) {
+        uint32_t w[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            int32_t x0 = barrett_reduce((int16_t)r[2 * q]), x1 = barrett_reduce((int16_t)r[2 * q + 1]);
+            if (a.out_canonical) {
+                x0 = (int32_t)gf_encode(x0);
+                x1 = (int32_t)gf_encode(x1);
+            }
+            w[q] = ((uint32_t)x0 & 0xFFFFu) | ((uint32_t)x1 << 16);
+        }
+        const int g = p / a.npg, i = p - g * a.npg;
+        const size_t off = (size_t)g * a.out_gstride + (a.dst_off ? (size_t)a.dst_off[i] : (size_t)i * 256);
+        uint4 *o = reinterpret_cast<uint4 *>(a.out + off + 16 * l);
+        o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+}
+
+// K6  r_i = tomont(Barrett(sum_l basemul(A[i][l], v[l])))      polyvec.c:202-214, poly.c:307-313
+// one thread per degree-1 factor (pair of coefficients); output canonical u16
+__global__ __launch_bounds__(128) void k_matvec_ntt(const int16_t *__restrict__ A, size_t A_stride,
+                                                    const int16_t *__restrict__ v, size_t v_stride, int v_slot,
+                                                    uint16_t *__restrict__ P, size_t proof_stride, int row0, int K)
+{
+    const int t = threadIdx.x, i = blockIdx.x, b = blockIdx.y;
+    const int32_t zeta = (t & 1) ? -(int32_t)kZetasDev.z[64 + (t >> 1)] : (int32_t)kZetasDev.z[64 + (t >> 1)];
+    const int16_t *Ai = A + (size_t)b * A_stride + (size_t)i * K * 256;
+    const int16_t *vb = v + (size_t)b * v_stride + (size_t)v_slot * 256;
+    int32_t r0 = 0, r1 = 0;
+    for (int l = 0; l < K; l++) {
+        const int32_t a0 = Ai[l * 256 + 2 * t], a1 = Ai[l * 256 + 2 * t + 1];
+        const int32_t b0 = vb[l * 256 + 2 * t], b1 = vb[l * 256 + 2 * t + 1];
+        // ntt.c:139-146 with int16 wrap-around of the reference's accumulation
+        int32_t x0 = fqmul(fqmul(a1, b1), zeta);
+        x0 = (int16_t)(x0 + fqmul(a0, b0));
+        int32_t x1 = fqmul(a0, b1);
+        x1 = (int16_t)(x1 + fqmul(a1, b0));
+        r0 = (int16_t)(r0 + x0);
+        r1 = (int16_t)(r1 + x1);
+    }
+    constexpr int32_t f = (int32_t)((1ULL << 32) % Q);
+    r0 = montgomery_reduce(barrett_reduce(r0) * f);
+    r1 = montgomery_reduce(barrett_reduce(r1) * f);
+    uint16_t *dst = P + (size_t)b * proof_stride + (size_t)(row0 + i) * RS;
+    *reinterpret_cast<uint32_t *>(dst + 2 * t) = gf_from_i32(r0) | (gf_from_i32(r1) << 16);
+}
+
+// =========================================================================
+// K1/K2  C[n][c_off + m] = sum_k A[m][k] * B[n][k]  mod q
+// A: centred int16 pairs packed along k, layout Apk[kp][Mpad] (k-pair major);
+// B rows: canonical u16, k contiguous; v_dot2c_i32_i16 accumulates two exact
+// products per lane per instruction (|sum| < 2^31 for <= 775 terms, reduced
+// mod q every 384 terms).  128 x 128 tile, 8 x 8 outputs per thread.
+// =========================================================================
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t center_pair(uint32_t w)
+{
+    short2v x = __builtin_bit_cast(short2v, w);
+    short2v m = x > (short2v)(Q / 2);
+    x = x - (m & (short2v)(Q));
+    return __builtin_bit_cast(uint32_t, x);
+}
+
+constexpr int GT = 128;  // tile edge
+constexpr int GKC = 16;  // k-pairs per chunk
+
+__global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t As[2][GKC][GT];
+    __shared__ __attribute__((aligned(16))) uint32_t Bs[2][GKC][GT];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int m_tile = blockIdx.x * GT;
+    const int grp = a.grouped ? (int)blockIdx.z : 0;
+    const uint32_t *__restrict__ Ap = a.A + (size_t)grp * a.a_gstride;
+
+    // B staging role: row n_local = tid >> 1, 16 k (8 pairs) per half
+    const int bn = tid >> 1, bh = tid & 1;
+    const int n_stage = blockIdx.y * GT + bn;
+    bool b_valid;
+    size_t b_off;
+    {
+        int g, i;
+        if (a.grouped) { g = grp; i = n_stage; b_valid = i < a.npg; }
+        else { g = n_stage / a.npg; i = n_stage - g * a.npg; b_valid = n_stage < a.npg * a.ngroups; }
+        b_off = b_valid ? (size_t)g * a.b_gstride + (size_t)(a.b_rows ? (int)a.b_rows[i] : i) * RS + a.b_koff : 0;
+    }
+    // A staging role: kp_local = tid >> 4, 8 words at m = (tid & 15) * 8
+    const int akp = tid >> 4, am = (tid & 15) * 8;
+
+    int32_t acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = 0;
+
+    uint4 ra0, ra1, rb0, rb1;
+    auto gload = [&](int chunk) {
+        const uint32_t *ap = Ap + (size_t)(chunk * GKC + akp) * a.Mpad + m_tile + am;
+        ra0 = *reinterpret_cast<const uint4 *>(ap);
+        ra1 = *reinterpret_cast<const uint4 *>(ap + 4);
+        if (b_valid) {
+            const uint16_t *bp = a.B + b_off + chunk * (2 * GKC) + bh * GKC;
+            rb0 = *reinterpret_cast<const uint4 *>(bp);
+            rb1 = *reinterpret_cast<const uint4 *>(bp + 8);
+        } else {
+            rb0 = make_uint4(0, 0, 0, 0);
+            rb1 = rb0;
+        }
+    };
+    auto lstore = [&](int buf) {
+        *reinterpret_cast<uint4 *>(&As[buf][akp][am]) = ra0;
+        *reinterpret_cast<uint4 *>(&As[buf][akp][am + 4]) = ra1;
+        const uint32_t w[8] = {rb0.x, rb0.y, rb0.z, rb0.w, rb1.x, rb1.y, rb1.z, rb1.w};
+#pragma unroll
+        for (int q = 0; q < 8; q++) Bs[buf][bh * 8 + q][bn] = center_pair(w[q]);
+    };
+
+    const int nchunks = a.KP / GKC;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; chunk++) {
+        const int buf = chunk & 1;
+        if (chunk + 1 < nchunks) gload(chunk + 1);
+#pragma unroll
+        for (int kp = 0; kp < GKC; kp++) {
+            const uint4 a0 = *reinterpret_cast<const uint4 *>(&As[buf][kp][tx * 4]);
+            const uint4 a1 = *reinterpret_cast<const uint4 *>(&As[buf][kp][64 + tx * 4]);
+            const uint4 b0 = *reinterpret_cast<const uint4 *>(&Bs[buf][kp][ty * 4]);
+            const uint4 b1 = *reinterpret_cast<const uint4 *>(&Bs[buf][kp][64 + ty * 4]);
+            const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const uint32_t bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    acc[i][j] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, bv[i]),
+                                                       __builtin_bit_cast(short2v, av[j]), acc[i][j], false);
+        }
+        if ((chunk % 12) == 11) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[i][j] %= Q;
+        }
+        if (chunk + 1 < nchunks) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: canonical u16, four contiguous m per 8-byte store
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int n_local = (i < 4) ? ty * 4 + i : 64 + ty * 4 + (i - 4);
+        const int n = blockIdx.y * GT + n_local;
+        int g, r;
+        bool valid;
+        if (a.grouped) { g = grp; r = n; valid = r < a.npg; }
+        else { g = n / a.npg; r = n - g * a.npg; valid = n < a.npg * a.ngroups; }
+        if (!valid) continue;
+        uint16_t *crow = a.C + (size_t)g * a.c_gstride + (size_t)(a.c_rows ? (int)a.c_rows[r] : r) * a.c_rstride + a.c_off;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int m0 = m_tile + h * 64 + tx * 4;
+            if (m0 >= a.M) continue;
+            const uint32_t v0 = gf_from_i32(acc[i][4 * h + 0]), v1 = gf_from_i32(acc[i][4 * h + 1]);
+            const uint32_t v2 = gf_from_i32(acc[i][4 * h + 2]), v3 = gf_from_i32(acc[i][4 * h + 3]);
+            *reinterpret_cast<uint2 *>(crow + m0) = make_uint2(v0 | (v1 << 16), v2 | (v3 << 16));
+        }
+    }
+}
+
+// =========================================================================
+// K3  beta / gamma / r / NTT_r : out_j[x] = base_j[x] + sum_{k>=1} alpha_j^k in_k[x]
+// mlwe_prover.cpp:159-203 (the k == 0 term of the r rows is in_71, :187,:196)
+// =========================================================================
+constexpr int LC_JC = 20;    // outputs per thread
+constexpr int LC_JPAD = 80;  // padded J in the power table
+
+// pwT[b][k][j] = centred alpha_j^k, int32
+__global__ __launch_bounds__(128) void k_pow_table(const uint16_t *__restrict__ alpha, int J, int M, int32_t *__restrict__ pwT)
+{
+    const int j = threadIdx.x, b = blockIdx.x;
+    if (j >= LC_JPAD) return;
+    int32_t *dst = pwT + (size_t)b * MAXM * LC_JPAD + j;
+    const uint32_t al = j < J ? alpha[(size_t)b * LC_JPAD + j] % (uint32_t)Q : 0;
+    uint32_t p = 1;
+    for (int k = 0; k < MAXM; k++) {
+        dst[(size_t)k * LC_JPAD] = (j < J && k < M) ? gf_center(p) : 0;
+        p = gf_mul(p, al);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lincomb(LincombArgs a)
+{
+    const int xi = blockIdx.x * 256 + threadIdx.x;
+    const int jc = blockIdx.y;
+    const int b = blockIdx.z >> 1, which = blockIdx.z & 1;
+    if (xi >= a.ncols) return;
+    const int col = a.col_map ? NSEC + (int)a.col_map[(size_t)b * a.col_map_stride + xi] : xi;
+    uint16_t *__restrict__ Pb = a.P + (size_t)b * a.proof_stride;
+    const uint16_t *__restrict__ in0 = Pb + (size_t)(which ? a.rm.tf : a.rm.f) * RS + col;
+    const int32_t *__restrict__ pw = a.pwT + (size_t)b * MAXM * LC_JPAD + jc * LC_JC;
+
+    int32_t acc[LC_JC];
+#pragma unroll
+    for (int j = 0; j < LC_JC; j++) acc[j] = 0;
+    for (int k = 1; k < a.rm.M; k++) {
+        const int32_t v = gf_center(in0[(size_t)k * RS]);
+        const int32_t *pk = pw + (size_t)k * LC_JPAD;
+#pragma unroll
+        for (int j = 0; j < LC_JC; j++) acc[j] += pk[j] * v;
+    }
+    const int32_t base_chk = in0[0], base_r = in0[(size_t)(NCHK + 1) * RS];
+#pragma unroll
+    for (int jj = 0; jj < LC_JC; jj++) {
+        const int j = jc * LC_JC + jj;
+        if (j >= a.J) break;
+        int row;
+        if (j < NCHK) row = which ? a.rm.gamma(j) : a.rm.beta(j);
+        else row = (which ? a.rm.nttr : a.rm.r) + (j - NCHK);
+        const int32_t base = j < NCHK ? base_chk : base_r;
+        Pb[(size_t)row * RS + col] = (uint16_t)gf_from_i32(acc[jj] + base);
+    }
+}
+
+// =========================================================================
+// K7  share-wise gates (ss.cpp:101-136 call sites in prove())
+// =========================================================================
+
+// after the first expansion: s - eta, e - eta, multiplication gates, u = z2d - z_d
+// mlwe_prover.cpp:338-381
+__global__ __launch_bounds__(256) void k_post_gates(uint16_t *__restrict__ P, size_t proof_stride, RowMap rm)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (x >= NPTS) return;
+    uint16_t *Pb = P + (size_t)b * proof_stride + x;
+    for (int who = 0; who < 2; who++)
+        for (int i = 0; i < rm.K; i++) {
+            const uint32_t v = Pb[(size_t)((who ? rm.e : rm.s) + i) * RS];
+            uint32_t prev = 0;
+            for (int m = 0; m < rm.E; m++) {
+                const uint32_t c = Pb[(size_t)((who ? rm.eeta : rm.seta) + i * rm.E + m) * RS];
+                const uint32_t d = gf_sub(v, c);
+                Pb[(size_t)((who ? rm.esub : rm.ssub) + i * rm.E + m) * RS] = (uint16_t)d;
+                if (m == 0) { prev = d; continue; }
+                const uint32_t z2 = gf_mul(prev, d);
+                const uint32_t zd = Pb[(size_t)(who ? rm.ze(i, m - 1) : rm.zs(i, m - 1)) * RS];
+                Pb[(size_t)(who ? rm.ue(i, m - 1) : rm.us(i, m - 1)) * RS] = (uint16_t)gf_sub(z2, zd);
+                prev = zd;
+            }
+        }
+}
+
+// sr = s + r_i, er = e + r_{i+K} on every evaluation point   mlwe_prover.cpp:222-245
+__global__ __launch_bounds__(256) void k_post_open(uint16_t *__restrict__ P, size_t proof_stride, RowMap rm)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (x >= NPTS) return;
+    uint16_t *Pb = P + (size_t)b * proof_stride + x;
+    for (int i = 0; i < rm.K; i++) {
+        Pb[(size_t)(rm.sr + i) * RS] = (uint16_t)gf_add(Pb[(size_t)(rm.s + i) * RS], Pb[(size_t)(rm.r + i) * RS]);
+        Pb[(size_t)(rm.er + i) * RS] = (uint16_t)gf_add(Pb[(size_t)(rm.e + i) * RS], Pb[(size_t)(rm.r + rm.K + i) * RS]);
+    }
+}
+
+// sr_rnd / er_rnd / ntt_Asr_rnd tails: values at points 256..406 of the re-shared
+// rows are those of sr / er / sr                          mlwe_prover.cpp:234-237, :312-314
+__global__ __launch_bounds__(192) void k_copy_tails(uint16_t *__restrict__ P, size_t proof_stride, RowMap rm)
+{
+    const int t = threadIdx.x, i = blockIdx.x, b = blockIdx.y;
+    if (t > NOPEN) return;
+    uint16_t *Pb = P + (size_t)b * proof_stride + NSEC + t;
+    const uint16_t s = Pb[(size_t)(rm.sr + i) * RS], e = Pb[(size_t)(rm.er + i) * RS];
+    Pb[(size_t)(rm.nttsr + i) * RS] = s;
+    Pb[(size_t)(rm.nttasr + i) * RS] = s;
+    Pb[(size_t)(rm.ntter + i) * RS] = e;
+}
+
+// NTT(s) = NTT(s+r) - NTT(r), NTT(e) likewise, A r = A(s+r) - A s, t = A s + e
+// mlwe_prover.cpp:301-303, :317, :321-323
+__global__ __launch_bounds__(256) void k_post_relation(uint16_t *__restrict__ P, size_t proof_stride, RowMap rm)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (x >= NPTS) return;
+    uint16_t *Pb = P + (size_t)b * proof_stride + x;
+    for (int i = 0; i < rm.K; i++) {
+        const uint32_t ns = gf_sub(Pb[(size_t)(rm.nttsr + i) * RS], Pb[(size_t)(rm.nttr + i) * RS]);
+        const uint32_t ne = gf_sub(Pb[(size_t)(rm.ntter + i) * RS], Pb[(size_t)(rm.nttr + rm.K + i) * RS]);
+        const uint32_t as = Pb[(size_t)(rm.nttas + i) * RS];
+        Pb[(size_t)(rm.ntts + i) * RS] = (uint16_t)ns;
+        Pb[(size_t)(rm.ntte + i) * RS] = (uint16_t)ne;
+        Pb[(size_t)(rm.nttar + i) * RS] = (uint16_t)gf_sub(Pb[(size_t)(rm.nttasr + i) * RS], as);
+        Pb[(size_t)(rm.t + i) * RS] = (uint16_t)gf_add(as, ne);
+    }
+}
+
+// =========================================================================
+// K8  proof wire image                                     mlwe_prover.cpp:480-537
+// field element [i][e] = P[rows[e]][256 + sel[i]] ; 64 parties per workgroup,
+// LDS transpose so that both the row reads and the image writes are coalesced
+// =========================================================================
+constexpr int ASM_W = 81; // padded field width in LDS
+
+__global__ __launch_bounds__(256) void k_assemble_fields(AssembleArgs a)
+{
+    __shared__ uint16_t tile[64 * ASM_W];
+    const FieldDesc fd = a.fields[blockIdx.y];
+    const int b = blockIdx.z;
+    const int np = fd.sel ? NREST : NOPEN;
+    const int i0 = blockIdx.x * 64;
+    if (i0 >= np) return;
+    const int cnt = min(64, np - i0);
+    const uint16_t *sel = (fd.sel ? a.rest : a.opened) + (size_t)b * a.sel_stride;
+    const uint16_t *Pb = a.P + (size_t)b * a.proof_stride;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane < cnt) {
+        const int col = NSEC + sel[i0 + lane];
+        for (int e = w; e < fd.width; e += 4)
+            tile[lane * ASM_W + e] = Pb[(size_t)a.rowtab[fd.rowtab_off + e] * RS + col];
+    }
+    __syncthreads();
+    uint16_t *out = reinterpret_cast<uint16_t *>(a.proof + (size_t)b * a.image_stride + fd.off) + (size_t)i0 * fd.width;
+    const int total = cnt * fd.width;
+    for (int q = threadIdx.x; q < total; q += 256) {
+        const int i = q / fd.width, e = q - i * fd.width;
+        out[q] = tile[i * ASM_W + e];
+    }
+}
+
+// Tcomm / comm of the unopened parties and the list I itself
+__global__ __launch_bounds__(256) void k_assemble_digests(AssembleArgs a, size_t off_tcomm, size_t off_comm, size_t off_I)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    uint8_t *img = a.proof + (size_t)b * a.image_stride;
+    if (q < NREST * 16) {
+        const int i = q >> 4, w = q & 15;
+        const size_t src = ((size_t)b * NPARTY + a.rest[(size_t)b * a.sel_stride + i]) * 32 + 2 * w;
+        reinterpret_cast<uint16_t *>(img + off_tcomm)[q] = *reinterpret_cast<const uint16_t *>(a.dig1 + src);
+        reinterpret_cast<uint16_t *>(img + off_comm)[q] = *reinterpret_cast<const uint16_t *>(a.dig2 + src);
+    }
+    if (q < NOPEN) reinterpret_cast<uint16_t *>(img + off_I)[q] = a.opened[(size_t)b * a.sel_stride + q];
+}
+
+// plain strided row copy (kernel-level ABI helpers): dst[r][0..count) = src[r][0..count)
+__global__ __launch_bounds__(256) void k_rows_copy(const uint16_t *__restrict__ src, size_t src_stride,
+                                                  uint16_t *__restrict__ dst, size_t dst_stride, int count)
+{
+    const int r = blockIdx.y;
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < count; x += gridDim.x * 256)
+        dst[(size_t)r * dst_stride + x] = src[(size_t)r * src_stride + x];
+}
+
+// =========================================================================
+// host-side launchers
+// =========================================================================
+template <int PW, int NR>
+static void launch_hash_t(const HashArgs &a, int ngroups, hipStream_t st)
+{
+    dim3 grid((a.lanes_per_group + 63) / 64, ngroups);
+    hipLaunchKernelGGL((k_commit_hash<PW, NR>), grid, dim3(64), 0, st, a);
+}
+
+hipError_t launch_commit_hash(const HashArgs &a, int ngroups, int K, bool view, hipStream_t st)
+{
+    // rows hashed per party: Tcomm 2(K+M); view (6+8 eta1)K + 2M   (M = 71+2K)
+    if (!view) {
+        if (K == 2) launch_hash_t<0, 154>(a, ngroups, st);
+        else if (K == 3) launch_hash_t<0, 160>(a, ngroups, st);
+        else launch_hash_t<0, 166>(a, ngroups, st);
+    } else {
+        if (K == 2) launch_hash_t<16, 210>(a, ngroups, st);
+        else if (K == 3) launch_hash_t<16, 220>(a, ngroups, st);
+        else launch_hash_t<16, 246>(a, ngroups, st);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_sha3_msgs(const uint8_t *in, size_t in_stride, int len, uint8_t *out, size_t out_stride,
+                            int outlen, int n, int domain, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sha3_msgs, dim3((n + 63) / 64), dim3(64), 0, st, in, in_stride, len, out, out_stride, outlen, n, domain);
+    return hipGetLastError();
+}
+
+hipError_t launch_rows_copy(const uint16_t *src, size_t src_stride, uint16_t *dst, size_t dst_stride, int count,
+                            int nrows, hipStream_t st)
+{
+    if (nrows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rows_copy, dim3((count + 255) / 256, nrows), dim3(256), 0, st, src, src_stride, dst, dst_stride, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand_f(const uint8_t *tape, size_t tape_stride, uint16_t *P, size_t proof_stride, int row_f,
+                           int M, int nproofs, hipStream_t st)
+{
+    const int n = M * nproofs;
+    hipLaunchKernelGGL(k_expand_f, dim3((n + 63) / 64), dim3(64), 0, st, tape, tape_stride, P, proof_stride, row_f, M, nproofs);
+    return hipGetLastError();
+}
+
+hipError_t launch_tape_randoms(const uint8_t *tape, size_t tape_stride, int slice0_off, const int16_t *fresh_rows,
+                               int nfresh, uint16_t *P, size_t proof_stride, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_tape_randoms, dim3(nfresh, nproofs), dim3(192), 0, st, tape, tape_stride, slice0_off, fresh_rows, P, proof_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_witness_secrets(const int16_t *se, size_t se_stride, uint16_t *P, size_t proof_stride,
+                                  const RowMap &rm, int eta1, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_witness_secrets, dim3(nproofs), dim3(256), 0, st, se, se_stride, P, proof_stride, rm, eta1);
+    return hipGetLastError();
+}
+
+hipError_t launch_ntt(const NttArgs &a, hipStream_t st)
+{
+    if (a.npoly <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ntt256, dim3((a.npoly + NTT_PPB - 1) / NTT_PPB), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_matvec_ntt(const int16_t *A, size_t A_stride, const int16_t *v, size_t v_stride, int v_slot,
+                             uint16_t *P, size_t proof_stride, int row0, int K, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_matvec_ntt, dim3(K, nproofs), dim3(128), 0, st, A, A_stride, v, v_stride, v_slot, P, proof_stride, row0, K);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm(const GemmArgs &a, hipStream_t st)
+{
+    const int ntot = a.grouped ? a.npg : a.npg * a.ngroups;
+    if (ntot <= 0) return hipSuccess;
+    dim3 grid(a.Mpad / GT, (ntot + GT - 1) / GT, a.grouped ? a.ngroups : 1);
+    hipLaunchKernelGGL(k_gemm_modq, grid, dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_pow_table(const uint16_t *alpha, int J, int M, int32_t *pwT, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pow_table, dim3(nproofs), dim3(128), 0, st, alpha, J, M, pwT);
+    return hipGetLastError();
+}
+
+hipError_t launch_lincomb(const LincombArgs &a, int nproofs, hipStream_t st)
+{
+    dim3 grid((a.ncols + 255) / 256, (a.J + LC_JC - 1) / LC_JC, nproofs * 2);
+    hipLaunchKernelGGL(k_lincomb, grid, dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_post_gates(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_post_gates, dim3((NPTS + 255) / 256, nproofs), dim3(256), 0, st, P, proof_stride, rm);
+    return hipGetLastError();
+}
+hipError_t launch_post_open(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_post_open, dim3((NPTS + 255) / 256, nproofs), dim3(256), 0, st, P, proof_stride, rm);
+    return hipGetLastError();
+}
+hipError_t launch_copy_tails(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_copy_tails, dim3(rm.K, nproofs), dim3(192), 0, st, P, proof_stride, rm);
+    return hipGetLastError();
+}
+hipError_t launch_post_relation(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_post_relation, dim3((NPTS + 255) / 256, nproofs), dim3(256), 0, st, P, proof_stride, rm);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble(const AssembleArgs &a, int nfields, size_t off_tcomm, size_t off_comm, size_t off_I,
+                           int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_assemble_fields, dim3((NREST + 63) / 64, nfields, nproofs), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_assemble_digests, dim3((NREST * 16 + 255) / 256, nproofs), dim3(256), 0, st, a, off_tcomm, off_comm, off_I);
+    return hipGetLastError();
+}
+
+} // namespace kosk

@@ -1,0 +1,104 @@
+"""ctypes access to oracle/libkosk_oracle.so (the CPU restatement) -- tests only."""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+lib = C.CDLL(os.path.join(ROOT, "oracle", "libkosk_oracle.so"))
+
+
+class Params(C.Structure):
+    _fields_ = [("K", C.c_int), ("eta1", C.c_int), ("M", C.c_int), ("V", C.c_int), ("E", C.c_int), ("Z", C.c_int),
+                ("pk_bytes", C.c_size_t), ("sk_bytes", C.c_size_t), ("proof_bytes", C.c_size_t), ("tape_bytes", C.c_size_t),
+                ("tape_calls", C.c_int), ("tcomm_msg_bytes", C.c_size_t), ("view_msg_bytes", C.c_size_t),
+                ("off", C.c_size_t * 24), ("size", C.c_size_t * 24)]
+
+
+class Tape(C.Structure):
+    _fields_ = [("buf", C.c_char_p), ("len", C.c_size_t), ("pos", C.c_size_t), ("calls", C.c_size_t), ("overrun", C.c_int)]
+
+
+class Trace(C.Structure):
+    _fields_ = [("tcomm", C.c_uint8 * (1454 * 32)), ("h1", C.c_uint8 * 32), ("alpha", C.c_uint16 * 78),
+                ("view_digest", C.c_uint8 * (1454 * 32)), ("ch", C.c_uint8 * 32),
+                ("sr_rec", C.c_uint16 * (4 * 256)), ("er_rec", C.c_uint16 * (4 * 256))]
+
+
+lib.ko_table_share_ddeg.restype = C.POINTER(C.c_uint16)
+lib.ko_table_recon_ddeg.restype = C.POINTER(C.c_uint16)
+lib.ko_table_recon_2ddeg.restype = C.POINTER(C.c_uint16)
+lib.ko_zetas.restype = C.POINTER(C.c_int16)
+lib.ko_gf_add.restype = lib.ko_gf_sub.restype = lib.ko_gf_mul.restype = lib.ko_gf_inv.restype = C.c_uint16
+lib.ko_gf_add.argtypes = lib.ko_gf_sub.argtypes = lib.ko_gf_mul.argtypes = [C.c_uint16, C.c_uint16]
+lib.ko_gf_inv.argtypes = [C.c_uint16]
+lib.ko_barrett_reduce.restype = C.c_int16
+lib.ko_barrett_reduce.argtypes = [C.c_int16]
+lib.ko_montgomery_reduce.restype = C.c_int16
+lib.ko_montgomery_reduce.argtypes = [C.c_int32]
+
+
+def params(k):
+    p = Params()
+    assert lib.ko_get_params(k, C.byref(p)) == 0
+    return p
+
+
+def tape_bytes_for(k, index, prefix="kosk-tape-v1:"):
+    """tape b = SHAKE256("kosk-tape-v1:<b>") byte stream."""
+    return hashlib.shake_256((prefix + str(index)).encode()).digest(params(k).tape_bytes)
+
+
+def verifiable_keygen(k, tape, trace=False):
+    p = params(k)
+    t = Tape(tape, len(tape), 0, 0, 0)
+    pk = C.create_string_buffer(p.pk_bytes); sk = C.create_string_buffer(p.sk_bytes); pi = C.create_string_buffer(p.proof_bytes)
+    tr = Trace() if trace else None
+    lib.ko_verifiable_keygen(k, C.byref(t), pk, sk, pi, C.byref(tr) if trace else None)
+    assert not t.overrun
+    out = (pk.raw, sk.raw, pi.raw, t.calls, t.pos)
+    return out + (tr,) if trace else out
+
+
+def kosk_verify(k, pi, pk):
+    why = C.create_string_buffer(256)
+    ok = lib.ko_kosk_verify(k, C.c_char_p(pi), C.c_char_p(pk), why, 256)
+    return bool(ok), why.value.decode()
+
+
+def sha3_256(data):
+    out = C.create_string_buffer(32)
+    lib.ko_sha3_256(out, C.c_char_p(bytes(data)), len(data))
+    return out.raw
+
+
+def shake256(data, n):
+    out = C.create_string_buffer(n)
+    lib.ko_shake256(out, n, C.c_char_p(bytes(data)), len(data))
+    return out.raw
+
+
+def poly_ntt(a):
+    a = np.ascontiguousarray(a, dtype=np.int16).copy()
+    lib.ko_poly_ntt(a.ctypes.data_as(C.c_void_p))
+    return a
+
+
+def recompute_shares(y407):
+    y = np.ascontiguousarray(y407, dtype=np.uint16)
+    out = np.zeros(1454, np.uint16)
+    lib.ko_recompute_share_secrets_ddeg(out.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def recon(shares, two_d=False):
+    s = np.ascontiguousarray(shares, dtype=np.uint16)
+    out = np.zeros(256, np.uint16)
+    (lib.ko_recon_secrets_2ddeg if two_d else lib.ko_recon_secrets_ddeg)(out.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def table(which):
+    fn, shape = [(lib.ko_table_share_ddeg, (1303, 407)), (lib.ko_table_recon_ddeg, (256, 407)), (lib.ko_table_recon_2ddeg, (256, 813))][which]
+    return np.ctypeslib.as_array(fn(), shape=shape).copy()
