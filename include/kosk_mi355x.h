@@ -67,6 +67,17 @@ int kosk_verify_resident(kosk_ctx *ctx, int n, uint8_t *ok);
 /* wall seconds of the phases of the last prove (7 values) */
 int kosk_phase_seconds(const kosk_ctx *ctx, double *out, int n);
 
+/* HIP-event timing of the library's own launches on its stream.  ids: 0 prover Tcomm hash, 1 prover view
+ * hash, 2 expansion GEMM #1, 3 expansion GEMM #2, 4 beta/gamma lincomb, 5 NTT(f), 6 wire image,
+ * 7/8 verifier Tcomm/view hash, 9 interpolation operators, 10 interpolation GEMM, 11 verifier expansion,
+ * 12 reconstruction GEMM, 13 verifier lincomb.  Reading returns the sum over launches since enable. */
+int kosk_profile_enable(kosk_ctx *ctx, int on);
+int kosk_profile_read(const kosk_ctx *ctx, int id, double *total_ms, long *launches);
+
+/* hipEvent pair on the ctx stream around caller-issued kernel-level calls (micro-benchmarks) */
+int kosk_stream_timer_start(kosk_ctx *ctx);
+int kosk_stream_timer_stop(kosk_ctx *ctx, double *ms);
+
 /* ---- kernel-level entry points on DEVICE pointers (stream 0 of the ctx) ----
  * Used by the parity tests and by bench.py's roofline leg. */
 

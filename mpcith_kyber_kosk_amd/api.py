@@ -45,6 +45,10 @@ def _load():
         "kosk_ntt256_batch": (C.c_int, [vp, vp, vp, C.c_int]),
         "kosk_lagrange_expand": (C.c_int, [vp, vp, vp, C.c_int]),
         "kosk_recon_secrets": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
+        "kosk_profile_enable": (C.c_int, [vp, C.c_int]),
+        "kosk_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+        "kosk_stream_timer_start": (C.c_int, [vp]),
+        "kosk_stream_timer_stop": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "kosk_device_synchronize": (C.c_int, [vp]),
         "kosk_resident_proofs": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
         "kosk_keygen": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp]),
@@ -67,7 +71,7 @@ EXPORTS = ["kosk_pk_bytes", "kosk_sk_bytes", "kosk_proof_bytes", "kosk_tape_byte
            "kosk_verify_fail_masks", "kosk_stage_prover_inputs", "kosk_prove_resident", "kosk_fetch_proofs",
            "kosk_stage_verifier_inputs", "kosk_verify_resident", "kosk_phase_seconds", "kosk_sha3_256_batch",
            "kosk_shake256_batch", "kosk_commit_hash_lanes", "kosk_ntt256_batch", "kosk_lagrange_expand",
-           "kosk_recon_secrets", "kosk_device_synchronize", "kosk_resident_proofs", "kosk_keygen", "kosk_fs_alpha",
+           "kosk_recon_secrets", "kosk_profile_enable", "kosk_profile_read", "kosk_stream_timer_start", "kosk_stream_timer_stop", "kosk_device_synchronize", "kosk_resident_proofs", "kosk_keygen", "kosk_fs_alpha",
            "kosk_fs_opened", "kosk_host_sha3_256", "kosk_host_shake256", "kosk_lagrange_table"]
 
 
@@ -222,6 +226,29 @@ class Kosk:
         out = (C.c_double * 7)()
         lib.kosk_phase_seconds(self._h, out, 7)
         return list(out)
+
+    PROFILE_IDS = ["hash_tcomm", "hash_view", "gemm_expand1", "gemm_expand2", "lincomb", "ntt_f", "assemble",
+                   "v_hash_tcomm", "v_hash_view", "v_interp_build", "v_gemm_interp", "v_gemm_expand", "v_gemm_recon", "v_lincomb"]
+
+    def profile_enable(self, on=True):
+        self._chk(lib.kosk_profile_enable(self._h, int(on)), "profile_enable")
+
+    def profile_read(self):
+        """{name: (total_ms, launches)} since profile_enable()"""
+        out = {}
+        for i, name in enumerate(self.PROFILE_IDS):
+            ms, cnt = C.c_double(), C.c_long()
+            lib.kosk_profile_read(self._h, i, C.byref(ms), C.byref(cnt))
+            out[name] = (ms.value, cnt.value)
+        return out
+
+    def timer_start(self):
+        self._chk(lib.kosk_stream_timer_start(self._h), "timer_start")
+
+    def timer_stop_ms(self):
+        ms = C.c_double()
+        self._chk(lib.kosk_stream_timer_stop(self._h, C.byref(ms)), "timer_stop")
+        return ms.value
 
     def synchronize(self):
         self._chk(lib.kosk_device_synchronize(self._h), "synchronize")

@@ -118,6 +118,43 @@ int kosk_phase_seconds(const kosk_ctx *ctx, double *out, int n)
     return 0;
 }
 
+int kosk_profile_enable(kosk_ctx *ctx, int on)
+{
+    if (!ctx) return -1;
+    Ctx &c = *ctx->c;
+    c.prof_on = on != 0;
+    for (int i = 0; i < PR_COUNT; i++) { c.prof_ms[i] = 0; c.prof_n[i] = 0; c.prof_used[i] = false; }
+    return 0;
+}
+int kosk_profile_read(const kosk_ctx *ctx, int id, double *total_ms, long *launches)
+{
+    if (!ctx || id < 0 || id >= PR_COUNT) return -1;
+    if (total_ms) *total_ms = ctx->c->prof_ms[id];
+    if (launches) *launches = ctx->c->prof_n[id];
+    return 0;
+}
+
+static hipEvent_t g_t0 = nullptr, g_t1 = nullptr;
+int kosk_stream_timer_start(kosk_ctx *ctx)
+{
+    if (!ctx) return -1;
+    Ctx &c = *ctx->c;
+    if (!g_t0) { HIPCHK_C(hipEventCreate(&g_t0)); HIPCHK_C(hipEventCreate(&g_t1)); }
+    HIPCHK_C(hipEventRecord(g_t0, c.stream));
+    return 0;
+}
+int kosk_stream_timer_stop(kosk_ctx *ctx, double *ms)
+{
+    if (!ctx || !g_t0) return -1;
+    Ctx &c = *ctx->c;
+    HIPCHK_C(hipEventRecord(g_t1, c.stream));
+    HIPCHK_C(hipEventSynchronize(g_t1));
+    float f = 0;
+    HIPCHK_C(hipEventElapsedTime(&f, g_t0, g_t1));
+    if (ms) *ms = f;
+    return 0;
+}
+
 int kosk_device_synchronize(kosk_ctx *ctx)
 {
     if (!ctx) return -1;
@@ -194,7 +231,7 @@ int kosk_lagrange_expand(kosk_ctx *ctx, const uint16_t *d_y407, uint16_t *d_shar
         HIPCHK_C(launch_rows_copy(d_y407 + (size_t)done * XLEN, XLEN, c.d_P, RS, XLEN, m, c.stream));
         GemmArgs ga{};
         ga.A = c.t_expand.d; ga.Mpad = c.t_expand.Mpad; ga.M = c.t_expand.M; ga.KP = c.t_expand.KP;
-        ga.B = c.d_P; ga.b_gstride = 0; ga.b_rows = nullptr; ga.b_koff = 0;
+        ga.B = c.d_P; ga.b_gstride = 0; ga.b_rows = nullptr; ga.b_rstride = RS; ga.b_koff = 0;
         ga.C = c.d_P; ga.c_gstride = 0; ga.c_rows = nullptr; ga.c_rstride = RS; ga.c_off = EXP_OFF;
         ga.npg = m; ga.ngroups = 1; ga.grouped = 0;
         HIPCHK_C(launch_gemm(ga, c.stream));
@@ -215,7 +252,7 @@ int kosk_recon_secrets(kosk_ctx *ctx, const uint16_t *d_shares, uint16_t *d_secr
         HIPCHK_C(launch_rows_copy(d_shares + (size_t)done * NPARTY, NPARTY, c.d_P + NSEC, RS, NPARTY, m, c.stream));
         GemmArgs ga{};
         ga.A = t.d; ga.Mpad = t.Mpad; ga.M = t.M; ga.KP = t.KP;
-        ga.B = c.d_P; ga.b_gstride = 0; ga.b_rows = nullptr; ga.b_koff = NSEC;
+        ga.B = c.d_P; ga.b_gstride = 0; ga.b_rows = nullptr; ga.b_rstride = RS; ga.b_koff = NSEC;
         ga.C = c.d_P; ga.c_gstride = 0; ga.c_rows = nullptr; ga.c_rstride = RS; ga.c_off = 0;
         ga.npg = m; ga.ngroups = 1; ga.grouped = 0;
         HIPCHK_C(launch_gemm(ga, c.stream));

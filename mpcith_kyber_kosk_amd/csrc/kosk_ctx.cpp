@@ -45,16 +45,32 @@ static hipError_t halloc(T **p, size_t n)
     return hipHostMalloc(reinterpret_cast<void **>(p), n * sizeof(T), hipHostMallocDefault);
 }
 
+void Ctx::prof_collect()
+{
+    if (!prof_on) return;
+    for (int i = 0; i < PR_COUNT; i++)
+        if (prof_used[i]) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, prof_ev[i][0], prof_ev[i][1]) == hipSuccess) { prof_ms[i] += ms; prof_n[i]++; }
+            prof_used[i] = false;
+        }
+}
+
 Ctx::~Ctx()
 {
+    for (auto &pe : prof_ev)
+        for (auto e : pe)
+            if (e) (void)hipEventDestroy(e);
     void *dev[] = {t_expand.d, t_recon_d.d, t_recon_2d.d, d_fresh_rows, d_gemm1_rows, d_gemm2_rows, d_off, d_fields,
                    d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_poly, d_t, d_alpha, d_I, d_rest, d_pwT,
-                   d_gather, d_gather2, d_W, d_W2, d_wtmp, d_sec, d_fail, d_vrows};
+                   d_gather, d_gather2, d_W, d_W2, d_w, d_ell, d_sec, d_sec_u1, d_sec_u2, d_fail, d_inv, d_vfields,
+                   d_vrowtab, d_rows_bg, d_rows_isrc, d_rows_idst, d_rows_u};
     for (void *p : dev)
         if (p) (void)hipFree(p);
-    void *host[] = {h_tape, h_dig, h_proof, h_A, h_se, h_t, h_alpha, h_I, h_rest, h_fail};
+    void *host[] = {h_tape, h_dig, h_proof, h_A, h_se, h_t, h_alpha, h_I, h_rest, h_fail, h_Iimg};
     for (void *p : host)
         if (p) (void)hipHostFree(p);
+    if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -194,6 +210,8 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     auto body = [&]() -> int {
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        for (auto &pe : c.prof_ev)
+            for (auto &e : pe) HIPCHK(hipEventCreate(&e));
         if (build_tables(c)) return -1;
         const Params &P = c.P;
         const size_t B = (size_t)max_batch;
@@ -303,7 +321,9 @@ int prove_resident(Ctx &c, int n)
     na.npg = P.M;
     na.npoly = P.M * n;
     na.out_canonical = 1;
+    c.prof_begin(PR_NTT_F);
     HIPCHK(launch_ntt(na, st));
+    c.prof_end(PR_NTT_F);
     na.src_off = c.d_off + c.off_s;            // NTT(s) -> poly slots 0..K-1   :256
     na.out = c.d_poly;
     na.out_gstride = c.poly_stride;
@@ -322,6 +342,7 @@ int prove_resident(Ctx &c, int n)
     ga.B = c.d_P;
     ga.b_gstride = c.proof_stride;
     ga.b_rows = c.d_gemm1_rows;
+    ga.b_rstride = RS;
     ga.b_koff = 0;
     ga.C = c.d_P;
     ga.c_gstride = c.proof_stride;
@@ -331,7 +352,9 @@ int prove_resident(Ctx &c, int n)
     ga.npg = c.n_gemm1;
     ga.ngroups = n;
     ga.grouped = 0;
+    c.prof_begin(PR_GEMM_EXPAND1);
     HIPCHK(launch_gemm(ga, st));
+    c.prof_end(PR_GEMM_EXPAND1);
     HIPCHK(launch_post_gates(c.d_P, c.proof_stride, rm, n, st));
 
     HashArgs ha{};
@@ -344,7 +367,9 @@ int prove_resident(Ctx &c, int n)
     ha.prefix = nullptr;
     ha.out = c.d_dig1;
     ha.out_lanes_per_group = NPARTY;
+    c.prof_begin(PR_HASH_TCOMM);
     HIPCHK(launch_commit_hash(ha, n, K, false, st));
+    c.prof_end(PR_HASH_TCOMM);
     HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig1, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     t1 = now_sec(); c.phase_sec[PH_GPU_COMMIT] = t1 - t0; t0 = t1;
@@ -364,7 +389,9 @@ int prove_resident(Ctx &c, int n)
     la.pwT = c.d_pwT;
     la.ncols = NPTS;
     la.col_map = nullptr;
+    c.prof_begin(PR_LINCOMB);
     HIPCHK(launch_lincomb(la, n, st));
+    c.prof_end(PR_LINCOMB);
     HIPCHK(launch_post_open(c.d_P, c.proof_stride, rm, n, st));
     na.in = reinterpret_cast<const int16_t *>(c.d_P);
     na.in_gstride = c.proof_stride;
@@ -386,11 +413,15 @@ int prove_resident(Ctx &c, int n)
     ga.b_rows = c.d_gemm2_rows;
     ga.c_rows = c.d_gemm2_rows;
     ga.npg = c.n_gemm2;
+    c.prof_begin(PR_GEMM_EXPAND2);
     HIPCHK(launch_gemm(ga, st));                // recompute_share_secrets_ddeg x 3K   :298-299,:315
+    c.prof_end(PR_GEMM_EXPAND2);
     HIPCHK(launch_post_relation(c.d_P, c.proof_stride, rm, n, st));
     ha.prefix = c.d_dig1;
     ha.out = c.d_dig2;
+    c.prof_begin(PR_HASH_VIEW);
     HIPCHK(launch_commit_hash(ha, n, K, true, st));
+    c.prof_end(PR_HASH_VIEW);
     HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig2, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     t1 = now_sec(); c.phase_sec[PH_GPU_RELATION] = t1 - t0; t0 = t1;
@@ -416,9 +447,12 @@ int prove_resident(Ctx &c, int n)
     aa.dig2 = c.d_dig2;
     aa.proof = c.d_proof;
     aa.image_stride = c.image_stride;
+    c.prof_begin(PR_ASSEMBLE);
     HIPCHK(launch_assemble(aa, c.nfields, P.off[F_TCOMM], P.off[F_COMM], P.off[F_I], n, st));
+    c.prof_end(PR_ASSEMBLE);
     HIPCHK(hipStreamSynchronize(st));
     t1 = now_sec(); c.phase_sec[PH_GPU_ASSEMBLE] = t1 - t0;
+    c.prof_collect();
     return 0;
 }
 

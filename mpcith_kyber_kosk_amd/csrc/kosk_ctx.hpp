@@ -16,6 +16,11 @@ typedef void (*randombytes_fn)(void *user, uint8_t *out, size_t len);
 
 enum Phase { PH_HOST_PRE = 0, PH_GPU_COMMIT, PH_FS_ALPHA, PH_GPU_RELATION, PH_FS_OPEN, PH_GPU_ASSEMBLE, PH_D2H, PH_COUNT };
 
+// HIP-event timing of individual launches on the ctx stream (bench.py roofline leg)
+enum ProfId { PR_HASH_TCOMM = 0, PR_HASH_VIEW, PR_GEMM_EXPAND1, PR_GEMM_EXPAND2, PR_LINCOMB, PR_NTT_F, PR_ASSEMBLE,
+              PR_V_HASH_TCOMM, PR_V_HASH_VIEW, PR_V_INTERP_BUILD, PR_V_GEMM_INTERP, PR_V_GEMM_EXPAND, PR_V_GEMM_RECON,
+              PR_V_LINCOMB, PR_COUNT };
+
 struct GemmTable {
     uint32_t *d = nullptr;
     int M = 0, Mpad = 0, KP = 0;
@@ -54,15 +59,25 @@ struct Ctx {
     uint16_t *d_t = nullptr; // pk's t, canonical (verifier)
     uint16_t *d_alpha = nullptr, *d_I = nullptr, *d_rest = nullptr;
     int32_t *d_pwT = nullptr;
-    // verifier workspace
-    uint16_t *d_gather = nullptr;  // [proof][vrows][416] values at the first 407 unopened nodes
-    uint16_t *d_gather2 = nullptr; // [proof][urows][832] values at the first 813 unopened nodes
-    uint32_t *d_W = nullptr, *d_W2 = nullptr; // per-proof interpolation operators, GEMM layout
-    uint16_t *d_wtmp = nullptr;
-    uint16_t *d_sec = nullptr;     // [proof][secrows][256] reconstructed secrets
-    uint32_t *d_fail = nullptr;    // [proof] bit mask of failed checks
-    int16_t *d_vrows = nullptr;
+    // verifier workspace (allocated on first use, kosk_verify.cpp)
+    bool verify_ready = false;
+    uint16_t *d_inv = nullptr;       // [Q] field inverses
+    FieldDesc *d_vfields = nullptr;  // proof image -> rows (verifier row assignment)
+    int16_t *d_vrowtab = nullptr;
+    int n_vfields = 0;
+    int16_t *d_rows_bg = nullptr;    // beta_0..69, gamma_0..69
+    int16_t *d_rows_isrc = nullptr, *d_rows_idst = nullptr; // degree-d interpolations: given rows -> recomputed rows
+    int16_t *d_rows_u = nullptr;     // us / ue rows (degree 2d)
     int n_interp_d = 0, n_interp_2d = 0;
+    uint16_t *d_w = nullptr, *d_ell = nullptr;
+    uint32_t *d_W = nullptr, *d_W2 = nullptr; // per-proof interpolation operators in GEMM operand layout
+    size_t w_stride = 0, w2_stride = 0;
+    int w_Mpad = 0, w_KP = 0, w2_Mpad = 0, w2_KP = 0;
+    uint16_t *d_gather = nullptr, *d_gather2 = nullptr;
+    uint16_t *d_sec = nullptr, *d_sec_u1 = nullptr, *d_sec_u2 = nullptr;
+    uint32_t *d_fail = nullptr;      // [proof] bit mask of failed checks (FailBit)
+    uint16_t *h_Iimg = nullptr;      // I fields as read from the proof images
+    hipEvent_t ev = nullptr;
 
     // pinned host staging
     uint8_t *h_tape = nullptr, *h_dig = nullptr, *h_proof = nullptr;
@@ -72,6 +87,14 @@ struct Ctx {
     uint32_t *h_fail = nullptr;
 
     double phase_sec[PH_COUNT] = {0};
+    bool prof_on = false;
+    hipEvent_t prof_ev[PR_COUNT][2] = {};
+    bool prof_used[PR_COUNT] = {};
+    double prof_ms[PR_COUNT] = {0};
+    long prof_n[PR_COUNT] = {0};
+    void prof_begin(int id) { if (prof_on) { (void)hipEventRecord(prof_ev[id][0], stream); } }
+    void prof_end(int id) { if (prof_on) { (void)hipEventRecord(prof_ev[id][1], stream); prof_used[id] = true; } }
+    void prof_collect(); // call after the stream has been synchronised
 
     ~Ctx();
 };

@@ -39,6 +39,7 @@ struct GemmArgs {
     const uint16_t *B;
     size_t b_gstride;
     const int16_t *b_rows; // row index per n (null: n itself)
+    int b_rstride;         // u16 between B rows
     int b_koff;
     uint16_t *C;
     size_t c_gstride;
@@ -78,6 +79,46 @@ struct AssembleArgs {
     uint8_t *proof;
     size_t image_stride;
 };
+
+// ---- verifier (kosk_verify_kernels.hip) ----
+enum FailBit {
+    FB_MALFORMED = 0, FB_BETA_GAMMA, FB_SR_ER_SHARES, FB_NTT_S_E, FB_A_SR, FB_T_PK, FB_T_RELATION,
+    FB_ETA_CONST, FB_SUB_ETA, FB_U_INTERP, FB_U_RECON, FB_OPENED_SET
+};
+
+struct VerifyArgs {
+    uint16_t *P;
+    size_t proof_stride;
+    RowMap rm;
+    int eta1;
+    const uint16_t *opened, *rest; // [proof][sel_stride]
+    int sel_stride;
+    uint32_t *fail; // [proof]
+};
+
+struct InterpArgs {
+    const uint16_t *rest;
+    int sel_stride;
+    const uint16_t *inv; // [Q] inverse table
+    uint16_t *w, *ell;   // [proof][2][832] weights / node polynomial values (set 0: 407 nodes, 1: 813 nodes)
+    uint32_t *W, *W2;    // [proof][KP][Mpad] GEMM operands
+    size_t w_stride, w2_stride;
+    int Mpad1, KP1, Mpad2, KP2;
+};
+
+hipError_t launch_disassemble(const VerifyArgs &v, const FieldDesc *fields, const int16_t *rowtab, int nfields,
+                              const uint8_t *proof, size_t image_stride, size_t off_tcomm, size_t off_comm,
+                              uint8_t *dig1, uint8_t *dig2, int nproofs, hipStream_t st);
+hipError_t launch_gates_opened(const VerifyArgs &v, int nproofs, hipStream_t st);
+hipError_t launch_interp_build(const InterpArgs &a, int nproofs, hipStream_t st);
+hipError_t launch_gather_cols(const uint16_t *P, size_t proof_stride, const int16_t *rows, int nrows, const uint16_t *rest,
+                              int sel_stride, int ncols, int out_cols, uint16_t *out, int nproofs, hipStream_t st);
+hipError_t launch_check_rest(const VerifyArgs &v, int nproofs, hipStream_t st);
+hipError_t launch_check_opened(const VerifyArgs &v, int nproofs, hipStream_t st);
+hipError_t launch_check_secrets(const VerifyArgs &v, const uint16_t *t_pk, int nproofs, hipStream_t st);
+hipError_t launch_check_pairs(const uint16_t *a, const uint16_t *b, size_t gstride, int nrows, uint32_t *fail, int bit,
+                              int nproofs, hipStream_t st);
+hipError_t launch_check_zero(const uint16_t *a, size_t gstride, int nrows, uint32_t *fail, int bit, int nproofs, hipStream_t st);
 
 hipError_t launch_commit_hash(const HashArgs &a, int ngroups, int K, bool view, hipStream_t st);
 hipError_t launch_sha3_msgs(const uint8_t *in, size_t in_stride, int len, uint8_t *out, size_t out_stride,

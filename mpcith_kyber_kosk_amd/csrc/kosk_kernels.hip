@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
         int g, i;
         if (a.grouped) { g = grp; i = n_stage; b_valid = i < a.npg; }
         else { g = n_stage / a.npg; i = n_stage - g * a.npg; b_valid = n_stage < a.npg * a.ngroups; }
-        b_off = b_valid ? (size_t)g * a.b_gstride + (size_t)(a.b_rows ? (int)a.b_rows[i] : i) * RS + a.b_koff : 0;
+        b_off = b_valid ? (size_t)g * a.b_gstride + (size_t)(a.b_rows ? (int)a.b_rows[i] : i) * a.b_rstride + a.b_koff : 0;
     }
     // A staging role: kp_local = tid >> 4, 8 words at m = (tid & 15) * 8
     const int akp = tid >> 4, am = (tid & 15) * 8;

@@ -1,0 +1,298 @@
+// gfx950 kernels that exist only on the verifier side (mlwe_verifier.cpp:4-686).
+// The heavy steps reuse kosk_kernels.hip: k_commit_hash (opened lanes through a
+// lane map), k_lincomb (opened columns), k_ntt256, k_matvec_ntt and k_gemm_modq
+// (recon_secrets_*, recompute_share_secrets_ddeg, and -- with a per-proof
+// operand -- the application of the interpolation operator that replaces NTL
+// interpolate()/eval(), mlwe_verifier.cpp:201-219 etc.).
+#include <hip/hip_runtime.h>
+
+#include "kosk_device.hpp"
+#include "kosk_math.hpp"
+
+namespace kosk {
+
+constexpr int DIS_W = 81;
+
+// inverse of k_assemble_fields: proof image -> rows at the listed party columns.
+// Non-canonical values (>= q) can never be produced by an honest prover; they are
+// folded mod q to keep arithmetic bounded and the proof is marked malformed.
+__global__ __launch_bounds__(256) void k_disassemble_fields(VerifyArgs v, const FieldDesc *__restrict__ fields,
+                                                           const int16_t *__restrict__ rowtab,
+                                                           const uint8_t *__restrict__ proof, size_t image_stride)
+{
+    __shared__ uint16_t tile[64 * DIS_W];
+    const FieldDesc fd = fields[blockIdx.y];
+    const int b = blockIdx.z;
+    const int np = fd.sel ? NREST : NOPEN;
+    const int i0 = blockIdx.x * 64;
+    if (i0 >= np) return;
+    const int cnt = min(64, np - i0);
+    const uint16_t *in = reinterpret_cast<const uint16_t *>(proof + (size_t)b * image_stride + fd.off) + (size_t)i0 * fd.width;
+    const int total = cnt * fd.width;
+    bool bad = false;
+    for (int q = threadIdx.x; q < total; q += 256) {
+        uint32_t x = in[q];
+        if (x >= (uint32_t)Q) { bad = true; x %= Q; }
+        const int i = q / fd.width, e = q - i * fd.width;
+        tile[i * DIS_W + e] = (uint16_t)x;
+    }
+    __syncthreads();
+    const uint16_t *sel = (fd.sel ? v.rest : v.opened) + (size_t)b * v.sel_stride;
+    uint16_t *Pb = v.P + (size_t)b * v.proof_stride;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane < cnt) {
+        const int col = NSEC + sel[i0 + lane];
+        for (int e = w; e < fd.width; e += 4) Pb[(size_t)rowtab[fd.rowtab_off + e] * RS + col] = tile[lane * DIS_W + e];
+    }
+    if (bad) atomicOr(&v.fail[b], 1u << FB_MALFORMED);
+}
+
+// Tcomm / comm of the unopened parties into the two digest tables  mlwe_verifier.cpp:36-38, :645-647
+__global__ __launch_bounds__(256) void k_disassemble_digests(const uint8_t *__restrict__ proof, size_t image_stride,
+                                                            size_t off_tcomm, size_t off_comm, const uint16_t *__restrict__ rest,
+                                                            int sel_stride, uint8_t *__restrict__ dig1, uint8_t *__restrict__ dig2)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (q >= NREST * 16) return;
+    const uint8_t *img = proof + (size_t)b * image_stride;
+    const int i = q >> 4, w = q & 15;
+    const size_t dst = ((size_t)b * NPARTY + rest[(size_t)b * sel_stride + i]) * 32 + 2 * w;
+    *reinterpret_cast<uint16_t *>(dig1 + dst) = reinterpret_cast<const uint16_t *>(img + off_tcomm)[q];
+    *reinterpret_cast<uint16_t *>(dig2 + dst) = reinterpret_cast<const uint16_t *>(img + off_comm)[q];
+}
+
+// u = z2d - z_d on the opened columns from the opened gate inputs   mlwe_verifier.cpp:469-495
+__global__ __launch_bounds__(192) void k_gates_opened(VerifyArgs v)
+{
+    const int t = threadIdx.x, b = blockIdx.x;
+    if (t >= NOPEN) return;
+    const RowMap &rm = v.rm;
+    uint16_t *Pb = v.P + (size_t)b * v.proof_stride + NSEC + v.opened[(size_t)b * v.sel_stride + t];
+    for (int who = 0; who < 2; who++)
+        for (int i = 0; i < rm.K; i++) {
+            const int sub0 = (who ? rm.esub : rm.ssub) + i * rm.E;
+            uint32_t prev = Pb[(size_t)sub0 * RS];
+            for (int j = 0; j < rm.Z; j++) {
+                const uint32_t z2 = gf_mul(prev, Pb[(size_t)(sub0 + j + 1) * RS]);
+                const uint32_t zd = Pb[(size_t)(who ? rm.ze(i, j) : rm.zs(i, j)) * RS];
+                Pb[(size_t)(who ? rm.ue(i, j) : rm.us(i, j)) * RS] = (uint16_t)gf_sub(z2, zd);
+                prev = zd;
+            }
+        }
+}
+
+// ---- interpolation operators over the nodes x_j = 256 + rest[j] ----------------
+// barycentric form: p(k) = l(k) * sum_j w_j y_j / (k - x_j),  w_j = 1 / prod_{m != j} (x_j - x_m)
+__device__ __forceinline__ uint32_t gf_pow_dev(uint32_t a, uint32_t e)
+{
+    uint32_t r = 1;
+    while (e) {
+        if (e & 1) r = gf_mul(r, a);
+        a = gf_mul(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+
+// set 0: 407 nodes (degree-d sharings), set 1: 813 nodes (degree-2d)
+__global__ __launch_bounds__(64) void k_interp_weights(InterpArgs a)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y, set = blockIdx.z;
+    const int n = set ? DEG2 + 1 : DEG + 1;
+    if (j >= 832) return;
+    uint16_t *w = a.w + ((size_t)b * 2 + set) * 832;
+    if (j >= n) { w[j] = 0; return; }
+    const uint16_t *rest = a.rest + (size_t)b * a.sel_stride;
+    const uint32_t xj = NSEC + rest[j];
+    uint32_t d = 1;
+    for (int m = 0; m < n; m++) {
+        const uint32_t xm = NSEC + rest[m];
+        d = gf_mul(d, m == j ? 1u : gf_sub(xj, xm));
+    }
+    w[j] = (uint16_t)gf_pow_dev(d, Q - 2);
+}
+
+// l(k) = prod_m (k - x_m) at the evaluation points k (0..406 for set 0, 0..255 for set 1)
+__global__ __launch_bounds__(64) void k_interp_ell(InterpArgs a)
+{
+    const int k = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y, set = blockIdx.z;
+    const int n = set ? DEG2 + 1 : DEG + 1, neval = set ? NSEC : DEG + 1;
+    if (k >= 832) return;
+    uint16_t *ell = a.ell + ((size_t)b * 2 + set) * 832;
+    if (k >= neval) { ell[k] = 0; return; }
+    const uint16_t *rest = a.rest + (size_t)b * a.sel_stride;
+    uint32_t l = 1;
+    for (int m = 0; m < n; m++) l = gf_mul(l, gf_sub((uint32_t)k, NSEC + rest[m]));
+    ell[k] = (uint16_t)l;
+}
+
+// Apk[kp][k] = centred pair (Wop[k][2kp], Wop[k][2kp+1]),  Wop[k][j] = [x_j == k] or l(k) w_j / (k - x_j)
+__global__ __launch_bounds__(256) void k_interp_matrix(InterpArgs a)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x, kp = blockIdx.y;
+    const int b = blockIdx.z >> 1, set = blockIdx.z & 1;
+    const int n = set ? DEG2 + 1 : DEG + 1, neval = set ? NSEC : DEG + 1;
+    const int Mpad = set ? a.Mpad2 : a.Mpad1, KP = set ? a.KP2 : a.KP1;
+    if (k >= Mpad || kp >= KP) return;
+    uint32_t *W = set ? a.W2 + (size_t)b * a.w2_stride : a.W + (size_t)b * a.w_stride;
+    uint32_t word = 0;
+    if (k < neval) {
+        const uint16_t *rest = a.rest + (size_t)b * a.sel_stride;
+        const uint16_t *w = a.w + ((size_t)b * 2 + set) * 832;
+        const uint32_t l = a.ell[((size_t)b * 2 + set) * 832 + k];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int j = 2 * kp + h;
+            uint32_t e = 0;
+            if (j < n) {
+                const uint32_t xj = NSEC + rest[j];
+                const uint32_t d = gf_sub((uint32_t)k, xj);
+                e = d == 0 ? 1u : gf_mul(gf_mul(l, w[j]), a.inv[d]);
+            }
+            word |= ((uint32_t)gf_center(e) & 0xFFFFu) << (16 * h);
+        }
+    }
+    W[(size_t)kp * Mpad + k] = word;
+}
+
+// out[b][r][j] = P[b][rows[r]][256 + rest[b][j]] for j < ncols, zero padded to out_cols
+__global__ __launch_bounds__(256) void k_gather_cols(const uint16_t *__restrict__ P, size_t proof_stride,
+                                                     const int16_t *__restrict__ rows, int nrows,
+                                                     const uint16_t *__restrict__ rest, int sel_stride, int ncols,
+                                                     int out_cols, uint16_t *__restrict__ out)
+{
+    const int r = blockIdx.y, b = blockIdx.z;
+    const uint16_t *src = P + (size_t)b * proof_stride + (size_t)rows[r] * RS + NSEC;
+    uint16_t *dst = out + ((size_t)b * nrows + r) * out_cols;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < out_cols; j += gridDim.x * 256)
+        dst[j] = j < ncols ? src[rest[(size_t)b * sel_stride + j]] : (uint16_t)0;
+}
+
+// ---- checks ---------------------------------------------------------------------
+// recomputed s+r / e+r shares against the unopened ones in the proof   mlwe_verifier.cpp:232-246
+__global__ __launch_bounds__(256) void k_check_rest(VerifyArgs v)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= NREST) return;
+    const RowMap &rm = v.rm;
+    const uint16_t *Pb = v.P + (size_t)b * v.proof_stride + NSEC + v.rest[(size_t)b * v.sel_stride + i];
+    bool bad = false;
+    for (int r = 0; r < rm.K; r++) {
+        bad |= Pb[(size_t)(rm.sr + r) * RS] != Pb[(size_t)(rm.sr_in + r) * RS];
+        bad |= Pb[(size_t)(rm.er + r) * RS] != Pb[(size_t)(rm.er_in + r) * RS];
+    }
+    if (bad) atomicOr(&v.fail[b], 1u << FB_SR_ER_SHARES);
+}
+
+// relation checks on the opened columns   mlwe_verifier.cpp:273-284, :304-312, :365-376, :447-466
+__global__ __launch_bounds__(192) void k_check_opened(VerifyArgs v)
+{
+    const int t = threadIdx.x, b = blockIdx.x;
+    if (t >= NOPEN) return;
+    const RowMap &rm = v.rm;
+    const uint16_t *Pb = v.P + (size_t)b * v.proof_stride + NSEC + v.opened[(size_t)b * v.sel_stride + t];
+    auto at = [&](int row) { return (uint32_t)Pb[(size_t)row * RS]; };
+    uint32_t bits = 0;
+    for (int i = 0; i < rm.K; i++) {
+        if (at(rm.ntts + i) != gf_sub(at(rm.nttsr + i), at(rm.nttr + i))) bits |= 1u << FB_NTT_S_E;
+        if (at(rm.ntte + i) != gf_sub(at(rm.ntter + i), at(rm.nttr + rm.K + i))) bits |= 1u << FB_NTT_S_E;
+        if (at(rm.nttasr + i) != gf_add(at(rm.nttas + i), at(rm.nttar + i))) bits |= 1u << FB_A_SR;
+        if (at(rm.t + i) != gf_add(at(rm.nttas + i), at(rm.ntte + i))) bits |= 1u << FB_T_RELATION;
+        for (int m = 0; m < rm.E; m++) {
+            if (at(rm.ssub + i * rm.E + m) != gf_sub(at(rm.s + i), at(rm.seta + i * rm.E + m))) bits |= 1u << FB_SUB_ETA;
+            if (at(rm.esub + i * rm.E + m) != gf_sub(at(rm.e + i), at(rm.eeta + i * rm.E + m))) bits |= 1u << FB_SUB_ETA;
+        }
+    }
+    if (bits) atomicOr(&v.fail[b], bits);
+}
+
+// interpolated packed secrets: t against the public key, range constants   mlwe_verifier.cpp:354-363, :418-429
+__global__ __launch_bounds__(256) void k_check_secrets(VerifyArgs v, const uint16_t *__restrict__ t_pk)
+{
+    const int k = threadIdx.x, b = blockIdx.x;
+    const RowMap &rm = v.rm;
+    const uint16_t *Pb = v.P + (size_t)b * v.proof_stride + k;
+    uint32_t bits = 0;
+    for (int i = 0; i < rm.K; i++) {
+        if (Pb[(size_t)(rm.t + i) * RS] != t_pk[((size_t)b * rm.K + i) * 256 + k]) bits |= 1u << FB_T_PK;
+        for (int m = 0; m < rm.E; m++) {
+            const uint32_t c = gf_encode(m - v.eta1);
+            if (Pb[(size_t)(rm.seta + i * rm.E + m) * RS] != c) bits |= 1u << FB_ETA_CONST;
+            if (Pb[(size_t)(rm.eeta + i * rm.E + m) * RS] != c) bits |= 1u << FB_ETA_CONST;
+        }
+    }
+    if (bits) atomicOr(&v.fail[b], bits);
+}
+
+// a[b][r][k] == b[b][r][k] for r < nrows, k < 256
+__global__ __launch_bounds__(256) void k_check_pairs(const uint16_t *__restrict__ x, const uint16_t *__restrict__ y,
+                                                     size_t gstride, uint32_t *fail, int bit)
+{
+    const size_t o = (size_t)blockIdx.y * gstride + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (x[o] != y[o]) atomicOr(&fail[blockIdx.y], 1u << bit);
+}
+__global__ __launch_bounds__(256) void k_check_zero(const uint16_t *__restrict__ x, size_t gstride, uint32_t *fail, int bit)
+{
+    const size_t o = (size_t)blockIdx.y * gstride + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (x[o] != 0) atomicOr(&fail[blockIdx.y], 1u << bit);
+}
+
+// ---- launchers --------------------------------------------------------------------
+hipError_t launch_disassemble(const VerifyArgs &v, const FieldDesc *fields, const int16_t *rowtab, int nfields,
+                              const uint8_t *proof, size_t image_stride, size_t off_tcomm, size_t off_comm,
+                              uint8_t *dig1, uint8_t *dig2, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_disassemble_fields, dim3((NREST + 63) / 64, nfields, nproofs), dim3(256), 0, st, v, fields, rowtab, proof, image_stride);
+    hipLaunchKernelGGL(k_disassemble_digests, dim3((NREST * 16 + 255) / 256, nproofs), dim3(256), 0, st, proof, image_stride,
+                       off_tcomm, off_comm, v.rest, v.sel_stride, dig1, dig2);
+    return hipGetLastError();
+}
+hipError_t launch_gates_opened(const VerifyArgs &v, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_gates_opened, dim3(nproofs), dim3(192), 0, st, v);
+    return hipGetLastError();
+}
+hipError_t launch_interp_build(const InterpArgs &a, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_interp_weights, dim3(13, nproofs, 2), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_interp_ell, dim3(13, nproofs, 2), dim3(64), 0, st, a);
+    const int mp = a.Mpad1 > a.Mpad2 ? a.Mpad1 : a.Mpad2, kp = a.KP1 > a.KP2 ? a.KP1 : a.KP2;
+    hipLaunchKernelGGL(k_interp_matrix, dim3((mp + 255) / 256, kp, nproofs * 2), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_gather_cols(const uint16_t *P, size_t proof_stride, const int16_t *rows, int nrows, const uint16_t *rest,
+                              int sel_stride, int ncols, int out_cols, uint16_t *out, int nproofs, hipStream_t st)
+{
+    if (nrows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_cols, dim3((out_cols + 255) / 256, nrows, nproofs), dim3(256), 0, st, P, proof_stride, rows, nrows,
+                       rest, sel_stride, ncols, out_cols, out);
+    return hipGetLastError();
+}
+hipError_t launch_check_rest(const VerifyArgs &v, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_check_rest, dim3((NREST + 255) / 256, nproofs), dim3(256), 0, st, v);
+    return hipGetLastError();
+}
+hipError_t launch_check_opened(const VerifyArgs &v, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_check_opened, dim3(nproofs), dim3(192), 0, st, v);
+    return hipGetLastError();
+}
+hipError_t launch_check_secrets(const VerifyArgs &v, const uint16_t *t_pk, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_check_secrets, dim3(nproofs), dim3(256), 0, st, v, t_pk);
+    return hipGetLastError();
+}
+hipError_t launch_check_pairs(const uint16_t *a, const uint16_t *b, size_t gstride, int nrows, uint32_t *fail, int bit,
+                              int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_check_pairs, dim3(nrows, nproofs), dim3(256), 0, st, a, b, gstride, fail, bit);
+    return hipGetLastError();
+}
+hipError_t launch_check_zero(const uint16_t *a, size_t gstride, int nrows, uint32_t *fail, int bit, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_check_zero, dim3(nrows, nproofs), dim3(256), 0, st, a, gstride, fail, bit);
+    return hipGetLastError();
+}
+
+} // namespace kosk
