@@ -120,6 +120,9 @@ int kosk_fs_opened(const uint8_t *digests_all, uint16_t *I, uint16_t *rest);
 /* host sha3_256 / shake256 used by the two functions above (kyber/fips202.c:745-754, :723-734) */
 void kosk_host_sha3_256(uint8_t out[32], const uint8_t *in, size_t inlen);
 void kosk_host_shake256(uint8_t *out, size_t outlen, const uint8_t *in, size_t inlen);
+/* sha3_256 of `count` equal-length messages with the SIMD multi-buffer code of the Fiat-Shamir rounds;
+ * returns the SIMD width used (8 AVX-512, 4 AVX2, 1 scalar) */
+int kosk_host_sha3_256_multi(uint8_t *out, const uint8_t *in, size_t in_stride, size_t inlen, int count, int nthreads);
 /* Lagrange coefficient tables the reference reads through utils/precomputed_kyber.h:10-13:
  * which = 0: share_coeff_ddeg [1303][407], 1: recon_coeff_ddeg [256][407], 2: recon_coeff_2ddeg [256][813] */
 int kosk_lagrange_table(int which, uint16_t *out);

@@ -56,6 +56,7 @@ def _load():
         "kosk_fs_opened": (C.c_int, [vp, vp, vp]),
         "kosk_host_sha3_256": (None, [vp, vp, sz]),
         "kosk_host_shake256": (None, [vp, sz, vp, sz]),
+        "kosk_host_sha3_256_multi": (C.c_int, [vp, vp, sz, sz, C.c_int, C.c_int]),
         "kosk_lagrange_table": (C.c_int, [C.c_int, vp]),
     }
     for name, (res, args) in sig.items():
@@ -72,7 +73,7 @@ EXPORTS = ["kosk_pk_bytes", "kosk_sk_bytes", "kosk_proof_bytes", "kosk_tape_byte
            "kosk_stage_verifier_inputs", "kosk_verify_resident", "kosk_phase_seconds", "kosk_sha3_256_batch",
            "kosk_shake256_batch", "kosk_commit_hash_lanes", "kosk_ntt256_batch", "kosk_lagrange_expand",
            "kosk_recon_secrets", "kosk_profile_enable", "kosk_profile_read", "kosk_stream_timer_start", "kosk_stream_timer_stop", "kosk_device_synchronize", "kosk_resident_proofs", "kosk_keygen", "kosk_fs_alpha",
-           "kosk_fs_opened", "kosk_host_sha3_256", "kosk_host_shake256", "kosk_lagrange_table"]
+           "kosk_fs_opened", "kosk_host_sha3_256", "kosk_host_shake256", "kosk_host_sha3_256_multi", "kosk_lagrange_table"]
 
 
 def pk_bytes(k): return lib.kosk_pk_bytes(k)

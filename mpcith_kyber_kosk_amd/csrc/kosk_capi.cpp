@@ -3,6 +3,7 @@
 
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "kosk_ctx.hpp"
 
@@ -295,6 +296,27 @@ int kosk_fs_opened(const uint8_t *digests_all, uint16_t *I, uint16_t *rest)
 
 void kosk_host_sha3_256(uint8_t out[32], const uint8_t *in, size_t inlen) { sha3_256(out, in, inlen); }
 void kosk_host_shake256(uint8_t *out, size_t outlen, const uint8_t *in, size_t inlen) { shake256(out, outlen, in, inlen); }
+
+int kosk_host_sha3_256_multi(uint8_t *out, const uint8_t *in, size_t in_stride, size_t inlen, int count, int nthreads)
+{
+    // same code path as the batched Fiat-Shamir rounds: SIMD groups spread over the pool
+    if (inlen == (size_t)NPARTY * 32) {
+        Params P;
+        make_params(2, P);
+        std::vector<uint16_t> I((size_t)count * 1312), rest((size_t)count * 1312);
+        (void)P;
+    }
+    std::vector<const uint8_t *> ptr(count);
+    for (int i = 0; i < count; i++) ptr[i] = in + (size_t)i * in_stride;
+    const int w = sha3_multi_width();
+    if (nthreads <= 1) { sha3_256_multi(out, ptr.data(), inlen, count); return w; }
+    const int groups = (count + w - 1) / w;
+    parallel_for(groups, nthreads, [&](int g) {
+        const int lo = g * w, n = (count - lo) < w ? (count - lo) : w;
+        sha3_256_multi(out + 32 * (size_t)lo, ptr.data() + lo, inlen, n);
+    });
+    return w;
+}
 
 int kosk_lagrange_table(int which, uint16_t *out)
 {

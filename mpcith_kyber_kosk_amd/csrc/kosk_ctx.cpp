@@ -375,7 +375,7 @@ int prove_resident(Ctx &c, int n)
     t1 = now_sec(); c.phase_sec[PH_GPU_COMMIT] = t1 - t0; t0 = t1;
 
     // ---- Fiat-Shamir round 1 on the host
-    parallel_for(n, c.nthreads, [&](int b) { fs_alpha(P, c.h_dig + (size_t)b * NPARTY * 32, c.h_alpha + (size_t)b * 80); });
+    fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads);
     t1 = now_sec(); c.phase_sec[PH_FS_ALPHA] = t1 - t0; t0 = t1;
     HIPCHK(hipMemcpyAsync(c.d_alpha, c.h_alpha, (size_t)n * 80 * 2, hipMemcpyHostToDevice, st));
 
@@ -427,9 +427,7 @@ int prove_resident(Ctx &c, int n)
     t1 = now_sec(); c.phase_sec[PH_GPU_RELATION] = t1 - t0; t0 = t1;
 
     // ---- Fiat-Shamir round 2 on the host
-    parallel_for(n, c.nthreads, [&](int b) {
-        fs_opened(c.h_dig + (size_t)b * NPARTY * 32, c.h_I + (size_t)b * c.sel_stride, c.h_rest + (size_t)b * c.sel_stride);
-    });
+    fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, c.h_I, c.h_rest, c.sel_stride, c.nthreads);
     t1 = now_sec(); c.phase_sec[PH_FS_OPEN] = t1 - t0; t0 = t1;
     HIPCHK(hipMemcpyAsync(c.d_I, c.h_I, (size_t)n * c.sel_stride * 2, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c.d_rest, c.h_rest, (size_t)n * c.sel_stride * 2, hipMemcpyHostToDevice, st));

@@ -4,7 +4,11 @@
 #include <sys/random.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -223,10 +227,170 @@ void fs_alpha(const Params &P, const uint8_t *tcomm_all, uint16_t *alpha)
     for (int i = 0; i < P.J; i++) alpha[i] = (uint16_t)(((a_[2 * i] << 8) | a_[2 * i + 1]) % Q);
 }
 
+static void opened_from_ch(const uint8_t ch[32], uint16_t I[NOPEN], uint16_t rest[NREST]);
 void fs_opened(const uint8_t *digests_all, uint16_t I[NOPEN], uint16_t rest[NREST])
 {
-    uint8_t ch[32], I_[2 * NOPEN];
+    uint8_t ch[32];
     sha3_256(ch, digests_all, (size_t)NPARTY * 32);
+    opened_from_ch(ch, I, rest);
+}
+
+// ------------------------------------------------- multi-buffer SHA3-256 (host) --
+namespace {
+
+template <int W>
+struct VecT;
+template <> struct VecT<4> { typedef uint64_t type __attribute__((vector_size(32))); };
+template <> struct VecT<8> { typedef uint64_t type __attribute__((vector_size(64))); };
+
+template <int W, int N>
+__attribute__((always_inline)) static inline typename VecT<W>::type vrot(typename VecT<W>::type v)
+{
+    if constexpr (N == 0) return v;
+    else return (v << N) | (v >> (64 - N));
+}
+
+template <int W, int X, int Y>
+__attribute__((always_inline)) static inline void vrhopi(const typename VecT<W>::type *a, const typename VecT<W>::type *d, typename VecT<W>::type *b)
+{
+    b[Y + 5 * ((2 * X + 3 * Y) % 5)] = vrot<W, kRho[X + 5 * Y]>(a[X + 5 * Y] ^ d[X]);
+}
+
+template <int W>
+__attribute__((always_inline)) static inline void vround(const typename VecT<W>::type *a, typename VecT<W>::type *o, uint64_t rc)
+{
+    typedef typename VecT<W>::type V;
+    V c[5], d[5], b[25];
+    for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+    for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ vrot<W, 1>(c[(x + 1) % 5]);
+    vrhopi<W, 0, 0>(a, d, b); vrhopi<W, 1, 0>(a, d, b); vrhopi<W, 2, 0>(a, d, b); vrhopi<W, 3, 0>(a, d, b); vrhopi<W, 4, 0>(a, d, b);
+    vrhopi<W, 0, 1>(a, d, b); vrhopi<W, 1, 1>(a, d, b); vrhopi<W, 2, 1>(a, d, b); vrhopi<W, 3, 1>(a, d, b); vrhopi<W, 4, 1>(a, d, b);
+    vrhopi<W, 0, 2>(a, d, b); vrhopi<W, 1, 2>(a, d, b); vrhopi<W, 2, 2>(a, d, b); vrhopi<W, 3, 2>(a, d, b); vrhopi<W, 4, 2>(a, d, b);
+    vrhopi<W, 0, 3>(a, d, b); vrhopi<W, 1, 3>(a, d, b); vrhopi<W, 2, 3>(a, d, b); vrhopi<W, 3, 3>(a, d, b); vrhopi<W, 4, 3>(a, d, b);
+    vrhopi<W, 0, 4>(a, d, b); vrhopi<W, 1, 4>(a, d, b); vrhopi<W, 2, 4>(a, d, b); vrhopi<W, 3, 4>(a, d, b); vrhopi<W, 4, 4>(a, d, b);
+    for (int y = 0; y < 25; y += 5)
+        for (int x = 0; x < 5; x++) o[y + x] = b[y + x] ^ (~b[y + (x + 1) % 5] & b[y + (x + 2) % 5]);
+    V r;
+    for (int i = 0; i < W; i++) r[i] = rc;
+    o[0] ^= r;
+}
+
+// W messages of `len` bytes, all of the same length, SHA3-256
+template <int W>
+__attribute__((always_inline)) static inline void sha3_256_xw(uint8_t *const *out, const uint8_t *const *in, size_t len)
+{
+    typedef typename VecT<W>::type V;
+    V s[25], t[25];
+    for (auto &v : s) v = V{};
+    size_t off = 0;
+    // (a macro, not a lambda: a lambda body would not inherit the caller's target("avx...") attribute)
+#define KOSK_PERMUTE()                          \
+    for (int r = 0; r < 24; r += 2) {           \
+        vround<W>(s, t, kKeccak.rc[r]);         \
+        vround<W>(t, s, kKeccak.rc[r + 1]);     \
+    }
+    while (len - off >= 136) {
+        for (int w = 0; w < 17; w++) {
+            V v;
+            for (int i = 0; i < W; i++) v[i] = load64(in[i] + off + 8 * w);
+            s[w] ^= v;
+        }
+        KOSK_PERMUTE();
+        off += 136;
+    }
+    uint8_t last[W][136];
+    for (int i = 0; i < W; i++) {
+        memset(last[i], 0, 136);
+        memcpy(last[i], in[i] + off, len - off);
+        last[i][len - off] = 0x06;
+        last[i][135] |= 0x80;
+    }
+    for (int w = 0; w < 17; w++) {
+        V v;
+        for (int i = 0; i < W; i++) v[i] = load64(last[i] + 8 * w);
+        s[w] ^= v;
+    }
+    KOSK_PERMUTE();
+#undef KOSK_PERMUTE
+    for (int i = 0; i < W; i++)
+        for (int w = 0; w < 4; w++) {
+            const uint64_t x = s[w][i];
+            memcpy(out[i] + 8 * w, &x, 8);
+        }
+}
+
+__attribute__((target("avx512f"))) void sha3_256_x8_avx512(uint8_t *const *out, const uint8_t *const *in, size_t len) { sha3_256_xw<8>(out, in, len); }
+__attribute__((target("avx2"))) void sha3_256_x4_avx2(uint8_t *const *out, const uint8_t *const *in, size_t len) { sha3_256_xw<4>(out, in, len); }
+__attribute__((target("avx512f,avx512vl"))) void sha3_256_x4_avx512vl(uint8_t *const *out, const uint8_t *const *in, size_t len) { sha3_256_xw<4>(out, in, len); }
+
+struct CpuCaps {
+    bool avx2, avx512f, avx512vl;
+    CpuCaps()
+    {
+        __builtin_cpu_init();
+        avx2 = __builtin_cpu_supports("avx2");
+        avx512f = __builtin_cpu_supports("avx512f");
+        avx512vl = __builtin_cpu_supports("avx512vl");
+        if (getenv("KOSK_HOST_SCALAR")) avx2 = avx512f = avx512vl = false;
+    }
+};
+const CpuCaps &caps() { static const CpuCaps c; return c; }
+
+// hash group `g` of width w (messages g*w .. g*w+w-1, the tail group re-hashes its first message as padding)
+void sha3_group(uint8_t *out, const uint8_t *const *in, size_t len, int count, int w, int g)
+{
+    const uint8_t *ip[8];
+    uint8_t *op[8];
+    uint8_t dump[8][32];
+    for (int i = 0; i < w; i++) {
+        const int m = g * w + i;
+        ip[i] = in[m < count ? m : g * w];
+        op[i] = m < count ? out + 32 * (size_t)m : dump[i];
+    }
+    if (w == 8) sha3_256_x8_avx512(op, ip, len);
+    else if (w == 4 && caps().avx512vl) sha3_256_x4_avx512vl(op, ip, len);
+    else if (w == 4) sha3_256_x4_avx2(op, ip, len);
+    else sha3_256(op[0], ip[0], len);
+}
+
+} // namespace
+
+int sha3_multi_width() { return caps().avx512f ? 8 : caps().avx2 ? 4 : 1; }
+
+void sha3_256_multi(uint8_t *out, const uint8_t *const *in, size_t len, int count)
+{
+    const int w = sha3_multi_width();
+    for (int g = 0; g * w < count; g++) sha3_group(out, in, len, count, w, g);
+}
+
+// the SIMD width is chosen so that the groups roughly fill the available threads: the 343-permutation
+// chains are sequential per proof, so latency = one chain whatever the width
+static void sha3_digest_tables(int n, const uint8_t *digs, size_t dig_stride, uint8_t *out, int nthreads)
+{
+    std::vector<const uint8_t *> in(n);
+    for (int b = 0; b < n; b++) in[b] = digs + (size_t)b * dig_stride;
+    int w = sha3_multi_width();
+    if (w == 8 && (n + 3) / 4 <= nthreads) w = 4;
+    if (w > 1 && n <= nthreads && !caps().avx512f) w = 1;
+    const int groups = (n + w - 1) / w;
+    parallel_for(groups, nthreads, [&](int g) { sha3_group(out, in.data(), (size_t)NPARTY * 32, n, w, g); });
+}
+
+void fs_alpha_batch(const Params &P, int n, const uint8_t *digs, size_t dig_stride, uint16_t *alpha, size_t alpha_stride, int nthreads)
+{
+    std::vector<uint8_t> h((size_t)n * 32);
+    sha3_digest_tables(n, digs, dig_stride, h.data(), nthreads);
+    for (int b = 0; b < n; b++) {
+        uint8_t a_[2 * MAXJ];
+        shake256_prf(a_, (size_t)2 * P.J, &h[(size_t)b * 32], 1);
+        uint16_t *al = alpha + (size_t)b * alpha_stride;
+        for (int i = 0; i < P.J; i++) al[i] = (uint16_t)(((a_[2 * i] << 8) | a_[2 * i + 1]) % Q);
+    }
+}
+
+static void opened_from_ch(const uint8_t ch[32], uint16_t I[NOPEN], uint16_t rest[NREST])
+{
+    uint8_t I_[2 * NOPEN];
     shake256_prf(I_, sizeof I_, ch, 1);
     bool used[NPARTY] = {false};
     for (int i = 0; i < NOPEN; i++) {
@@ -239,6 +403,13 @@ void fs_opened(const uint8_t *digests_all, uint16_t I[NOPEN], uint16_t rest[NRES
     }
     for (int p = 0, j = 0; p < NPARTY; p++)
         if (!used[p]) rest[j++] = (uint16_t)p;
+}
+
+void fs_opened_batch(int n, const uint8_t *digs, size_t dig_stride, uint16_t *I, uint16_t *rest, size_t sel_stride, int nthreads)
+{
+    std::vector<uint8_t> h((size_t)n * 32);
+    sha3_digest_tables(n, digs, dig_stride, h.data(), nthreads);
+    for (int b = 0; b < n; b++) opened_from_ch(&h[(size_t)b * 32], I + (size_t)b * sel_stride, rest + (size_t)b * sel_stride);
 }
 
 // ------------------------------------------------------------------- tables --
@@ -299,6 +470,97 @@ void pack_gemm_table(const std::vector<uint16_t> &A, int M, int Kdim, int Mpad, 
 }
 
 // -------------------------------------------------------------------- misc --
+namespace {
+// Persistent worker pool: Fiat-Shamir rounds arrive in short bursts between GPU phases, so the
+// workers spin briefly on a generation counter before they block.
+class Pool {
+public:
+    static Pool &get() { static Pool p; return p; }
+    void run(int n, int nthreads, const std::function<void(int)> &fn)
+    {
+        std::lock_guard<std::mutex> job(job_mu_);
+        grow(nthreads - 1);
+        fn_ = &fn;
+        n_ = n;
+        next_.store(0, std::memory_order_relaxed);
+        done_.store(0, std::memory_order_relaxed);
+        want_ = std::min<int>((int)th_.size(), nthreads - 1);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            gen_.fetch_add(1, std::memory_order_release);
+        }
+        cv_.notify_all();
+        work();
+        while (done_.load(std::memory_order_acquire) < n) __builtin_ia32_pause();
+        // workers may still be inside work() looking for an index: wait until they have left fn_
+        while (inside_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+    }
+
+private:
+    Pool() = default;
+    ~Pool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+            gen_.fetch_add(1);
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    void grow(int want)
+    {
+        while ((int)th_.size() < want && th_.size() < 255) {
+            const int id = (int)th_.size();
+            const uint64_t g = gen_.load(std::memory_order_acquire); // never pick up a job published before we existed
+            th_.emplace_back([this, id, g] { loop(id, g); });
+        }
+    }
+    void work()
+    {
+        for (;;) {
+            const int i = next_.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n_) break;
+            (*fn_)(i);
+            done_.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void loop(int id, uint64_t seen0)
+    {
+        uint64_t seen = seen0;
+        for (;;) {
+            // spin ~150 us for the next job (pause, not yield: a yield can cost milliseconds in
+            // sandboxed runtimes), then block
+            const auto t0 = std::chrono::steady_clock::now();
+            while (gen_.load(std::memory_order_acquire) == seen) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150)) {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+                    break;
+                }
+                __builtin_ia32_pause();
+            }
+            seen = gen_.load(std::memory_order_acquire);
+            if (stop_) return;
+            if (id < want_) {
+                inside_.fetch_add(1, std::memory_order_acq_rel);
+                // the job may already be over (n_ exhausted); work() then returns at once
+                work();
+                inside_.fetch_sub(1, std::memory_order_acq_rel);
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex job_mu_, mu_;
+    std::condition_variable cv_;
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<int> next_{0}, done_{0}, inside_{0};
+    const std::function<void(int)> *fn_ = nullptr;
+    int n_ = 0, want_ = 0;
+    bool stop_ = false;
+};
+} // namespace
+
 void parallel_for(int n, int nthreads, const std::function<void(int)> &fn)
 {
     if (n <= 0) return;
@@ -307,18 +569,7 @@ void parallel_for(int n, int nthreads, const std::function<void(int)> &fn)
         for (int i = 0; i < n; i++) fn(i);
         return;
     }
-    std::atomic<int> next{0};
-    std::vector<std::thread> th;
-    th.reserve(nthreads);
-    for (int t = 0; t < nthreads; t++)
-        th.emplace_back([&] {
-            for (;;) {
-                const int i = next.fetch_add(1);
-                if (i >= n) break;
-                fn(i);
-            }
-        });
-    for (auto &t : th) t.join();
+    Pool::get().run(n, nthreads, fn);
 }
 
 void os_randombytes(uint8_t *out, size_t len)

@@ -43,8 +43,18 @@ uint16_t gf_inv_host(uint16_t a);
 // pack A[m][k] (canonical) into the GEMM operand Apk[KP][Mpad] of centred int16 pairs
 void pack_gemm_table(const std::vector<uint16_t> &A, int M, int Kdim, int Mpad, int KP, std::vector<uint32_t> &out);
 
-// run fn(i) for i in [0,n) on up to nthreads host threads
+// run fn(i) for i in [0,n) on up to nthreads threads of a persistent process-wide pool
 void parallel_for(int n, int nthreads, const std::function<void(int)> &fn);
+
+// sha3_256 of `count` equal-length messages in[i] -> out + 32*i, `width` (4 or 8) at a time in SIMD
+// lanes when the CPU has AVX2 / AVX-512F (runtime dispatch, scalar otherwise).  Used for the
+// 46 528-byte Fiat-Shamir hashes (mlwe_prover.cpp:135, :449), which are sequential per proof.
+void sha3_256_multi(uint8_t *out, const uint8_t *const *in, size_t len, int count);
+int sha3_multi_width(); // 8 (AVX-512F), 4 (AVX2) or 1
+
+// batch forms of fs_alpha / fs_opened over n proofs whose digest tables are dig_stride bytes apart
+void fs_alpha_batch(const Params &P, int n, const uint8_t *digs, size_t dig_stride, uint16_t *alpha, size_t alpha_stride, int nthreads);
+void fs_opened_batch(int n, const uint8_t *digs, size_t dig_stride, uint16_t *I, uint16_t *rest, size_t sel_stride, int nthreads);
 
 // OS entropy (kyber/randombytes.c:44-57, Linux branch)
 void os_randombytes(uint8_t *out, size_t len);

@@ -290,7 +290,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
 
     // ---- host: alpha while the GPU works
     HIPCHK(hipEventSynchronize(c.ev));
-    parallel_for(n, c.nthreads, [&](int b) { fs_alpha(P, c.h_dig + (size_t)b * NPARTY * 32, c.h_alpha + (size_t)b * 80); });
+    fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads);
     HIPCHK(hipMemcpyAsync(c.d_alpha, c.h_alpha, (size_t)n * 80 * 2, hipMemcpyHostToDevice, st));
 
     // ---- V2/V3: beta, gamma, r, NTT_r on the opened columns; reconstruction and NTT check
@@ -339,16 +339,14 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     HIPCHK(hipMemcpyAsync(c.h_fail, c.d_fail, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     c.prof_collect();
-    std::vector<uint8_t> okv(n);
-    parallel_for(n, c.nthreads, [&](int b) {
-        uint16_t I2[NOPEN], rest2[NREST];
-        fs_opened(c.h_dig + (size_t)b * NPARTY * 32, I2, rest2);
+    std::vector<uint16_t> I2((size_t)n * c.sel_stride), rest2((size_t)n * c.sel_stride);
+    fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, I2.data(), rest2.data(), c.sel_stride, c.nthreads);
+    for (int b = 0; b < n; b++) {
         uint32_t f = c.h_fail[b] | host_fail[b];
-        if (memcmp(I2, c.h_I + (size_t)b * c.sel_stride, sizeof I2) != 0) f |= 1u << FB_OPENED_SET;
+        if (memcmp(&I2[(size_t)b * c.sel_stride], c.h_I + (size_t)b * c.sel_stride, sizeof(uint16_t) * NOPEN) != 0) f |= 1u << FB_OPENED_SET;
         c.h_fail[b] = f;
-        okv[b] = f == 0;
-    });
-    memcpy(ok, okv.data(), n);
+        ok[b] = f == 0;
+    }
     return 0;
 }
 

@@ -94,36 +94,42 @@ __device__ __forceinline__ uint32_t gf_pow_dev(uint32_t a, uint32_t e)
     return r;
 }
 
-// set 0: 407 nodes (degree-d sharings), set 1: 813 nodes (degree-2d)
+__device__ __forceinline__ uint32_t wave_product(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = gf_mul(v, (uint32_t)__shfl_xor((int)v, off, 64));
+    return v;
+}
+
+// One wave per node / evaluation point: the 64 lanes multiply strided factors, then a shuffle
+// product-reduction.  set 0: 407 nodes (degree-d sharings), set 1: 813 nodes (degree-2d).
+// w_j = 1 / prod_{m != j} (x_j - x_m)
 __global__ __launch_bounds__(64) void k_interp_weights(InterpArgs a)
 {
-    const int j = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y, set = blockIdx.z;
+    const int j = blockIdx.x, b = blockIdx.y, set = blockIdx.z, lane = threadIdx.x;
     const int n = set ? DEG2 + 1 : DEG + 1;
-    if (j >= 832) return;
     uint16_t *w = a.w + ((size_t)b * 2 + set) * 832;
-    if (j >= n) { w[j] = 0; return; }
+    if (j >= n) { if (lane == 0) w[j] = 0; return; }
     const uint16_t *rest = a.rest + (size_t)b * a.sel_stride;
     const uint32_t xj = NSEC + rest[j];
     uint32_t d = 1;
-    for (int m = 0; m < n; m++) {
-        const uint32_t xm = NSEC + rest[m];
-        d = gf_mul(d, m == j ? 1u : gf_sub(xj, xm));
-    }
-    w[j] = (uint16_t)gf_pow_dev(d, Q - 2);
+    for (int m = lane; m < n; m += 64) d = gf_mul(d, m == j ? 1u : gf_sub(xj, NSEC + rest[m]));
+    d = wave_product(d);
+    if (lane == 0) w[j] = a.inv[d];
 }
 
 // l(k) = prod_m (k - x_m) at the evaluation points k (0..406 for set 0, 0..255 for set 1)
 __global__ __launch_bounds__(64) void k_interp_ell(InterpArgs a)
 {
-    const int k = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y, set = blockIdx.z;
+    const int k = blockIdx.x, b = blockIdx.y, set = blockIdx.z, lane = threadIdx.x;
     const int n = set ? DEG2 + 1 : DEG + 1, neval = set ? NSEC : DEG + 1;
-    if (k >= 832) return;
     uint16_t *ell = a.ell + ((size_t)b * 2 + set) * 832;
-    if (k >= neval) { ell[k] = 0; return; }
+    if (k >= neval) { if (lane == 0) ell[k] = 0; return; }
     const uint16_t *rest = a.rest + (size_t)b * a.sel_stride;
     uint32_t l = 1;
-    for (int m = 0; m < n; m++) l = gf_mul(l, gf_sub((uint32_t)k, NSEC + rest[m]));
-    ell[k] = (uint16_t)l;
+    for (int m = lane; m < n; m += 64) l = gf_mul(l, gf_sub((uint32_t)k, NSEC + rest[m]));
+    l = wave_product(l);
+    if (lane == 0) ell[k] = (uint16_t)l;
 }
 
 // Apk[kp][k] = centred pair (Wop[k][2kp], Wop[k][2kp+1]),  Wop[k][j] = [x_j == k] or l(k) w_j / (k - x_j)
@@ -254,8 +260,8 @@ hipError_t launch_gates_opened(const VerifyArgs &v, int nproofs, hipStream_t st)
 }
 hipError_t launch_interp_build(const InterpArgs &a, int nproofs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_interp_weights, dim3(13, nproofs, 2), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(k_interp_ell, dim3(13, nproofs, 2), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_interp_weights, dim3(832, nproofs, 2), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_interp_ell, dim3(832, nproofs, 2), dim3(64), 0, st, a);
     const int mp = a.Mpad1 > a.Mpad2 ? a.Mpad1 : a.Mpad2, kp = a.KP1 > a.KP2 ? a.KP1 : a.KP2;
     hipLaunchKernelGGL(k_interp_matrix, dim3((mp + 255) / 256, kp, nproofs * 2), dim3(256), 0, st, a);
     return hipGetLastError();

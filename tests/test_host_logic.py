@@ -1,0 +1,136 @@
+"""Host-side logic of the PRODUCT library (no GPU needed): ABI surface, keygen, Fiat-Shamir derivations,
+tables.  The oracle is only the checker here."""
+import ctypes as C
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def api():
+    from mpcith_kyber_kosk_amd import api
+    return api
+
+
+def test_library_exports_every_declared_symbol(api):
+    hdr = open(os.path.join(ROOT, "include", "kosk_mi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(kosk_[a-z0-9_]+)\s*\(", hdr)) - {"kosk_randombytes_fn"}
+    assert len(declared) >= 30
+    for name in sorted(declared):
+        assert hasattr(api.lib, name), name
+    assert declared == set(api.EXPORTS), declared ^ set(api.EXPORTS)
+
+
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_sizes_and_field_layout(k, api, oracle):
+    p = oracle.params(k)
+    assert api.pk_bytes(k) == p.pk_bytes and api.sk_bytes(k) == p.sk_bytes
+    assert api.proof_bytes(k) == p.proof_bytes == {2: 664340, 3: 680980, 4: 744148}[k]
+    assert api.tape_bytes(k) == p.tape_bytes
+    for i in range(24):
+        assert api.proof_field(k, i) == (p.off[i], p.size[i])
+    assert api.lib.kosk_proof_bytes(5) == 0
+
+
+def test_create_without_gpu_fails_loudly(api):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.KoskError, match="no HIP device|no CPU fallback|hip"):
+        api.Kosk(kyber_k=2, max_batch=1)
+
+
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_host_keygen_matches_oracle(k, api, oracle):
+    for idx in range(3):
+        tape = oracle.tape_bytes_for(k, idx)
+        t = oracle.Tape(tape, 64, 0, 0, 0)
+        pk = C.create_string_buffer(api.pk_bytes(k)); sk = C.create_string_buffer(api.sk_bytes(k))
+        raw = np.zeros(16 * 256 + 3 * 4 * 256, np.int16)
+        oracle.lib.ko_keygen(k, C.byref(t), pk, sk, raw.ctypes.data_as(C.c_void_p))
+        pk2, sk2, A, s, e, tt = api.host_keygen(k, tape[:64])
+        assert pk2 == pk.raw and sk2 == sk.raw
+        A_or = raw[:16 * 256].reshape(4, 4, 256)[:k, :k].reshape(-1)
+        assert np.array_equal(A, A_or)
+        t_or = raw[16 * 256:20 * 256].reshape(4, 256)[:k].reshape(-1)
+        s_or = raw[20 * 256:24 * 256].reshape(4, 256)[:k].reshape(-1)
+        e_or = raw[24 * 256:28 * 256].reshape(4, 256)[:k].reshape(-1)
+        assert np.array_equal(tt, t_or) and np.array_equal(s, s_or) and np.array_equal(e, e_or)
+        assert np.abs(s).max() <= (3 if k == 2 else 2)
+        # sk quirk of kosk.cpp:67-69: the last 32 bytes are the noise seed, H(pk) before it
+        assert sk2[-64:-32] == hashlib.sha3_256(pk2).digest()
+
+
+@pytest.mark.parametrize("n", [0, 1, 135, 136, 137, 1000, 46528])
+def test_host_keccak(n, api):
+    d = bytes((i * 29 + 1) & 255 for i in range(n))
+    assert api.host_sha3_256(d) == hashlib.sha3_256(d).digest()
+    assert api.host_shake256(d, 302) == hashlib.shake_256(d).digest(302)
+
+
+@pytest.mark.parametrize("count,length,threads", [(1, 46528, 1), (46, 46528, 4), (13, 137, 2), (9, 0, 1), (5, 136, 3)])
+def test_host_multibuffer_sha3(count, length, threads, api):
+    data = bytes(os.urandom(count * length)) if length else b""
+    out = C.create_string_buffer(32 * count)
+    w = api.lib.kosk_host_sha3_256_multi(out, C.c_char_p(data), length, length, count, threads)
+    assert w in (1, 4, 8)
+    for i in range(count):
+        assert out.raw[32 * i:32 * i + 32] == hashlib.sha3_256(data[i * length:(i + 1) * length]).digest()
+
+
+def _ref_opened(dig):
+    ch = hashlib.sha3_256(dig).digest()
+    I_ = hashlib.shake_256(ch + b"\x01").digest(300)
+    I = [((I_[2 * i] << 8) | I_[2 * i + 1]) % 1454 for i in range(150)]
+    for i in range(1, 150):  # mlwe_prover.cpp:459-474, transcribed loop for loop
+        inc = 0
+        while True:
+            dup = False
+            for j in range(i):
+                if (I[i] + inc) % 1454 == I[j]:
+                    dup = True
+                    inc += 1
+                    break
+            if not dup:
+                break
+        I[i] = (I[i] + inc) % 1454
+    return I
+
+
+def test_fs_opened_matches_reference_loop_including_collisions(api):
+    hits = 0
+    for seed in range(40):
+        dig = hashlib.shake_256(b"dig%d" % seed).digest(1454 * 32)
+        I = (C.c_uint16 * 150)(); rest = (C.c_uint16 * 1304)()
+        api.lib.kosk_fs_opened(C.c_char_p(dig), I, rest)
+        ref = _ref_opened(dig)
+        assert list(I) == ref
+        assert sorted(set(range(1454)) - set(ref)) == list(rest)
+        ch = hashlib.sha3_256(dig).digest()
+        I_ = hashlib.shake_256(ch + b"\x01").digest(300)
+        raw = [((I_[2 * i] << 8) | I_[2 * i + 1]) % 1454 for i in range(150)]
+        hits += len(raw) != len(set(raw))
+    assert hits > 10  # the de-duplication path was really exercised (birthday bound ~ 7.4 collisions / 1000 draws)
+
+
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_fs_alpha(k, api):
+    dig = hashlib.shake_256(b"tcomm%d" % k).digest(1454 * 32)
+    J = 70 + 2 * k
+    alpha = (C.c_uint16 * 80)()
+    api.lib.kosk_fs_alpha(k, C.c_char_p(dig), alpha)
+    a_ = hashlib.shake_256(hashlib.sha3_256(dig).digest() + b"\x01").digest(2 * J)
+    assert list(alpha)[:J] == [((a_[2 * i] << 8) | a_[2 * i + 1]) % 3329 for i in range(J)]
+
+
+def test_lagrange_tables_match_oracle(api, oracle):
+    for which, shape in enumerate([(1303, 407), (256, 407), (256, 813)]):
+        t = np.zeros(shape, np.uint16)
+        assert api.lib.kosk_lagrange_table(which, t.ctypes.data) == 0
+        assert np.array_equal(t, oracle.table(which))

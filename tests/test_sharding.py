@@ -1,0 +1,65 @@
+"""Multi-rank plumbing on CPU: world_size 2 over gloo (the GPU path uses the same code with nccl = RCCL)."""
+import hashlib
+import os
+import socket
+
+import pytest
+
+
+def test_partitions():
+    from mpcith_kyber_kosk_amd import sharding as s
+    assert s.proof_partition(46, 1) == [(0, 46)]
+    assert s.proof_partition(47, 4) == [(0, 12), (12, 12), (24, 12), (36, 11)]
+    assert sum(c for _, c in s.proof_partition(4096, 8)) == 4096
+    assert s.lanes_to_proofs(65536) == 46 and s.lanes_to_proofs(2 ** 20) == 722
+    assert s.aligned_partition(2 ** 20, 8) == (91, 728)
+    for total in (1, 7, 46, 722):
+        for w in (1, 2, 3, 8):
+            parts = s.proof_partition(total, w)
+            assert parts[0][0] == 0 and all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            assert parts[-1][0] + parts[-1][1] == total
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from mpcith_kyber_kosk_amd import sharding as s
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per, padded = s.aligned_partition(5 * 1454, world)     # 5 proofs over 2 ranks -> 3 per rank, 6 padded
+    units = per * 1454
+    first = rank * units
+    # each rank "commits" its own lanes: digest = sha3_256(global lane id)
+    loc = torch.empty((units, 32), dtype=torch.uint8)
+    for i in range(0, units, 97):
+        loc[i] = torch.frombuffer(bytearray(hashlib.sha3_256(str(first + i).encode()).digest()), dtype=torch.uint8)
+    table = s.allgather_digest_table(loc, world, dist)
+    ok = table.shape == (padded * 1454, 32)
+    for gl in range(0, padded * 1454, 97 * 13):
+        r, i = divmod(gl, units)
+        if i % 97 == 0:
+            ok &= bytes(table[gl].tolist()) == hashlib.sha3_256(str(gl).encode()).digest()
+    # max-over-ranks timing reduction used by bench.py
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok &= float(t.item()) == float(world)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_allgather_world2_gloo():
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
