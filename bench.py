@@ -162,12 +162,14 @@ def main():
         kern = {}
         for name, (ms, cnt_) in prof.items():
             if cnt_:
-                kern[name] = {"avg_us": ms / cnt_ * 1e3, "launches": cnt_}
-        # dominant graded kernel: the SHA3-256 view commitment (K4); algorithmic bytes = message + digest per lane
+                kern[name] = {"avg_us": ms / cnt_ * 1e3, "launches": cnt_, "total_ms": ms}
+        # graded kernel: the SHA3-256 view commitment (K4); algorithmic bytes = message + digest per party lane.
+        # A step's lanes are spread over `streams` launches (one per sub-batch), so bytes/launch = total/launches.
         hv = kern.get("hash_view")
         roof = None
+        lanes_total = args.steps * B * 1454
         if hv:
-            nbytes = B * 1454 * (p_view + 32)
+            nbytes = lanes_total * (p_view + 32) / hv["launches"]
             ach = nbytes / (hv["avg_us"] * 1e-6) / 1e9
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "traffic.json")
@@ -175,15 +177,16 @@ def main():
                 traffic = json.load(open(tfile)).get("hash_view_hbm_bytes_per_launch")
             roof = {"kernel": "k_commit_hash<16,220> (SHA3-256 view commitment, one party lane per thread)",
                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": hv["avg_us"]}
+                    "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": hv["avg_us"],
+                    "lanes_per_launch": lanes_total / hv["launches"]}
             ht = kern.get("hash_tcomm")
             if ht:
-                ht["GBps"] = B * 1454 * (p_tcomm + 32) / (ht["avg_us"] * 1e-6) / 1e9
+                ht["GBps"] = lanes_total * (p_tcomm + 32) / (ht["total_ms"] * 1e-3) / 1e9
             hv["GBps"] = ach
         g1 = kern.get("gemm_expand1")
         if g1:
             rows = {2: 214 - 6, 3: 226 - 9, 4: 254 - 12}[k]
-            g1["useful_GMACps"] = B * rows * 1303 * 407 / (g1["avg_us"] * 1e-6) / 1e9
+            g1["useful_GMACps"] = args.steps * B * rows * 1303 * 407 / (g1["total_ms"] * 1e-3) / 1e9
         line = {
             "metric": "kyber768_kosk_proofs_per_sec_prove_plus_verify" if k == 3 else "kyber%d_kosk_proofs_per_sec_prove_plus_verify" % (256 * k),
             "value": total / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -192,7 +195,8 @@ def main():
             "config": {"workload": "Kyber-768 (KYBER_K=3), 46 proofs = 66 884 party lanes per GPU per step, "
                                    "prove (offline+online) + verify, inputs resident in HBM" if k == 3 and B == 46 else
                                    "KYBER_K=%d, %d proofs per GPU per step, prove + verify" % (k, B),
-                       "kyber_k": k, "proofs_per_gpu": B, "party_lanes_per_gpu": B * 1454, "sharding": "by proof"},
+                       "kyber_k": k, "proofs_per_gpu": B, "party_lanes_per_gpu": B * 1454, "sharding": "by proof",
+                       "streams_per_gpu": ctx.streams, "host_threads": os.environ.get("KOSK_HOST_THREADS", "auto(<=16)")},
             "roofline": roof,
             "kernels_in_pipeline": kern,
             "prove_phase_ms": dict(zip(["host_pre", "gpu_commit", "fs_alpha_host", "gpu_relation", "fs_open_host", "gpu_assemble", "d2h"],

@@ -101,7 +101,10 @@ int kosk_lagrange_expand(kosk_ctx *ctx, const uint16_t *d_y407, uint16_t *d_shar
 /* recon_secrets_ddeg / recon_secrets_2ddeg (ss.cpp:37-73): in n x 1454 u16, out n x 256 u16 */
 int kosk_recon_secrets(kosk_ctx *ctx, const uint16_t *d_shares, uint16_t *d_secrets, int n, int two_d);
 int kosk_device_synchronize(kosk_ctx *ctx);
-/* device pointer / stride of the resident proof images, for callers chaining work in HBM */
+/* number of sub-batches a handle keeps in flight on separate HIP streams (env KOSK_STREAMS, default 1) */
+int kosk_streams(const kosk_ctx *ctx);
+/* device pointer / stride of the resident proof images of sub-batch 0, for callers chaining work in HBM
+ * (with KOSK_STREAMS=1 this is the whole batch) */
 int kosk_resident_proofs(kosk_ctx *ctx, void **d_proofs, size_t *stride);
 
 /* ---- host-only pieces of the path (no device needed) ------------------------ */

@@ -50,6 +50,7 @@ def _load():
         "kosk_stream_timer_start": (C.c_int, [vp]),
         "kosk_stream_timer_stop": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "kosk_device_synchronize": (C.c_int, [vp]),
+        "kosk_streams": (C.c_int, [vp]),
         "kosk_resident_proofs": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
         "kosk_keygen": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp]),
         "kosk_fs_alpha": (C.c_int, [C.c_int, vp, vp]),
@@ -72,7 +73,7 @@ EXPORTS = ["kosk_pk_bytes", "kosk_sk_bytes", "kosk_proof_bytes", "kosk_tape_byte
            "kosk_verify_fail_masks", "kosk_stage_prover_inputs", "kosk_prove_resident", "kosk_fetch_proofs",
            "kosk_stage_verifier_inputs", "kosk_verify_resident", "kosk_phase_seconds", "kosk_sha3_256_batch",
            "kosk_shake256_batch", "kosk_commit_hash_lanes", "kosk_ntt256_batch", "kosk_lagrange_expand",
-           "kosk_recon_secrets", "kosk_profile_enable", "kosk_profile_read", "kosk_stream_timer_start", "kosk_stream_timer_stop", "kosk_device_synchronize", "kosk_resident_proofs", "kosk_keygen", "kosk_fs_alpha",
+           "kosk_recon_secrets", "kosk_profile_enable", "kosk_profile_read", "kosk_stream_timer_start", "kosk_stream_timer_stop", "kosk_device_synchronize", "kosk_streams", "kosk_resident_proofs", "kosk_keygen", "kosk_fs_alpha",
            "kosk_fs_opened", "kosk_host_sha3_256", "kosk_host_shake256", "kosk_host_sha3_256_multi", "kosk_lagrange_table"]
 
 
@@ -250,6 +251,10 @@ class Kosk:
         ms = C.c_double()
         self._chk(lib.kosk_stream_timer_stop(self._h, C.byref(ms)), "timer_stop")
         return ms.value
+
+    @property
+    def streams(self):
+        return lib.kosk_streams(self._h)
 
     def synchronize(self):
         self._chk(lib.kosk_device_synchronize(self._h), "synchronize")

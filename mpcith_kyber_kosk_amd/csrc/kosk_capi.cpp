@@ -3,14 +3,49 @@
 
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kosk_ctx.hpp"
 
 using namespace kosk;
 
+// A handle owns S sub-contexts (own stream + HBM workspace each).  A batch call splits its proofs into S
+// contiguous sub-batches that run concurrently on S host threads: while one sub-batch sits in a host
+// Fiat-Shamir round trip the GPU works on the other, and kernels of different streams share the CUs.
 struct kosk_ctx {
-    Ctx *c;
+    std::vector<Ctx *> sub;
+    Ctx *c; // sub[0]: kernel-level entry points, error text, sizes
+    int max_batch;
+    std::string err;
+
+    // [first, count) of sub-batch i of an n-proof call
+    void split(int n, int i, int &first, int &count) const
+    {
+        const int S = (int)sub.size();
+        const int base = n / S, rem = n % S;
+        count = base + (i < rem ? 1 : 0);
+        first = i * base + (i < rem ? i : rem);
+    }
+    template <typename F>
+    int run(int n, F &&fn)
+    {
+        const int S = (int)sub.size();
+        std::vector<int> rc(S, 0);
+        std::vector<std::thread> th;
+        for (int i = 1; i < S; i++) {
+            int first, count;
+            split(n, i, first, count);
+            if (count > 0) th.emplace_back([&, i, first, count] { rc[i] = fn(*sub[i], first, count); });
+        }
+        int first, count;
+        split(n, 0, first, count);
+        if (count > 0) rc[0] = fn(*sub[0], first, count);
+        for (auto &t : th) t.join();
+        for (int i = 0; i < S; i++)
+            if (rc[i]) { err = sub[i]->err; c->err = err; return -1; }
+        return 0;
+    }
 };
 
 static std::string g_create_err;
@@ -42,50 +77,105 @@ int kosk_proof_field(int k, int idx, size_t *offset, size_t *size)
 int kosk_create(kosk_ctx **ctx, int device, int kyber_k, int max_batch)
 {
     if (!ctx) return -1;
-    Ctx *c = nullptr;
-    if (ctx_create(&c, device, kyber_k, max_batch, g_create_err)) return -1;
-    *ctx = new kosk_ctx{c};
+    int S = 1; // KOSK_STREAMS: sub-batches in flight per handle (1 measured best at 46 proofs: kernels sit on latency floors)
+    if (const char *e = getenv("KOSK_STREAMS")) S = atoi(e) > 0 ? atoi(e) : S;
+    if (S > max_batch) S = max_batch > 0 ? max_batch : 1;
+    if (S > 8) S = 8;
+    kosk_ctx *h = new kosk_ctx();
+    h->max_batch = max_batch;
+    const int per = (max_batch + S - 1) / S;
+    for (int i = 0; i < S; i++) {
+        Ctx *c = nullptr;
+        if (ctx_create(&c, device, kyber_k, per, g_create_err)) {
+            for (Ctx *x : h->sub) delete x;
+            delete h;
+            return -1;
+        }
+        h->sub.push_back(c);
+    }
+    h->c = h->sub[0];
+    *ctx = h;
     return 0;
 }
 void kosk_destroy(kosk_ctx *ctx)
 {
     if (!ctx) return;
-    delete ctx->c;
+    for (Ctx *c : ctx->sub) delete c;
     delete ctx;
 }
-const char *kosk_last_error(const kosk_ctx *ctx) { return ctx ? ctx->c->err.c_str() : g_create_err.c_str(); }
+const char *kosk_last_error(const kosk_ctx *ctx)
+{
+    if (!ctx) return g_create_err.c_str();
+    return ctx->err.empty() ? ctx->c->err.c_str() : ctx->err.c_str();
+}
 int kosk_set_randombytes(kosk_ctx *ctx, kosk_randombytes_fn fn, void *user)
 {
     if (!ctx) return -1;
-    ctx->c->rb = fn;
-    ctx->c->rb_user = user;
+    for (Ctx *c : ctx->sub) { c->rb = fn; c->rb_user = user; }
     return 0;
 }
 
 int kosk_stage_prover_inputs(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk)
 {
-    return ctx ? stage_prover_inputs(*ctx->c, n, tapes, tape_stride, pk, sk) : -1;
+    if (!ctx || n < 1 || n > ctx->max_batch) return -1;
+    const Params &P = ctx->c->P;
+    if (!tapes) {
+        // the randombytes callback is stateful: draw every tape sequentially, in proof order, then stage in parallel
+        std::vector<uint8_t> drawn((size_t)n * P.tape_bytes);
+        Ctx &c0 = *ctx->c;
+        uint8_t *tp = drawn.data();
+        auto draw = [&](size_t len) { if (c0.rb) c0.rb(c0.rb_user, tp, len); else os_randombytes(tp, len); tp += len; };
+        for (int b = 0; b < n; b++) { // reference call order: kosk.cpp:12, mlwe_prover.cpp:9, ss.cpp:5
+            draw(64);
+            for (int i = 0; i < P.M; i++) draw(32);
+            for (int i = 0; i < P.nfresh; i++) draw(302);
+        }
+        return ctx->run(n, [&](Ctx &c, int first, int count) {
+            return stage_prover_inputs(c, count, drawn.data() + (size_t)first * P.tape_bytes, P.tape_bytes,
+                                       pk + (size_t)first * P.pk_bytes, sk + (size_t)first * P.sk_bytes);
+        });
+    }
+    return ctx->run(n, [&](Ctx &c, int first, int count) {
+        return stage_prover_inputs(c, count, tapes + (size_t)first * tape_stride, tape_stride,
+                                   pk + (size_t)first * P.pk_bytes, sk + (size_t)first * P.sk_bytes);
+    });
 }
-int kosk_prove_resident(kosk_ctx *ctx, int n) { return ctx ? prove_resident(*ctx->c, n) : -1; }
-int kosk_fetch_proofs(kosk_ctx *ctx, int n, uint8_t *pi) { return ctx ? fetch_proofs(*ctx->c, n, pi) : -1; }
+int kosk_prove_resident(kosk_ctx *ctx, int n)
+{
+    if (!ctx || n < 1 || n > ctx->max_batch) return -1;
+    return ctx->run(n, [&](Ctx &c, int, int count) { return prove_resident(c, count); });
+}
+int kosk_fetch_proofs(kosk_ctx *ctx, int n, uint8_t *pi)
+{
+    if (!ctx || n < 1 || n > ctx->max_batch) return -1;
+    const Params &P = ctx->c->P;
+    return ctx->run(n, [&](Ctx &c, int first, int count) { return fetch_proofs(c, count, pi + (size_t)first * P.proof_bytes); });
+}
 int kosk_stage_verifier_inputs(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk)
 {
-    return ctx ? stage_verifier_inputs(*ctx->c, n, pi, pk) : -1;
+    if (!ctx || n < 1 || n > ctx->max_batch) return -1;
+    const Params &P = ctx->c->P;
+    return ctx->run(n, [&](Ctx &c, int first, int count) {
+        return stage_verifier_inputs(c, count, pi + (size_t)first * P.proof_bytes, pk + (size_t)first * P.pk_bytes);
+    });
 }
-int kosk_verify_resident(kosk_ctx *ctx, int n, uint8_t *ok) { return ctx ? verify_resident(*ctx->c, n, ok) : -1; }
+int kosk_verify_resident(kosk_ctx *ctx, int n, uint8_t *ok)
+{
+    if (!ctx || n < 1 || n > ctx->max_batch) return -1;
+    return ctx->run(n, [&](Ctx &c, int first, int count) { return verify_resident(c, count, ok + first); });
+}
 
 int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride,
                                  uint8_t *pk, uint8_t *sk, uint8_t *pi)
 {
     if (!ctx || n < 0) return -1;
-    Ctx &c = *ctx->c;
-    const Params &P = c.P;
+    const Params &P = ctx->c->P;
     for (int done = 0; done < n;) {
-        const int m = (n - done) < c.max_batch ? (n - done) : c.max_batch;
+        const int m = (n - done) < ctx->max_batch ? (n - done) : ctx->max_batch;
         const uint8_t *tp = tapes ? tapes + (size_t)done * tape_stride : nullptr;
-        if (stage_prover_inputs(c, m, tp, tape_stride, pk + (size_t)done * P.pk_bytes, sk + (size_t)done * P.sk_bytes)) return -1;
-        if (prove_resident(c, m)) return -1;
-        if (fetch_proofs(c, m, pi + (size_t)done * P.proof_bytes)) return -1;
+        if (kosk_stage_prover_inputs(ctx, m, tp, tape_stride, pk + (size_t)done * P.pk_bytes, sk + (size_t)done * P.sk_bytes)) return -1;
+        if (kosk_prove_resident(ctx, m)) return -1;
+        if (kosk_fetch_proofs(ctx, m, pi + (size_t)done * P.proof_bytes)) return -1;
         done += m;
     }
     return 0;
@@ -94,12 +184,11 @@ int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, siz
 int kosk_verify_batch(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk, uint8_t *ok)
 {
     if (!ctx || n < 0) return -1;
-    Ctx &c = *ctx->c;
-    const Params &P = c.P;
+    const Params &P = ctx->c->P;
     for (int done = 0; done < n;) {
-        const int m = (n - done) < c.max_batch ? (n - done) : c.max_batch;
-        if (stage_verifier_inputs(c, m, pi + (size_t)done * P.proof_bytes, pk + (size_t)done * P.pk_bytes)) return -1;
-        if (verify_resident(c, m, ok + done)) return -1;
+        const int m = (n - done) < ctx->max_batch ? (n - done) : ctx->max_batch;
+        if (kosk_stage_verifier_inputs(ctx, m, pi + (size_t)done * P.proof_bytes, pk + (size_t)done * P.pk_bytes)) return -1;
+        if (kosk_verify_resident(ctx, m, ok + done)) return -1;
         done += m;
     }
     return 0;
@@ -107,8 +196,12 @@ int kosk_verify_batch(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk
 
 int kosk_verify_fail_masks(const kosk_ctx *ctx, uint32_t *masks, int n)
 {
-    if (!ctx || n < 0 || n > ctx->c->max_batch) return -1;
-    memcpy(masks, ctx->c->h_fail, sizeof(uint32_t) * (size_t)n);
+    if (!ctx || n < 0 || n > ctx->max_batch) return -1;
+    for (int i = 0; i < (int)ctx->sub.size(); i++) {
+        int first, count;
+        ctx->split(n, i, first, count);
+        if (count > 0) memcpy(masks + first, ctx->sub[i]->h_fail, sizeof(uint32_t) * (size_t)count);
+    }
     return 0;
 }
 
@@ -122,16 +215,21 @@ int kosk_phase_seconds(const kosk_ctx *ctx, double *out, int n)
 int kosk_profile_enable(kosk_ctx *ctx, int on)
 {
     if (!ctx) return -1;
-    Ctx &c = *ctx->c;
-    c.prof_on = on != 0;
-    for (int i = 0; i < PR_COUNT; i++) { c.prof_ms[i] = 0; c.prof_n[i] = 0; c.prof_used[i] = false; }
+    for (Ctx *cp : ctx->sub) {
+        Ctx &c = *cp;
+        c.prof_on = on != 0;
+        for (int i = 0; i < PR_COUNT; i++) { c.prof_ms[i] = 0; c.prof_n[i] = 0; c.prof_used[i] = false; }
+    }
     return 0;
 }
 int kosk_profile_read(const kosk_ctx *ctx, int id, double *total_ms, long *launches)
 {
     if (!ctx || id < 0 || id >= PR_COUNT) return -1;
-    if (total_ms) *total_ms = ctx->c->prof_ms[id];
-    if (launches) *launches = ctx->c->prof_n[id];
+    double ms = 0;
+    long cnt = 0;
+    for (const Ctx *c : ctx->sub) { ms += c->prof_ms[id]; cnt += c->prof_n[id]; }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = cnt;
     return 0;
 }
 
@@ -159,10 +257,13 @@ int kosk_stream_timer_stop(kosk_ctx *ctx, double *ms)
 int kosk_device_synchronize(kosk_ctx *ctx)
 {
     if (!ctx) return -1;
-    Ctx &c = *ctx->c;
-    HIPCHK_C(hipStreamSynchronize(c.stream));
+    for (Ctx *cp : ctx->sub) {
+        Ctx &c = *cp;
+        HIPCHK_C(hipStreamSynchronize(c.stream));
+    }
     return 0;
 }
+int kosk_streams(const kosk_ctx *ctx) { return ctx ? (int)ctx->sub.size() : -1; }
 
 int kosk_resident_proofs(kosk_ctx *ctx, void **d_proofs, size_t *stride)
 {
