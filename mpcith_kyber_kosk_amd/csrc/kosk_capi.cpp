@@ -1,6 +1,7 @@
 // extern "C" boundary (include/kosk_mi355x.h) over kosk::Ctx.
 #include "../../include/kosk_mi355x.h"
 
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -327,16 +328,14 @@ int kosk_lagrange_expand(kosk_ctx *ctx, const uint16_t *d_y407, uint16_t *d_shar
 {
     if (!ctx) return -1;
     Ctx &c = *ctx->c;
-    const int cap = c.max_batch * c.rm.nrows; // the row matrix doubles as scratch
+    const int cap_rows = c.max_batch * c.rm.nrows; // the row matrix doubles as scratch
+    const int cap = std::min<long>(cap_rows, (long)(c.limb_cap / (7 * 128)) - 64);
     for (int done = 0; done < n;) {
         const int m = (n - done) < cap ? (n - done) : cap;
         HIPCHK_C(launch_rows_copy(d_y407 + (size_t)done * XLEN, XLEN, c.d_P, RS, XLEN, m, c.stream));
-        GemmArgs ga{};
-        ga.A = c.t_expand.d; ga.Mpad = c.t_expand.Mpad; ga.M = c.t_expand.M; ga.KP = c.t_expand.KP;
-        ga.B = c.d_P; ga.b_gstride = 0; ga.b_rows = nullptr; ga.b_rstride = RS; ga.b_koff = 0;
-        ga.C = c.d_P; ga.c_gstride = 0; ga.c_rows = nullptr; ga.c_rstride = RS; ga.c_off = EXP_OFF;
-        ga.npg = m; ga.ngroups = 1; ga.grouped = 0;
-        HIPCHK_C(launch_gemm(ga, c.stream));
+        const GemmSrc gs{c.d_P, 0, nullptr, RS, 0, XLEN};
+        const GemmDst gd{c.d_P, 0, nullptr, RS, EXP_OFF};
+        if (gemm_modq(c, c.t_expand, gs, gd, m, 1)) return -1;
         HIPCHK_C(launch_rows_copy(c.d_P + NSEC, RS, d_shares + (size_t)done * NPARTY, NPARTY, NPARTY, m, c.stream));
         done += m;
     }
@@ -348,16 +347,14 @@ int kosk_recon_secrets(kosk_ctx *ctx, const uint16_t *d_shares, uint16_t *d_secr
     if (!ctx) return -1;
     Ctx &c = *ctx->c;
     const GemmTable &t = two_d ? c.t_recon_2d : c.t_recon_d;
-    const int cap = c.max_batch * c.rm.nrows;
+    const int cap_rows = c.max_batch * c.rm.nrows;
+    const int cap = std::min<long>(cap_rows, (long)(c.limb_cap / ((size_t)t.KS * 128)) - 64);
     for (int done = 0; done < n;) {
         const int m = (n - done) < cap ? (n - done) : cap;
         HIPCHK_C(launch_rows_copy(d_shares + (size_t)done * NPARTY, NPARTY, c.d_P + NSEC, RS, NPARTY, m, c.stream));
-        GemmArgs ga{};
-        ga.A = t.d; ga.Mpad = t.Mpad; ga.M = t.M; ga.KP = t.KP;
-        ga.B = c.d_P; ga.b_gstride = 0; ga.b_rows = nullptr; ga.b_rstride = RS; ga.b_koff = NSEC;
-        ga.C = c.d_P; ga.c_gstride = 0; ga.c_rows = nullptr; ga.c_rstride = RS; ga.c_off = 0;
-        ga.npg = m; ga.ngroups = 1; ga.grouped = 0;
-        HIPCHK_C(launch_gemm(ga, c.stream));
+        const GemmSrc gs{c.d_P, 0, nullptr, RS, NSEC, t.Kdim};
+        const GemmDst gd{c.d_P, 0, nullptr, RS, 0};
+        if (gemm_modq(c, t, gs, gd, m, 1)) return -1;
         HIPCHK_C(launch_rows_copy(c.d_P, RS, d_secrets + (size_t)done * NSEC, NSEC, NSEC, m, c.stream));
         done += m;
     }

@@ -62,7 +62,7 @@ Ctx::~Ctx()
         for (auto e : pe)
             if (e) (void)hipEventDestroy(e);
     void *dev[] = {t_expand.d, t_recon_d.d, t_recon_2d.d, d_fresh_rows, d_gemm1_rows, d_gemm2_rows, d_off, d_fields,
-                   d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_poly, d_t, d_alpha, d_I, d_rest, d_pwT,
+                   d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_poly, d_t, d_alpha, d_I, d_rest, d_pwT, d_limbs,
                    d_gather, d_gather2, d_W, d_W2, d_w, d_ell, d_sec, d_sec_u1, d_sec_u2, d_fail, d_inv, d_vfields,
                    d_vrowtab, d_rows_bg, d_rows_isrc, d_rows_idst, d_rows_u};
     for (void *p : dev)
@@ -77,12 +77,34 @@ Ctx::~Ctx()
 static int upload_table(Ctx &c, GemmTable &t, const std::vector<uint16_t> &A, int M, int Kdim)
 {
     t.M = M;
+    t.Kdim = Kdim;
     t.Mpad = (M + 127) / 128 * 128;
-    t.KP = ((Kdim + 31) / 32 * 32) / 2;
-    std::vector<uint32_t> pk;
-    pack_gemm_table(A, M, Kdim, t.Mpad, t.KP, pk);
+    t.KS = (Kdim + 63) / 64;
+    std::vector<uint8_t> pk;
+    pack_limb_table(A, M, Kdim, t.Mpad, t.KS, pk);
     HIPCHK(dalloc(&t.d, pk.size()));
-    HIPCHK(hipMemcpy(t.d, pk.data(), pk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t.d, pk.data(), pk.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int gemm_modq(Ctx &c, const uint8_t *A, size_t a_gstride, int Mpad, int M, int KS, const GemmSrc &s, const GemmDst &d,
+              int npg, int ngroups, bool grouped)
+{
+    if (npg <= 0 || ngroups <= 0) return 0;
+    const int npg_pad = grouped ? (npg + 63) / 64 * 64 : npg;
+    const int rows = ((grouped ? npg_pad * ngroups : npg * ngroups) + 63) / 64 * 64;
+    const int RT = rows / 16;
+    if ((size_t)RT * KS * 2048 > c.limb_cap) { c.err = "gemm_modq: limb staging buffer too small"; return -1; }
+    LimbArgs la{};
+    la.src = s.src; la.src_gstride = s.gstride; la.rows = s.rows; la.src_rstride = s.rstride; la.src_koff = s.koff;
+    la.ncols = s.ncols; la.KS = KS; la.dst = c.d_limbs; la.RT = RT; la.npg = npg; la.npg_pad = npg_pad; la.ngroups = ngroups;
+    HIPCHK(launch_rows_to_limbs(la, c.stream));
+    GemmArgs ga{};
+    ga.A = A; ga.a_gstride = a_gstride; ga.Mpad = Mpad; ga.M = M; ga.KS = KS;
+    ga.B = c.d_limbs; ga.BRT = RT;
+    ga.C = d.C; ga.c_gstride = d.gstride; ga.c_rows = d.rows; ga.c_rstride = d.rstride; ga.c_off = d.off;
+    ga.npg = npg; ga.npg_pad = npg_pad; ga.ngroups = ngroups; ga.grouped = grouped ? 1 : 0;
+    HIPCHK(launch_gemm(ga, c.stream));
     return 0;
 }
 
@@ -236,6 +258,9 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
         HIPCHK(dalloc(&c.d_I, B * c.sel_stride));
         HIPCHK(dalloc(&c.d_rest, B * c.sel_stride));
         HIPCHK(dalloc(&c.d_pwT, B * MAXM * 80));
+        // data operand of the largest GEMM: every fresh sharing of every proof (<= 256 per proof), 13 k-steps
+        c.limb_cap = ((B * 256 + 63) / 64 * 64 / 16) * (size_t)13 * 2048;
+        HIPCHK(dalloc(&c.d_limbs, c.limb_cap));
         HIPCHK(dalloc(&c.d_fail, B));
         HIPCHK(halloc(&c.h_tape, B * c.tape_stride));
         HIPCHK(halloc(&c.h_dig, B * NPARTY * 32));
@@ -334,26 +359,10 @@ int prove_resident(Ctx &c, int n)
     HIPCHK(launch_ntt(na, st));
     HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_poly, c.poly_stride, 0, c.d_P, c.proof_stride, rm.nttas, K, n, st)); // :284-285
 
-    GemmArgs ga{};
-    ga.A = c.t_expand.d;
-    ga.Mpad = c.t_expand.Mpad;
-    ga.M = c.t_expand.M;
-    ga.KP = c.t_expand.KP;
-    ga.B = c.d_P;
-    ga.b_gstride = c.proof_stride;
-    ga.b_rows = c.d_gemm1_rows;
-    ga.b_rstride = RS;
-    ga.b_koff = 0;
-    ga.C = c.d_P;
-    ga.c_gstride = c.proof_stride;
-    ga.c_rows = c.d_gemm1_rows;
-    ga.c_rstride = RS;
-    ga.c_off = EXP_OFF;
-    ga.npg = c.n_gemm1;
-    ga.ngroups = n;
-    ga.grouped = 0;
+    const GemmSrc xsrc{c.d_P, c.proof_stride, c.d_gemm1_rows, RS, 0, XLEN};
+    const GemmDst xdst{c.d_P, c.proof_stride, c.d_gemm1_rows, RS, EXP_OFF};
     c.prof_begin(PR_GEMM_EXPAND1);
-    HIPCHK(launch_gemm(ga, st));
+    if (gemm_modq(c, c.t_expand, xsrc, xdst, c.n_gemm1, n)) return -1;
     c.prof_end(PR_GEMM_EXPAND1);
     HIPCHK(launch_post_gates(c.d_P, c.proof_stride, rm, n, st));
 
@@ -410,11 +419,10 @@ int prove_resident(Ctx &c, int n)
     HIPCHK(launch_ntt(na, st));
     HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_poly, c.poly_stride, K, c.d_P, c.proof_stride, rm.nttasr, K, n, st)); // :287-288
     HIPCHK(launch_copy_tails(c.d_P, c.proof_stride, rm, n, st));
-    ga.b_rows = c.d_gemm2_rows;
-    ga.c_rows = c.d_gemm2_rows;
-    ga.npg = c.n_gemm2;
+    const GemmSrc x2src{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, 0, XLEN};
+    const GemmDst x2dst{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, EXP_OFF};
     c.prof_begin(PR_GEMM_EXPAND2);
-    HIPCHK(launch_gemm(ga, st));                // recompute_share_secrets_ddeg x 3K   :298-299,:315
+    if (gemm_modq(c, c.t_expand, x2src, x2dst, c.n_gemm2, n)) return -1; // recompute_share_secrets_ddeg x 3K   :298-299,:315
     c.prof_end(PR_GEMM_EXPAND2);
     HIPCHK(launch_post_relation(c.d_P, c.proof_stride, rm, n, st));
     ha.prefix = c.d_dig1;

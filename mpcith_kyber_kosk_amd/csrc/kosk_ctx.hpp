@@ -22,8 +22,22 @@ enum ProfId { PR_HASH_TCOMM = 0, PR_HASH_VIEW, PR_GEMM_EXPAND1, PR_GEMM_EXPAND2,
               PR_V_LINCOMB, PR_COUNT };
 
 struct GemmTable {
-    uint32_t *d = nullptr;
-    int M = 0, Mpad = 0, KP = 0;
+    uint8_t *d = nullptr; // limb matrix (kosk_device.hpp)
+    int M = 0, Mpad = 0, KS = 0, Kdim = 0;
+};
+
+// source rows / destination rows of one mod-q GEMM
+struct GemmSrc {
+    const uint16_t *src;
+    size_t gstride;
+    const int16_t *rows;
+    int rstride, koff, ncols;
+};
+struct GemmDst {
+    uint16_t *C;
+    size_t gstride;
+    const int16_t *rows;
+    int rstride, off;
 };
 
 struct Ctx {
@@ -59,6 +73,8 @@ struct Ctx {
     uint16_t *d_t = nullptr; // pk's t, canonical (verifier)
     uint16_t *d_alpha = nullptr, *d_I = nullptr, *d_rest = nullptr;
     int32_t *d_pwT = nullptr;
+    uint8_t *d_limbs = nullptr; // limb-matrix staging of the GEMM data operand
+    size_t limb_cap = 0;
     // verifier workspace (allocated on first use, kosk_verify.cpp)
     bool verify_ready = false;
     uint16_t *d_inv = nullptr;       // [Q] field inverses
@@ -70,9 +86,9 @@ struct Ctx {
     int16_t *d_rows_u = nullptr;     // us / ue rows (degree 2d)
     int n_interp_d = 0, n_interp_2d = 0;
     uint16_t *d_w = nullptr, *d_ell = nullptr;
-    uint32_t *d_W = nullptr, *d_W2 = nullptr; // per-proof interpolation operators in GEMM operand layout
+    uint8_t *d_W = nullptr, *d_W2 = nullptr; // per-proof interpolation operators as limb matrices
     size_t w_stride = 0, w2_stride = 0;
-    int w_Mpad = 0, w_KP = 0, w2_Mpad = 0, w2_KP = 0;
+    int w_Mpad = 0, w_KS = 0, w2_Mpad = 0, w2_KS = 0;
     uint16_t *d_gather = nullptr, *d_gather2 = nullptr;
     uint16_t *d_sec = nullptr, *d_sec_u1 = nullptr, *d_sec_u2 = nullptr;
     uint32_t *d_fail = nullptr;      // [proof] bit mask of failed checks (FailBit)
@@ -100,6 +116,14 @@ struct Ctx {
 };
 
 int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &err);
+
+// C[g][rows_d[i]][off + m] = sum_k A[m][k] * src[g][rows_s[i]][koff + k] mod q  (conversion to limbs + MFMA GEMM)
+int gemm_modq(Ctx &c, const uint8_t *A, size_t a_gstride, int Mpad, int M, int KS, const GemmSrc &s, const GemmDst &d,
+              int npg, int ngroups, bool grouped);
+inline int gemm_modq(Ctx &c, const GemmTable &t, const GemmSrc &s, const GemmDst &d, int npg, int ngroups)
+{
+    return gemm_modq(c, t.d, 0, t.Mpad, t.M, t.KS, s, d, npg, ngroups, false);
+}
 
 // host tapes -> pk/sk on host, tape + key material resident in HBM
 int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk);

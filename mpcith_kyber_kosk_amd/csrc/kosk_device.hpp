@@ -32,22 +32,52 @@ struct NttArgs {
     int out_canonical; // 1: [0,q) (encode_to_gf3329), 0: centred int16 (poly_ntt)
 };
 
+// ---- "limb matrix": the MFMA operand format of the mod-q GEMM -------------------------------
+// A matrix X[r][k] of field elements is stored as two int8 limbs of its centred representative
+// c = c0 + 64 c1 (c0 in [-32,31], c1 in [-26,26]) in 16-row x 64-k tiles of 1 KiB each:
+//   byte(r, k, limb) = ((kstep * RT + r/16) * 2 + limb) * 1024 + (r%16)*64 + ((k%64/16) ^ swz(r%16))*16 + k%16
+// kstep = k/64, RT = row tiles.  swz(r) = (-(r>>2)) & 3 makes the 16-byte fragment reads of
+// v_mfma_i32_16x16x64_i8 (lane l: row l&15, k-chunk l>>4) conflict-free for ds_read_b128.
+KOSK_HD inline int limb_swz(int r) { return (-(r >> 2)) & 3; }
+KOSK_HD inline size_t limb_offset(int r, int k, int limb, int RT)
+{
+    const int ks = k >> 6, kc = (k >> 4) & 3, rr = r & 15;
+    return ((size_t)(ks * RT + (r >> 4)) * 2 + limb) * 1024 + rr * 64 + ((kc ^ limb_swz(rr)) << 4) + (k & 15);
+}
+KOSK_HD inline void limb_split(int32_t centred, int &c0, int &c1)
+{
+    c0 = ((centred + 32) & 63) - 32;
+    c1 = (centred - c0) >> 6;
+}
+
+// rows of canonical u16 -> limb matrix (k_rows_to_limbs)
+struct LimbArgs {
+    const uint16_t *src;
+    size_t src_gstride;    // u16 between groups
+    const int16_t *rows;   // row index per i (null: i)
+    int src_rstride;       // u16 between rows
+    int src_koff;
+    int ncols;             // valid k (rest zero), padded to KS*64
+    int KS;
+    uint8_t *dst;
+    int RT;                // row tiles of the destination (= total rows / 16)
+    int npg, npg_pad, ngroups; // destination row = g*npg_pad + i
+};
+
+// C[n][c_off + m] = sum_k A[m][k] * B[n][k] mod q, both operands limb matrices
 struct GemmArgs {
-    const uint32_t *A; // Apk[KP][Mpad] centred int16 pairs
-    size_t a_gstride;  // u32 between groups (grouped mode), else unused
-    int Mpad, M, KP;   // KP multiple of 16
-    const uint16_t *B;
-    size_t b_gstride;
-    const int16_t *b_rows; // row index per n (null: n itself)
-    int b_rstride;         // u16 between B rows
-    int b_koff;
+    const uint8_t *A;  // table limb matrix, RT = Mpad/16
+    size_t a_gstride;  // bytes between per-group operands (grouped mode)
+    int Mpad, M, KS;   // Mpad multiple of 128; m < M is stored
+    const uint8_t *B;  // data limb matrix, rows n = g*npg_pad + i
+    int BRT;           // row tiles of B
     uint16_t *C;
     size_t c_gstride;
-    const int16_t *c_rows;
+    const int16_t *c_rows; // output row per i (null: i)
     int c_rstride;
     int c_off;
-    int npg, ngroups;
-    int grouped; // 1: blockIdx.z = group (per-group A), 0: n flattened over groups
+    int npg, npg_pad, ngroups;
+    int grouped; // 1: A + g*a_gstride (npg_pad must be a multiple of 64)
 };
 
 struct LincombArgs {
@@ -101,9 +131,9 @@ struct InterpArgs {
     int sel_stride;
     const uint16_t *inv; // [Q] inverse table
     uint16_t *w, *ell;   // [proof][2][832] weights / node polynomial values (set 0: 407 nodes, 1: 813 nodes)
-    uint32_t *W, *W2;    // [proof][KP][Mpad] GEMM operands
-    size_t w_stride, w2_stride;
-    int Mpad1, KP1, Mpad2, KP2;
+    uint8_t *W, *W2;     // per-proof operators as limb matrices (rows = evaluation point, k = node)
+    size_t w_stride, w2_stride; // bytes
+    int Mpad1, KS1, Mpad2, KS2;
 };
 
 hipError_t launch_disassemble(const VerifyArgs &v, const FieldDesc *fields, const int16_t *rowtab, int nfields,
@@ -134,6 +164,7 @@ hipError_t launch_witness_secrets(const int16_t *se, size_t se_stride, uint16_t 
 hipError_t launch_ntt(const NttArgs &a, hipStream_t st);
 hipError_t launch_matvec_ntt(const int16_t *A, size_t A_stride, const int16_t *v, size_t v_stride, int v_slot,
                              uint16_t *P, size_t proof_stride, int row0, int K, int nproofs, hipStream_t st);
+hipError_t launch_rows_to_limbs(const LimbArgs &a, hipStream_t st);
 hipError_t launch_gemm(const GemmArgs &a, hipStream_t st);
 hipError_t launch_pow_table(const uint16_t *alpha, int J, int M, int32_t *pwT, int nproofs, hipStream_t st);
 hipError_t launch_lincomb(const LincombArgs &a, int nproofs, hipStream_t st);

@@ -457,15 +457,18 @@ void lagrange_row(uint16_t *row, int n, int a, int t)
     }
 }
 
-void pack_gemm_table(const std::vector<uint16_t> &A, int M, int Kdim, int Mpad, int KP, std::vector<uint32_t> &out)
+void pack_limb_table(const std::vector<uint16_t> &A, int M, int Kdim, int Mpad, int KS, std::vector<uint8_t> &out)
 {
-    out.assign((size_t)KP * Mpad, 0);
+    const int RT = Mpad / 16;
+    out.assign((size_t)KS * RT * 2048, 0);
     for (int m = 0; m < M; m++)
-        for (int kp = 0; kp < KP; kp++) {
-            const int k0 = 2 * kp, k1 = 2 * kp + 1;
-            const int32_t v0 = k0 < Kdim ? gf_center(A[(size_t)m * Kdim + k0]) : 0;
-            const int32_t v1 = k1 < Kdim ? gf_center(A[(size_t)m * Kdim + k1]) : 0;
-            out[(size_t)kp * Mpad + m] = ((uint32_t)v0 & 0xFFFFu) | ((uint32_t)v1 << 16);
+        for (int k = 0; k < Kdim; k++) {
+            const int32_t c = gf_center(A[(size_t)m * Kdim + k]);
+            const int c0 = ((c + 32) & 63) - 32, c1 = (c - c0) >> 6;
+            const int ks = k >> 6, kc = (k >> 4) & 3, rr = m & 15;
+            const size_t base = ((size_t)(ks * RT + (m >> 4)) * 2) * 1024 + rr * 64 + ((kc ^ ((-(rr >> 2)) & 3)) << 4) + (k & 15);
+            out[base] = (uint8_t)(int8_t)c0;
+            out[base + 1024] = (uint8_t)(int8_t)c1;
         }
 }
 

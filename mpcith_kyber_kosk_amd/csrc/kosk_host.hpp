@@ -40,8 +40,8 @@ void fs_opened(const uint8_t *digests_all /* [1454][32] */, uint16_t I[NOPEN], u
 void lagrange_row(uint16_t *row, int n, int a, int t);
 uint16_t gf_inv_host(uint16_t a);
 
-// pack A[m][k] (canonical) into the GEMM operand Apk[KP][Mpad] of centred int16 pairs
-void pack_gemm_table(const std::vector<uint16_t> &A, int M, int Kdim, int Mpad, int KP, std::vector<uint32_t> &out);
+// pack A[m][k] (canonical) into the limb-matrix operand format of the MFMA GEMM (kosk_device.hpp)
+void pack_limb_table(const std::vector<uint16_t> &A, int M, int Kdim, int Mpad, int KS, std::vector<uint8_t> &out);
 
 // run fn(i) for i in [0,n) on up to nthreads threads of a persistent process-wide pool
 void parallel_for(int n, int nthreads, const std::function<void(int)> &fn);

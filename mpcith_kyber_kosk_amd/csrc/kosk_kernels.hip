@@ -9,7 +9,7 @@
 //   k_tape_randoms       ss.cpp:5-11
 //   k_ntt256        K5   kyber/ntt.c:80-95 + poly.c:261-265
 //   k_matvec_ntt    K6   polyvec.c:202-214 + poly.c:307-313
-//   k_gemm_modq     K1/K2 ss.cpp:23-32, :44-51, :63-70, :88-97 (+ verifier interpolation apply)
+//   k_rows_to_limbs, k_gemm_modq  K1/K2 ss.cpp:23-32, :44-51, :63-70, :88-97 (+ verifier interpolation apply)
 //   k_lincomb       K3   mlwe_prover.cpp:159-203 ; mlwe_verifier.cpp:68-89, :149-170
 //   k_witness_secrets, k_post_*  K7  ss.cpp:101-136 call sites in prove()
 //   k_assemble_*    K8   mlwe_prover.cpp:480-537
@@ -339,126 +339,146 @@ __global__ __launch_bounds__(128) void k_matvec_ntt(const int16_t *__restrict__ 
 }
 
 // =========================================================================
-// K1/K2  C[n][c_off + m] = sum_k A[m][k] * B[n][k]  mod q
-// A: centred int16 pairs packed along k, layout Apk[kp][Mpad] (k-pair major);
-// B rows: canonical u16, k contiguous; v_dot2c_i32_i16 accumulates two exact
-// products per lane per instruction (|sum| < 2^31 for <= 775 terms, reduced
-// mod q every 384 terms).  128 x 128 tile, 8 x 8 outputs per thread.
+// K1/K2  C[n][c_off + m] = sum_k A[m][k] * B[n][k]  mod q   on the matrix cores.
+// GF(3329) values are exact in two int8 limbs of the centred representative (c = c0 + 64 c1), so
+//   A*B = sum a0 b0 + 64 sum (a0 b1 + a1 b0) + 4096 sum a1 b1
+// is four v_mfma_i32_16x16x64_i8 per 16x16x64 block into three exact i32 accumulators
+// (|S0| <= 2^20, |S1| <= 2^21, |S2| <= 2^20 for k <= 832), recombined mod q (4096 = 767 mod q).
+// Both operands arrive pre-tiled as limb matrices (kosk_device.hpp); a workgroup computes 128 m x 64 n,
+// a wave 64 x 32 (4 x 2 MFMA blocks), double-buffered through LDS with plain 16-byte copies.
 // =========================================================================
-typedef short short2v __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ uint32_t center_pair(uint32_t w)
+// canonical u16 rows -> limb matrix; one thread per (row, 16-k chunk)
+__global__ __launch_bounds__(256) void k_rows_to_limbs(LimbArgs a)
 {
-    short2v x = __builtin_bit_cast(short2v, w);
-    short2v m = x > (short2v)(Q / 2);
-    x = x - (m & (short2v)(Q));
-    return __builtin_bit_cast(uint32_t, x);
+    const int t = threadIdx.x;
+    const int ks = blockIdx.x * 4 + (t >> 6);
+    const int rt = blockIdx.y; // destination row tile
+    if (ks >= a.KS) return;
+    const int rr = t & 15, kc = (t >> 4) & 3;
+    const int r = rt * 16 + rr;
+    const int g = r / a.npg_pad, i = r - g * a.npg_pad;
+    uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+    if (g < a.ngroups && i < a.npg) {
+        const int k0 = ks * 64 + kc * 16;
+        const uint16_t *src = a.src + (size_t)g * a.src_gstride + (size_t)(a.rows ? (int)a.rows[i] : i) * a.src_rstride + a.src_koff + k0;
+        uint16_t v[16];
+        if (k0 + 16 <= a.ncols && ((a.src_koff | a.src_rstride) & 7) == 0 && (a.src_gstride & 7) == 0) {
+            const uint4 x0 = *reinterpret_cast<const uint4 *>(src), x1 = *reinterpret_cast<const uint4 *>(src + 8);
+            const uint32_t w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+            for (int q = 0; q < 8; q++) { v[2 * q] = (uint16_t)w[q]; v[2 * q + 1] = (uint16_t)(w[q] >> 16); }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; q++) v[q] = (k0 + q < a.ncols) ? src[q] : (uint16_t)0;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            int c0, c1;
+            limb_split(gf_center(v[q] >= Q ? v[q] % Q : v[q]), c0, c1);
+            lo[q >> 2] |= ((uint32_t)c0 & 0xFFu) << (8 * (q & 3));
+            hi[q >> 2] |= ((uint32_t)c1 & 0xFFu) << (8 * (q & 3));
+        }
+    }
+    uint8_t *d = a.dst + ((size_t)(ks * a.RT + rt) * 2) * 1024 + rr * 64 + ((kc ^ limb_swz(rr)) << 4);
+    *reinterpret_cast<uint4 *>(d) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    *reinterpret_cast<uint4 *>(d + 1024) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
 }
 
-constexpr int GT = 128;  // tile edge
-constexpr int GKC = 16;  // k-pairs per chunk
+constexpr int GM_TM = 128, GM_TN = 64;            // workgroup tile
+constexpr int GM_A_BYTES = (GM_TM / 16) * 2048;    // 16 KiB per k-step
+constexpr int GM_B_BYTES = (GM_TN / 16) * 2048;    //  8 KiB per k-step
 
 __global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t As[2][GKC][GT];
-    __shared__ __attribute__((aligned(16))) uint32_t Bs[2][GKC][GT];
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int m_tile = blockIdx.x * GT;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2][GM_A_BYTES + GM_B_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w & 1, wn = w >> 1;
     const int grp = a.grouped ? (int)blockIdx.z : 0;
-    const uint32_t *__restrict__ Ap = a.A + (size_t)grp * a.a_gstride;
+    const int mt0 = blockIdx.x * (GM_TM / 16);     // first A row tile of this workgroup
+    const int nt0 = blockIdx.y * (GM_TN / 16) + (a.grouped ? grp * (a.npg_pad / 16) : 0);
+    const uint8_t *__restrict__ Ag = a.A + (size_t)grp * a.a_gstride;
+    const int ART = a.Mpad / 16;
 
-    // B staging role: row n_local = tid >> 1, 16 k (8 pairs) per half
-    const int bn = tid >> 1, bh = tid & 1;
-    const int n_stage = blockIdx.y * GT + bn;
-    bool b_valid;
-    size_t b_off;
-    {
-        int g, i;
-        if (a.grouped) { g = grp; i = n_stage; b_valid = i < a.npg; }
-        else { g = n_stage / a.npg; i = n_stage - g * a.npg; b_valid = n_stage < a.npg * a.ngroups; }
-        b_off = b_valid ? (size_t)g * a.b_gstride + (size_t)(a.b_rows ? (int)a.b_rows[i] : i) * a.b_rstride + a.b_koff : 0;
-    }
-    // A staging role: kp_local = tid >> 4, 8 words at m = (tid & 15) * 8
-    const int akp = tid >> 4, am = (tid & 15) * 8;
-
-    int32_t acc[8][8];
+    // staging: A 16 KiB = 4 x 16 B per thread, B 8 KiB = 2 x 16 B per thread, both contiguous per k-step
+    uint4 ra[4], rb[2];
+    auto gload = [&](int ks) {
+        const uint4 *ap = reinterpret_cast<const uint4 *>(Ag + ((size_t)ks * ART + mt0) * 2048);
+        const uint4 *bp = reinterpret_cast<const uint4 *>(a.B + ((size_t)ks * a.BRT + nt0) * 2048);
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+        for (int q = 0; q < 4; q++) ra[q] = ap[tid + 256 * q];
 #pragma unroll
-        for (int j = 0; j < 8; j++) acc[i][j] = 0;
-
-    uint4 ra0, ra1, rb0, rb1;
-    auto gload = [&](int chunk) {
-        const uint32_t *ap = Ap + (size_t)(chunk * GKC + akp) * a.Mpad + m_tile + am;
-        ra0 = *reinterpret_cast<const uint4 *>(ap);
-        ra1 = *reinterpret_cast<const uint4 *>(ap + 4);
-        if (b_valid) {
-            const uint16_t *bp = a.B + b_off + chunk * (2 * GKC) + bh * GKC;
-            rb0 = *reinterpret_cast<const uint4 *>(bp);
-            rb1 = *reinterpret_cast<const uint4 *>(bp + 8);
-        } else {
-            rb0 = make_uint4(0, 0, 0, 0);
-            rb1 = rb0;
-        }
+        for (int q = 0; q < 2; q++) rb[q] = bp[tid + 256 * q];
     };
     auto lstore = [&](int buf) {
-        *reinterpret_cast<uint4 *>(&As[buf][akp][am]) = ra0;
-        *reinterpret_cast<uint4 *>(&As[buf][akp][am + 4]) = ra1;
-        const uint32_t w[8] = {rb0.x, rb0.y, rb0.z, rb0.w, rb1.x, rb1.y, rb1.z, rb1.w};
+        uint4 *la = reinterpret_cast<uint4 *>(lds[buf]);
+        uint4 *lb = reinterpret_cast<uint4 *>(lds[buf] + GM_A_BYTES);
 #pragma unroll
-        for (int q = 0; q < 8; q++) Bs[buf][bh * 8 + q][bn] = center_pair(w[q]);
+        for (int q = 0; q < 4; q++) la[tid + 256 * q] = ra[q];
+#pragma unroll
+        for (int q = 0; q < 2; q++) lb[tid + 256 * q] = rb[q];
     };
 
-    const int nchunks = a.KP / GKC;
+    v4i s0[4][2], s1[4][2], s2[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) { s0[i][j] = (v4i){0, 0, 0, 0}; s1[i][j] = s0[i][j]; s2[i][j] = s0[i][j]; }
+
+    // fragment address inside a 1 KiB tile: row l&15, k-chunk l>>4 (swizzled)
+    const int frag = (lane & 15) * 64 + (((lane >> 4) ^ limb_swz(lane & 15)) << 4);
+
     gload(0);
     lstore(0);
     __syncthreads();
-    for (int chunk = 0; chunk < nchunks; chunk++) {
-        const int buf = chunk & 1;
-        if (chunk + 1 < nchunks) gload(chunk + 1);
+    for (int ks = 0; ks < a.KS; ks++) {
+        const int buf = ks & 1;
+        if (ks + 1 < a.KS) gload(ks + 1);
+        const uint8_t *la = lds[buf] + (wm * 4) * 2048 + frag;
+        const uint8_t *lb = lds[buf] + GM_A_BYTES + (wn * 2) * 2048 + frag;
+        v4i a0[4], a1[4], b0[2], b1[2];
 #pragma unroll
-        for (int kp = 0; kp < GKC; kp++) {
-            const uint4 a0 = *reinterpret_cast<const uint4 *>(&As[buf][kp][tx * 4]);
-            const uint4 a1 = *reinterpret_cast<const uint4 *>(&As[buf][kp][64 + tx * 4]);
-            const uint4 b0 = *reinterpret_cast<const uint4 *>(&Bs[buf][kp][ty * 4]);
-            const uint4 b1 = *reinterpret_cast<const uint4 *>(&Bs[buf][kp][64 + ty * 4]);
-            const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            const uint32_t bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    acc[i][j] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, bv[i]),
-                                                       __builtin_bit_cast(short2v, av[j]), acc[i][j], false);
+        for (int i = 0; i < 4; i++) {
+            a0[i] = *reinterpret_cast<const v4i *>(la + i * 2048);
+            a1[i] = *reinterpret_cast<const v4i *>(la + i * 2048 + 1024);
         }
-        if ((chunk % 12) == 11) {
 #pragma unroll
-            for (int i = 0; i < 8; i++)
-#pragma unroll
-                for (int j = 0; j < 8; j++) acc[i][j] %= Q;
+        for (int j = 0; j < 2; j++) {
+            b0[j] = *reinterpret_cast<const v4i *>(lb + j * 2048);
+            b1[j] = *reinterpret_cast<const v4i *>(lb + j * 2048 + 1024);
         }
-        if (chunk + 1 < nchunks) lstore(buf ^ 1);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                s0[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[i], b0[j], s0[i][j], 0, 0, 0);
+                s1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[i], b1[j], s1[i][j], 0, 0, 0);
+                s1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[i], b0[j], s1[i][j], 0, 0, 0);
+                s2[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[i], b1[j], s2[i][j], 0, 0, 0);
+            }
+        if (ks + 1 < a.KS) lstore(buf ^ 1);
         __syncthreads();
     }
 
-    // epilogue: canonical u16, four contiguous m per 8-byte store
+    // D[row = m: 4(l>>4)+r][col = n: l&15] -> four consecutive m per lane: one 8-byte store per block
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int n_local = (i < 4) ? ty * 4 + i : 64 + ty * 4 + (i - 4);
-        const int n = blockIdx.y * GT + n_local;
-        int g, r;
+    for (int j = 0; j < 2; j++) {
+        const int n_loc = blockIdx.y * GM_TN + wn * 32 + j * 16 + (lane & 15); // row inside the group (grouped) or flat
+        int g, i;
         bool valid;
-        if (a.grouped) { g = grp; r = n; valid = r < a.npg; }
-        else { g = n / a.npg; r = n - g * a.npg; valid = n < a.npg * a.ngroups; }
+        if (a.grouped) { g = grp; i = n_loc; valid = i < a.npg; }
+        else { g = n_loc / a.npg; i = n_loc - g * a.npg; valid = n_loc < a.npg * a.ngroups; }
         if (!valid) continue;
-        uint16_t *crow = a.C + (size_t)g * a.c_gstride + (size_t)(a.c_rows ? (int)a.c_rows[r] : r) * a.c_rstride + a.c_off;
+        uint16_t *crow = a.C + (size_t)g * a.c_gstride + (size_t)(a.c_rows ? (int)a.c_rows[i] : i) * a.c_rstride + a.c_off;
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int m0 = m_tile + h * 64 + tx * 4;
+        for (int ib = 0; ib < 4; ib++) {
+            const int m0 = blockIdx.x * GM_TM + wm * 64 + ib * 16 + (lane >> 4) * 4;
             if (m0 >= a.M) continue;
-            const uint32_t v0 = gf_from_i32(acc[i][4 * h + 0]), v1 = gf_from_i32(acc[i][4 * h + 1]);
-            const uint32_t v2 = gf_from_i32(acc[i][4 * h + 2]), v3 = gf_from_i32(acc[i][4 * h + 3]);
-            *reinterpret_cast<uint2 *>(crow + m0) = make_uint2(v0 | (v1 << 16), v2 | (v3 << 16));
+            uint32_t v[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = gf_from_i32(s0[ib][j][r] + 64 * s1[ib][j][r] + 767 * s2[ib][j][r]); // < 2^31 for k <= 832
+            *reinterpret_cast<uint2 *>(crow + m0) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
         }
     }
 }
@@ -721,11 +741,18 @@ hipError_t launch_matvec_ntt(const int16_t *A, size_t A_stride, const int16_t *v
     return hipGetLastError();
 }
 
+hipError_t launch_rows_to_limbs(const LimbArgs &a, hipStream_t st)
+{
+    if (a.RT <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rows_to_limbs, dim3((a.KS + 3) / 4, a.RT), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm(const GemmArgs &a, hipStream_t st)
 {
     const int ntot = a.grouped ? a.npg : a.npg * a.ngroups;
     if (ntot <= 0) return hipSuccess;
-    dim3 grid(a.Mpad / GT, (ntot + GT - 1) / GT, a.grouped ? a.ngroups : 1);
+    dim3 grid(a.Mpad / GM_TM, (ntot + GM_TN - 1) / GM_TN, a.grouped ? a.ngroups : 1);
     hipLaunchKernelGGL(k_gemm_modq, grid, dim3(256), 0, st, a);
     return hipGetLastError();
 }

@@ -106,10 +106,10 @@ static int ensure_verify_workspace(Ctx &c)
         upload_vec(c, &c.d_rows_u, urows))
         return -1;
 
-    c.w_Mpad = 512;  c.w_KP = 208;   // 407 evaluation points x 407 nodes (padded 416)
-    c.w2_Mpad = 256; c.w2_KP = 416;  // 256 evaluation points x 813 nodes (padded 832)
-    c.w_stride = (size_t)c.w_KP * c.w_Mpad;
-    c.w2_stride = (size_t)c.w2_KP * c.w2_Mpad;
+    c.w_Mpad = 512;  c.w_KS = 7;    // 407 evaluation points (pad 512) x 407 nodes (pad 448)
+    c.w2_Mpad = 256; c.w2_KS = 13;  // 256 evaluation points x 813 nodes (pad 832)
+    c.w_stride = (size_t)c.w_KS * (c.w_Mpad / 16) * 2048;
+    c.w2_stride = (size_t)c.w2_KS * (c.w2_Mpad / 16) * 2048;
     HIPCHK(dalloc(&c.d_W, B * c.w_stride));
     HIPCHK(dalloc(&c.d_W2, B * c.w2_stride));
     HIPCHK(dalloc(&c.d_w, B * 2 * 832));
@@ -223,44 +223,38 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     ia.W2 = c.d_W2;
     ia.w_stride = c.w_stride;
     ia.w2_stride = c.w2_stride;
-    ia.Mpad1 = c.w_Mpad; ia.KP1 = c.w_KP; ia.Mpad2 = c.w2_Mpad; ia.KP2 = c.w2_KP;
+    ia.Mpad1 = c.w_Mpad; ia.KS1 = c.w_KS; ia.Mpad2 = c.w2_Mpad; ia.KS2 = c.w2_KS;
     c.prof_begin(PR_V_INTERP_BUILD);
     HIPCHK(launch_interp_build(ia, n, st));
     c.prof_end(PR_V_INTERP_BUILD);
     HIPCHK(launch_gather_cols(c.d_P, c.proof_stride, c.d_rows_isrc, c.n_interp_d, c.d_rest, c.sel_stride, DEG + 1, 416, c.d_gather, n, st));
     HIPCHK(launch_gather_cols(c.d_P, c.proof_stride, c.d_rows_u, c.n_interp_2d, c.d_rest, c.sel_stride, DEG2 + 1, 832, c.d_gather2, n, st));
-    GemmArgs ga{};
-    ga.A = c.d_W; ga.a_gstride = c.w_stride; ga.Mpad = c.w_Mpad; ga.M = DEG + 1; ga.KP = c.w_KP;
-    ga.B = c.d_gather; ga.b_gstride = (size_t)c.n_interp_d * 416; ga.b_rows = nullptr; ga.b_rstride = 416; ga.b_koff = 0;
-    ga.C = c.d_P; ga.c_gstride = c.proof_stride; ga.c_rows = c.d_rows_idst; ga.c_rstride = RS; ga.c_off = 0;
-    ga.npg = c.n_interp_d; ga.ngroups = n; ga.grouped = 1;
-    c.prof_begin(PR_V_GEMM_INTERP);
-    HIPCHK(launch_gemm(ga, st)); // values at points 0..406 of every interpolated sharing
-    c.prof_end(PR_V_GEMM_INTERP);
-    ga = GemmArgs{};
-    ga.A = c.t_expand.d; ga.Mpad = c.t_expand.Mpad; ga.M = c.t_expand.M; ga.KP = c.t_expand.KP;
-    ga.B = c.d_P; ga.b_gstride = c.proof_stride; ga.b_rows = c.d_rows_idst; ga.b_rstride = RS; ga.b_koff = 0;
-    ga.C = c.d_P; ga.c_gstride = c.proof_stride; ga.c_rows = c.d_rows_idst; ga.c_rstride = RS; ga.c_off = EXP_OFF;
-    ga.npg = c.n_interp_d; ga.ngroups = n; ga.grouped = 0;
-    c.prof_begin(PR_V_GEMM_EXPAND);
-    HIPCHK(launch_gemm(ga, st)); // recompute_share_secrets_ddeg           :224-225, :351, :441-442
-    c.prof_end(PR_V_GEMM_EXPAND);
+    { // values at points 0..406 of every interpolated sharing, then recompute_share_secrets_ddeg   :224-225, :351, :441-442
+        const GemmSrc gs{c.d_gather, (size_t)c.n_interp_d * 416, nullptr, 416, 0, DEG + 1};
+        const GemmDst gd{c.d_P, c.proof_stride, c.d_rows_idst, RS, 0};
+        c.prof_begin(PR_V_GEMM_INTERP);
+        if (gemm_modq(c, c.d_W, c.w_stride, c.w_Mpad, DEG + 1, c.w_KS, gs, gd, c.n_interp_d, n, true)) return -1;
+        c.prof_end(PR_V_GEMM_INTERP);
+        const GemmSrc xs{c.d_P, c.proof_stride, c.d_rows_idst, RS, 0, XLEN};
+        const GemmDst xd{c.d_P, c.proof_stride, c.d_rows_idst, RS, EXP_OFF};
+        c.prof_begin(PR_V_GEMM_EXPAND);
+        if (gemm_modq(c, c.t_expand, xs, xd, c.n_interp_d, n)) return -1;
+        c.prof_end(PR_V_GEMM_EXPAND);
+    }
     HIPCHK(launch_check_rest(va, n, st));
     HIPCHK(launch_check_secrets(va, c.d_t, n, st));
     // degree-2d: u must interpolate to 0 on the packed positions, and reconstruct to 0   :497-571
-    ga = GemmArgs{};
-    ga.A = c.d_W2; ga.a_gstride = c.w2_stride; ga.Mpad = c.w2_Mpad; ga.M = NSEC; ga.KP = c.w2_KP;
-    ga.B = c.d_gather2; ga.b_gstride = (size_t)c.n_interp_2d * 832; ga.b_rows = nullptr; ga.b_rstride = 832; ga.b_koff = 0;
-    ga.C = c.d_sec_u1; ga.c_gstride = (size_t)c.n_interp_2d * 256; ga.c_rows = nullptr; ga.c_rstride = 256; ga.c_off = 0;
-    ga.npg = c.n_interp_2d; ga.ngroups = n; ga.grouped = 1;
-    HIPCHK(launch_gemm(ga, st));
+    {
+        const GemmSrc gs{c.d_gather2, (size_t)c.n_interp_2d * 832, nullptr, 832, 0, DEG2 + 1};
+        const GemmDst gd{c.d_sec_u1, (size_t)c.n_interp_2d * 256, nullptr, 256, 0};
+        if (gemm_modq(c, c.d_W2, c.w2_stride, c.w2_Mpad, NSEC, c.w2_KS, gs, gd, c.n_interp_2d, n, true)) return -1;
+    }
     HIPCHK(launch_check_zero(c.d_sec_u1, (size_t)c.n_interp_2d * 256, c.n_interp_2d, c.d_fail, FB_U_INTERP, n, st));
-    ga = GemmArgs{};
-    ga.A = c.t_recon_2d.d; ga.Mpad = c.t_recon_2d.Mpad; ga.M = c.t_recon_2d.M; ga.KP = c.t_recon_2d.KP;
-    ga.B = c.d_P; ga.b_gstride = c.proof_stride; ga.b_rows = c.d_rows_u; ga.b_rstride = RS; ga.b_koff = NSEC;
-    ga.C = c.d_sec_u2; ga.c_gstride = (size_t)c.n_interp_2d * 256; ga.c_rows = nullptr; ga.c_rstride = 256; ga.c_off = 0;
-    ga.npg = c.n_interp_2d; ga.ngroups = n; ga.grouped = 0;
-    HIPCHK(launch_gemm(ga, st));
+    {
+        const GemmSrc gs{c.d_P, c.proof_stride, c.d_rows_u, RS, NSEC, DEG2 + 1};
+        const GemmDst gd{c.d_sec_u2, (size_t)c.n_interp_2d * 256, nullptr, 256, 0};
+        if (gemm_modq(c, c.t_recon_2d, gs, gd, c.n_interp_2d, n)) return -1;
+    }
     HIPCHK(launch_check_zero(c.d_sec_u2, (size_t)c.n_interp_2d * 256, c.n_interp_2d, c.d_fail, FB_U_RECON, n, st));
     // NTT(s+r), NTT(e+r), A(s+r) and their re-sharing depend only on the interpolated rows   :257-271, :287-301
     NttArgs na{};
@@ -281,12 +275,11 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     HIPCHK(launch_ntt(na, st));
     HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_poly, c.poly_stride, K, c.d_P, c.proof_stride, rm.nttasr, K, n, st));
     HIPCHK(launch_copy_tails(c.d_P, c.proof_stride, rm, n, st));
-    ga = GemmArgs{};
-    ga.A = c.t_expand.d; ga.Mpad = c.t_expand.Mpad; ga.M = c.t_expand.M; ga.KP = c.t_expand.KP;
-    ga.B = c.d_P; ga.b_gstride = c.proof_stride; ga.b_rows = c.d_gemm2_rows; ga.b_rstride = RS; ga.b_koff = 0;
-    ga.C = c.d_P; ga.c_gstride = c.proof_stride; ga.c_rows = c.d_gemm2_rows; ga.c_rstride = RS; ga.c_off = EXP_OFF;
-    ga.npg = c.n_gemm2; ga.ngroups = n; ga.grouped = 0;
-    HIPCHK(launch_gemm(ga, st));
+    {
+        const GemmSrc xs{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, 0, XLEN};
+        const GemmDst xd{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, EXP_OFF};
+        if (gemm_modq(c, c.t_expand, xs, xd, c.n_gemm2, n)) return -1;
+    }
 
     // ---- host: alpha while the GPU works
     HIPCHK(hipEventSynchronize(c.ev));
@@ -307,14 +300,13 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     c.prof_begin(PR_V_LINCOMB);
     HIPCHK(launch_lincomb(la, n, st));
     c.prof_end(PR_V_LINCOMB);
-    ga = GemmArgs{};
-    ga.A = c.t_recon_d.d; ga.Mpad = c.t_recon_d.Mpad; ga.M = c.t_recon_d.M; ga.KP = c.t_recon_d.KP;
-    ga.B = c.d_P; ga.b_gstride = c.proof_stride; ga.b_rows = c.d_rows_bg; ga.b_rstride = RS; ga.b_koff = NSEC;
-    ga.C = c.d_sec; ga.c_gstride = (size_t)2 * NCHK * 256; ga.c_rows = nullptr; ga.c_rstride = 256; ga.c_off = 0;
-    ga.npg = 2 * NCHK; ga.ngroups = n; ga.grouped = 0;
-    c.prof_begin(PR_V_GEMM_RECON);
-    HIPCHK(launch_gemm(ga, st)); // recon_secrets_ddeg x 140   :106-107
-    c.prof_end(PR_V_GEMM_RECON);
+    {
+        const GemmSrc gs{c.d_P, c.proof_stride, c.d_rows_bg, RS, NSEC, XLEN};
+        const GemmDst gd{c.d_sec, (size_t)2 * NCHK * 256, nullptr, 256, 0};
+        c.prof_begin(PR_V_GEMM_RECON);
+        if (gemm_modq(c, c.t_recon_d, gs, gd, 2 * NCHK, n)) return -1; // recon_secrets_ddeg x 140   :106-107
+        c.prof_end(PR_V_GEMM_RECON);
+    }
     na = NttArgs{};
     na.in = reinterpret_cast<const int16_t *>(c.d_sec);
     na.in_gstride = (size_t)2 * NCHK * 256;

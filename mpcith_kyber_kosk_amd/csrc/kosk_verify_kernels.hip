@@ -83,17 +83,6 @@ __global__ __launch_bounds__(192) void k_gates_opened(VerifyArgs v)
 
 // ---- interpolation operators over the nodes x_j = 256 + rest[j] ----------------
 // barycentric form: p(k) = l(k) * sum_j w_j y_j / (k - x_j),  w_j = 1 / prod_{m != j} (x_j - x_m)
-__device__ __forceinline__ uint32_t gf_pow_dev(uint32_t a, uint32_t e)
-{
-    uint32_t r = 1;
-    while (e) {
-        if (e & 1) r = gf_mul(r, a);
-        a = gf_mul(a, a);
-        e >>= 1;
-    }
-    return r;
-}
-
 __device__ __forceinline__ uint32_t wave_product(uint32_t v)
 {
 #pragma unroll
@@ -132,33 +121,39 @@ __global__ __launch_bounds__(64) void k_interp_ell(InterpArgs a)
     if (lane == 0) ell[k] = (uint16_t)l;
 }
 
-// Apk[kp][k] = centred pair (Wop[k][2kp], Wop[k][2kp+1]),  Wop[k][j] = [x_j == k] or l(k) w_j / (k - x_j)
+// Operator rows in limb-matrix form (kosk_device.hpp): row = evaluation point k, column = node j,
+//   Wop[k][j] = [x_j == k]  or  l(k) w_j / (k - x_j).   One thread per (k, 16-node chunk).
 __global__ __launch_bounds__(256) void k_interp_matrix(InterpArgs a)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x, kp = blockIdx.y;
+    const int k = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ch = blockIdx.y * 4 + (threadIdx.x >> 6); // 16-node chunk
     const int b = blockIdx.z >> 1, set = blockIdx.z & 1;
     const int n = set ? DEG2 + 1 : DEG + 1, neval = set ? NSEC : DEG + 1;
-    const int Mpad = set ? a.Mpad2 : a.Mpad1, KP = set ? a.KP2 : a.KP1;
-    if (k >= Mpad || kp >= KP) return;
-    uint32_t *W = set ? a.W2 + (size_t)b * a.w2_stride : a.W + (size_t)b * a.w_stride;
-    uint32_t word = 0;
+    const int Mpad = set ? a.Mpad2 : a.Mpad1, KS = set ? a.KS2 : a.KS1;
+    if (k >= Mpad || ch >= KS * 4) return;
+    uint8_t *W = set ? a.W2 + (size_t)b * a.w2_stride : a.W + (size_t)b * a.w_stride;
+    uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
     if (k < neval) {
         const uint16_t *rest = a.rest + (size_t)b * a.sel_stride;
         const uint16_t *w = a.w + ((size_t)b * 2 + set) * 832;
         const uint32_t l = a.ell[((size_t)b * 2 + set) * 832 + k];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int j = 2 * kp + h;
+        for (int q = 0; q < 16; q++) {
+            const int j = ch * 16 + q;
             uint32_t e = 0;
             if (j < n) {
-                const uint32_t xj = NSEC + rest[j];
-                const uint32_t d = gf_sub((uint32_t)k, xj);
+                const uint32_t d = gf_sub((uint32_t)k, NSEC + rest[j]);
                 e = d == 0 ? 1u : gf_mul(gf_mul(l, w[j]), a.inv[d]);
             }
-            word |= ((uint32_t)gf_center(e) & 0xFFFFu) << (16 * h);
+            int c0, c1;
+            limb_split(gf_center(e), c0, c1);
+            lo[q >> 2] |= ((uint32_t)c0 & 0xFFu) << (8 * (q & 3));
+            hi[q >> 2] |= ((uint32_t)c1 & 0xFFu) << (8 * (q & 3));
         }
     }
-    W[(size_t)kp * Mpad + k] = word;
+    uint8_t *d = W + limb_offset(k, ch * 16, 0, Mpad / 16);
+    *reinterpret_cast<uint4 *>(d) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    *reinterpret_cast<uint4 *>(d + 1024) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
 }
 
 // out[b][r][j] = P[b][rows[r]][256 + rest[b][j]] for j < ncols, zero padded to out_cols
@@ -262,8 +257,8 @@ hipError_t launch_interp_build(const InterpArgs &a, int nproofs, hipStream_t st)
 {
     hipLaunchKernelGGL(k_interp_weights, dim3(832, nproofs, 2), dim3(64), 0, st, a);
     hipLaunchKernelGGL(k_interp_ell, dim3(832, nproofs, 2), dim3(64), 0, st, a);
-    const int mp = a.Mpad1 > a.Mpad2 ? a.Mpad1 : a.Mpad2, kp = a.KP1 > a.KP2 ? a.KP1 : a.KP2;
-    hipLaunchKernelGGL(k_interp_matrix, dim3((mp + 255) / 256, kp, nproofs * 2), dim3(256), 0, st, a);
+    const int mp = a.Mpad1 > a.Mpad2 ? a.Mpad1 : a.Mpad2, ks = a.KS1 > a.KS2 ? a.KS1 : a.KS2;
+    hipLaunchKernelGGL(k_interp_matrix, dim3((mp + 63) / 64, ks, nproofs * 2), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 hipError_t launch_gather_cols(const uint16_t *P, size_t proof_stride, const int16_t *rows, int nrows, const uint16_t *rest,
