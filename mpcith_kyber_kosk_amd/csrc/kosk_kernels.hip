@@ -15,6 +15,8 @@
 //   k_assemble_*    K8   mlwe_prover.cpp:480-537
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kosk_device.hpp"
 #include "kosk_keccak_dev.hpp"
 #include "kosk_math.hpp"
@@ -398,27 +400,24 @@ __global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
     const int grp = a.grouped ? (int)blockIdx.z : 0;
     const int mt0 = blockIdx.x * (GM_TM / 16);     // first A row tile of this workgroup
     const int nt0 = blockIdx.y * (GM_TN / 16) + (a.grouped ? grp * (a.npg_pad / 16) : 0);
-    const uint8_t *__restrict__ Ag = a.A + (size_t)grp * a.a_gstride;
     const int ART = a.Mpad / 16;
-
-    // staging: A 16 KiB = 4 x 16 B per thread, B 8 KiB = 2 x 16 B per thread, both contiguous per k-step
-    uint4 ra[4], rb[2];
-    auto gload = [&](int ks) {
-        const uint4 *ap = reinterpret_cast<const uint4 *>(Ag + ((size_t)ks * ART + mt0) * 2048);
-        const uint4 *bp = reinterpret_cast<const uint4 *>(a.B + ((size_t)ks * a.BRT + nt0) * 2048);
-#pragma unroll
-        for (int q = 0; q < 4; q++) ra[q] = ap[tid + 256 * q];
-#pragma unroll
-        for (int q = 0; q < 2; q++) rb[q] = bp[tid + 256 * q];
-    };
-    auto lstore = [&](int buf) {
-        uint4 *la = reinterpret_cast<uint4 *>(lds[buf]);
-        uint4 *lb = reinterpret_cast<uint4 *>(lds[buf] + GM_A_BYTES);
-#pragma unroll
-        for (int q = 0; q < 4; q++) la[tid + 256 * q] = ra[q];
-#pragma unroll
-        for (int q = 0; q < 2; q++) lb[tid + 256 * q] = rb[q];
-    };
+    // staging: A 16 KiB = 4 x 16 B per thread, B 8 KiB = 2 x 16 B per thread, both contiguous per k-step.
+    // (named registers on purpose: arrays captured by a lambda end up in scratch memory)
+    const uint4 *__restrict__ ap = reinterpret_cast<const uint4 *>(a.A + (size_t)grp * a.a_gstride + (size_t)mt0 * 2048) + tid;
+    const uint4 *__restrict__ bp = reinterpret_cast<const uint4 *>(a.B + (size_t)nt0 * 2048) + tid;
+    const size_t a_step = (size_t)ART * 128, b_step = (size_t)a.BRT * 128; // uint4 per k-step
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1;
+#define GM_GLOAD()                                                           \
+    ra0 = ap[0]; ra1 = ap[256]; ra2 = ap[512]; ra3 = ap[768];                \
+    rb0 = bp[0]; rb1 = bp[256];                                              \
+    ap += a_step; bp += b_step;
+#define GM_LSTORE(buf)                                                       \
+    {                                                                        \
+        uint4 *la_ = reinterpret_cast<uint4 *>(lds[buf]) + tid;              \
+        uint4 *lb_ = reinterpret_cast<uint4 *>(lds[buf] + GM_A_BYTES) + tid; \
+        la_[0] = ra0; la_[256] = ra1; la_[512] = ra2; la_[768] = ra3;        \
+        lb_[0] = rb0; lb_[256] = rb1;                                        \
+    }
 
     v4i s0[4][2], s1[4][2], s2[4][2];
 #pragma unroll
@@ -429,12 +428,12 @@ __global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
     // fragment address inside a 1 KiB tile: row l&15, k-chunk l>>4 (swizzled)
     const int frag = (lane & 15) * 64 + (((lane >> 4) ^ limb_swz(lane & 15)) << 4);
 
-    gload(0);
-    lstore(0);
+    GM_GLOAD();
+    GM_LSTORE(0);
     __syncthreads();
     for (int ks = 0; ks < a.KS; ks++) {
         const int buf = ks & 1;
-        if (ks + 1 < a.KS) gload(ks + 1);
+        if (ks + 1 < a.KS) { GM_GLOAD(); }
         const uint8_t *la = lds[buf] + (wm * 4) * 2048 + frag;
         const uint8_t *lb = lds[buf] + GM_A_BYTES + (wn * 2) * 2048 + frag;
         v4i a0[4], a1[4], b0[2], b1[2];
@@ -457,9 +456,13 @@ __global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
                 s1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[i], b0[j], s1[i][j], 0, 0, 0);
                 s2[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[i], b1[j], s2[i][j], 0, 0, 0);
             }
-        if (ks + 1 < a.KS) lstore(buf ^ 1);
+        if (ks + 1 < a.KS) {
+            if (buf) { GM_LSTORE(0); } else { GM_LSTORE(1); }
+        }
         __syncthreads();
     }
+#undef GM_GLOAD
+#undef GM_LSTORE
 
     // D[row = m: 4(l>>4)+r][col = n: l&15] -> four consecutive m per lane: one 8-byte store per block
 #pragma unroll
