@@ -5,6 +5,9 @@ One "step" = one pass of the hot path over one batch of synthetic input per GPU:
 B = 46 independent Kyber-768 verifiable-keygen proofs (46 x 1454 = 66 884 party
 lanes >= the 65 536 of BASELINE.json configs[2]) are PROVED and then VERIFIED, with the
 randomness tapes, key material and (for verify) proof images already resident in HBM.
+Several whole batches are kept in flight per GPU (--slots, one HIP stream each): the protocol has
+two host Fiat-Shamir round trips per prove and per verify, and a slot's host phase hides under
+another slot's kernels.  Every step is still a complete prove + verify of its own 46 proofs.
 Ranks shard by proof (independent units, no data-path collective): scaling = weak.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
@@ -98,6 +101,9 @@ def main():
     ap.add_argument("--cpu-proofs", type=int, default=12, help="bounded CPU baseline sample (about 13 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--slots", type=int, default=int(os.environ.get("KOSK_BENCH_SLOTS", "3")),
+                    help="independent batches kept in flight per GPU (own HIP stream + host threads each); "
+                         "steps are dealt round-robin to the slots")
     args = ap.parse_args()
 
     import torch
@@ -116,34 +122,67 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from mpcith_kyber_kosk_amd import api
-    k, B = args.kyber_k, args.batch
-    ctx = api.Kosk(kyber_k=k, max_batch=B, device=local_rank)
-    tapes = tapes_for(k, rank * B, B, ctx.tape_bytes)
-    ctx.stage_prover_inputs(tapes)  # randomness tapes + key material -> HBM (outside the timed region)
+    import threading
+    k, B, S = args.kyber_k, args.batch, max(1, args.slots)
+    # S pipeline slots: each owns a context (HIP stream, HBM workspace, host worker threads) and a resident
+    # batch of B proofs' inputs.  While one slot waits for a host Fiat-Shamir round, the GPU runs another's kernels.
+    slots = [api.Kosk(kyber_k=k, max_batch=B, device=local_rank) for _ in range(S)]
+    ctx = slots[0]
+    tapes = None
+    for si, c in enumerate(slots):
+        t = tapes_for(k, (rank * S + si) * B, B, c.tape_bytes)
+        if si == 0:
+            tapes = t
+        c.stage_prover_inputs(t)  # randomness tapes + key material -> HBM (outside the timed region)
 
-    def step():
-        ctx.prove_resident(B)
-        ok = ctx.verify_resident(B)
+    def step(c):
+        c.prove_resident(B)
+        ok = c.verify_resident(B)
         if not all(ok):
             raise RuntimeError("rank %d: verifier rejected %d of %d honest proofs" % (rank, ok.count(False), B))
 
+    def run_steps(nsteps):
+        """deal nsteps whole batches round-robin to the slots; returns when all are proved and verified"""
+        errs = []
+
+        def worker(si):
+            try:
+                for _ in range(si, nsteps, S):
+                    step(slots[si])
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+        if S == 1:
+            worker(0)
+        else:
+            th = [threading.Thread(target=worker, args=(si,)) for si in range(S)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        if errs:
+            raise errs[0]
+
     def barrier():
         torch.cuda.synchronize()
-        ctx.synchronize()
+        for c in slots:
+            c.synchronize()
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    ctx.profile_enable(True)
+    run_steps(args.warmup)
+    for c in slots:
+        c.profile_enable(True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    prof = ctx.profile_read()
-    ctx.profile_enable(False)
+    prof = {}
+    for c in slots:
+        for name, (ms, cnt_) in c.profile_read().items():
+            a, b = prof.get(name, (0.0, 0))
+            prof[name] = (a + ms, b + cnt_)
+        c.profile_enable(False)
     phases = ctx.phase_seconds()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -196,7 +235,7 @@ def main():
                                    "prove (offline+online) + verify, inputs resident in HBM" if k == 3 and B == 46 else
                                    "KYBER_K=%d, %d proofs per GPU per step, prove + verify" % (k, B),
                        "kyber_k": k, "proofs_per_gpu": B, "party_lanes_per_gpu": B * 1454, "sharding": "by proof",
-                       "streams_per_gpu": ctx.streams, "host_threads": os.environ.get("KOSK_HOST_THREADS", "auto(<=16)")},
+                       "pipeline_slots_per_gpu": S, "host_threads_per_slot": os.environ.get("KOSK_HOST_THREADS", "auto(<=16)")},
             "roofline": roof,
             "kernels_in_pipeline": kern,
             "prove_phase_ms": dict(zip(["host_pre", "gpu_commit", "fs_alpha_host", "gpu_relation", "fs_open_host", "gpu_assemble", "d2h"],
@@ -210,7 +249,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for c in slots:
+        c.close()
 
 
 if __name__ == "__main__":

@@ -70,6 +70,7 @@ Ctx::~Ctx()
     void *host[] = {h_tape, h_dig, h_proof, h_A, h_se, h_t, h_alpha, h_I, h_rest, h_fail, h_Iimg};
     for (void *p : host)
         if (p) (void)hipHostFree(p);
+    if (pool) pool_destroy(pool);
     if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -225,6 +226,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     c.device = device;
     c.max_batch = max_batch;
     c.rm = make_rowmap(c.P);
+    c.pool = pool_create();
     unsigned hc = std::thread::hardware_concurrency();
     c.nthreads = hc ? (int)(hc > 16 ? 16 : hc) : 1;
     if (const char *e = getenv("KOSK_HOST_THREADS")) c.nthreads = atoi(e) > 0 ? atoi(e) : c.nthreads;
@@ -302,7 +304,7 @@ int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride,
             for (int i = 0; i < P.nfresh; i++) draw(302);
         }
     }
-    parallel_for(n, c.nthreads, [&](int b) {
+    parallel_for(c.pool, n, c.nthreads, [&](int b) {
         uint8_t *tp = c.h_tape + (size_t)b * c.tape_stride;
         if (tapes) {
             memcpy(tp, tapes + (size_t)b * tape_stride, P.tape_bytes);
@@ -384,7 +386,7 @@ int prove_resident(Ctx &c, int n)
     t1 = now_sec(); c.phase_sec[PH_GPU_COMMIT] = t1 - t0; t0 = t1;
 
     // ---- Fiat-Shamir round 1 on the host
-    fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads);
+    fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool);
     t1 = now_sec(); c.phase_sec[PH_FS_ALPHA] = t1 - t0; t0 = t1;
     HIPCHK(hipMemcpyAsync(c.d_alpha, c.h_alpha, (size_t)n * 80 * 2, hipMemcpyHostToDevice, st));
 
@@ -435,7 +437,7 @@ int prove_resident(Ctx &c, int n)
     t1 = now_sec(); c.phase_sec[PH_GPU_RELATION] = t1 - t0; t0 = t1;
 
     // ---- Fiat-Shamir round 2 on the host
-    fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, c.h_I, c.h_rest, c.sel_stride, c.nthreads);
+    fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, c.h_I, c.h_rest, c.sel_stride, c.nthreads, c.pool);
     t1 = now_sec(); c.phase_sec[PH_FS_OPEN] = t1 - t0; t0 = t1;
     HIPCHK(hipMemcpyAsync(c.d_I, c.h_I, (size_t)n * c.sel_stride * 2, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c.d_rest, c.h_rest, (size_t)n * c.sel_stride * 2, hipMemcpyHostToDevice, st));

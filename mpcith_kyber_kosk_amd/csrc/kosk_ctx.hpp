@@ -46,6 +46,7 @@ struct Ctx {
     RowMap rm{};
     int max_batch = 0;
     int nthreads = 1;
+    Pool *pool = nullptr; // this context's host worker threads
     hipStream_t stream = nullptr;
     std::string err;
     randombytes_fn rb = nullptr;

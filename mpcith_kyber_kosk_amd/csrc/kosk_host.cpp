@@ -365,21 +365,23 @@ void sha3_256_multi(uint8_t *out, const uint8_t *const *in, size_t len, int coun
 
 // the SIMD width is chosen so that the groups roughly fill the available threads: the 343-permutation
 // chains are sequential per proof, so latency = one chain whatever the width
-static void sha3_digest_tables(int n, const uint8_t *digs, size_t dig_stride, uint8_t *out, int nthreads)
+static void sha3_digest_tables(int n, const uint8_t *digs, size_t dig_stride, uint8_t *out, int nthreads, Pool *pool)
 {
     std::vector<const uint8_t *> in(n);
     for (int b = 0; b < n; b++) in[b] = digs + (size_t)b * dig_stride;
     int w = sha3_multi_width();
-    if (w == 8 && (n + 3) / 4 <= nthreads) w = 4;
+    static const int forced = getenv("KOSK_FS_WIDTH") ? atoi(getenv("KOSK_FS_WIDTH")) : 0;
+    if (forced == 8 || forced == 4 || forced == 1) w = forced <= w ? forced : w;
+    else if (w == 8 && (n + 3) / 4 <= nthreads) w = 4;
     if (w > 1 && n <= nthreads && !caps().avx512f) w = 1;
     const int groups = (n + w - 1) / w;
-    parallel_for(groups, nthreads, [&](int g) { sha3_group(out, in.data(), (size_t)NPARTY * 32, n, w, g); });
+    parallel_for(pool, groups, nthreads, [&](int g) { sha3_group(out, in.data(), (size_t)NPARTY * 32, n, w, g); });
 }
 
-void fs_alpha_batch(const Params &P, int n, const uint8_t *digs, size_t dig_stride, uint16_t *alpha, size_t alpha_stride, int nthreads)
+void fs_alpha_batch(const Params &P, int n, const uint8_t *digs, size_t dig_stride, uint16_t *alpha, size_t alpha_stride, int nthreads, Pool *pool)
 {
     std::vector<uint8_t> h((size_t)n * 32);
-    sha3_digest_tables(n, digs, dig_stride, h.data(), nthreads);
+    sha3_digest_tables(n, digs, dig_stride, h.data(), nthreads, pool);
     for (int b = 0; b < n; b++) {
         uint8_t a_[2 * MAXJ];
         shake256_prf(a_, (size_t)2 * P.J, &h[(size_t)b * 32], 1);
@@ -405,10 +407,10 @@ static void opened_from_ch(const uint8_t ch[32], uint16_t I[NOPEN], uint16_t res
         if (!used[p]) rest[j++] = (uint16_t)p;
 }
 
-void fs_opened_batch(int n, const uint8_t *digs, size_t dig_stride, uint16_t *I, uint16_t *rest, size_t sel_stride, int nthreads)
+void fs_opened_batch(int n, const uint8_t *digs, size_t dig_stride, uint16_t *I, uint16_t *rest, size_t sel_stride, int nthreads, Pool *pool)
 {
     std::vector<uint8_t> h((size_t)n * 32);
-    sha3_digest_tables(n, digs, dig_stride, h.data(), nthreads);
+    sha3_digest_tables(n, digs, dig_stride, h.data(), nthreads, pool);
     for (int b = 0; b < n; b++) opened_from_ch(&h[(size_t)b * 32], I + (size_t)b * sel_stride, rest + (size_t)b * sel_stride);
 }
 
@@ -473,12 +475,22 @@ void pack_limb_table(const std::vector<uint16_t> &A, int M, int Kdim, int Mpad, 
 }
 
 // -------------------------------------------------------------------- misc --
-namespace {
 // Persistent worker pool: Fiat-Shamir rounds arrive in short bursts between GPU phases, so the
 // workers spin briefly on a generation counter before they block.
 class Pool {
 public:
     static Pool &get() { static Pool p; return p; }
+    Pool() = default;
+    ~Pool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+            gen_.fetch_add(1);
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
     void run(int n, int nthreads, const std::function<void(int)> &fn)
     {
         std::lock_guard<std::mutex> job(job_mu_);
@@ -500,17 +512,6 @@ public:
     }
 
 private:
-    Pool() = default;
-    ~Pool()
-    {
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            stop_ = true;
-            gen_.fetch_add(1);
-        }
-        cv_.notify_all();
-        for (auto &t : th_) t.join();
-    }
     void grow(int want)
     {
         while ((int)th_.size() < want && th_.size() < 255) {
@@ -562,9 +563,11 @@ private:
     int n_ = 0, want_ = 0;
     bool stop_ = false;
 };
-} // namespace
 
-void parallel_for(int n, int nthreads, const std::function<void(int)> &fn)
+Pool *pool_create() { return new Pool(); }
+void pool_destroy(Pool *p) { delete p; }
+
+void parallel_for(Pool *pool, int n, int nthreads, const std::function<void(int)> &fn)
 {
     if (n <= 0) return;
     if (nthreads > n) nthreads = n;
@@ -572,7 +575,7 @@ void parallel_for(int n, int nthreads, const std::function<void(int)> &fn)
         for (int i = 0; i < n; i++) fn(i);
         return;
     }
-    Pool::get().run(n, nthreads, fn);
+    (pool ? *pool : Pool::get()).run(n, nthreads, fn);
 }
 
 void os_randombytes(uint8_t *out, size_t len)

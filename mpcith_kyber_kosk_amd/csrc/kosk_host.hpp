@@ -43,8 +43,14 @@ uint16_t gf_inv_host(uint16_t a);
 // pack A[m][k] (canonical) into the limb-matrix operand format of the MFMA GEMM (kosk_device.hpp)
 void pack_limb_table(const std::vector<uint16_t> &A, int M, int Kdim, int Mpad, int KS, std::vector<uint8_t> &out);
 
-// run fn(i) for i in [0,n) on up to nthreads threads of a persistent process-wide pool
-void parallel_for(int n, int nthreads, const std::function<void(int)> &fn);
+// Persistent worker pool.  One per library context: several contexts (pipeline slots) run their
+// Fiat-Shamir rounds concurrently, each on its own few threads.
+class Pool;
+Pool *pool_create();
+void pool_destroy(Pool *);
+// run fn(i) for i in [0,n) on up to nthreads threads of `pool` (nullptr: a process-wide default pool)
+void parallel_for(Pool *pool, int n, int nthreads, const std::function<void(int)> &fn);
+inline void parallel_for(int n, int nthreads, const std::function<void(int)> &fn) { parallel_for(nullptr, n, nthreads, fn); }
 
 // sha3_256 of `count` equal-length messages in[i] -> out + 32*i, `width` (4 or 8) at a time in SIMD
 // lanes when the CPU has AVX2 / AVX-512F (runtime dispatch, scalar otherwise).  Used for the
@@ -53,8 +59,8 @@ void sha3_256_multi(uint8_t *out, const uint8_t *const *in, size_t len, int coun
 int sha3_multi_width(); // 8 (AVX-512F), 4 (AVX2) or 1
 
 // batch forms of fs_alpha / fs_opened over n proofs whose digest tables are dig_stride bytes apart
-void fs_alpha_batch(const Params &P, int n, const uint8_t *digs, size_t dig_stride, uint16_t *alpha, size_t alpha_stride, int nthreads);
-void fs_opened_batch(int n, const uint8_t *digs, size_t dig_stride, uint16_t *I, uint16_t *rest, size_t sel_stride, int nthreads);
+void fs_alpha_batch(const Params &P, int n, const uint8_t *digs, size_t dig_stride, uint16_t *alpha, size_t alpha_stride, int nthreads, Pool *pool = nullptr);
+void fs_opened_batch(int n, const uint8_t *digs, size_t dig_stride, uint16_t *I, uint16_t *rest, size_t sel_stride, int nthreads, Pool *pool = nullptr);
 
 // OS entropy (kyber/randombytes.c:44-57, Linux branch)
 void os_randombytes(uint8_t *out, size_t len);

@@ -130,7 +130,7 @@ int stage_verifier_inputs(Ctx &c, int n, const uint8_t *pi, const uint8_t *pk)
     if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
     HIPCHK(hipSetDevice(c.device));
     const Params &P = c.P;
-    parallel_for(n, c.nthreads, [&](int b) {
+    parallel_for(c.pool, n, c.nthreads, [&](int b) {
         HostKey key;
         host_decode_pk(P, pk + (size_t)b * P.pk_bytes, key);
         memcpy(c.h_A + (size_t)b * c.key_stride, key.A, c.key_stride * sizeof(int16_t));
@@ -283,7 +283,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
 
     // ---- host: alpha while the GPU works
     HIPCHK(hipEventSynchronize(c.ev));
-    fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads);
+    fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool);
     HIPCHK(hipMemcpyAsync(c.d_alpha, c.h_alpha, (size_t)n * 80 * 2, hipMemcpyHostToDevice, st));
 
     // ---- V2/V3: beta, gamma, r, NTT_r on the opened columns; reconstruction and NTT check
@@ -332,7 +332,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     HIPCHK(hipStreamSynchronize(st));
     c.prof_collect();
     std::vector<uint16_t> I2((size_t)n * c.sel_stride), rest2((size_t)n * c.sel_stride);
-    fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, I2.data(), rest2.data(), c.sel_stride, c.nthreads);
+    fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, I2.data(), rest2.data(), c.sel_stride, c.nthreads, c.pool);
     for (int b = 0; b < n; b++) {
         uint32_t f = c.h_fail[b] | host_fail[b];
         if (memcmp(&I2[(size_t)b * c.sel_stride], c.h_I + (size_t)b * c.sel_stride, sizeof(uint16_t) * NOPEN) != 0) f |= 1u << FB_OPENED_SET;
