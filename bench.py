@@ -114,12 +114,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+    # rehearsal hook (1-GPU box): KOSK_BENCH_REHEARSE=1 runs all ranks on cuda:0 over gloo to exercise the N>1 code path
+    rehearse = os.environ.get("KOSK_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from mpcith_kyber_kosk_amd import api
     import threading
@@ -185,13 +192,20 @@ def main():
         c.profile_enable(False)
     phases = ctx.phase_seconds()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        cdev = "cpu" if rehearse else "cuda"
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # result gather: how many proofs verified across the job (not part of the timed data path)
-        cnt = torch.tensor([B * args.steps], dtype=torch.int64, device="cuda")
+        cnt = torch.tensor([B * args.steps], dtype=torch.int64, device=cdev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         total = int(cnt.item())
+        # and a digest per rank over its last batch of proofs, all-gathered (RCCL over xGMI on a real node)
+        from mpcith_kyber_kosk_amd import sharding
+        pr = slots[0].fetch_proofs(B)
+        mine = torch.frombuffer(bytearray(hashlib.sha3_256(b"".join(pr)).digest()), dtype=torch.uint8).reshape(1, 32).to(cdev)
+        table = sharding.allgather_digest_table(mine, world, dist)
+        assert table.shape == (world, 32) and bytes(table[rank].tolist()) == bytes(mine[0].tolist())
     else:
         total = B * args.steps
 

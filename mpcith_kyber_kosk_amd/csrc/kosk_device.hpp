@@ -126,12 +126,22 @@ struct VerifyArgs {
     uint32_t *fail; // [proof]
 };
 
+// Interpolation through the nodes x_j = 256 + rest[j] (j < 407 resp. 813), barycentric form
+//   p(k) = l(k) * sum_j (w_j y_j) / (k - x_j):
+// the y are scaled by w_j when gathered, the GEMM operand is the plain Cauchy matrix 1/(k - x_j)
+// (a table lookup per entry), and l(k) is applied afterwards (set 0) or not needed at all (set 1:
+// p(k) == 0 <=> the Cauchy sum is 0).  The nodes are "all parties in [lo, hi] except the opened ones in
+// between" (holes), so w_j and l(k) are factorials times a product over the <= 150 holes.
 struct InterpArgs {
-    const uint16_t *rest;
+    const uint16_t *rest;    // [proof][sel_stride] unopened parties, ascending
+    const uint16_t *isort;   // [proof][sel_stride] opened parties, ascending
+    const uint16_t *hrange;  // [proof][4]: hole index range [h0,h1) into isort for set 0, then set 1
     int sel_stride;
-    const uint16_t *inv; // [Q] inverse table
-    uint16_t *w, *ell;   // [proof][2][832] weights / node polynomial values (set 0: 407 nodes, 1: 813 nodes)
-    uint8_t *W, *W2;     // per-proof operators as limb matrices (rows = evaluation point, k = node)
+    const uint16_t *inv, *fact, *invfact; // field inverses, k!, 1/k!  (k < 3329)
+    uint16_t *w;             // [proof][2][832] barycentric weights
+    uint16_t *ell;           // [proof][416]   l(k) of set 0 (0 where k is a node)
+    int16_t *node_of;        // [proof][416]   j if evaluation point k is node x_j, else -1
+    uint8_t *W, *W2;         // per-proof Cauchy operators as limb matrices (rows = evaluation point, k = node)
     size_t w_stride, w2_stride; // bytes
     int Mpad1, KS1, Mpad2, KS2;
 };
@@ -141,8 +151,13 @@ hipError_t launch_disassemble(const VerifyArgs &v, const FieldDesc *fields, cons
                               uint8_t *dig1, uint8_t *dig2, int nproofs, hipStream_t st);
 hipError_t launch_gates_opened(const VerifyArgs &v, int nproofs, hipStream_t st);
 hipError_t launch_interp_build(const InterpArgs &a, int nproofs, hipStream_t st);
+// out[b][r][j] = w[b][set][j] * P[b][rows[r]][256 + rest[b][j]]
 hipError_t launch_gather_cols(const uint16_t *P, size_t proof_stride, const int16_t *rows, int nrows, const uint16_t *rest,
-                              int sel_stride, int ncols, int out_cols, uint16_t *out, int nproofs, hipStream_t st);
+                              int sel_stride, int ncols, int out_cols, const uint16_t *w, int set, uint16_t *out, int nproofs,
+                              hipStream_t st);
+// P[b][dst_rows[r]][k] = node(k) ? P[b][src_rows[r]][256 + rest[node]] : ell[k] * P[b][dst_rows[r]][k],  k < 407
+hipError_t launch_interp_fixup(uint16_t *P, size_t proof_stride, const int16_t *src_rows, const int16_t *dst_rows, int nrows,
+                               const InterpArgs &a, int nproofs, hipStream_t st);
 hipError_t launch_check_rest(const VerifyArgs &v, int nproofs, hipStream_t st);
 hipError_t launch_check_opened(const VerifyArgs &v, int nproofs, hipStream_t st);
 hipError_t launch_check_secrets(const VerifyArgs &v, const uint16_t *t_pk, int nproofs, hipStream_t st);

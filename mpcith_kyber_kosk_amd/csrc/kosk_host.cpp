@@ -529,15 +529,20 @@ private:
             done_.fetch_add(1, std::memory_order_release);
         }
     }
+    static int spin_us()
+    {
+        static const int v = getenv("KOSK_POOL_SPIN_US") ? atoi(getenv("KOSK_POOL_SPIN_US")) : 20;
+        return v;
+    }
     void loop(int id, uint64_t seen0)
     {
         uint64_t seen = seen0;
         for (;;) {
-            // spin ~150 us for the next job (pause, not yield: a yield can cost milliseconds in
-            // sandboxed runtimes), then block
+            // spin briefly for the next job (pause, not yield: a yield can cost milliseconds in sandboxed
+            // runtimes), then block: CPU time is usually under a cgroup quota shared with the other slots
             const auto t0 = std::chrono::steady_clock::now();
             while (gen_.load(std::memory_order_acquire) == seen) {
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150)) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us())) {
                     std::unique_lock<std::mutex> lk(mu_);
                     cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
                     break;

@@ -51,6 +51,11 @@ static int ensure_verify_workspace(Ctx &c)
     std::vector<uint16_t> inv(Q);
     for (int a = 0; a < Q; a++) inv[a] = gf_inv_host((uint16_t)a);
     if (upload_vec(c, &c.d_inv, inv)) return -1;
+    std::vector<uint16_t> fact(Q), invfact(Q);
+    fact[0] = 1;
+    for (int a = 1; a < Q; a++) fact[a] = (uint16_t)((uint32_t)fact[a - 1] * a % Q);
+    for (int a = 0; a < Q; a++) invfact[a] = gf_inv_host(fact[a]);
+    if (upload_vec(c, &c.d_fact, fact) || upload_vec(c, &c.d_invfact, invfact)) return -1;
 
     // where each proof field lands in the verifier's row matrix
     std::vector<FieldDesc> vf;
@@ -113,8 +118,13 @@ static int ensure_verify_workspace(Ctx &c)
     HIPCHK(dalloc(&c.d_W, B * c.w_stride));
     HIPCHK(dalloc(&c.d_W2, B * c.w2_stride));
     HIPCHK(dalloc(&c.d_w, B * 2 * 832));
-    HIPCHK(dalloc(&c.d_ell, B * 2 * 832));
-    HIPCHK(dalloc(&c.d_gather, B * c.n_interp_d * 416));
+    HIPCHK(dalloc(&c.d_ell, B * 416));
+    HIPCHK(dalloc(&c.d_node_of, B * 416));
+    HIPCHK(dalloc(&c.d_isort, B * c.sel_stride));
+    HIPCHK(dalloc(&c.d_hrange, B * 4));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c.h_isort), B * c.sel_stride * 2, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c.h_hrange), B * 4 * 2, hipHostMallocDefault));
+    HIPCHK(dalloc(&c.d_gather, B * c.n_interp_d * 416 + 64));
     HIPCHK(dalloc(&c.d_gather2, B * c.n_interp_2d * 832));
     HIPCHK(dalloc(&c.d_sec, B * 2 * NCHK * 256));
     HIPCHK(dalloc(&c.d_sec_u1, B * c.n_interp_2d * 256));
@@ -177,7 +187,22 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
         }
         for (int p = 0, j = 0; p < NPARTY; p++)
             if (!used[p]) rest[j++] = (uint16_t)p;
+        // opened parties ascending + which of them lie strictly inside the node spans of the two interpolations
+        uint16_t *is = c.h_isort + (size_t)b * c.sel_stride, *hr = c.h_hrange + (size_t)b * 4;
+        for (int p = 0, j = 0; p < NPARTY; p++)
+            if (used[p]) is[j++] = (uint16_t)p;
+        for (int set = 0; set < 2; set++) {
+            const int lo = rest[0], hi = rest[set ? DEG2 : DEG];
+            int h0 = 0, h1 = 0;
+            while (h0 < NOPEN && is[h0] < lo) h0++;
+            h1 = h0;
+            while (h1 < NOPEN && is[h1] < hi) h1++;
+            hr[2 * set] = (uint16_t)h0;
+            hr[2 * set + 1] = (uint16_t)h1;
+        }
     }
+    HIPCHK(hipMemcpyAsync(c.d_isort, c.h_isort, (size_t)n * c.sel_stride * 2, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c.d_hrange, c.h_hrange, (size_t)n * 4 * 2, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c.d_I, c.h_I, (size_t)n * c.sel_stride * 2, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c.d_rest, c.h_rest, (size_t)n * c.sel_stride * 2, hipMemcpyHostToDevice, st));
 
@@ -215,10 +240,15 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     // ---- alpha-independent GPU work queued behind the copy: interpolation of the unopened shares
     InterpArgs ia{};
     ia.rest = c.d_rest;
+    ia.isort = c.d_isort;
+    ia.hrange = c.d_hrange;
     ia.sel_stride = c.sel_stride;
     ia.inv = c.d_inv;
+    ia.fact = c.d_fact;
+    ia.invfact = c.d_invfact;
     ia.w = c.d_w;
     ia.ell = c.d_ell;
+    ia.node_of = c.d_node_of;
     ia.W = c.d_W;
     ia.W2 = c.d_W2;
     ia.w_stride = c.w_stride;
@@ -227,14 +257,15 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     c.prof_begin(PR_V_INTERP_BUILD);
     HIPCHK(launch_interp_build(ia, n, st));
     c.prof_end(PR_V_INTERP_BUILD);
-    HIPCHK(launch_gather_cols(c.d_P, c.proof_stride, c.d_rows_isrc, c.n_interp_d, c.d_rest, c.sel_stride, DEG + 1, 416, c.d_gather, n, st));
-    HIPCHK(launch_gather_cols(c.d_P, c.proof_stride, c.d_rows_u, c.n_interp_2d, c.d_rest, c.sel_stride, DEG2 + 1, 832, c.d_gather2, n, st));
+    HIPCHK(launch_gather_cols(c.d_P, c.proof_stride, c.d_rows_isrc, c.n_interp_d, c.d_rest, c.sel_stride, DEG + 1, 416, c.d_w, 0, c.d_gather, n, st));
+    HIPCHK(launch_gather_cols(c.d_P, c.proof_stride, c.d_rows_u, c.n_interp_2d, c.d_rest, c.sel_stride, DEG2 + 1, 832, c.d_w, 1, c.d_gather2, n, st));
     { // values at points 0..406 of every interpolated sharing, then recompute_share_secrets_ddeg   :224-225, :351, :441-442
         const GemmSrc gs{c.d_gather, (size_t)c.n_interp_d * 416, nullptr, 416, 0, DEG + 1};
         const GemmDst gd{c.d_P, c.proof_stride, c.d_rows_idst, RS, 0};
         c.prof_begin(PR_V_GEMM_INTERP);
         if (gemm_modq(c, c.d_W, c.w_stride, c.w_Mpad, DEG + 1, c.w_KS, gs, gd, c.n_interp_d, n, true)) return -1;
         c.prof_end(PR_V_GEMM_INTERP);
+        HIPCHK(launch_interp_fixup(c.d_P, c.proof_stride, c.d_rows_isrc, c.d_rows_idst, c.n_interp_d, ia, n, st));
         const GemmSrc xs{c.d_P, c.proof_stride, c.d_rows_idst, RS, 0, XLEN};
         const GemmDst xd{c.d_P, c.proof_stride, c.d_rows_idst, RS, EXP_OFF};
         c.prof_begin(PR_V_GEMM_EXPAND);

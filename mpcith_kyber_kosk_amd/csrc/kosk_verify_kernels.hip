@@ -81,49 +81,63 @@ __global__ __launch_bounds__(192) void k_gates_opened(VerifyArgs v)
         }
 }
 
-// ---- interpolation operators over the nodes x_j = 256 + rest[j] ----------------
-// barycentric form: p(k) = l(k) * sum_j w_j y_j / (k - x_j),  w_j = 1 / prod_{m != j} (x_j - x_m)
-__device__ __forceinline__ uint32_t wave_product(uint32_t v)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = gf_mul(v, (uint32_t)__shfl_xor((int)v, off, 64));
-    return v;
-}
+// ---- interpolation operators over the nodes x_j = 256 + rest[j] (see InterpArgs) ---------------
+__device__ __forceinline__ uint32_t gf_neg_if(uint32_t v, int odd) { return (odd & 1) && v ? (uint32_t)Q - v : v; }
 
-// One wave per node / evaluation point: the 64 lanes multiply strided factors, then a shuffle
-// product-reduction.  set 0: 407 nodes (degree-d sharings), set 1: 813 nodes (degree-2d).
-// w_j = 1 / prod_{m != j} (x_j - x_m)
-__global__ __launch_bounds__(64) void k_interp_weights(InterpArgs a)
+// weights of both sets, l(k) and the node map of set 0
+__global__ __launch_bounds__(256) void k_interp_setup(InterpArgs a)
 {
-    const int j = blockIdx.x, b = blockIdx.y, set = blockIdx.z, lane = threadIdx.x;
+    const int t = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y, set = blockIdx.z;
     const int n = set ? DEG2 + 1 : DEG + 1;
-    uint16_t *w = a.w + ((size_t)b * 2 + set) * 832;
-    if (j >= n) { if (lane == 0) w[j] = 0; return; }
     const uint16_t *rest = a.rest + (size_t)b * a.sel_stride;
-    const uint32_t xj = NSEC + rest[j];
-    uint32_t d = 1;
-    for (int m = lane; m < n; m += 64) d = gf_mul(d, m == j ? 1u : gf_sub(xj, NSEC + rest[m]));
-    d = wave_product(d);
-    if (lane == 0) w[j] = a.inv[d];
+    const uint16_t *is = a.isort + (size_t)b * a.sel_stride;
+    const int h0 = a.hrange[b * 4 + 2 * set], h1 = a.hrange[b * 4 + 2 * set + 1];
+    const int lo = rest[0], hi = rest[n - 1]; // parties; the nodes are [lo, hi] minus the holes is[h0..h1)
+    if (t < 832) { // w_j = prod_holes (x_j - h) / ((x_j - lo)! (hi - x_j)! (-1)^(hi - x_j))
+        uint32_t w = 0;
+        if (t < n) {
+            const int xj = rest[t];
+            uint32_t pr = 1;
+            for (int h = h0; h < h1; h++) pr = gf_mul(pr, gf_from_i32(xj - (int)is[h]));
+            w = gf_mul(pr, gf_mul(a.invfact[xj - lo], a.invfact[hi - xj]));
+            w = gf_neg_if(w, hi - xj);
+        }
+        a.w[((size_t)b * 2 + set) * 832 + t] = (uint16_t)w;
+    }
+    if (set == 0 && t < 416) { // l(k) = prod_{p in [lo,hi]} (k - 256 - p) / prod_holes (k - 256 - h)
+        uint32_t l = 0;
+        int node = -1;
+        if (t <= DEG) {
+            const int kp = t - NSEC; // evaluation point as a "party" coordinate (negative for packed secrets)
+            bool is_hole = false;
+            uint32_t den = 1;
+            int below = 0;
+            for (int h = h0; h < h1; h++) {
+                const int d = kp - (int)is[h];
+                if (d == 0) is_hole = true;
+                else den = gf_mul(den, gf_from_i32(d));
+                below += (int)is[h] < kp;
+            }
+            if (kp < lo) { // (-1)^cnt (hi - kp)! / (lo - 1 - kp)!
+                l = gf_mul(a.fact[hi - kp], a.invfact[lo - 1 - kp]);
+                l = gf_neg_if(l, hi - lo + 1);
+                l = gf_mul(l, a.inv[den]);
+            } else if (is_hole) { // inside the span on an opened party: skip the zero factor on both sides
+                l = gf_mul(a.fact[kp - lo], a.fact[hi - kp]);
+                l = gf_neg_if(l, hi - kp);
+                l = gf_mul(l, a.inv[den]);
+            } else { // kp is a node: p(k) is the given share itself
+                node = kp - lo - below;
+            }
+        }
+        a.ell[(size_t)b * 416 + t] = (uint16_t)l;
+        a.node_of[(size_t)b * 416 + t] = (int16_t)node;
+    }
 }
 
-// l(k) = prod_m (k - x_m) at the evaluation points k (0..406 for set 0, 0..255 for set 1)
-__global__ __launch_bounds__(64) void k_interp_ell(InterpArgs a)
-{
-    const int k = blockIdx.x, b = blockIdx.y, set = blockIdx.z, lane = threadIdx.x;
-    const int n = set ? DEG2 + 1 : DEG + 1, neval = set ? NSEC : DEG + 1;
-    uint16_t *ell = a.ell + ((size_t)b * 2 + set) * 832;
-    if (k >= neval) { if (lane == 0) ell[k] = 0; return; }
-    const uint16_t *rest = a.rest + (size_t)b * a.sel_stride;
-    uint32_t l = 1;
-    for (int m = lane; m < n; m += 64) l = gf_mul(l, gf_sub((uint32_t)k, NSEC + rest[m]));
-    l = wave_product(l);
-    if (lane == 0) ell[k] = (uint16_t)l;
-}
-
-// Operator rows in limb-matrix form (kosk_device.hpp): row = evaluation point k, column = node j,
-//   Wop[k][j] = [x_j == k]  or  l(k) w_j / (k - x_j).   One thread per (k, 16-node chunk).
-__global__ __launch_bounds__(256) void k_interp_matrix(InterpArgs a)
+// Cauchy operators in limb-matrix form (kosk_device.hpp): row = evaluation point k, column = node j,
+// entry 1/(k - x_j) (0 when k == x_j).  One thread per (k, 16-node chunk).
+__global__ __launch_bounds__(256) void k_interp_cauchy(InterpArgs a)
 {
     const int k = blockIdx.x * 64 + (threadIdx.x & 63);
     const int ch = blockIdx.y * 4 + (threadIdx.x >> 6); // 16-node chunk
@@ -133,18 +147,12 @@ __global__ __launch_bounds__(256) void k_interp_matrix(InterpArgs a)
     if (k >= Mpad || ch >= KS * 4) return;
     uint8_t *W = set ? a.W2 + (size_t)b * a.w2_stride : a.W + (size_t)b * a.w_stride;
     uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
-    if (k < neval) {
-        const uint16_t *rest = a.rest + (size_t)b * a.sel_stride;
-        const uint16_t *w = a.w + ((size_t)b * 2 + set) * 832;
-        const uint32_t l = a.ell[((size_t)b * 2 + set) * 832 + k];
+    if (k < neval && ch * 16 < n) {
+        const uint16_t *rest = a.rest + (size_t)b * a.sel_stride + ch * 16;
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            const int j = ch * 16 + q;
             uint32_t e = 0;
-            if (j < n) {
-                const uint32_t d = gf_sub((uint32_t)k, NSEC + rest[j]);
-                e = d == 0 ? 1u : gf_mul(gf_mul(l, w[j]), a.inv[d]);
-            }
+            if (ch * 16 + q < n) e = a.inv[gf_from_i32(k - NSEC - (int)rest[q])];
             int c0, c1;
             limb_split(gf_center(e), c0, c1);
             lo[q >> 2] |= ((uint32_t)c0 & 0xFFu) << (8 * (q & 3));
@@ -156,17 +164,32 @@ __global__ __launch_bounds__(256) void k_interp_matrix(InterpArgs a)
     *reinterpret_cast<uint4 *>(d + 1024) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
 }
 
-// out[b][r][j] = P[b][rows[r]][256 + rest[b][j]] for j < ncols, zero padded to out_cols
+// out[b][r][j] = w[b][set][j] * P[b][rows[r]][256 + rest[b][j]] for j < ncols, zero padded to out_cols
 __global__ __launch_bounds__(256) void k_gather_cols(const uint16_t *__restrict__ P, size_t proof_stride,
                                                      const int16_t *__restrict__ rows, int nrows,
                                                      const uint16_t *__restrict__ rest, int sel_stride, int ncols,
-                                                     int out_cols, uint16_t *__restrict__ out)
+                                                     int out_cols, const uint16_t *__restrict__ w, int set,
+                                                     uint16_t *__restrict__ out)
 {
     const int r = blockIdx.y, b = blockIdx.z;
     const uint16_t *src = P + (size_t)b * proof_stride + (size_t)rows[r] * RS + NSEC;
+    const uint16_t *wb = w + ((size_t)b * 2 + set) * 832;
     uint16_t *dst = out + ((size_t)b * nrows + r) * out_cols;
     for (int j = blockIdx.x * 256 + threadIdx.x; j < out_cols; j += gridDim.x * 256)
-        dst[j] = j < ncols ? src[rest[(size_t)b * sel_stride + j]] : (uint16_t)0;
+        dst[j] = j < ncols ? (uint16_t)gf_mul(wb[j], src[rest[(size_t)b * sel_stride + j]]) : (uint16_t)0;
+}
+
+__global__ __launch_bounds__(448) void k_interp_fixup(uint16_t *__restrict__ P, size_t proof_stride,
+                                                      const int16_t *__restrict__ src_rows, const int16_t *__restrict__ dst_rows,
+                                                      InterpArgs a)
+{
+    const int k = threadIdx.x, r = blockIdx.x, b = blockIdx.y;
+    if (k > DEG) return;
+    uint16_t *Pb = P + (size_t)b * proof_stride;
+    uint16_t *d = Pb + (size_t)dst_rows[r] * RS + k;
+    const int node = a.node_of[(size_t)b * 416 + k];
+    if (node >= 0) *d = Pb[(size_t)src_rows[r] * RS + NSEC + a.rest[(size_t)b * a.sel_stride + node]];
+    else *d = (uint16_t)gf_mul(a.ell[(size_t)b * 416 + k], *d);
 }
 
 // ---- checks ---------------------------------------------------------------------
@@ -255,18 +278,24 @@ hipError_t launch_gates_opened(const VerifyArgs &v, int nproofs, hipStream_t st)
 }
 hipError_t launch_interp_build(const InterpArgs &a, int nproofs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_interp_weights, dim3(832, nproofs, 2), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(k_interp_ell, dim3(832, nproofs, 2), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_interp_setup, dim3(4, nproofs, 2), dim3(256), 0, st, a);
     const int mp = a.Mpad1 > a.Mpad2 ? a.Mpad1 : a.Mpad2, ks = a.KS1 > a.KS2 ? a.KS1 : a.KS2;
-    hipLaunchKernelGGL(k_interp_matrix, dim3((mp + 63) / 64, ks, nproofs * 2), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_interp_cauchy, dim3((mp + 63) / 64, ks, nproofs * 2), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 hipError_t launch_gather_cols(const uint16_t *P, size_t proof_stride, const int16_t *rows, int nrows, const uint16_t *rest,
-                              int sel_stride, int ncols, int out_cols, uint16_t *out, int nproofs, hipStream_t st)
+                              int sel_stride, int ncols, int out_cols, const uint16_t *w, int set, uint16_t *out, int nproofs,
+                              hipStream_t st)
 {
     if (nrows <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_gather_cols, dim3((out_cols + 255) / 256, nrows, nproofs), dim3(256), 0, st, P, proof_stride, rows, nrows,
-                       rest, sel_stride, ncols, out_cols, out);
+                       rest, sel_stride, ncols, out_cols, w, set, out);
+    return hipGetLastError();
+}
+hipError_t launch_interp_fixup(uint16_t *P, size_t proof_stride, const int16_t *src_rows, const int16_t *dst_rows, int nrows,
+                               const InterpArgs &a, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_interp_fixup, dim3(nrows, nproofs), dim3(448), 0, st, P, proof_stride, src_rows, dst_rows, a);
     return hipGetLastError();
 }
 hipError_t launch_check_rest(const VerifyArgs &v, int nproofs, hipStream_t st)
