@@ -62,7 +62,7 @@ Ctx::~Ctx()
         for (auto e : pe)
             if (e) (void)hipEventDestroy(e);
     void *dev[] = {t_expand.d, t_recon_d.d, t_recon_2d.d, d_fresh_rows, d_gemm1_rows, d_gemm2_rows, d_off, d_fields,
-                   d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_poly, d_t, d_alpha, d_I, d_rest, d_pwT, d_limbs,
+                   d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_poly, d_t, d_alpha, d_I, d_rest, d_pwT, d_limbs, d_linA, d_coef, d_lin_rows,
                    d_gather, d_gather2, d_W, d_W2, d_w, d_ell, d_sec, d_sec_u1, d_sec_u2, d_fail, d_inv, d_vfields,
                    d_vrowtab, d_rows_bg, d_rows_isrc, d_rows_idst, d_rows_u, d_fact, d_invfact, d_node_of, d_isort, d_hrange};
     for (void *p : dev)
@@ -159,6 +159,15 @@ static int build_tables(Ctx &c)
     for (int i = 0; i < K; i++) { g2.push_back((int16_t)(rm.nttsr + i)); g2.push_back((int16_t)(rm.ntter + i)); g2.push_back((int16_t)(rm.nttasr + i)); }
     if (upload_vec(c, &c.d_gemm2_rows, g2)) return -1;
     c.n_gemm2 = (int)g2.size();
+
+    { // output rows of the lincomb GEMM: group 0 (f rows) -> beta_j, r_j ; group 1 (NTT f rows) -> gamma_j, NTT_r_j
+        std::vector<int16_t> lr(256, 0);
+        for (int j = 0; j < P.J; j++) {
+            lr[j] = (int16_t)(j < NCHK ? rm.beta(j) : rm.r + (j - NCHK));
+            lr[128 + j] = (int16_t)(j < NCHK ? rm.gamma(j) : rm.nttr + (j - NCHK));
+        }
+        if (upload_vec(c, &c.d_lin_rows, lr)) return -1;
+    }
 
     // NTT source / destination offsets (u16 units inside one proof group)
     std::vector<int32_t> off;
@@ -263,6 +272,8 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
         // data operand of the largest GEMM: every fresh sharing of every proof (<= 256 per proof), 13 k-steps
         c.limb_cap = ((B * 256 + 63) / 64 * 64 / 16) * (size_t)13 * 2048;
         HIPCHK(dalloc(&c.d_limbs, c.limb_cap));
+        HIPCHK(dalloc(&c.d_linA, B * 2 * (size_t)(1792 / 16) * 2 * 2048));
+        HIPCHK(dalloc(&c.d_coef, B * 2 * (size_t)8 * 2 * 2048));
         HIPCHK(dalloc(&c.d_fail, B));
         HIPCHK(halloc(&c.h_tape, B * c.tape_stride));
         HIPCHK(halloc(&c.h_dig, B * NPARTY * 32));
@@ -391,18 +402,19 @@ int prove_resident(Ctx &c, int n)
     HIPCHK(hipMemcpyAsync(c.d_alpha, c.h_alpha, (size_t)n * 80 * 2, hipMemcpyHostToDevice, st));
 
     // ---- online relation phase
-    HIPCHK(launch_pow_table(c.d_alpha, P.J, P.M, c.d_pwT, n, st));
-    LincombArgs la{};
-    la.P = c.d_P;
-    la.proof_stride = c.proof_stride;
-    la.rm = rm;
-    la.J = P.J;
-    la.pwT = c.d_pwT;
-    la.ncols = NPTS;
-    la.col_map = nullptr;
-    c.prof_begin(PR_LINCOMB);
-    HIPCHK(launch_lincomb(la, n, st));
-    c.prof_end(PR_LINCOMB);
+    { // beta, gamma, r, NTT_r on every evaluation point: per proof a [J x M] x [M x 1710] product mod q   :159-203
+        const size_t a_gstride = (size_t)(1792 / 16) * 2 * 2048;
+        c.prof_begin(PR_LINCOMB);
+        HIPCHK(launch_cols_to_limbs(c.d_P, c.proof_stride, rm.f, rm.tf, P.M, c.d_linA, a_gstride, n, st));
+        HIPCHK(launch_coef_limbs(c.d_alpha, P.J, P.M, c.d_coef, n, st));
+        GemmArgs ga{};
+        ga.A = c.d_linA; ga.a_gstride = a_gstride; ga.Mpad = 1792; ga.M = NPTS; ga.KS = 2;
+        ga.B = c.d_coef; ga.BRT = 2 * n * 8;
+        ga.C = c.d_P; ga.c_gstride = c.proof_stride; ga.c_rows = c.d_lin_rows; ga.c_rstride = RS; ga.c_off = 0;
+        ga.npg = P.J; ga.npg_pad = 128; ga.ngroups = 2 * n; ga.grouped = 1; ga.c_gdiv = 2; ga.c_rows_gstride = 128;
+        HIPCHK(launch_gemm(ga, st));
+        c.prof_end(PR_LINCOMB);
+    }
     HIPCHK(launch_post_open(c.d_P, c.proof_stride, rm, n, st));
     na.in = reinterpret_cast<const int16_t *>(c.d_P);
     na.in_gstride = c.proof_stride;

@@ -75,6 +75,8 @@ struct Ctx {
     uint16_t *d_alpha = nullptr, *d_I = nullptr, *d_rest = nullptr;
     int32_t *d_pwT = nullptr;
     uint8_t *d_limbs = nullptr; // limb-matrix staging of the GEMM data operand
+    uint8_t *d_linA = nullptr, *d_coef = nullptr; // K3 operands: transposed f / NTT-f rows, alpha-power coefficients
+    int16_t *d_lin_rows = nullptr; // [2][128] output rows of the lincomb GEMM (beta/r, gamma/NTT_r)
     size_t limb_cap = 0;
     // verifier workspace (allocated on first use, kosk_verify.cpp)
     bool verify_ready = false;

@@ -78,6 +78,8 @@ struct GemmArgs {
     int c_off;
     int npg, npg_pad, ngroups;
     int grouped; // 1: A + g*a_gstride (npg_pad must be a multiple of 64)
+    int c_gdiv;  // groups per output block: C + (g / c_gdiv) * c_gstride, rows from c_rows + (g % c_gdiv) * c_rows_gstride
+    int c_rows_gstride;
 };
 
 struct LincombArgs {
@@ -181,6 +183,10 @@ hipError_t launch_matvec_ntt(const int16_t *A, size_t A_stride, const int16_t *v
                              uint16_t *P, size_t proof_stride, int row0, int K, int nproofs, hipStream_t st);
 hipError_t launch_rows_to_limbs(const LimbArgs &a, hipStream_t st);
 hipError_t launch_gemm(const GemmArgs &a, hipStream_t st);
+// K3 on the matrix cores (prover): transposed f / NTT-f rows and the alpha-power coefficient matrix as limb matrices
+hipError_t launch_cols_to_limbs(const uint16_t *P, size_t proof_stride, int row_f, int row_tf, int M, uint8_t *A, size_t a_gstride,
+                                int nproofs, hipStream_t st);
+hipError_t launch_coef_limbs(const uint16_t *alpha, int J, int M, uint8_t *B, int nproofs, hipStream_t st);
 hipError_t launch_pow_table(const uint16_t *alpha, int J, int M, int32_t *pwT, int nproofs, hipStream_t st);
 hipError_t launch_lincomb(const LincombArgs &a, int nproofs, hipStream_t st);
 hipError_t launch_post_gates(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st);

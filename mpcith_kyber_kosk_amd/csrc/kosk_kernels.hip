@@ -473,7 +473,9 @@ __global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
         if (a.grouped) { g = grp; i = n_loc; valid = i < a.npg; }
         else { g = n_loc / a.npg; i = n_loc - g * a.npg; valid = n_loc < a.npg * a.ngroups; }
         if (!valid) continue;
-        uint16_t *crow = a.C + (size_t)g * a.c_gstride + (size_t)(a.c_rows ? (int)a.c_rows[i] : i) * a.c_rstride + a.c_off;
+        const int gd = a.c_gdiv > 1 ? a.c_gdiv : 1;
+        uint16_t *crow = a.C + (size_t)(g / gd) * a.c_gstride +
+                         (size_t)(a.c_rows ? (int)a.c_rows[(g % gd) * a.c_rows_gstride + i] : i) * a.c_rstride + a.c_off;
 #pragma unroll
         for (int ib = 0; ib < 4; ib++) {
             const int m0 = blockIdx.x * GM_TM + wm * 64 + ib * 16 + (lane >> 4) * 4;
@@ -486,12 +488,77 @@ __global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
     }
 }
 
+// ---- K3 (prover) on the matrix cores: out_j[x] = sum_k Coef[j][k] * in_k[x] as the same GEMM -----
+// "A" operand: the 77 f (or NTT f) rows of one proof transposed: limb-matrix row = evaluation point x,
+// k = row index (padded to 128).  Loads are coalesced along x.
+constexpr int LC_JPAD = 80;  // padded J in the alpha / power tables
+constexpr int LIN_MPAD = 1792, LIN_K = 128;
+__global__ __launch_bounds__(256) void k_cols_to_limbs(const uint16_t *__restrict__ P, size_t proof_stride, int row_f, int row_tf,
+                                                       int M, uint8_t *__restrict__ A, size_t a_gstride)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ch = blockIdx.y * 4 + (threadIdx.x >> 6); // 16-row chunk of the k dimension
+    const int gg = blockIdx.z, b = gg >> 1, which = gg & 1;
+    const uint16_t *src = P + (size_t)b * proof_stride + (size_t)(which ? row_tf : row_f) * RS + x;
+    uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+    if (x < NPTS) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int k = ch * 16 + q;
+            if (k < M) {
+                int c0, c1;
+                limb_split(gf_center(src[(size_t)k * RS]), c0, c1);
+                lo[q >> 2] |= ((uint32_t)c0 & 0xFFu) << (8 * (q & 3));
+                hi[q >> 2] |= ((uint32_t)c1 & 0xFFu) << (8 * (q & 3));
+            }
+        }
+    }
+    uint8_t *d = A + (size_t)gg * a_gstride + limb_offset(x, ch * 16, 0, LIN_MPAD / 16);
+    *reinterpret_cast<uint4 *>(d) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    *reinterpret_cast<uint4 *>(d + 1024) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+}
+
+// "B" operand: Coef[j][k] = alpha_j^k for the 70 check rows; for the r rows (j >= 70) the constant term is
+// f_71 instead of f_0 (mlwe_prover.cpp:187,196): Coef[j][0] = 0 and Coef[j][71] = alpha_j^71 + 1.
+// Written for both groups (f and NTT f) of the proof.  One thread per (j, 16-k chunk).
+__global__ __launch_bounds__(1024) void k_coef_limbs(const uint16_t *__restrict__ alpha, int J, int M, uint8_t *__restrict__ B, int BRT)
+{
+    const int j = threadIdx.x & 127, ch = threadIdx.x >> 7, b = blockIdx.x;
+    uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+    if (j < J) {
+        const uint32_t al = alpha[(size_t)b * LC_JPAD + j] % (uint32_t)Q;
+        uint32_t p = 1, base = al;
+        for (int e = ch * 16; e; e >>= 1) { // alpha^(16 ch)
+            if (e & 1) p = gf_mul(p, base);
+            base = gf_mul(base, base);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int k = ch * 16 + q;
+            uint32_t c = k < M ? p : 0;
+            if (j >= NCHK) {
+                if (k == 0) c = 0;
+                if (k == NCHK + 1) c = gf_add(c, 1);
+            }
+            int c0, c1;
+            limb_split(gf_center(c), c0, c1);
+            lo[q >> 2] |= ((uint32_t)c0 & 0xFFu) << (8 * (q & 3));
+            hi[q >> 2] |= ((uint32_t)c1 & 0xFFu) << (8 * (q & 3));
+            p = gf_mul(p, al);
+        }
+    }
+    for (int which = 0; which < 2; which++) {
+        uint8_t *d = B + limb_offset((2 * b + which) * 128 + j, ch * 16, 0, BRT);
+        *reinterpret_cast<uint4 *>(d) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        *reinterpret_cast<uint4 *>(d + 1024) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    }
+}
+
 // =========================================================================
 // K3  beta / gamma / r / NTT_r : out_j[x] = base_j[x] + sum_{k>=1} alpha_j^k in_k[x]
 // mlwe_prover.cpp:159-203 (the k == 0 term of the r rows is in_71, :187,:196)
 // =========================================================================
 constexpr int LC_JC = 20;    // outputs per thread
-constexpr int LC_JPAD = 80;  // padded J in the power table
 
 // pwT[b][k][j] = centred alpha_j^k, int32
 __global__ __launch_bounds__(128) void k_pow_table(const uint16_t *__restrict__ alpha, int J, int M, int32_t *__restrict__ pwT)
@@ -757,6 +824,18 @@ hipError_t launch_gemm(const GemmArgs &a, hipStream_t st)
     if (ntot <= 0) return hipSuccess;
     dim3 grid(a.Mpad / GM_TM, (ntot + GM_TN - 1) / GM_TN, a.grouped ? a.ngroups : 1);
     hipLaunchKernelGGL(k_gemm_modq, grid, dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_cols_to_limbs(const uint16_t *P, size_t proof_stride, int row_f, int row_tf, int M, uint8_t *A, size_t a_gstride,
+                                int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_cols_to_limbs, dim3(LIN_MPAD / 64, LIN_K / 64, 2 * nproofs), dim3(256), 0, st, P, proof_stride, row_f, row_tf, M, A, a_gstride);
+    return hipGetLastError();
+}
+hipError_t launch_coef_limbs(const uint16_t *alpha, int J, int M, uint8_t *B, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_coef_limbs, dim3(nproofs), dim3(1024), 0, st, alpha, J, M, B, 2 * nproofs * 8);
     return hipGetLastError();
 }
 

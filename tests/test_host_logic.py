@@ -134,3 +134,18 @@ def test_lagrange_tables_match_oracle(api, oracle):
         t = np.zeros(shape, np.uint16)
         assert api.lib.kosk_lagrange_table(which, t.ctypes.data) == 0
         assert np.array_equal(t, oracle.table(which))
+
+
+def test_compat_header_proof_size_macro(api):
+    """include/kosk_compat.hpp restates sizeof(mpcith_proof) as a macro; check it for K=2,3,4 with the host compiler."""
+    import subprocess, tempfile
+    src = '#include "kosk_compat.hpp"\n#include <cstdio>\nextern "C" void randombytes(uint8_t*, size_t) {}\nint main(){ printf("%zu %d %d", (size_t)MPCITH_PROOF_SIZE, (int)KYBER_PUBLICKEYBYTES, (int)KYBER_SECRETKEYBYTES); }\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.cpp"), "w").write(src)
+        for k in (2, 3, 4):
+            exe = os.path.join(d, "t%d" % k)
+            subprocess.check_call(["g++", "-std=c++17", "-DKYBER_K=%d" % k, "-I" + os.path.join(ROOT, "include"), os.path.join(d, "t.cpp"),
+                                   "-L" + os.path.join(ROOT, "mpcith_kyber_kosk_amd"), "-lkosk_mi355x",
+                                   "-Wl,-rpath," + os.path.join(ROOT, "mpcith_kyber_kosk_amd"), "-o", exe])
+            out = subprocess.check_output([exe], text=True).split()
+            assert [int(x) for x in out] == [api.proof_bytes(k), api.pk_bytes(k), api.sk_bytes(k)]
