@@ -179,11 +179,15 @@ def main():
     run_steps(args.warmup)
     for c in slots:
         c.profile_enable(True)
+    import resource
     barrier()
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     prof = {}
     for c in slots:
         for name, (ms, cnt_) in c.profile_read().items():
@@ -249,8 +253,9 @@ def main():
                                    "prove (offline+online) + verify, inputs resident in HBM" if k == 3 and B == 46 else
                                    "KYBER_K=%d, %d proofs per GPU per step, prove + verify" % (k, B),
                        "kyber_k": k, "proofs_per_gpu": B, "party_lanes_per_gpu": B * 1454, "sharding": "by proof",
-                       "pipeline_slots_per_gpu": S, "host_threads_per_slot": os.environ.get("KOSK_HOST_THREADS", "auto(<=16)")},
+                       "pipeline_slots_per_gpu": S, "host_threads_per_slot": os.environ.get("KOSK_HOST_THREADS", "auto(<=8)")},
             "roofline": roof,
+            "host_cpu_cores_busy": round(host_cpu_s / (time.perf_counter() - t0), 2) if False else round(host_cpu_s / max(dt, 1e-9), 2),
             "kernels_in_pipeline": kern,
             "prove_phase_ms": dict(zip(["host_pre", "gpu_commit", "fs_alpha_host", "gpu_relation", "fs_open_host", "gpu_assemble", "d2h"],
                                        [round(x * 1e3, 3) for x in phases])),

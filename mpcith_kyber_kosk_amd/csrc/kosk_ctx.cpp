@@ -92,19 +92,24 @@ int gemm_modq(Ctx &c, const uint8_t *A, size_t a_gstride, int Mpad, int M, int K
               int npg, int ngroups, bool grouped)
 {
     if (npg <= 0 || ngroups <= 0) return 0;
-    const int npg_pad = grouped ? (npg + 63) / 64 * 64 : npg;
-    const int rows = ((grouped ? npg_pad * ngroups : npg * ngroups) + 63) / 64 * 64;
-    const int RT = rows / 16;
-    if ((size_t)RT * KS * 2048 > c.limb_cap) { c.err = "gemm_modq: limb staging buffer too small"; return -1; }
-    LimbArgs la{};
-    la.src = s.src; la.src_gstride = s.gstride; la.rows = s.rows; la.src_rstride = s.rstride; la.src_koff = s.koff;
-    la.ncols = s.ncols; la.KS = KS; la.dst = c.d_limbs; la.RT = RT; la.npg = npg; la.npg_pad = npg_pad; la.ngroups = ngroups;
-    HIPCHK(launch_rows_to_limbs(la, c.stream));
     GemmArgs ga{};
     ga.A = A; ga.a_gstride = a_gstride; ga.Mpad = Mpad; ga.M = M; ga.KS = KS;
-    ga.B = c.d_limbs; ga.BRT = RT;
     ga.C = d.C; ga.c_gstride = d.gstride; ga.c_rows = d.rows; ga.c_rstride = d.rstride; ga.c_off = d.off;
-    ga.npg = npg; ga.npg_pad = npg_pad; ga.ngroups = ngroups; ga.grouped = grouped ? 1 : 0;
+    ga.npg = npg; ga.npg_pad = grouped ? (npg + 63) / 64 * 64 : npg; ga.ngroups = ngroups; ga.grouped = grouped ? 1 : 0;
+    const int rows = ((grouped ? ga.npg_pad * ngroups : npg * ngroups) + 63) / 64 * 64;
+    const int mtiles = Mpad / 128;
+    if (mtiles >= 4 && rows >= 2048 && (size_t)(rows / 16) * KS * 2048 <= c.limb_cap) {
+        // large product: every data row is used by many table tiles -> convert it to limbs once, in its own pass
+        LimbArgs la{};
+        la.src = s.src; la.src_gstride = s.gstride; la.rows = s.rows; la.src_rstride = s.rstride; la.src_koff = s.koff;
+        la.ncols = s.ncols; la.KS = KS; la.dst = c.d_limbs; la.RT = rows / 16; la.npg = npg; la.npg_pad = ga.npg_pad; la.ngroups = ngroups;
+        HIPCHK(launch_rows_to_limbs(la, c.stream));
+        ga.B = c.d_limbs; ga.BRT = rows / 16;
+    } else {
+        // small product (latency-bound): convert inside the GEMM's own staging and save a launch
+        ga.B = nullptr; ga.BRT = 0;
+        ga.src = s.src; ga.src_gstride = s.gstride; ga.src_rows = s.rows; ga.src_rstride = s.rstride; ga.src_koff = s.koff;
+    }
     HIPCHK(launch_gemm(ga, c.stream));
     return 0;
 }
@@ -172,13 +177,12 @@ static int build_tables(Ctx &c)
     // NTT source / destination offsets (u16 units inside one proof group)
     std::vector<int32_t> off;
     auto push_rows = [&](int row0, int n) { int b = (int)off.size(); for (int i = 0; i < n; i++) off.push_back((row0 + i) * RS); return b; };
-    auto push_slots = [&](int s0, int n) { int b = (int)off.size(); for (int i = 0; i < n; i++) off.push_back((s0 + i) * 256); return b; };
-    c.off_f = push_rows(rm.f, M);
-    c.off_tf = push_rows(rm.tf, M);
-    c.off_s = push_rows(rm.s, K);
-    c.off_slot0 = push_slots(0, K);
+    c.off_ntt1_src = push_rows(rm.f, M);
+    push_rows(rm.s, K);
+    c.off_ntt1_dst = push_rows(rm.tf, M);
+    push_rows(rm.shat, K);
+    c.n_ntt1 = M + K;
     c.off_sr_er = push_rows(rm.sr, 2 * K);        // sr rows then er rows (adjacent in the row map)
-    c.off_slotK = push_slots(K, 2 * K);
     c.off_nttsr_er = push_rows(rm.nttsr, 2 * K);  // nttsr rows then ntter rows
     if (rm.er != rm.sr + K || rm.ntter != rm.nttsr + K) { c.err = "internal: row map adjacency"; return -1; }
     if (upload_vec(c, &c.d_off, off)) return -1;
@@ -237,7 +241,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     c.rm = make_rowmap(c.P);
     c.pool = pool_create();
     unsigned hc = std::thread::hardware_concurrency();
-    c.nthreads = hc ? (int)(hc > 16 ? 16 : hc) : 1;
+    c.nthreads = hc ? (int)(hc > 8 ? 8 : hc) : 1; // per context; several contexts (pipeline slots) share the host
     if (const char *e = getenv("KOSK_HOST_THREADS")) c.nthreads = atoi(e) > 0 ? atoi(e) : c.nthreads;
 
     auto body = [&]() -> int {
@@ -352,25 +356,17 @@ int prove_resident(Ctx &c, int n)
     NttArgs na{};
     na.in = reinterpret_cast<const int16_t *>(c.d_P);
     na.in_gstride = c.proof_stride;
-    na.src_off = c.d_off + c.off_f;            // NTT(f_i) -> Tf_i secrets   mlwe_prover.cpp:17-26
+    na.src_off = c.d_off + c.off_ntt1_src;     // NTT(f_i) -> Tf_i secrets (mlwe_prover.cpp:17-26) and NTT(s_i) (:256)
     na.out = reinterpret_cast<int16_t *>(c.d_P);
     na.out_gstride = c.proof_stride;
-    na.dst_off = c.d_off + c.off_tf;
-    na.npg = P.M;
-    na.npoly = P.M * n;
+    na.dst_off = c.d_off + c.off_ntt1_dst;
+    na.npg = c.n_ntt1;
+    na.npoly = c.n_ntt1 * n;
     na.out_canonical = 1;
     c.prof_begin(PR_NTT_F);
     HIPCHK(launch_ntt(na, st));
     c.prof_end(PR_NTT_F);
-    na.src_off = c.d_off + c.off_s;            // NTT(s) -> poly slots 0..K-1   :256
-    na.out = c.d_poly;
-    na.out_gstride = c.poly_stride;
-    na.dst_off = c.d_off + c.off_slot0;
-    na.npg = K;
-    na.npoly = K * n;
-    na.out_canonical = 0;
-    HIPCHK(launch_ntt(na, st));
-    HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_poly, c.poly_stride, 0, c.d_P, c.proof_stride, rm.nttas, K, n, st)); // :284-285
+    HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_P, c.proof_stride, rm.shat, rm.nttas, K, n, st)); // :284-285
 
     const GemmSrc xsrc{c.d_P, c.proof_stride, c.d_gemm1_rows, RS, 0, XLEN};
     const GemmDst xdst{c.d_P, c.proof_stride, c.d_gemm1_rows, RS, EXP_OFF};
@@ -421,17 +417,12 @@ int prove_resident(Ctx &c, int n)
     na.src_off = c.d_off + c.off_sr_er;        // NTT of the opened s+r, e+r     :260-277
     na.npg = 2 * K;
     na.npoly = 2 * K * n;
-    na.out = c.d_poly;
-    na.out_gstride = c.poly_stride;
-    na.dst_off = c.d_off + c.off_slotK;
-    na.out_canonical = 0;
-    HIPCHK(launch_ntt(na, st));
     na.out = reinterpret_cast<int16_t *>(c.d_P);
     na.out_gstride = c.proof_stride;
     na.dst_off = c.d_off + c.off_nttsr_er;
     na.out_canonical = 1;
     HIPCHK(launch_ntt(na, st));
-    HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_poly, c.poly_stride, K, c.d_P, c.proof_stride, rm.nttasr, K, n, st)); // :287-288
+    HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_P, c.proof_stride, rm.nttsr, rm.nttasr, K, n, st)); // :287-288
     HIPCHK(launch_copy_tails(c.d_P, c.proof_stride, rm, n, st));
     const GemmSrc x2src{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, 0, XLEN};
     const GemmDst x2dst{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, EXP_OFF};

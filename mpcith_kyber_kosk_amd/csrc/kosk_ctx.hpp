@@ -57,7 +57,8 @@ struct Ctx {
     int16_t *d_fresh_rows = nullptr, *d_gemm1_rows = nullptr, *d_gemm2_rows = nullptr;
     int n_gemm1 = 0, n_gemm2 = 0;
     int32_t *d_off = nullptr; // NTT offset tables, see build_tables()
-    int off_f = 0, off_tf = 0, off_s = 0, off_slot0 = 0, off_sr_er = 0, off_slotK = 0, off_nttsr_er = 0;
+    int off_ntt1_src = 0, off_ntt1_dst = 0, n_ntt1 = 0; // NTT(f_i) -> Tf_i and NTT(s_i) -> shat_i in one launch
+    int off_sr_er = 0, off_nttsr_er = 0;
     FieldDesc *d_fields = nullptr;
     int16_t *d_rowtab = nullptr;
     int nfields = 0;

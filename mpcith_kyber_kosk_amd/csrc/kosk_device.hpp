@@ -69,8 +69,13 @@ struct GemmArgs {
     const uint8_t *A;  // table limb matrix, RT = Mpad/16
     size_t a_gstride;  // bytes between per-group operands (grouped mode)
     int Mpad, M, KS;   // Mpad multiple of 128; m < M is stored
-    const uint8_t *B;  // data limb matrix, rows n = g*npg_pad + i
+    const uint8_t *B;  // data operand as a limb matrix, rows n = g*npg_pad + i (null: convert from `src` on the fly)
     int BRT;           // row tiles of B
+    // data operand as canonical u16 rows, k contiguous: row (g, i) at src + g*src_gstride + src_rows[i]*src_rstride + src_koff
+    const uint16_t *src;
+    size_t src_gstride;
+    const int16_t *src_rows; // null: i
+    int src_rstride, src_koff;
     uint16_t *C;
     size_t c_gstride;
     const int16_t *c_rows; // output row per i (null: i)
@@ -179,8 +184,8 @@ hipError_t launch_tape_randoms(const uint8_t *tape, size_t tape_stride, int slic
 hipError_t launch_witness_secrets(const int16_t *se, size_t se_stride, uint16_t *P, size_t proof_stride,
                                   const RowMap &rm, int eta1, int nproofs, hipStream_t st);
 hipError_t launch_ntt(const NttArgs &a, hipStream_t st);
-hipError_t launch_matvec_ntt(const int16_t *A, size_t A_stride, const int16_t *v, size_t v_stride, int v_slot,
-                             uint16_t *P, size_t proof_stride, int row0, int K, int nproofs, hipStream_t st);
+hipError_t launch_matvec_ntt(const int16_t *A, size_t A_stride, uint16_t *P, size_t proof_stride, int v_row0, int row0, int K,
+                             int nproofs, hipStream_t st);
 hipError_t launch_rows_to_limbs(const LimbArgs &a, hipStream_t st);
 hipError_t launch_gemm(const GemmArgs &a, hipStream_t st);
 // K3 on the matrix cores (prover): transposed f / NTT-f rows and the alpha-power coefficient matrix as limb matrices

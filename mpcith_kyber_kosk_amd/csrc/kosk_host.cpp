@@ -372,7 +372,7 @@ static void sha3_digest_tables(int n, const uint8_t *digs, size_t dig_stride, ui
     int w = sha3_multi_width();
     static const int forced = getenv("KOSK_FS_WIDTH") ? atoi(getenv("KOSK_FS_WIDTH")) : 0;
     if (forced == 8 || forced == 4 || forced == 1) w = forced <= w ? forced : w;
-    else if (w == 8 && (n + 3) / 4 <= nthreads) w = 4;
+    else if (w == 8 && n <= 4 * nthreads && n < 16) w = 4; // few proofs: shorter chains per group beat fewer groups
     if (w > 1 && n <= nthreads && !caps().avx512f) w = 1;
     const int groups = (n + w - 1) / w;
     parallel_for(pool, groups, nthreads, [&](int g) { sha3_group(out, in.data(), (size_t)NPARTY * 32, n, w, g); });

@@ -314,17 +314,19 @@ __global__ __launch_bounds__(256) void k_ntt256(NttArgs a)
 // K6  r_i = tomont(Barrett(sum_l basemul(A[i][l], v[l])))      polyvec.c:202-214, poly.c:307-313
 // one thread per degree-1 factor (pair of coefficients); output canonical u16
 __global__ __launch_bounds__(128) void k_matvec_ntt(const int16_t *__restrict__ A, size_t A_stride,
-                                                    const int16_t *__restrict__ v, size_t v_stride, int v_slot,
-                                                    uint16_t *__restrict__ P, size_t proof_stride, int row0, int K)
+                                                    uint16_t *__restrict__ P, size_t proof_stride, int v_row0, int row0, int K)
 {
     const int t = threadIdx.x, i = blockIdx.x, b = blockIdx.y;
     const int32_t zeta = (t & 1) ? -(int32_t)kZetasDev.z[64 + (t >> 1)] : (int32_t)kZetasDev.z[64 + (t >> 1)];
     const int16_t *Ai = A + (size_t)b * A_stride + (size_t)i * K * 256;
-    const int16_t *vb = v + (size_t)b * v_stride + (size_t)v_slot * 256;
+    // the vector operand is the canonical NTT image stored in the packed-secret part of K consecutive rows
+    // (any representative < q gives the same residues, and the output is canonicalised)
+    const uint16_t *vb = P + (size_t)b * proof_stride + (size_t)v_row0 * RS;
+    constexpr int VS = RS; // u16 between the K polynomials
     int32_t r0 = 0, r1 = 0;
     for (int l = 0; l < K; l++) {
         const int32_t a0 = Ai[l * 256 + 2 * t], a1 = Ai[l * 256 + 2 * t + 1];
-        const int32_t b0 = vb[l * 256 + 2 * t], b1 = vb[l * 256 + 2 * t + 1];
+        const int32_t b0 = vb[l * VS + 2 * t], b1 = vb[l * VS + 2 * t + 1];
         // ntt.c:139-146 with int16 wrap-around of the reference's accumulation
         int32_t x0 = fqmul(fqmul(a1, b1), zeta);
         x0 = (int16_t)(x0 + fqmul(a0, b0));
@@ -392,6 +394,27 @@ constexpr int GM_TM = 128, GM_TN = 64;            // workgroup tile
 constexpr int GM_A_BYTES = (GM_TM / 16) * 2048;    // 16 KiB per k-step
 constexpr int GM_B_BYTES = (GM_TN / 16) * 2048;    //  8 KiB per k-step
 
+// 16 canonical u16 (two uint4) -> 16 low-limb bytes + 16 high-limb bytes of the centred representatives
+__device__ __forceinline__ void gm_split16(const uint4 &x0, const uint4 &x1, uint4 &lo, uint4 &hi)
+{
+    const uint32_t w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    uint32_t l[4] = {0, 0, 0, 0}, h[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        uint32_t v = (q & 1) ? (w[q >> 1] >> 16) : (w[q >> 1] & 0xFFFFu);
+        if (v >= (uint32_t)Q) v %= Q; // never for honest data; keeps arbitrary input bounded
+        int c0, c1;
+        limb_split(gf_center(v), c0, c1);
+        l[q >> 2] |= ((uint32_t)c0 & 0xFFu) << (8 * (q & 3));
+        h[q >> 2] |= ((uint32_t)c1 & 0xFFu) << (8 * (q & 3));
+    }
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+}
+
+// BLIMB: the data operand is already a limb matrix (lincomb coefficients); otherwise it is converted from
+// canonical u16 rows while it is staged (16 values per thread and k-step), which saves a conversion launch.
+template <bool BLIMB>
 __global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[2][GM_A_BYTES + GM_B_BYTES];
@@ -399,24 +422,53 @@ __global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
     const int wm = w & 1, wn = w >> 1;
     const int grp = a.grouped ? (int)blockIdx.z : 0;
     const int mt0 = blockIdx.x * (GM_TM / 16);     // first A row tile of this workgroup
-    const int nt0 = blockIdx.y * (GM_TN / 16) + (a.grouped ? grp * (a.npg_pad / 16) : 0);
     const int ART = a.Mpad / 16;
-    // staging: A 16 KiB = 4 x 16 B per thread, B 8 KiB = 2 x 16 B per thread, both contiguous per k-step.
+    // staging: A 16 KiB = 4 x 16 B per thread and k-step, contiguous in the limb matrix.
     // (named registers on purpose: arrays captured by a lambda end up in scratch memory)
     const uint4 *__restrict__ ap = reinterpret_cast<const uint4 *>(a.A + (size_t)grp * a.a_gstride + (size_t)mt0 * 2048) + tid;
-    const uint4 *__restrict__ bp = reinterpret_cast<const uint4 *>(a.B + (size_t)nt0 * 2048) + tid;
-    const size_t a_step = (size_t)ART * 128, b_step = (size_t)a.BRT * 128; // uint4 per k-step
+    const size_t a_step = (size_t)ART * 128; // uint4 per k-step
+    // B: either 8 KiB of limb tiles (2 x 16 B per thread), or 64 rows x 64 u16 (32 B per thread: row tid>>2, chunk tid&3)
+    const uint4 *__restrict__ bp;
+    size_t b_step;
+    int b_lds; // byte offset of this thread's converted 16 bytes inside the B region (limb 0)
+    bool b_ok = true;
+    if (BLIMB) {
+        const int nt0 = blockIdx.y * (GM_TN / 16) + (a.grouped ? grp * (a.npg_pad / 16) : 0);
+        bp = reinterpret_cast<const uint4 *>(a.B + (size_t)nt0 * 2048) + tid;
+        b_step = (size_t)a.BRT * 128;
+        b_lds = 0;
+    } else {
+        const int row_l = tid >> 2, kc = tid & 3;
+        const int n_loc = blockIdx.y * GM_TN + row_l;
+        int g, i;
+        if (a.grouped) { g = grp; i = n_loc; b_ok = i < a.npg; }
+        else { g = n_loc / a.npg; i = n_loc - g * a.npg; b_ok = n_loc < a.npg * a.ngroups; }
+        const size_t off = b_ok ? (size_t)g * a.src_gstride + (size_t)(a.src_rows ? (int)a.src_rows[i] : i) * a.src_rstride + a.src_koff + kc * 16 : 0;
+        bp = reinterpret_cast<const uint4 *>(a.src + off);
+        b_step = 8; // 64 u16 per k-step
+        b_lds = (row_l >> 4) * 2048 + (row_l & 15) * 64 + ((kc ^ limb_swz(row_l & 15)) << 4);
+    }
     uint4 ra0, ra1, ra2, ra3, rb0, rb1;
 #define GM_GLOAD()                                                           \
     ra0 = ap[0]; ra1 = ap[256]; ra2 = ap[512]; ra3 = ap[768];                \
-    rb0 = bp[0]; rb1 = bp[256];                                              \
+    if (BLIMB) { rb0 = bp[0]; rb1 = bp[256]; }                               \
+    else if (b_ok) { rb0 = bp[0]; rb1 = bp[1]; }                             \
+    else { rb0 = make_uint4(0, 0, 0, 0); rb1 = rb0; }                        \
     ap += a_step; bp += b_step;
 #define GM_LSTORE(buf)                                                       \
     {                                                                        \
         uint4 *la_ = reinterpret_cast<uint4 *>(lds[buf]) + tid;              \
-        uint4 *lb_ = reinterpret_cast<uint4 *>(lds[buf] + GM_A_BYTES) + tid; \
         la_[0] = ra0; la_[256] = ra1; la_[512] = ra2; la_[768] = ra3;        \
-        lb_[0] = rb0; lb_[256] = rb1;                                        \
+        if (BLIMB) {                                                         \
+            uint4 *lb_ = reinterpret_cast<uint4 *>(lds[buf] + GM_A_BYTES) + tid; \
+            lb_[0] = rb0; lb_[256] = rb1;                                    \
+        } else {                                                             \
+            uint4 lo_, hi_;                                                  \
+            gm_split16(rb0, rb1, lo_, hi_);                                  \
+            uint8_t *lb_ = lds[buf] + GM_A_BYTES + b_lds;                    \
+            *reinterpret_cast<uint4 *>(lb_) = lo_;                           \
+            *reinterpret_cast<uint4 *>(lb_ + 1024) = hi_;                    \
+        }                                                                    \
     }
 
     v4i s0[4][2], s1[4][2], s2[4][2];
@@ -804,10 +856,10 @@ hipError_t launch_ntt(const NttArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_matvec_ntt(const int16_t *A, size_t A_stride, const int16_t *v, size_t v_stride, int v_slot,
-                             uint16_t *P, size_t proof_stride, int row0, int K, int nproofs, hipStream_t st)
+hipError_t launch_matvec_ntt(const int16_t *A, size_t A_stride, uint16_t *P, size_t proof_stride, int v_row0, int row0, int K,
+                             int nproofs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_matvec_ntt, dim3(K, nproofs), dim3(128), 0, st, A, A_stride, v, v_stride, v_slot, P, proof_stride, row0, K);
+    hipLaunchKernelGGL(k_matvec_ntt, dim3(K, nproofs), dim3(128), 0, st, A, A_stride, P, proof_stride, v_row0, row0, K);
     return hipGetLastError();
 }
 
@@ -823,7 +875,8 @@ hipError_t launch_gemm(const GemmArgs &a, hipStream_t st)
     const int ntot = a.grouped ? a.npg : a.npg * a.ngroups;
     if (ntot <= 0) return hipSuccess;
     dim3 grid(a.Mpad / GM_TM, (ntot + GM_TN - 1) / GM_TN, a.grouped ? a.ngroups : 1);
-    hipLaunchKernelGGL(k_gemm_modq, grid, dim3(256), 0, st, a);
+    if (a.B) hipLaunchKernelGGL(k_gemm_modq<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_gemm_modq<false>, grid, dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -94,6 +94,7 @@ struct RowMap {
     int s, e, f, tf, beta0, gamma0, sr, er, gate, RV;
     int beta1, gamma1, r, nttr, seta, eeta, nttsr, ntter, nttasr, nttas, z2s, z2e;
     int ntts, ntte, nttar, t, ssub, esub;
+    int shat; // NTT(s) secrets (K rows, only x < 256 used)
     int sr_in, er_in, t_in, seta_in, eeta_in, us_in, ue_in; // verifier: values as given in the proof
     int nrows;
 
@@ -123,6 +124,7 @@ inline RowMap make_rowmap(const Params &p)
     r.z2s = take(K * Z); r.z2e = take(K * Z);
     r.ntts = take(K); r.ntte = take(K); r.nttar = take(K); r.t = take(K);
     r.ssub = take(K * E); r.esub = take(K * E);
+    r.shat = take(K);
     r.sr_in = take(K); r.er_in = take(K); r.t_in = take(K);
     r.seta_in = take(K * E); r.eeta_in = take(K * E);
     r.us_in = take(K * Z); r.ue_in = take(K * Z);

@@ -294,17 +294,12 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     na.src_off = c.d_off + c.off_sr_er;
     na.npg = 2 * K;
     na.npoly = 2 * K * n;
-    na.out = c.d_poly;
-    na.out_gstride = c.poly_stride;
-    na.dst_off = c.d_off + c.off_slotK;
-    na.out_canonical = 0;
-    HIPCHK(launch_ntt(na, st));
     na.out = reinterpret_cast<int16_t *>(c.d_P);
     na.out_gstride = c.proof_stride;
     na.dst_off = c.d_off + c.off_nttsr_er;
     na.out_canonical = 1;
     HIPCHK(launch_ntt(na, st));
-    HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_poly, c.poly_stride, K, c.d_P, c.proof_stride, rm.nttasr, K, n, st));
+    HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_P, c.proof_stride, rm.nttsr, rm.nttasr, K, n, st));
     HIPCHK(launch_copy_tails(c.d_P, c.proof_stride, rm, n, st));
     {
         const GemmSrc xs{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, 0, XLEN};

@@ -1,0 +1,16 @@
+#!/bin/bash
+# GPU-busy time per bench step (sum of kernel durations, 1 slot) -- the stable optimisation metric.
+# usage (on the GPU box, from the repo root): tools/gpu_busy.sh [outdir]
+out=${1:-gpurun_out/busy}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rm -rf $out
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --steps 8 --warmup 2 --slots 1 --no-cpu-baseline --no-kernels > /dev/null 2>&1
+f=$(find $out -name "*kernel_stats.csv" | head -1)
+python3 - $f <<PY
+import csv,sys
+rows=list(csv.DictReader(open(sys.argv[1])))
+tot=sum(float(r["TotalDurationNs"]) for r in rows)
+for r in rows[:int("${2:-16}")]:
+    print("%-40s calls/step %5.1f  avg %7.1f us  per-step %6.1f us"%(r["Name"].split("(")[0].replace("void ","").replace("kosk::","")[:40], int(r["Calls"])/10, float(r["AverageNs"])/1e3, float(r["TotalDurationNs"])/1e4))
+print("GPU busy per step: %.0f us"%(tot/1e4))
+PY
