@@ -75,6 +75,23 @@ def kernel_microbench(ctx, torch, k, lanes=65536, reps=20):
         perms = lanes * ((2 * words + 32 * wp) // 136 + 1)
         out[name] = {"lanes": lanes, "msg_bytes": 2 * words + 32 * wp, "us": ms * 1e3, "GBps": nbytes / ms / 1e6,
                      "frac_hbm_peak": nbytes / ms / 1e6 / HBM_PEAK_GBS, "keccak_f_per_s": perms / ms * 1e3}
+    # the same view-hash kernel with enough lanes to give every SIMD >= 4 waves (its saturated rate)
+    for big in (262144, 1048576):
+        rows_b = torch.randint(0, 3329, (vw_words, big), dtype=torch.int16, device="cuda", generator=g)
+        pre_b = torch.randint(0, 256, (big, 32), dtype=torch.uint8, device="cuda", generator=g)
+        dig_b = torch.zeros((big, 32), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(2):
+            ctx.commit_hash_lanes(rows_b.data_ptr(), big, big, pre_b.data_ptr(), 1, dig_b.data_ptr())
+        ctx.synchronize()
+        ctx.timer_start()
+        for _ in range(5):
+            ctx.commit_hash_lanes(rows_b.data_ptr(), big, big, pre_b.data_ptr(), 1, dig_b.data_ptr())
+        ms = ctx.timer_stop_ms() / 5
+        nbytes = big * (2 * vw_words + 64)
+        out["sha3_view_%d_lanes" % big] = {"us": ms * 1e3, "GBps": nbytes / ms / 1e6, "frac_hbm_peak": nbytes / ms / 1e6 / HBM_PEAK_GBS,
+                                           "keccak_f_per_s": big * 4 / ms * 1e3}
+        del rows_b, pre_b, dig_b
     polys = torch.randint(0, 3329, (lanes, 256), dtype=torch.int16, device="cuda", generator=g)
     outp = torch.zeros_like(polys)
     for _ in range(3):
@@ -86,16 +103,62 @@ def kernel_microbench(ctx, torch, k, lanes=65536, reps=20):
     ms = ctx.timer_stop_ms() / reps
     out["ntt256"] = {"polys": lanes, "us": ms * 1e3, "GBps": lanes * 1024 / ms / 1e6,
                      "frac_hbm_peak": lanes * 1024 / ms / 1e6 / HBM_PEAK_GBS}
-    y = torch.randint(0, 3329, (8192, 407), dtype=torch.int16, device="cuda", generator=g)
-    sh = torch.zeros((8192, 1454), dtype=torch.int16, device="cuda")
+    return out
+
+
+def extras(api, torch, k, B, tapes):
+    """Untimed-region extras for DESIGN.md: PCIe-inclusive end-to-end rate and a throughput-mode sample."""
+    out = {}
+    import ctypes as C
+    c = api.Kosk(kyber_k=k, max_batch=B)
+    blob = C.create_string_buffer(b"".join(tapes), c.tape_bytes * B)
+    pk = C.create_string_buffer(c.pk_bytes * B); sk = C.create_string_buffer(c.sk_bytes * B)
+    pi = C.create_string_buffer(c.proof_bytes * B); okb = C.create_string_buffer(B)
+    lib, h = api.lib, c.handle
+
+    def once():
+        # the two top-level ABI calls on HOST buffers: host keygen, tape H2D, proof D2H (31 MB), proof/pk H2D for verify
+        assert lib.kosk_verifiable_keygen_batch(h, B, blob, c.tape_bytes, pk, sk, pi) == 0
+        assert lib.kosk_verify_batch(h, B, pi, pk, okb) == 0 and okb.raw == b"\x01" * B
+    once()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        once()
+    out["pcie_inclusive_proofs_per_s"] = reps * B / (time.perf_counter() - t0)
+    c.close()
+    import threading
+    BT, ST, steps = 512, 2, 3
+    slots = [api.Kosk(kyber_k=k, max_batch=BT) for _ in range(ST)]
+    for si, sc in enumerate(slots):
+        sc.stage_prover_inputs(tapes_for(k, 1000 + si * BT, BT, sc.tape_bytes))
+
+    def work(sc):
+        for _ in range(steps):
+            sc.prove_resident(BT)
+            assert all(sc.verify_resident(BT))
+    for sc in slots:
+        work_warm = threading.Thread(target=lambda s_=sc: (s_.prove_resident(BT), s_.verify_resident(BT)))
+        work_warm.start(); work_warm.join()
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(sc,)) for sc in slots]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dtt = time.perf_counter() - t0
+    out["throughput_mode"] = {"proofs_per_batch": BT, "slots": ST, "proofs_per_s": ST * steps * BT / dtt,
+                              "batch_latency_ms": dtt / steps * 1e3, "note": "BASELINE configs[4] per-GPU share: 512 Kyber-768 keygens in one batch"}
+    for sc in slots:
+        sc.close()
     return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--kyber-k", type=int, default=3)
     ap.add_argument("--batch", type=int, default=46, help="proofs per GPU per step (46 x 1454 = 66 884 party lanes)")
     ap.add_argument("--cpu-proofs", type=int, default=12, help="bounded CPU baseline sample (about 13 s)")
@@ -141,6 +204,9 @@ def main():
         if si == 0:
             tapes = t
         c.stage_prover_inputs(t)  # randomness tapes + key material -> HBM (outside the timed region)
+        # setup, not a benchmark step: first use allocates the verifier workspace and builds its tables
+        c.prove_resident(B)
+        assert all(c.verify_resident(B))
 
     def step(c):
         c.prove_resident(B)
@@ -148,26 +214,37 @@ def main():
         if not all(ok):
             raise RuntimeError("rank %d: verifier rejected %d of %d honest proofs" % (rank, ok.count(False), B))
 
-    def run_steps(nsteps):
-        """deal nsteps whole batches round-robin to the slots; returns when all are proved and verified"""
-        errs = []
+    # one persistent worker thread per slot (created once: a thread's first HIP call pays thread-local set-up)
+    import queue
+    jobs = [queue.Queue() for _ in range(S)]
+    done = queue.Queue()
 
-        def worker(si):
+    def worker(si):
+        while True:
+            n_my = jobs[si].get()
+            if n_my is None:
+                return
+            err = None
             try:
-                for _ in range(si, nsteps, S):
+                for _ in range(n_my):
                     step(slots[si])
             except Exception as e:  # noqa: BLE001
-                errs.append(e)
-        if S == 1:
-            worker(0)
-        else:
-            th = [threading.Thread(target=worker, args=(si,)) for si in range(S)]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-        if errs:
-            raise errs[0]
+                err = e
+            done.put(err)
+    workers = [threading.Thread(target=worker, args=(si,), daemon=True) for si in range(S)]
+    for wt in workers:
+        wt.start()
+
+    def run_steps(nsteps):
+        """deal nsteps whole batches round-robin to the slots; returns when all are proved and verified"""
+        for si in range(S):
+            jobs[si].put(len(range(si, nsteps, S)))
+        errs = [done.get() for _ in range(S)]
+        for e in errs:
+            if e is not None:
+                raise e
+
+    run_steps(S)  # setup: every worker thread touches the GPU once before anything is timed
 
     def barrier():
         torch.cuda.synchronize()
@@ -262,12 +339,15 @@ def main():
         }
         if world == 1 and not args.no_kernels:
             line["kernels_65536_lanes"] = kernel_microbench(ctx, torch, k)
+            line["extras"] = extras(api, torch, k, B, tapes)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(k, tapes, min(args.cpu_proofs, B))
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    for q in jobs:
+        q.put(None)
     for c in slots:
         c.close()
 
