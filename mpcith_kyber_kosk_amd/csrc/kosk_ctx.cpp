@@ -62,12 +62,12 @@ Ctx::~Ctx()
         for (auto e : pe)
             if (e) (void)hipEventDestroy(e);
     void *dev[] = {t_expand.d, t_recon_d.d, t_recon_2d.d, d_fresh_rows, d_gemm1_rows, d_gemm2_rows, d_off, d_fields,
-                   d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_poly, d_t, d_alpha, d_I, d_rest, d_pwT, d_limbs, d_linA, d_coef, d_lin_rows,
+                   d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_seeds, d_pk, d_sb, d_sehat, d_t, d_alpha, d_I, d_rest, d_pwT, d_limbs, d_linA, d_coef, d_lin_rows,
                    d_gather, d_gather2, d_W, d_W2, d_w, d_ell, d_sec, d_sec_u1, d_sec_u2, d_fail, d_inv, d_vfields,
                    d_vrowtab, d_rows_bg, d_rows_isrc, d_rows_idst, d_rows_u, d_fact, d_invfact, d_node_of, d_isort, d_hrange};
     for (void *p : dev)
         if (p) (void)hipFree(p);
-    void *host[] = {h_tape, h_dig, h_proof, h_A, h_se, h_t, h_alpha, h_I, h_rest, h_fail, h_Iimg, h_isort, h_hrange};
+    void *host[] = {h_tape, h_dig, h_proof, h_alpha, h_I, h_rest, h_fail, h_Iimg, h_isort, h_hrange, h_seeds, h_pk, h_sb};
     for (void *p : host)
         if (p) (void)hipHostFree(p);
     if (pool) pool_destroy(pool);
@@ -257,7 +257,6 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
         c.image_stride = (P.proof_bytes + 63) / 64 * 64;
         c.key_stride = (size_t)P.K * P.K * 256;
         c.se_stride = (size_t)2 * P.K * 256;
-        c.poly_stride = (size_t)3 * P.K * 256;
         c.sel_stride = 1312;
         HIPCHK(dalloc(&c.d_P, B * c.proof_stride));
         HIPCHK(hipMemsetAsync(c.d_P, 0, B * c.proof_stride * 2, c.stream));
@@ -267,8 +266,16 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
         HIPCHK(dalloc(&c.d_proof, B * c.image_stride));
         HIPCHK(dalloc(&c.d_A, B * c.key_stride));
         HIPCHK(dalloc(&c.d_se, B * c.se_stride));
-        HIPCHK(dalloc(&c.d_poly, B * c.poly_stride));
         HIPCHK(dalloc(&c.d_t, B * P.K * 256));
+        c.pk_stride = (P.pk_bytes + 15) / 16 * 16;
+        c.sb_stride = (size_t)384 * P.K;
+        HIPCHK(dalloc(&c.d_seeds, B * 64));
+        HIPCHK(dalloc(&c.d_pk, B * c.pk_stride));
+        HIPCHK(dalloc(&c.d_sb, B * c.sb_stride));
+        HIPCHK(dalloc(&c.d_sehat, B * c.se_stride));
+        HIPCHK(halloc(&c.h_seeds, B * 64));
+        HIPCHK(halloc(&c.h_pk, B * c.pk_stride));
+        HIPCHK(halloc(&c.h_sb, B * c.sb_stride));
         HIPCHK(dalloc(&c.d_alpha, B * 80));
         HIPCHK(dalloc(&c.d_I, B * c.sel_stride));
         HIPCHK(dalloc(&c.d_rest, B * c.sel_stride));
@@ -282,9 +289,6 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
         HIPCHK(halloc(&c.h_tape, B * c.tape_stride));
         HIPCHK(halloc(&c.h_dig, B * NPARTY * 32));
         HIPCHK(halloc(&c.h_proof, B * c.image_stride));
-        HIPCHK(halloc(&c.h_A, B * c.key_stride));
-        HIPCHK(halloc(&c.h_se, B * c.se_stride));
-        HIPCHK(halloc(&c.h_t, B * P.K * 256));
         HIPCHK(halloc(&c.h_alpha, B * 80));
         HIPCHK(halloc(&c.h_I, B * c.sel_stride));
         HIPCHK(halloc(&c.h_rest, B * c.sel_stride));
@@ -319,22 +323,31 @@ int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride,
             for (int i = 0; i < P.nfresh; i++) draw(302);
         }
     }
-    parallel_for(c.pool, n, c.nthreads, [&](int b) {
-        uint8_t *tp = c.h_tape + (size_t)b * c.tape_stride;
-        if (tapes) {
-            memcpy(tp, tapes + (size_t)b * tape_stride, P.tape_bytes);
-        }
-        HostKey key;
-        host_keygen(P, tp, pk + (size_t)b * P.pk_bytes, sk + (size_t)b * P.sk_bytes, key);
-        memcpy(c.h_A + (size_t)b * c.key_stride, key.A, c.key_stride * sizeof(int16_t));
-        memcpy(c.h_se + (size_t)b * c.se_stride, key.se, c.se_stride * sizeof(int16_t));
-        for (int i = 0; i < P.K * 256; i++) c.h_t[(size_t)b * P.K * 256 + i] = (uint16_t)gf_encode(key.t[i]);
-    });
+    if (tapes)
+        parallel_for(c.pool, n, c.nthreads, [&](int b) { memcpy(c.h_tape + (size_t)b * c.tape_stride, tapes + (size_t)b * tape_stride, P.tape_bytes); });
     HIPCHK(hipMemcpyAsync(c.d_tape, c.h_tape, (size_t)n * c.tape_stride, hipMemcpyHostToDevice, c.stream));
-    HIPCHK(hipMemcpyAsync(c.d_A, c.h_A, (size_t)n * c.key_stride * 2, hipMemcpyHostToDevice, c.stream));
-    HIPCHK(hipMemcpyAsync(c.d_se, c.h_se, (size_t)n * c.se_stride * 2, hipMemcpyHostToDevice, c.stream));
-    HIPCHK(hipMemcpyAsync(c.d_t, c.h_t, (size_t)n * P.K * 256 * 2, hipMemcpyHostToDevice, c.stream));
+    // kyber_keygen on the device (kosk.cpp:4-70): A, s, e never leave HBM; only pk, NTT(s) bytes and the seeds come back
+    const int K = P.K;
+    HIPCHK(launch_keygen(c.d_tape, c.tape_stride, c.d_seeds, c.d_A, c.key_stride, c.d_se, c.se_stride, K, P.eta1, n, c.stream));
+    NttArgs na{};
+    na.in = c.d_se; na.in_gstride = c.se_stride; na.src_off = nullptr;
+    na.out = c.d_sehat; na.out_gstride = c.se_stride; na.dst_off = nullptr;
+    na.npg = 2 * K; na.npoly = 2 * K * n; na.out_canonical = 0;
+    HIPCHK(launch_ntt(na, c.stream)); // polyvec_ntt(s), polyvec_ntt(e)   kosk.cpp:39-40
+    HIPCHK(launch_keygen_pack(c.d_A, c.key_stride, c.d_sehat, c.se_stride, c.d_seeds, c.d_t, c.d_pk, c.pk_stride, c.d_sb,
+                              c.sb_stride, K, n, c.stream));
+    HIPCHK(hipMemcpyAsync(c.h_pk, c.d_pk, (size_t)n * c.pk_stride, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipMemcpyAsync(c.h_sb, c.d_sb, (size_t)n * c.sb_stride, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipMemcpyAsync(c.h_seeds, c.d_seeds, (size_t)n * 64, hipMemcpyDeviceToHost, c.stream));
     HIPCHK(hipStreamSynchronize(c.stream));
+    parallel_for(c.pool, n, c.nthreads, [&](int b) { // sk = NTT(s) bytes || pk || H(pk) || z, z = noise seed   kosk.cpp:62-69
+        uint8_t *pkb = pk + (size_t)b * P.pk_bytes, *skb = sk + (size_t)b * P.sk_bytes;
+        memcpy(pkb, c.h_pk + (size_t)b * c.pk_stride, P.pk_bytes);
+        memcpy(skb, c.h_sb + (size_t)b * c.sb_stride, c.sb_stride);
+        memcpy(skb + c.sb_stride, pkb, P.pk_bytes);
+        sha3_256(skb + P.sk_bytes - 64, pkb, P.pk_bytes);
+        memcpy(skb + P.sk_bytes - 32, c.h_seeds + (size_t)b * 64 + 32, 32);
+    });
     c.phase_sec[PH_HOST_PRE] = now_sec() - t0;
     return 0;
 }

@@ -67,11 +67,16 @@ struct Ctx {
 
     // per-batch workspace
     size_t proof_stride = 0; // u16 per proof in the row matrix
-    size_t tape_stride = 0, image_stride = 0, key_stride = 0, se_stride = 0, poly_stride = 0;
+    size_t tape_stride = 0, image_stride = 0, key_stride = 0, se_stride = 0;
     int sel_stride = 0;
     uint16_t *d_P = nullptr;
     uint8_t *d_tape = nullptr, *d_dig1 = nullptr, *d_dig2 = nullptr, *d_proof = nullptr;
-    int16_t *d_A = nullptr, *d_se = nullptr, *d_poly = nullptr;
+    int16_t *d_A = nullptr, *d_se = nullptr;
+    // key generation on the device (kosk_keygen_kernels.hip)
+    uint8_t *d_seeds = nullptr, *d_pk = nullptr, *d_sb = nullptr; // sha3_512 output, packed pk, packed NTT(s)
+    int16_t *d_sehat = nullptr;
+    size_t pk_stride = 0, sb_stride = 0;
+    uint8_t *h_seeds = nullptr, *h_pk = nullptr, *h_sb = nullptr;
     uint16_t *d_t = nullptr; // pk's t, canonical (verifier)
     uint16_t *d_alpha = nullptr, *d_I = nullptr, *d_rest = nullptr;
     int32_t *d_pwT = nullptr;
@@ -103,8 +108,6 @@ struct Ctx {
 
     // pinned host staging
     uint8_t *h_tape = nullptr, *h_dig = nullptr, *h_proof = nullptr;
-    int16_t *h_A = nullptr, *h_se = nullptr;
-    uint16_t *h_t = nullptr;
     uint16_t *h_alpha = nullptr, *h_I = nullptr, *h_rest = nullptr;
     uint32_t *h_fail = nullptr;
 

@@ -172,6 +172,14 @@ hipError_t launch_check_pairs(const uint16_t *a, const uint16_t *b, size_t gstri
                               int nproofs, hipStream_t st);
 hipError_t launch_check_zero(const uint16_t *a, size_t gstride, int nrows, uint32_t *fail, int bit, int nproofs, hipStream_t st);
 
+// ---- key generation (kosk_keygen_kernels.hip) ----
+hipError_t launch_keygen(const uint8_t *tape, size_t tape_stride, uint8_t *seeds, int16_t *A, size_t A_stride, int16_t *se,
+                         size_t se_stride, int K, int eta1, int n, hipStream_t st);
+hipError_t launch_keygen_pack(const int16_t *A, size_t A_stride, const int16_t *sehat, size_t sehat_stride, const uint8_t *seeds,
+                              uint16_t *t_out, uint8_t *pk, size_t pk_stride, uint8_t *shat_bytes, size_t sb_stride, int K, int n,
+                              hipStream_t st);
+hipError_t launch_decode_pk(const uint8_t *pk, size_t pk_stride, uint16_t *t_out, int16_t *A, size_t A_stride, int K, int n, hipStream_t st);
+
 hipError_t launch_commit_hash(const HashArgs &a, int ngroups, int K, bool view, hipStream_t st);
 hipError_t launch_sha3_msgs(const uint8_t *in, size_t in_stride, int len, uint8_t *out, size_t out_stride,
                             int outlen, int n, int domain, hipStream_t st);

@@ -735,11 +735,13 @@ __global__ __launch_bounds__(256) void k_post_relation(uint16_t *__restrict__ P,
 // field element [i][e] = P[rows[e]][256 + sel[i]] ; 64 parties per workgroup,
 // LDS transpose so that both the row reads and the image writes are coalesced
 // =========================================================================
-constexpr int ASM_W = 81; // padded field width in LDS
+constexpr int ASM_TILE = 64 * 80; // u16 per tile: 64 parties x the widest field (79)
 
 __global__ __launch_bounds__(256) void k_assemble_fields(AssembleArgs a)
 {
-    __shared__ uint16_t tile[64 * ASM_W];
+    // the tile is kept in IMAGE order (party-major, no padding): the second phase is a straight 4-byte copy.
+    // Field widths are odd multiples or not of 32 banks; the stride width*2 B is conflict-free enough for 2-byte stores.
+    __shared__ __attribute__((aligned(16))) uint16_t tile[ASM_TILE];
     const FieldDesc fd = a.fields[blockIdx.y];
     const int b = blockIdx.z;
     const int np = fd.sel ? NREST : NOPEN;
@@ -750,17 +752,17 @@ __global__ __launch_bounds__(256) void k_assemble_fields(AssembleArgs a)
     const uint16_t *Pb = a.P + (size_t)b * a.proof_stride;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane < cnt) {
-        const int col = NSEC + sel[i0 + lane];
-        for (int e = w; e < fd.width; e += 4)
-            tile[lane * ASM_W + e] = Pb[(size_t)a.rowtab[fd.rowtab_off + e] * RS + col];
+        const uint16_t *src = Pb + NSEC + sel[i0 + lane];
+        const int16_t *rt = a.rowtab + fd.rowtab_off;
+        uint16_t *t = tile + lane * fd.width;
+        for (int e = w; e < fd.width; e += 4) t[e] = src[(size_t)rt[e] * RS];
     }
     __syncthreads();
-    uint16_t *out = reinterpret_cast<uint16_t *>(a.proof + (size_t)b * a.image_stride + fd.off) + (size_t)i0 * fd.width;
-    const int total = cnt * fd.width;
-    for (int q = threadIdx.x; q < total; q += 256) {
-        const int i = q / fd.width, e = q - i * fd.width;
-        out[q] = tile[i * ASM_W + e];
-    }
+    // every field offset and every 64-party chunk is a multiple of 4 bytes (T = 150 and R = 1304 are even)
+    uint32_t *out = reinterpret_cast<uint32_t *>(a.proof + (size_t)b * a.image_stride + fd.off + (size_t)i0 * fd.width * 2);
+    const uint32_t *t32 = reinterpret_cast<const uint32_t *>(tile);
+    const int words = cnt * fd.width / 2; // cnt*width is even: cnt is 64, 24 (1304 % 64) or 22 (150 % 64)
+    for (int q = threadIdx.x; q < words; q += 256) out[q] = t32[q];
 }
 
 // Tcomm / comm of the unopened parties and the list I itself

@@ -92,10 +92,10 @@ inline bool make_params(int K, Params &p)
 struct RowMap {
     int K, M, E, Z;
     int s, e, f, tf, beta0, gamma0, sr, er, gate, RV;
-    int beta1, gamma1, r, nttr, seta, eeta, nttsr, ntter, nttasr, nttas, z2s, z2e;
+    int beta1, gamma1, r, nttr, seta, eeta, nttsr, ntter, nttasr, nttas;
     int ntts, ntte, nttar, t, ssub, esub;
     int shat; // NTT(s) secrets (K rows, only x < 256 used)
-    int sr_in, er_in, t_in, seta_in, eeta_in, us_in, ue_in; // verifier: values as given in the proof
+    int sr_in, er_in, t_in, seta_in, eeta_in; // verifier: unopened values as given in the proof (before re-computation)
     int nrows;
 
     KOSK_HD int beta(int j) const { return j < K ? beta0 + j : beta1 + (j - K); }
@@ -121,13 +121,11 @@ inline RowMap make_rowmap(const Params &p)
     r.r = take(2 * K); r.nttr = take(2 * K);
     r.seta = take(K * E); r.eeta = take(K * E);
     r.nttsr = take(K); r.ntter = take(K); r.nttasr = take(K); r.nttas = take(K);
-    r.z2s = take(K * Z); r.z2e = take(K * Z);
     r.ntts = take(K); r.ntte = take(K); r.nttar = take(K); r.t = take(K);
     r.ssub = take(K * E); r.esub = take(K * E);
     r.shat = take(K);
     r.sr_in = take(K); r.er_in = take(K); r.t_in = take(K);
     r.seta_in = take(K * E); r.eeta_in = take(K * E);
-    r.us_in = take(K * Z); r.ue_in = take(K * Z);
     r.nrows = n;
     return r;
 }

@@ -140,16 +140,14 @@ int stage_verifier_inputs(Ctx &c, int n, const uint8_t *pi, const uint8_t *pk)
     if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
     HIPCHK(hipSetDevice(c.device));
     const Params &P = c.P;
-    parallel_for(c.pool, n, c.nthreads, [&](int b) {
-        HostKey key;
-        host_decode_pk(P, pk + (size_t)b * P.pk_bytes, key);
-        memcpy(c.h_A + (size_t)b * c.key_stride, key.A, c.key_stride * sizeof(int16_t));
-        for (int i = 0; i < P.K * 256; i++) c.h_t[(size_t)b * P.K * 256 + i] = (uint16_t)key.t[i];
+    for (int b = 0; b < n; b++) {
+        memcpy(c.h_pk + (size_t)b * c.pk_stride, pk + (size_t)b * P.pk_bytes, P.pk_bytes);
         memcpy(c.h_proof + (size_t)b * c.image_stride, pi + (size_t)b * P.proof_bytes, P.proof_bytes);
-    });
-    HIPCHK(hipMemcpyAsync(c.d_A, c.h_A, (size_t)n * c.key_stride * 2, hipMemcpyHostToDevice, c.stream));
-    HIPCHK(hipMemcpyAsync(c.d_t, c.h_t, (size_t)n * P.K * 256 * 2, hipMemcpyHostToDevice, c.stream));
+    }
+    HIPCHK(hipMemcpyAsync(c.d_pk, c.h_pk, (size_t)n * c.pk_stride, hipMemcpyHostToDevice, c.stream));
     HIPCHK(hipMemcpyAsync(c.d_proof, c.h_proof, (size_t)n * c.image_stride, hipMemcpyHostToDevice, c.stream));
+    // polyvec_frombytes(t) and gen_matrix(A, seed) on the device   kosk.cpp:94-99
+    HIPCHK(launch_decode_pk(c.d_pk, c.pk_stride, c.d_t, c.d_A, c.key_stride, P.K, n, c.stream));
     HIPCHK(hipStreamSynchronize(c.stream));
     return 0;
 }

@@ -11,7 +11,7 @@
 
 namespace kosk {
 
-constexpr int DIS_W = 81;
+constexpr int DIS_TILE = 64 * 80;
 
 // inverse of k_assemble_fields: proof image -> rows at the listed party columns.
 // Non-canonical values (>= q) can never be produced by an honest prover; they are
@@ -20,29 +20,32 @@ __global__ __launch_bounds__(256) void k_disassemble_fields(VerifyArgs v, const 
                                                            const int16_t *__restrict__ rowtab,
                                                            const uint8_t *__restrict__ proof, size_t image_stride)
 {
-    __shared__ uint16_t tile[64 * DIS_W];
+    __shared__ __attribute__((aligned(16))) uint16_t tile[DIS_TILE]; // image order, filled by 4-byte copies
     const FieldDesc fd = fields[blockIdx.y];
     const int b = blockIdx.z;
     const int np = fd.sel ? NREST : NOPEN;
     const int i0 = blockIdx.x * 64;
     if (i0 >= np) return;
     const int cnt = min(64, np - i0);
-    const uint16_t *in = reinterpret_cast<const uint16_t *>(proof + (size_t)b * image_stride + fd.off) + (size_t)i0 * fd.width;
-    const int total = cnt * fd.width;
+    const uint32_t *in = reinterpret_cast<const uint32_t *>(proof + (size_t)b * image_stride + fd.off + (size_t)i0 * fd.width * 2);
+    uint32_t *t32 = reinterpret_cast<uint32_t *>(tile);
+    const int words = cnt * fd.width / 2;
     bool bad = false;
-    for (int q = threadIdx.x; q < total; q += 256) {
+    for (int q = threadIdx.x; q < words; q += 256) {
         uint32_t x = in[q];
-        if (x >= (uint32_t)Q) { bad = true; x %= Q; }
-        const int i = q / fd.width, e = q - i * fd.width;
-        tile[i * DIS_W + e] = (uint16_t)x;
+        uint32_t lo = x & 0xFFFFu, hi = x >> 16;
+        if (lo >= (uint32_t)Q || hi >= (uint32_t)Q) { bad = true; lo %= Q; hi %= Q; x = lo | (hi << 16); }
+        t32[q] = x;
     }
     __syncthreads();
     const uint16_t *sel = (fd.sel ? v.rest : v.opened) + (size_t)b * v.sel_stride;
     uint16_t *Pb = v.P + (size_t)b * v.proof_stride;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane < cnt) {
-        const int col = NSEC + sel[i0 + lane];
-        for (int e = w; e < fd.width; e += 4) Pb[(size_t)rowtab[fd.rowtab_off + e] * RS + col] = tile[lane * DIS_W + e];
+        uint16_t *dst = Pb + NSEC + sel[i0 + lane];
+        const int16_t *rt = rowtab + fd.rowtab_off;
+        const uint16_t *t = tile + lane * fd.width;
+        for (int e = w; e < fd.width; e += 4) dst[(size_t)rt[e] * RS] = t[e];
     }
     if (bad) atomicOr(&v.fail[b], 1u << FB_MALFORMED);
 }
