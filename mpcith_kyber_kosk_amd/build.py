@@ -16,7 +16,7 @@ OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libkosk_mi355x.so")
 HIP_SOURCES = ["kosk_kernels.hip", "kosk_verify_kernels.hip", "kosk_keygen_kernels.hip", "kosk_ctx.cpp", "kosk_verify.cpp", "kosk_capi.cpp"]
 CXX_SOURCES = ["kosk_host.cpp"]
-COMMON = ["-O3", "-std=c++17", "-fPIC"]
+COMMON = ["-O3", "-std=c++20", "-fPIC"]
 
 
 def _headers():

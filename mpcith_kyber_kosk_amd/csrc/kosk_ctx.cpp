@@ -487,7 +487,7 @@ int fetch_proofs(Ctx &c, int n, uint8_t *pi)
     const double t0 = now_sec();
     HIPCHK(hipMemcpyAsync(c.h_proof, c.d_proof, (size_t)n * c.image_stride, hipMemcpyDeviceToHost, c.stream));
     HIPCHK(hipStreamSynchronize(c.stream));
-    for (int b = 0; b < n; b++) memcpy(pi + (size_t)b * c.P.proof_bytes, c.h_proof + (size_t)b * c.image_stride, c.P.proof_bytes);
+    parallel_for(c.pool, n, c.nthreads, [&](int b) { memcpy(pi + (size_t)b * c.P.proof_bytes, c.h_proof + (size_t)b * c.image_stride, c.P.proof_bytes); });
     c.phase_sec[PH_D2H] = now_sec() - t0;
     return 0;
 }

@@ -156,6 +156,21 @@ struct InterpArgs {
 hipError_t launch_disassemble(const VerifyArgs &v, const FieldDesc *fields, const int16_t *rowtab, int nfields,
                               const uint8_t *proof, size_t image_stride, size_t off_tcomm, size_t off_comm,
                               uint8_t *dig1, uint8_t *dig2, int nproofs, hipStream_t st);
+// Tcomm / view hash of the OPENED parties straight from the proof image (mlwe_verifier.cpp:23-35, :585-632):
+// s, e, f, NTT f, z_s, z_e are contiguous per party there; only beta, gamma, s+r, e+r, u come from rows.
+struct OpenedHashArgs {
+    const uint8_t *proof;
+    size_t image_stride;
+    uint32_t off_s, off_e, off_f, off_nttf, off_zs, off_ze;
+    const uint16_t *P;
+    size_t proof_stride;
+    RowMap rm;
+    const uint16_t *opened;
+    int sel_stride;
+    const uint8_t *prefix; // Tcomm digest table [proof][NPARTY][32] (view hash only)
+    uint8_t *out;          // digest table, written at the party's index
+};
+hipError_t launch_opened_hash(const OpenedHashArgs &a, int K, bool view, int nproofs, hipStream_t st);
 hipError_t launch_gates_opened(const VerifyArgs &v, int nproofs, hipStream_t st);
 hipError_t launch_interp_build(const InterpArgs &a, int nproofs, hipStream_t st);
 // out[b][r][j] = w[b][set][j] * P[b][rows[r]][256 + rest[b][j]]

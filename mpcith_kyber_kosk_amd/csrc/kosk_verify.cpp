@@ -140,10 +140,10 @@ int stage_verifier_inputs(Ctx &c, int n, const uint8_t *pi, const uint8_t *pk)
     if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
     HIPCHK(hipSetDevice(c.device));
     const Params &P = c.P;
-    for (int b = 0; b < n; b++) {
+    parallel_for(c.pool, n, c.nthreads, [&](int b) {
         memcpy(c.h_pk + (size_t)b * c.pk_stride, pk + (size_t)b * P.pk_bytes, P.pk_bytes);
         memcpy(c.h_proof + (size_t)b * c.image_stride, pi + (size_t)b * P.proof_bytes, P.proof_bytes);
-    }
+    });
     HIPCHK(hipMemcpyAsync(c.d_pk, c.h_pk, (size_t)n * c.pk_stride, hipMemcpyHostToDevice, c.stream));
     HIPCHK(hipMemcpyAsync(c.d_proof, c.h_proof, (size_t)n * c.image_stride, hipMemcpyHostToDevice, c.stream));
     // polyvec_frombytes(t) and gen_matrix(A, seed) on the device   kosk.cpp:94-99
@@ -218,19 +218,20 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     HIPCHK(launch_disassemble(va, c.d_vfields, c.d_vrowtab, c.n_vfields, c.d_proof, c.image_stride, P.off[F_TCOMM],
                               P.off[F_COMM], c.d_dig1, c.d_dig2, n, st));
     HIPCHK(launch_gates_opened(va, n, st));
-    HashArgs ha{};
-    ha.rows = c.d_P;
-    ha.group_stride = c.proof_stride;
-    ha.row_stride = RS;
-    ha.col_off = NSEC;
-    ha.lanes_per_group = NOPEN;
-    ha.lane_map = c.d_I;
-    ha.lane_map_stride = c.sel_stride;
-    ha.prefix = nullptr;
-    ha.out = c.d_dig1;
-    ha.out_lanes_per_group = NPARTY;
+    OpenedHashArgs oh{};
+    oh.proof = c.d_proof;
+    oh.image_stride = c.image_stride;
+    oh.off_s = (uint32_t)P.off[F_S]; oh.off_e = (uint32_t)P.off[F_E]; oh.off_f = (uint32_t)P.off[F_F];
+    oh.off_nttf = (uint32_t)P.off[F_NTTF]; oh.off_zs = (uint32_t)P.off[F_ZS]; oh.off_ze = (uint32_t)P.off[F_ZE];
+    oh.P = c.d_P;
+    oh.proof_stride = c.proof_stride;
+    oh.rm = rm;
+    oh.opened = c.d_I;
+    oh.sel_stride = c.sel_stride;
+    oh.prefix = nullptr;
+    oh.out = c.d_dig1;
     c.prof_begin(PR_V_HASH_TCOMM);
-    HIPCHK(launch_commit_hash(ha, n, K, false, st));
+    HIPCHK(launch_opened_hash(oh, K, false, n, st)); // Tcomm of the opened parties, read from the image   :22-35
     c.prof_end(PR_V_HASH_TCOMM);
     HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig1, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c.ev, st));
@@ -346,10 +347,10 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     HIPCHK(launch_check_opened(va, n, st));
 
     // ---- V10: view hashes of the opened parties
-    ha.prefix = c.d_dig1;
-    ha.out = c.d_dig2;
+    oh.prefix = c.d_dig1;
+    oh.out = c.d_dig2;
     c.prof_begin(PR_V_HASH_VIEW);
-    HIPCHK(launch_commit_hash(ha, n, K, true, st));
+    HIPCHK(launch_opened_hash(oh, K, true, n, st));
     c.prof_end(PR_V_HASH_VIEW);
     HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig2, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(c.h_fail, c.d_fail, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st));

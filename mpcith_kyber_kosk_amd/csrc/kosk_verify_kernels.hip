@@ -6,7 +6,10 @@
 // interpolate()/eval(), mlwe_verifier.cpp:201-219 etc.).
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "kosk_device.hpp"
+#include "kosk_keccak_dev.hpp"
 #include "kosk_math.hpp"
 
 namespace kosk {
@@ -62,6 +65,108 @@ __global__ __launch_bounds__(256) void k_disassemble_digests(const uint8_t *__re
     const size_t dst = ((size_t)b * NPARTY + rest[(size_t)b * sel_stride + i]) * 32 + 2 * w;
     *reinterpret_cast<uint16_t *>(dig1 + dst) = reinterpret_cast<const uint16_t *>(img + off_tcomm)[q];
     *reinterpret_cast<uint16_t *>(dig2 + dst) = reinterpret_cast<const uint16_t *>(img + off_comm)[q];
+}
+
+// ---- SHA3-256 of the opened parties' Tcomm / view messages, one opened party per thread ---------------
+// word w (u16) of opened party i's message, K / VIEW compile-time so that every source is resolved statically
+template <int K, bool VIEW>
+struct OpenedMsg {
+    static constexpr int M = NCHK + 2 * K + 1, Z = 2 * (K == 2 ? 3 : 2);
+    static constexpr int BASE = 2 * K + 2 * M;                      // s, e, f, NTT f
+    static constexpr int WORDS = VIEW ? BASE + 4 * K + 4 * Z * K : BASE; // + beta, gamma, s+r, e+r, gates
+    template <int W>
+    static __device__ __forceinline__ uint32_t word(const OpenedHashArgs &a, const uint8_t *img, const uint16_t *col, int i)
+    {
+        auto im = [&](uint32_t off, int idx) { return (uint32_t)reinterpret_cast<const uint16_t *>(img + off)[idx]; };
+        if constexpr (W < K) return im(a.off_s, i * K + W);
+        else if constexpr (W < 2 * K) return im(a.off_e, i * K + (W - K));
+        else if constexpr (W < 2 * K + M) return im(a.off_f, i * M + (W - 2 * K));
+        else if constexpr (W < BASE) return im(a.off_nttf, i * M + (W - 2 * K - M));
+        else if constexpr (W < BASE + K) return col[(size_t)(a.rm.beta0 + (W - BASE)) * RS];
+        else if constexpr (W < BASE + 2 * K) return col[(size_t)(a.rm.gamma0 + (W - BASE - K)) * RS];
+        else if constexpr (W < BASE + 3 * K) return col[(size_t)(a.rm.sr + (W - BASE - 2 * K)) * RS];
+        else if constexpr (W < BASE + 4 * K) return col[(size_t)(a.rm.er + (W - BASE - 3 * K)) * RS];
+        else {
+            constexpr int g = W - (BASE + 4 * K), j = g / (4 * Z), q = g % (4 * Z), part = q / Z, z = q % Z;
+            if constexpr (part == 0) return im(a.off_zs, (i * K + j) * Z + z);
+            else if constexpr (part == 1) return im(a.off_ze, (i * K + j) * Z + z);
+            else if constexpr (part == 2) return col[(size_t)(a.rm.gate + j * 4 * Z + 2 * Z + z) * RS];
+            else return col[(size_t)(a.rm.gate + j * 4 * Z + 3 * Z + z) * RS];
+        }
+    }
+};
+
+template <int K, bool VIEW, int W0, int N>
+__device__ __forceinline__ void opened_absorb_block(KState &s, const OpenedHashArgs &a, const uint8_t *img, const uint16_t *col, int i,
+                                                    const uint8_t *prefix)
+{
+    // message words W0 .. W0+N-1 (N <= 68) into lanes 0..16; with VIEW the first 16 words are the 32-byte prefix
+    using Msg = OpenedMsg<K, VIEW>;
+    constexpr int PW = VIEW ? 16 : 0, TOTAL = PW + Msg::WORDS;
+    auto put = [&](auto wc) {
+        constexpr int w = decltype(wc)::value; // word inside this block, even
+        constexpr int gw = W0 + w;
+        if constexpr (gw < TOTAL) {
+            uint32_t v;
+            if constexpr (gw + 1 < PW + 1 && gw < PW) v = *reinterpret_cast<const uint32_t *>(prefix + 2 * gw);
+            else {
+                v = Msg::template word<gw - PW>(a, img, col, i);
+                if constexpr (gw + 1 < TOTAL) v |= Msg::template word<gw + 1 - PW>(a, img, col, i) << 16;
+            }
+            if constexpr ((w & 2) == 0) s.lo[w / 4] ^= v;
+            else s.hi[w / 4] ^= v;
+        }
+    };
+    [&]<int... Is>(std::integer_sequence<int, Is...>) { (put(std::integral_constant<int, 2 * Is>{}), ...); }(std::make_integer_sequence<int, 34>{});
+    (void)N;
+}
+
+template <int K, bool VIEW>
+__global__ __launch_bounds__(64) void k_opened_hash(OpenedHashArgs a)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
+    if (i >= NOPEN) return;
+    using Msg = OpenedMsg<K, VIEW>;
+    constexpr int PW = VIEW ? 16 : 0, TOTAL = PW + Msg::WORDS, NBLK = TOTAL / 68 + 1;
+    const int party = a.opened[(size_t)b * a.sel_stride + i];
+    const uint8_t *img = a.proof + (size_t)b * a.image_stride;
+    const uint16_t *col = a.P + (size_t)b * a.proof_stride + NSEC + party;
+    const size_t dig = ((size_t)b * NPARTY + party) * 32;
+    const uint8_t *prefix = VIEW ? a.prefix + dig : nullptr;
+    KState s;
+    kstate_zero(s);
+    [&]<int... Bs>(std::integer_sequence<int, Bs...>) {
+        (([&] {
+             opened_absorb_block<K, VIEW, Bs * 68, 68>(s, a, img, col, i, prefix);
+             if constexpr (Bs == NBLK - 1) {
+                 constexpr int padbyte = 2 * TOTAL - (NBLK - 1) * 136;
+                 constexpr uint32_t padv = 0x06u << (8 * (padbyte % 4));
+                 if constexpr ((padbyte % 8) < 4) s.lo[padbyte / 8] ^= padv;
+                 else s.hi[padbyte / 8] ^= padv;
+                 s.hi[16] ^= 0x80000000u;
+             }
+             keccak_f1600_dev(s);
+         }()),
+         ...);
+    }(std::make_integer_sequence<int, NBLK>{});
+    uint4 *o = reinterpret_cast<uint4 *>(a.out + dig);
+    o[0] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
+    o[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
+}
+
+template <int K>
+static void launch_opened_hash_k(const OpenedHashArgs &a, bool view, int nproofs, hipStream_t st)
+{
+    dim3 grid((NOPEN + 63) / 64, nproofs);
+    if (view) hipLaunchKernelGGL((k_opened_hash<K, true>), grid, dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_opened_hash<K, false>), grid, dim3(64), 0, st, a);
+}
+hipError_t launch_opened_hash(const OpenedHashArgs &a, int K, bool view, int nproofs, hipStream_t st)
+{
+    if (K == 2) launch_opened_hash_k<2>(a, view, nproofs, st);
+    else if (K == 3) launch_opened_hash_k<3>(a, view, nproofs, st);
+    else launch_opened_hash_k<4>(a, view, nproofs, st);
+    return hipGetLastError();
 }
 
 // u = z2d - z_d on the opened columns from the opened gate inputs   mlwe_verifier.cpp:469-495
