@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <utility>
 
 #include "kosk_device.hpp"
 #include "kosk_keccak_dev.hpp"
@@ -28,7 +29,8 @@ namespace kosk {
 // in VGPRs (v_bitop3_b32 / v_alignbit_b32), message words gathered from the
 // row matrix with one coalesced 128-byte line per wave per row.
 // =========================================================================
-template <int PREFIX_WORDS, int NROWS>
+// PIPE: software-pipelined loads (more registers, for launches with few waves per SIMD)
+template <int PREFIX_WORDS, int NROWS, bool PIPE>
 __global__ __launch_bounds__(64) void k_commit_hash(HashArgs a)
 {
     const int lane = blockIdx.x * 64 + threadIdx.x;
@@ -45,30 +47,83 @@ __global__ __launch_bounds__(64) void k_commit_hash(HashArgs a)
     KState s;
     kstate_zero(s);
 
-#pragma unroll
-    for (int blk = 0; blk < NBLK; blk++) {
-#pragma unroll
-        for (int w = 0; w < RATE_W; w += 2) {
-            const int gw = blk * RATE_W + w; // first of two u16 words forming half a lane
-            if (gw >= W) continue;
-            uint32_t v = 0;
-            if (gw + 1 < PREFIX_WORDS) {
-                v = *reinterpret_cast<const uint32_t *>(a.prefix + dig + 2 * gw);
-            } else {
-                v = base[(size_t)(gw - PREFIX_WORDS) * a.row_stride];
-                if (gw + 1 < W) v |= (uint32_t)base[(size_t)(gw + 1 - PREFIX_WORDS) * a.row_stride] << 16;
+    if constexpr (PIPE) {
+        // Software pipeline over the 136-byte blocks: the 68 row loads of block i+1 are issued BEFORE the
+        // permutation of block i, so their latency hides under ~4300 VALU instructions (with one wave per
+        // SIMD nothing else would hide it).  34 dwords of look-ahead.
+        uint32_t cur[RATE_W / 2], nxt[RATE_W / 2];
+        auto load_block = [&](auto blkc, uint32_t (&dst)[RATE_W / 2]) {
+            constexpr int blk = decltype(blkc)::value;
+    #pragma unroll
+            for (int w = 0; w < RATE_W; w += 2) {
+                const int gw = blk * RATE_W + w; // first of two u16 words forming half a lane
+                uint32_t v = 0;
+                if (gw < W) {
+                    if (gw + 1 < PREFIX_WORDS) {
+                        v = *reinterpret_cast<const uint32_t *>(a.prefix + dig + 2 * gw);
+                    } else {
+                        v = base[(size_t)(gw - PREFIX_WORDS) * a.row_stride];
+                        if (gw + 1 < W) v |= (uint32_t)base[(size_t)(gw + 1 - PREFIX_WORDS) * a.row_stride] << 16;
+                    }
+                }
+                dst[w / 2] = v;
             }
-            if ((w & 2) == 0) s.lo[w / 4] ^= v;
-            else s.hi[w / 4] ^= v;
+        };
+        auto run = [&]<int... Bs>(std::integer_sequence<int, Bs...>) {
+            load_block(std::integral_constant<int, 0>{}, cur);
+            (([&] {
+                 if constexpr (Bs + 1 < NBLK) load_block(std::integral_constant<int, Bs + 1>{}, nxt);
+    #pragma unroll
+                 for (int q = 0; q < RATE_W / 2; q++) {
+                     if ((q & 1) == 0) s.lo[q / 2] ^= cur[q];
+                     else s.hi[q / 2] ^= cur[q];
+                 }
+                 if constexpr (Bs == NBLK - 1) {
+                     constexpr int padbyte = 2 * W - (NBLK - 1) * 136;
+                     constexpr uint32_t padv = 0x06u << (8 * (padbyte % 4));
+                     if constexpr ((padbyte % 8) < 4) s.lo[padbyte / 8] ^= padv;
+                     else s.hi[padbyte / 8] ^= padv;
+                     s.hi[16] ^= 0x80000000u;
+                 }
+                 // keep the look-ahead at ONE block: without these fences the compiler hoists every block's loads to
+                 // the top (187 VGPRs, 2 waves/SIMD), which costs the saturated rate at large lane counts
+                 asm volatile("" ::: "memory");
+                 keccak_f1600_dev(s);
+                 asm volatile("" ::: "memory");
+                 if constexpr (Bs + 1 < NBLK) {
+    #pragma unroll
+                     for (int q = 0; q < RATE_W / 2; q++) cur[q] = nxt[q];
+                 }
+             }()),
+             ...);
+        };
+        run(std::make_integer_sequence<int, NBLK>{});
+    } else {
+#pragma unroll
+        for (int blk = 0; blk < NBLK; blk++) {
+#pragma unroll
+            for (int w = 0; w < RATE_W; w += 2) {
+                const int gw = blk * RATE_W + w; // first of two u16 words forming half a lane
+                if (gw >= W) continue;
+                uint32_t v = 0;
+                if (gw + 1 < PREFIX_WORDS) {
+                    v = *reinterpret_cast<const uint32_t *>(a.prefix + dig + 2 * gw);
+                } else {
+                    v = base[(size_t)(gw - PREFIX_WORDS) * a.row_stride];
+                    if (gw + 1 < W) v |= (uint32_t)base[(size_t)(gw + 1 - PREFIX_WORDS) * a.row_stride] << 16;
+                }
+                if ((w & 2) == 0) s.lo[w / 4] ^= v;
+                else s.hi[w / 4] ^= v;
+            }
+            if (blk == NBLK - 1) {
+                constexpr int padbyte = 2 * W - (NBLK - 1) * 136;
+                constexpr uint32_t padv = 0x06u << (8 * (padbyte % 4));
+                if ((padbyte % 8) < 4) s.lo[padbyte / 8] ^= padv;
+                else s.hi[padbyte / 8] ^= padv;
+                s.hi[16] ^= 0x80000000u;
+            }
+            keccak_f1600_dev(s);
         }
-        if (blk == NBLK - 1) {
-            constexpr int padbyte = 2 * W - (NBLK - 1) * 136;
-            constexpr uint32_t padv = 0x06u << (8 * (padbyte % 4));
-            if ((padbyte % 8) < 4) s.lo[padbyte / 8] ^= padv;
-            else s.hi[padbyte / 8] ^= padv;
-            s.hi[16] ^= 0x80000000u;
-        }
-        keccak_f1600_dev(s);
     }
     uint4 *o = reinterpret_cast<uint4 *>(a.out + dig);
     o[0] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
@@ -795,7 +850,10 @@ template <int PW, int NR>
 static void launch_hash_t(const HashArgs &a, int ngroups, hipStream_t st)
 {
     dim3 grid((a.lanes_per_group + 63) / 64, ngroups);
-    hipLaunchKernelGGL((k_commit_hash<PW, NR>), grid, dim3(64), 0, st, a);
+    // fewer than ~3 waves per SIMD (1024 SIMDs): nothing else hides the row loads -> pipelined variant
+    const long waves = (long)grid.x * grid.y;
+    if (waves < 3 * 1024) hipLaunchKernelGGL((k_commit_hash<PW, NR, true>), grid, dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_commit_hash<PW, NR, false>), grid, dim3(64), 0, st, a);
 }
 
 hipError_t launch_commit_hash(const HashArgs &a, int ngroups, int K, bool view, hipStream_t st)
