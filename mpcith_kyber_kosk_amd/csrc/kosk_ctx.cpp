@@ -88,6 +88,18 @@ static int upload_table(Ctx &c, GemmTable &t, const std::vector<uint16_t> &A, in
     return 0;
 }
 
+GemmArgs gemm_args_small(const uint8_t *A, size_t a_gstride, int Mpad, int M, int KS, const GemmSrc &s, const GemmDst &d, int npg,
+                         int ngroups, bool grouped)
+{
+    GemmArgs ga{};
+    ga.A = A; ga.a_gstride = a_gstride; ga.Mpad = Mpad; ga.M = M; ga.KS = KS;
+    ga.C = d.C; ga.c_gstride = d.gstride; ga.c_rows = d.rows; ga.c_rstride = d.rstride; ga.c_off = d.off;
+    ga.npg = npg; ga.npg_pad = grouped ? (npg + 63) / 64 * 64 : npg; ga.ngroups = ngroups; ga.grouped = grouped ? 1 : 0;
+    ga.B = nullptr; ga.BRT = 0;
+    ga.src = s.src; ga.src_gstride = s.gstride; ga.src_rows = s.rows; ga.src_rstride = s.rstride; ga.src_koff = s.koff;
+    return ga;
+}
+
 int gemm_modq(Ctx &c, const uint8_t *A, size_t a_gstride, int Mpad, int M, int KS, const GemmSrc &s, const GemmDst &d,
               int npg, int ngroups, bool grouped)
 {

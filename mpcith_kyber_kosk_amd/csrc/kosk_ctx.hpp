@@ -129,6 +129,9 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
 // C[g][rows_d[i]][off + m] = sum_k A[m][k] * src[g][rows_s[i]][koff + k] mod q  (conversion to limbs + MFMA GEMM)
 int gemm_modq(Ctx &c, const uint8_t *A, size_t a_gstride, int Mpad, int M, int KS, const GemmSrc &s, const GemmDst &d,
               int npg, int ngroups, bool grouped);
+// argument block of a small product (data operand converted inside the kernel), for launch_gemm_batch
+GemmArgs gemm_args_small(const uint8_t *A, size_t a_gstride, int Mpad, int M, int KS, const GemmSrc &s, const GemmDst &d, int npg,
+                         int ngroups, bool grouped);
 inline int gemm_modq(Ctx &c, const GemmTable &t, const GemmSrc &s, const GemmDst &d, int npg, int ngroups)
 {
     return gemm_modq(c, t.d, 0, t.Mpad, t.M, t.KS, s, d, npg, ngroups, false);

@@ -209,6 +209,13 @@ hipError_t launch_witness_secrets(const int16_t *se, size_t se_stride, uint16_t 
 hipError_t launch_ntt(const NttArgs &a, hipStream_t st);
 hipError_t launch_matvec_ntt(const int16_t *A, size_t A_stride, uint16_t *P, size_t proof_stride, int v_row0, int row0, int K,
                              int nproofs, hipStream_t st);
+// several independent products in ONE launch (the small ones are latency-bound: run them side by side)
+struct GemmBatch {
+    GemmArgs g[3];
+    int nblk[3]; // workgroups of each product
+    int count;
+};
+hipError_t launch_gemm_batch(const GemmArgs *list, int count, hipStream_t st);
 hipError_t launch_rows_to_limbs(const LimbArgs &a, hipStream_t st);
 hipError_t launch_gemm(const GemmArgs &a, hipStream_t st);
 // K3 on the matrix cores (prover): transposed f / NTT-f rows and the alpha-power coefficient matrix as limb matrices

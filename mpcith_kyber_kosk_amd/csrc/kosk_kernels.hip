@@ -470,13 +470,13 @@ __device__ __forceinline__ void gm_split16(const uint4 &x0, const uint4 &x1, uin
 // BLIMB: the data operand is already a limb matrix (lincomb coefficients); otherwise it is converted from
 // canonical u16 rows while it is staged (16 values per thread and k-step), which saves a conversion launch.
 template <bool BLIMB>
-__global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
+__device__ __forceinline__ void gemm_modq_block(const GemmArgs &a, const int bx, const int by, const int bz,
+                                                uint8_t (&lds)[2][GM_A_BYTES + GM_B_BYTES])
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[2][GM_A_BYTES + GM_B_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w & 1, wn = w >> 1;
-    const int grp = a.grouped ? (int)blockIdx.z : 0;
-    const int mt0 = blockIdx.x * (GM_TM / 16);     // first A row tile of this workgroup
+    const int grp = a.grouped ? bz : 0;
+    const int mt0 = bx * (GM_TM / 16);     // first A row tile of this workgroup
     const int ART = a.Mpad / 16;
     // staging: A 16 KiB = 4 x 16 B per thread and k-step, contiguous in the limb matrix.
     // (named registers on purpose: arrays captured by a lambda end up in scratch memory)
@@ -488,13 +488,13 @@ __global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
     int b_lds; // byte offset of this thread's converted 16 bytes inside the B region (limb 0)
     bool b_ok = true;
     if (BLIMB) {
-        const int nt0 = blockIdx.y * (GM_TN / 16) + (a.grouped ? grp * (a.npg_pad / 16) : 0);
+        const int nt0 = by * (GM_TN / 16) + (a.grouped ? grp * (a.npg_pad / 16) : 0);
         bp = reinterpret_cast<const uint4 *>(a.B + (size_t)nt0 * 2048) + tid;
         b_step = (size_t)a.BRT * 128;
         b_lds = 0;
     } else {
         const int row_l = tid >> 2, kc = tid & 3;
-        const int n_loc = blockIdx.y * GM_TN + row_l;
+        const int n_loc = by * GM_TN + row_l;
         int g, i;
         if (a.grouped) { g = grp; i = n_loc; b_ok = i < a.npg; }
         else { g = n_loc / a.npg; i = n_loc - g * a.npg; b_ok = n_loc < a.npg * a.ngroups; }
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
     // D[row = m: 4(l>>4)+r][col = n: l&15] -> four consecutive m per lane: one 8-byte store per block
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-        const int n_loc = blockIdx.y * GM_TN + wn * 32 + j * 16 + (lane & 15); // row inside the group (grouped) or flat
+        const int n_loc = by * GM_TN + wn * 32 + j * 16 + (lane & 15); // row inside the group (grouped) or flat
         int g, i;
         bool valid;
         if (a.grouped) { g = grp; i = n_loc; valid = i < a.npg; }
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
                          (size_t)(a.c_rows ? (int)a.c_rows[(g % gd) * a.c_rows_gstride + i] : i) * a.c_rstride + a.c_off;
 #pragma unroll
         for (int ib = 0; ib < 4; ib++) {
-            const int m0 = blockIdx.x * GM_TM + wm * 64 + ib * 16 + (lane >> 4) * 4;
+            const int m0 = bx * GM_TM + wm * 64 + ib * 16 + (lane >> 4) * 4;
             if (m0 >= a.M) continue;
             uint32_t v[4];
 #pragma unroll
@@ -593,6 +593,27 @@ __global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
             *reinterpret_cast<uint2 *>(crow + m0) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
         }
     }
+}
+
+template <bool BLIMB>
+__global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2][GM_A_BYTES + GM_B_BYTES];
+    gemm_modq_block<BLIMB>(a, blockIdx.x, blockIdx.y, blockIdx.z, lds);
+}
+
+// up to three independent products (data operand as u16 rows) side by side in one launch
+__global__ __launch_bounds__(256) void k_gemm_modq_batch(GemmBatch bt)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2][GM_A_BYTES + GM_B_BYTES];
+    int id = blockIdx.x, d = 0;
+    while (d + 1 < bt.count && id >= bt.nblk[d]) { id -= bt.nblk[d]; d++; }
+    const GemmArgs &a = bt.g[d];
+    const int mt = a.Mpad / GM_TM;
+    const int ntot = a.grouped ? a.npg : a.npg * a.ngroups;
+    const int nt = (ntot + GM_TN - 1) / GM_TN;
+    const int bx = id % mt, by = (id / mt) % nt, bz = id / (mt * nt);
+    gemm_modq_block<false>(a, bx, by, bz, lds);
 }
 
 // ---- K3 (prover) on the matrix cores: out_j[x] = sum_k Coef[j][k] * in_k[x] as the same GEMM -----
@@ -927,6 +948,22 @@ hipError_t launch_rows_to_limbs(const LimbArgs &a, hipStream_t st)
 {
     if (a.RT <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_rows_to_limbs, dim3((a.KS + 3) / 4, a.RT), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_batch(const GemmArgs *list, int count, hipStream_t st)
+{
+    GemmBatch bt{};
+    bt.count = count;
+    int total = 0;
+    for (int d = 0; d < count; d++) {
+        bt.g[d] = list[d];
+        const int ntot = list[d].grouped ? list[d].npg : list[d].npg * list[d].ngroups;
+        bt.nblk[d] = (list[d].Mpad / GM_TM) * ((ntot + GM_TN - 1) / GM_TN) * (list[d].grouped ? list[d].ngroups : 1);
+        total += bt.nblk[d];
+    }
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gemm_modq_batch, dim3(total), dim3(256), 0, st, bt);
     return hipGetLastError();
 }
 

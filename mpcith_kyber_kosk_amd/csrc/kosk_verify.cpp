@@ -258,33 +258,32 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     c.prof_end(PR_V_INTERP_BUILD);
     HIPCHK(launch_gather_cols(c.d_P, c.proof_stride, c.d_rows_isrc, c.n_interp_d, c.d_rest, c.sel_stride, DEG + 1, 416, c.d_w, 0, c.d_gather, n, st));
     HIPCHK(launch_gather_cols(c.d_P, c.proof_stride, c.d_rows_u, c.n_interp_2d, c.d_rest, c.sel_stride, DEG2 + 1, 832, c.d_w, 1, c.d_gather2, n, st));
-    { // values at points 0..406 of every interpolated sharing, then recompute_share_secrets_ddeg   :224-225, :351, :441-442
+    { // three independent products in one launch: values at points 0..406 of every interpolated sharing (:201-219 etc.),
+      // the 813-node Cauchy sums of the u shares at the packed positions (:523-543), and recon_secrets_2ddeg of the
+      // merged u rows (:555-556)
         const GemmSrc gs{c.d_gather, (size_t)c.n_interp_d * 416, nullptr, 416, 0, DEG + 1};
         const GemmDst gd{c.d_P, c.proof_stride, c.d_rows_idst, RS, 0};
+        const GemmSrc gs2{c.d_gather2, (size_t)c.n_interp_2d * 832, nullptr, 832, 0, DEG2 + 1};
+        const GemmDst gd2{c.d_sec_u1, (size_t)c.n_interp_2d * 256, nullptr, 256, 0};
+        const GemmSrc gs3{c.d_P, c.proof_stride, c.d_rows_u, RS, NSEC, DEG2 + 1};
+        const GemmDst gd3{c.d_sec_u2, (size_t)c.n_interp_2d * 256, nullptr, 256, 0};
+        const GemmArgs list[3] = {
+            gemm_args_small(c.d_W, c.w_stride, c.w_Mpad, DEG + 1, c.w_KS, gs, gd, c.n_interp_d, n, true),
+            gemm_args_small(c.d_W2, c.w2_stride, c.w2_Mpad, NSEC, c.w2_KS, gs2, gd2, c.n_interp_2d, n, true),
+            gemm_args_small(c.t_recon_2d.d, 0, c.t_recon_2d.Mpad, c.t_recon_2d.M, c.t_recon_2d.KS, gs3, gd3, c.n_interp_2d, n, false)};
         c.prof_begin(PR_V_GEMM_INTERP);
-        if (gemm_modq(c, c.d_W, c.w_stride, c.w_Mpad, DEG + 1, c.w_KS, gs, gd, c.n_interp_d, n, true)) return -1;
+        HIPCHK(launch_gemm_batch(list, 3, st));
         c.prof_end(PR_V_GEMM_INTERP);
         HIPCHK(launch_interp_fixup(c.d_P, c.proof_stride, c.d_rows_isrc, c.d_rows_idst, c.n_interp_d, ia, n, st));
         const GemmSrc xs{c.d_P, c.proof_stride, c.d_rows_idst, RS, 0, XLEN};
         const GemmDst xd{c.d_P, c.proof_stride, c.d_rows_idst, RS, EXP_OFF};
         c.prof_begin(PR_V_GEMM_EXPAND);
-        if (gemm_modq(c, c.t_expand, xs, xd, c.n_interp_d, n)) return -1;
+        if (gemm_modq(c, c.t_expand, xs, xd, c.n_interp_d, n)) return -1; // recompute_share_secrets_ddeg   :224-225, :351, :441-442
         c.prof_end(PR_V_GEMM_EXPAND);
     }
     HIPCHK(launch_check_rest(va, n, st));
     HIPCHK(launch_check_secrets(va, c.d_t, n, st));
-    // degree-2d: u must interpolate to 0 on the packed positions, and reconstruct to 0   :497-571
-    {
-        const GemmSrc gs{c.d_gather2, (size_t)c.n_interp_2d * 832, nullptr, 832, 0, DEG2 + 1};
-        const GemmDst gd{c.d_sec_u1, (size_t)c.n_interp_2d * 256, nullptr, 256, 0};
-        if (gemm_modq(c, c.d_W2, c.w2_stride, c.w2_Mpad, NSEC, c.w2_KS, gs, gd, c.n_interp_2d, n, true)) return -1;
-    }
     HIPCHK(launch_check_zero(c.d_sec_u1, (size_t)c.n_interp_2d * 256, c.n_interp_2d, c.d_fail, FB_U_INTERP, n, st));
-    {
-        const GemmSrc gs{c.d_P, c.proof_stride, c.d_rows_u, RS, NSEC, DEG2 + 1};
-        const GemmDst gd{c.d_sec_u2, (size_t)c.n_interp_2d * 256, nullptr, 256, 0};
-        if (gemm_modq(c, c.t_recon_2d, gs, gd, c.n_interp_2d, n)) return -1;
-    }
     HIPCHK(launch_check_zero(c.d_sec_u2, (size_t)c.n_interp_2d * 256, c.n_interp_2d, c.d_fail, FB_U_RECON, n, st));
     // NTT(s+r), NTT(e+r), A(s+r) and their re-sharing depend only on the interpolated rows   :257-271, :287-301
     NttArgs na{};
