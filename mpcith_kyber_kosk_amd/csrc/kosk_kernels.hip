@@ -716,7 +716,8 @@ __global__ __launch_bounds__(256) void k_lincomb(LincombArgs a)
     int32_t acc[LC_JC];
 #pragma unroll
     for (int j = 0; j < LC_JC; j++) acc[j] = 0;
-    for (int k = 1; k < a.rm.M; k++) {
+#pragma unroll 8
+    for (int k = 1; k < a.rm.M; k++) { // independent gathers: unrolled so that eight are in flight
         const int32_t v = gf_center(in0[(size_t)k * RS]);
         const int32_t *pk = pw + (size_t)k * LC_JPAD;
 #pragma unroll
@@ -740,27 +741,49 @@ __global__ __launch_bounds__(256) void k_lincomb(LincombArgs a)
 // =========================================================================
 
 // after the first expansion: s - eta, e - eta, multiplication gates, u = z2d - z_d
-// mlwe_prover.cpp:338-381
+// mlwe_prover.cpp:338-381.  Eight evaluation points per thread (one 16-byte access per row).
+struct U16x8 {
+    uint32_t v[8];
+};
+__device__ __forceinline__ U16x8 ld8(const uint16_t *p)
+{
+    const uint4 x = *reinterpret_cast<const uint4 *>(p);
+    U16x8 r;
+    r.v[0] = x.x & 0xFFFFu; r.v[1] = x.x >> 16; r.v[2] = x.y & 0xFFFFu; r.v[3] = x.y >> 16;
+    r.v[4] = x.z & 0xFFFFu; r.v[5] = x.z >> 16; r.v[6] = x.w & 0xFFFFu; r.v[7] = x.w >> 16;
+    return r;
+}
+__device__ __forceinline__ void st8(uint16_t *p, const U16x8 &r)
+{
+    *reinterpret_cast<uint4 *>(p) = make_uint4(r.v[0] | (r.v[1] << 16), r.v[2] | (r.v[3] << 16), r.v[4] | (r.v[5] << 16), r.v[6] | (r.v[7] << 16));
+}
+
+// grid (1, proofs, 2K): one (s|e, i) gate chain per block; all of its E + Z + 1 input rows are
+// loaded before the first store so that the loads overlap.
+template <int E>
 __global__ __launch_bounds__(256) void k_post_gates(uint16_t *__restrict__ P, size_t proof_stride, RowMap rm)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (x >= NPTS) return;
+    const int x = threadIdx.x * 8, b = blockIdx.y;
+    if (x >= NPTS) return; // the last group covers 1704..1711: columns >= 1710 are row padding
+    const int who = (int)blockIdx.z >= rm.K, i = blockIdx.z - (who ? rm.K : 0);
     uint16_t *Pb = P + (size_t)b * proof_stride + x;
-    for (int who = 0; who < 2; who++)
-        for (int i = 0; i < rm.K; i++) {
-            const uint32_t v = Pb[(size_t)((who ? rm.e : rm.s) + i) * RS];
-            uint32_t prev = 0;
-            for (int m = 0; m < rm.E; m++) {
-                const uint32_t c = Pb[(size_t)((who ? rm.eeta : rm.seta) + i * rm.E + m) * RS];
-                const uint32_t d = gf_sub(v, c);
-                Pb[(size_t)((who ? rm.esub : rm.ssub) + i * rm.E + m) * RS] = (uint16_t)d;
-                if (m == 0) { prev = d; continue; }
-                const uint32_t z2 = gf_mul(prev, d);
-                const uint32_t zd = Pb[(size_t)(who ? rm.ze(i, m - 1) : rm.zs(i, m - 1)) * RS];
-                Pb[(size_t)(who ? rm.ue(i, m - 1) : rm.us(i, m - 1)) * RS] = (uint16_t)gf_sub(z2, zd);
-                prev = zd;
-            }
+    const U16x8 v = ld8(Pb + (size_t)((who ? rm.e : rm.s) + i) * RS);
+    U16x8 c[E], zd[E - 1];
+#pragma unroll
+    for (int m = 0; m < E; m++) c[m] = ld8(Pb + (size_t)((who ? rm.eeta : rm.seta) + i * E + m) * RS);
+#pragma unroll
+    for (int m = 0; m < E - 1; m++) zd[m] = ld8(Pb + (size_t)(who ? rm.ze(i, m) : rm.zs(i, m)) * RS);
+#pragma unroll
+    for (int m = 0; m < E; m++) {
+        U16x8 d, u;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            d.v[q] = gf_sub(v.v[q], c[m].v[q]);
+            if (m > 0) u.v[q] = gf_sub(gf_mul(m == 1 ? gf_sub(v.v[q], c[0].v[q]) : zd[m > 1 ? m - 2 : 0].v[q], d.v[q]), zd[m > 0 ? m - 1 : 0].v[q]);
         }
+        st8(Pb + (size_t)((who ? rm.esub : rm.ssub) + i * E + m) * RS, d);
+        if (m > 0) st8(Pb + (size_t)(who ? rm.ue(i, m - 1) : rm.us(i, m - 1)) * RS, u);
+    }
 }
 
 // sr = s + r_i, er = e + r_{i+K} on every evaluation point   mlwe_prover.cpp:222-245
@@ -1004,7 +1027,9 @@ hipError_t launch_lincomb(const LincombArgs &a, int nproofs, hipStream_t st)
 
 hipError_t launch_post_gates(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_post_gates, dim3((NPTS + 255) / 256, nproofs), dim3(256), 0, st, P, proof_stride, rm);
+    const dim3 g(1, nproofs, 2 * rm.K); // 214 threads x 8 points per gate chain
+    if (rm.E == 7) hipLaunchKernelGGL(k_post_gates<7>, g, dim3(256), 0, st, P, proof_stride, rm);
+    else hipLaunchKernelGGL(k_post_gates<5>, g, dim3(256), 0, st, P, proof_stride, rm);
     return hipGetLastError();
 }
 hipError_t launch_post_open(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st)

@@ -176,7 +176,9 @@ __global__ __launch_bounds__(192) void k_gates_opened(VerifyArgs v)
     if (t >= NOPEN) return;
     const RowMap &rm = v.rm;
     uint16_t *Pb = v.P + (size_t)b * v.proof_stride + NSEC + v.opened[(size_t)b * v.sel_stride + t];
+#pragma unroll
     for (int who = 0; who < 2; who++)
+#pragma unroll 4
         for (int i = 0; i < rm.K; i++) {
             const int sub0 = (who ? rm.esub : rm.ssub) + i * rm.E;
             uint32_t prev = Pb[(size_t)sub0 * RS];
