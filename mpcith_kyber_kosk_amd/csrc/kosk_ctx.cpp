@@ -62,12 +62,12 @@ Ctx::~Ctx()
         for (auto e : pe)
             if (e) (void)hipEventDestroy(e);
     void *dev[] = {t_expand.d, t_recon_d.d, t_recon_2d.d, d_fresh_rows, d_gemm1_rows, d_gemm2_rows, d_off, d_fields,
-                   d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_seeds, d_pk, d_sb, d_sehat, d_t, d_alpha, d_I, d_rest, d_pwT, d_limbs, d_linA, d_coef, d_lin_rows,
+                   d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_seeds, d_pk, d_sb, d_sehat, d_t, d_alpha, d_I, d_pwT, d_limbs, d_linA, d_coef, d_lin_rows,
                    d_gather, d_gather2, d_W, d_W2, d_w, d_ell, d_sec, d_sec_u1, d_sec_u2, d_fail, d_inv, d_vfields,
                    d_vrowtab, d_rows_bg, d_rows_isrc, d_rows_idst, d_rows_u, d_fact, d_invfact, d_node_of, d_isort, d_hrange};
     for (void *p : dev)
         if (p) (void)hipFree(p);
-    void *host[] = {h_tape, h_dig, h_proof, h_alpha, h_I, h_rest, h_fail, h_Iimg, h_isort, h_hrange, h_seeds, h_pk, h_sb};
+    void *host[] = {h_tape, h_dig, h_proof, h_alpha, h_I, h_fail, h_Iimg, h_seeds, h_pk, h_sb};
     for (void *p : host)
         if (p) (void)hipHostFree(p);
     if (pool) pool_destroy(pool);
@@ -289,8 +289,8 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
         HIPCHK(halloc(&c.h_pk, B * c.pk_stride));
         HIPCHK(halloc(&c.h_sb, B * c.sb_stride));
         HIPCHK(dalloc(&c.d_alpha, B * 80));
-        HIPCHK(dalloc(&c.d_I, B * c.sel_stride));
-        HIPCHK(dalloc(&c.d_rest, B * c.sel_stride));
+        HIPCHK(dalloc(&c.d_I, 2 * B * c.sel_stride)); // I rows then complement rows: one upload
+        c.d_rest = c.d_I + B * c.sel_stride;
         HIPCHK(dalloc(&c.d_pwT, B * MAXM * 80));
         // data operand of the largest GEMM: every fresh sharing of every proof (<= 256 per proof), 13 k-steps
         c.limb_cap = ((B * 256 + 63) / 64 * 64 / 16) * (size_t)13 * 2048;
@@ -302,8 +302,8 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
         HIPCHK(halloc(&c.h_dig, B * NPARTY * 32));
         HIPCHK(halloc(&c.h_proof, B * c.image_stride));
         HIPCHK(halloc(&c.h_alpha, B * 80));
-        HIPCHK(halloc(&c.h_I, B * c.sel_stride));
-        HIPCHK(halloc(&c.h_rest, B * c.sel_stride));
+        HIPCHK(halloc(&c.h_I, 2 * B * c.sel_stride));
+        c.h_rest = c.h_I + B * c.sel_stride;
         HIPCHK(halloc(&c.h_fail, B));
         memset(c.h_alpha, 0, B * 80 * sizeof(uint16_t));
         HIPCHK(hipStreamSynchronize(c.stream));
@@ -467,8 +467,7 @@ int prove_resident(Ctx &c, int n)
     // ---- Fiat-Shamir round 2 on the host
     fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, c.h_I, c.h_rest, c.sel_stride, c.nthreads, c.pool);
     t1 = now_sec(); c.phase_sec[PH_FS_OPEN] = t1 - t0; t0 = t1;
-    HIPCHK(hipMemcpyAsync(c.d_I, c.h_I, (size_t)n * c.sel_stride * 2, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c.d_rest, c.h_rest, (size_t)n * c.sel_stride * 2, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c.d_I, c.h_I, ((size_t)c.max_batch + n) * c.sel_stride * 2, hipMemcpyHostToDevice, st)); // I and its complement
 
     // ---- wire image
     AssembleArgs aa{};

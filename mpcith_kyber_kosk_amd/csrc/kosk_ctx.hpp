@@ -96,7 +96,7 @@ struct Ctx {
     int n_interp_d = 0, n_interp_2d = 0;
     uint16_t *d_w = nullptr, *d_ell = nullptr, *d_fact = nullptr, *d_invfact = nullptr;
     int16_t *d_node_of = nullptr;
-    uint16_t *d_isort = nullptr, *d_hrange = nullptr, *h_isort = nullptr, *h_hrange = nullptr;
+    uint16_t *d_isort = nullptr, *d_hrange = nullptr;
     uint8_t *d_W = nullptr, *d_W2 = nullptr; // per-proof interpolation operators as limb matrices
     size_t w_stride = 0, w2_stride = 0;
     int w_Mpad = 0, w_KS = 0, w2_Mpad = 0, w2_KS = 0;

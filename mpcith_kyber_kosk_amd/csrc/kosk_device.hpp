@@ -153,6 +153,9 @@ struct InterpArgs {
     int Mpad1, KS1, Mpad2, KS2;
 };
 
+// opened list from the image -> I, complement, sorted I, hole ranges, MALFORMED bit (overwrites fail[])
+hipError_t launch_opened_setup(const uint8_t *proof, size_t image_stride, size_t off_I, uint16_t *I, uint16_t *rest, uint16_t *isort,
+                               uint16_t *hrange, size_t sel_stride, uint32_t *fail, int nproofs, hipStream_t st);
 hipError_t launch_disassemble(const VerifyArgs &v, const FieldDesc *fields, const int16_t *rowtab, int nfields,
                               const uint8_t *proof, size_t image_stride, size_t off_tcomm, size_t off_comm,
                               uint8_t *dig1, uint8_t *dig2, int nproofs, hipStream_t st);

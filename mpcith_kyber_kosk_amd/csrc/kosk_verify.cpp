@@ -122,8 +122,6 @@ static int ensure_verify_workspace(Ctx &c)
     HIPCHK(dalloc(&c.d_node_of, B * 416));
     HIPCHK(dalloc(&c.d_isort, B * c.sel_stride));
     HIPCHK(dalloc(&c.d_hrange, B * 4));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c.h_isort), B * c.sel_stride * 2, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c.h_hrange), B * 4 * 2, hipHostMallocDefault));
     HIPCHK(dalloc(&c.d_gather, B * c.n_interp_d * 416 + 64));
     HIPCHK(dalloc(&c.d_gather2, B * c.n_interp_2d * 832));
     HIPCHK(dalloc(&c.d_sec, B * 2 * NCHK * 256));
@@ -162,47 +160,10 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     const int K = P.K;
     hipStream_t st = c.stream;
 
-    // ---- V0: opened list from the image, validated on the host
+    // ---- V0: opened list from the image, validated and expanded on the GPU (no host round trip); the host
+    // only needs the list itself for the final Fiat-Shamir comparison and receives it with the first digests
+    HIPCHK(launch_opened_setup(c.d_proof, c.image_stride, P.off[F_I], c.d_I, c.d_rest, c.d_isort, c.d_hrange, c.sel_stride, c.d_fail, n, st));
     HIPCHK(hipMemcpy2DAsync(c.h_Iimg, 2 * NOPEN, c.d_proof + P.off[F_I], c.image_stride, 2 * NOPEN, n, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemsetAsync(c.d_fail, 0, sizeof(uint32_t) * n, st));
-    HIPCHK(hipStreamSynchronize(st));
-    std::vector<uint32_t> host_fail(n, 0);
-    for (int b = 0; b < n; b++) {
-        uint16_t *I = c.h_I + (size_t)b * c.sel_stride, *rest = c.h_rest + (size_t)b * c.sel_stride;
-        bool used[NPARTY] = {false};
-        bool good = true;
-        for (int i = 0; i < NOPEN; i++) {
-            const uint16_t v = c.h_Iimg[(size_t)b * NOPEN + i];
-            if (v >= NPARTY || used[v]) { good = false; break; }
-            used[v] = true;
-            I[i] = v;
-        }
-        if (!good) { // can never reproduce I in V10 (and is out-of-bounds indexing in the reference): reject,
-                     // but keep the kernels on a well-formed index set
-            host_fail[b] |= 1u << FB_MALFORMED;
-            memset(used, 0, sizeof used);
-            for (int i = 0; i < NOPEN; i++) { I[i] = (uint16_t)i; used[i] = true; }
-        }
-        for (int p = 0, j = 0; p < NPARTY; p++)
-            if (!used[p]) rest[j++] = (uint16_t)p;
-        // opened parties ascending + which of them lie strictly inside the node spans of the two interpolations
-        uint16_t *is = c.h_isort + (size_t)b * c.sel_stride, *hr = c.h_hrange + (size_t)b * 4;
-        for (int p = 0, j = 0; p < NPARTY; p++)
-            if (used[p]) is[j++] = (uint16_t)p;
-        for (int set = 0; set < 2; set++) {
-            const int lo = rest[0], hi = rest[set ? DEG2 : DEG];
-            int h0 = 0, h1 = 0;
-            while (h0 < NOPEN && is[h0] < lo) h0++;
-            h1 = h0;
-            while (h1 < NOPEN && is[h1] < hi) h1++;
-            hr[2 * set] = (uint16_t)h0;
-            hr[2 * set + 1] = (uint16_t)h1;
-        }
-    }
-    HIPCHK(hipMemcpyAsync(c.d_isort, c.h_isort, (size_t)n * c.sel_stride * 2, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c.d_hrange, c.h_hrange, (size_t)n * 4 * 2, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c.d_I, c.h_I, (size_t)n * c.sel_stride * 2, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c.d_rest, c.h_rest, (size_t)n * c.sel_stride * 2, hipMemcpyHostToDevice, st));
 
     VerifyArgs va{};
     va.P = c.d_P;
@@ -358,8 +319,8 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     std::vector<uint16_t> I2((size_t)n * c.sel_stride), rest2((size_t)n * c.sel_stride);
     fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, I2.data(), rest2.data(), c.sel_stride, c.nthreads, c.pool);
     for (int b = 0; b < n; b++) {
-        uint32_t f = c.h_fail[b] | host_fail[b];
-        if (memcmp(&I2[(size_t)b * c.sel_stride], c.h_I + (size_t)b * c.sel_stride, sizeof(uint16_t) * NOPEN) != 0) f |= 1u << FB_OPENED_SET;
+        uint32_t f = c.h_fail[b];
+        if (memcmp(&I2[(size_t)b * c.sel_stride], c.h_Iimg + (size_t)b * NOPEN, sizeof(uint16_t) * NOPEN) != 0) f |= 1u << FB_OPENED_SET;
         c.h_fail[b] = f;
         ok[b] = f == 0;
     }

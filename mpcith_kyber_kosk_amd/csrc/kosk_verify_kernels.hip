@@ -371,7 +371,88 @@ __global__ __launch_bounds__(256) void k_check_zero(const uint16_t *__restrict__
     if (x[o] != 0) atomicOr(&fail[blockIdx.y], 1u << bit);
 }
 
+// Opened list I of every proof, straight from the image: validated (range, duplicates), its complement
+// (the unopened parties ascending), the opened parties ascending, and for the two interpolations how many
+// opened parties lie below the first / the last node.  Replaces a device->host->device round trip.
+// mlwe_verifier.cpp never validates I (it indexes with it); a malformed list can never be reproduced by
+// the final Fiat-Shamir comparison, so it is rejected here and the kernels continue on I = 0..149.
+__global__ __launch_bounds__(256) void k_opened_setup(const uint8_t *__restrict__ proof, size_t image_stride, uint32_t off_I,
+                                                     uint16_t *__restrict__ I, uint16_t *__restrict__ rest,
+                                                     uint16_t *__restrict__ isort, uint16_t *__restrict__ hrange,
+                                                     size_t sel_stride, uint32_t *__restrict__ fail)
+{
+    __shared__ uint32_t cnt[NPARTY];
+    __shared__ int bad, wave_used[4], node[3];
+    const int t = threadIdx.x, b = blockIdx.x;
+    for (int p = t; p < NPARTY; p += 256) cnt[p] = 0;
+    if (t == 0) bad = 0;
+    __syncthreads();
+    uint32_t v = t;
+    if (t < NOPEN) {
+        v = reinterpret_cast<const uint16_t *>(proof + (size_t)b * image_stride + off_I)[t];
+        if (v >= NPARTY || atomicAdd(&cnt[v], 1u) != 0) atomicOr(&bad, 1);
+    }
+    __syncthreads();
+    const bool malformed = bad != 0;
+    if (malformed) {
+        __syncthreads();
+        for (int p = t; p < NPARTY; p += 256) cnt[p] = p < NOPEN;
+        v = t;
+        __syncthreads();
+    }
+    if (t < NOPEN) I[(size_t)b * sel_stride + t] = (uint16_t)v;
+    // parties 6t..6t+5 per thread; exclusive scan of the opened counts over the block
+    int u[6], mine = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int p = 6 * t + k;
+        u[k] = p < NPARTY && cnt[p] != 0;
+        mine += u[k];
+    }
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if ((t & 63) >= d) incl += o;
+    }
+    if ((t & 63) == 63) wave_used[t >> 6] = incl;
+    __syncthreads();
+    int used_before = incl - mine;
+    for (int w = 0; w < (t >> 6); w++) used_before += wave_used[w];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int p = 6 * t + k;
+        if (p >= NPARTY) break;
+        if (u[k]) {
+            isort[(size_t)b * sel_stride + used_before] = (uint16_t)p;
+            used_before++;
+        } else {
+            const int j = p - used_before;
+            rest[(size_t)b * sel_stride + j] = (uint16_t)p;
+            if (j == 0) node[0] = p;
+            if (j == DEG) node[1] = p;
+            if (j == DEG2) node[2] = p;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        // every party below the first unopened one is opened; below the D-th unopened one there are D unopened
+        uint16_t *hr = hrange + (size_t)b * 4;
+        hr[0] = (uint16_t)node[0];
+        hr[1] = (uint16_t)(node[1] - DEG);
+        hr[2] = (uint16_t)node[0];
+        hr[3] = (uint16_t)(node[2] - DEG2);
+        fail[b] = malformed ? 1u << FB_MALFORMED : 0u;
+    }
+}
+
 // ---- launchers --------------------------------------------------------------------
+hipError_t launch_opened_setup(const uint8_t *proof, size_t image_stride, size_t off_I, uint16_t *I, uint16_t *rest, uint16_t *isort,
+                               uint16_t *hrange, size_t sel_stride, uint32_t *fail, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_opened_setup, dim3(nproofs), dim3(256), 0, st, proof, image_stride, (uint32_t)off_I, I, rest, isort, hrange, sel_stride, fail);
+    return hipGetLastError();
+}
 hipError_t launch_disassemble(const VerifyArgs &v, const FieldDesc *fields, const int16_t *rowtab, int nfields,
                               const uint8_t *proof, size_t image_stride, size_t off_tcomm, size_t off_comm,
                               uint8_t *dig1, uint8_t *dig2, int nproofs, hipStream_t st)
