@@ -64,13 +64,18 @@ int kosk_prove_resident(kosk_ctx *ctx, int n);
 int kosk_fetch_proofs(kosk_ctx *ctx, int n, uint8_t *pi);
 int kosk_stage_verifier_inputs(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk);
 int kosk_verify_resident(kosk_ctx *ctx, int n, uint8_t *ok);
-/* wall seconds of the phases of the last prove (7 values) */
+/* wall seconds of the phases of the last prove / verify on this context (16 values: host_pre, gpu_commit,
+ * fs_alpha, gpu_relation, fs_open, gpu_assemble, d2h, then the host time spent issuing the prover's three
+ * segments, and the verifier's issue1, wait1, fs_alpha, issue2, wait2, fs_open) */
 int kosk_phase_seconds(const kosk_ctx *ctx, double *out, int n);
 
 /* HIP-event timing of the library's own launches on its stream.  ids: 0 prover Tcomm hash, 1 prover view
  * hash, 2 expansion GEMM #1, 3 expansion GEMM #2, 4 beta/gamma lincomb, 5 NTT(f), 6 wire image,
  * 7/8 verifier Tcomm/view hash, 9 interpolation operators, 10 interpolation GEMM, 11 verifier expansion,
- * 12 reconstruction GEMM, 13 verifier lincomb.  Reading returns the sum over launches since enable. */
+ * 12 reconstruction GEMM, 13 verifier lincomb.  Reading returns the sum over launches since enable.
+ * on = 1: only the view-commitment hashes (ids 1 and 8), which are plain launches; everything else keeps
+ * running as captured hipGraph segments (the production path).  on = 2: every id, with plain stream launches
+ * instead of graphs (diagnostic: changes the launch overhead being measured).  on = 0: off. */
 int kosk_profile_enable(kosk_ctx *ctx, int on);
 int kosk_profile_read(const kosk_ctx *ctx, int id, double *total_ms, long *launches);
 

@@ -225,8 +225,8 @@ class Kosk:
         return [pi.raw[i * self.proof_bytes:(i + 1) * self.proof_bytes] for i in range(n)]
 
     def phase_seconds(self):
-        out = (C.c_double * 7)()
-        lib.kosk_phase_seconds(self._h, out, 7)
+        out = (C.c_double * 16)()
+        lib.kosk_phase_seconds(self._h, out, 16)
         return list(out)
 
     PROFILE_IDS = ["hash_tcomm", "hash_view", "gemm_expand1", "gemm_expand2", "lincomb", "ntt_f", "assemble",

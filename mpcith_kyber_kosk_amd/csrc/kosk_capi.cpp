@@ -218,7 +218,7 @@ int kosk_profile_enable(kosk_ctx *ctx, int on)
     if (!ctx) return -1;
     for (Ctx *cp : ctx->sub) {
         Ctx &c = *cp;
-        c.prof_on = on != 0;
+        c.prof_on = on < 0 ? 0 : (on > 2 ? 2 : on);
         for (int i = 0; i < PR_COUNT; i++) { c.prof_ms[i] = 0; c.prof_n[i] = 0; c.prof_used[i] = false; }
     }
     return 0;

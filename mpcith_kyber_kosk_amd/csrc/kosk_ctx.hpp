@@ -14,7 +14,10 @@ namespace kosk {
 
 typedef void (*randombytes_fn)(void *user, uint8_t *out, size_t len);
 
-enum Phase { PH_HOST_PRE = 0, PH_GPU_COMMIT, PH_FS_ALPHA, PH_GPU_RELATION, PH_FS_OPEN, PH_GPU_ASSEMBLE, PH_D2H, PH_COUNT };
+enum Phase { PH_HOST_PRE = 0, PH_GPU_COMMIT, PH_FS_ALPHA, PH_GPU_RELATION, PH_FS_OPEN, PH_GPU_ASSEMBLE, PH_D2H,
+             // host time spent issuing each segment (part of the GPU phases above) and the verifier's phases
+             PH_P1_ISSUE, PH_P2_ISSUE, PH_P3_ISSUE, PH_V1_ISSUE, PH_V1_WAIT, PH_V_FS_ALPHA, PH_V2_ISSUE, PH_V2_WAIT, PH_V_FS_OPEN,
+             PH_COUNT };
 
 // HIP-event timing of individual launches on the ctx stream (bench.py roofline leg)
 enum ProfId { PR_HASH_TCOMM = 0, PR_HASH_VIEW, PR_GEMM_EXPAND1, PR_GEMM_EXPAND2, PR_LINCOMB, PR_NTT_F, PR_ASSEMBLE,
@@ -111,18 +114,63 @@ struct Ctx {
     uint16_t *h_alpha = nullptr, *h_I = nullptr, *h_rest = nullptr;
     uint32_t *h_fail = nullptr;
 
+    // hipGraph per pipeline segment (the launches between two host Fiat-Shamir rounds), captured once per
+    // batch size and replayed: one API call instead of ~15 launches of kernels that run 3-6 us each.
+    enum SegId { SEG_P1 = 0, SEG_P2, SEG_P3, SEG_V1, SEG_V1B, SEG_V2, SEG_COUNT };
+    struct SegGraph {
+        hipGraphExec_t exec = nullptr;
+        int n = 0;
+    };
+    SegGraph seg[SEG_COUNT];
+    bool use_graphs = false; // KOSK_GRAPHS=1 turns them on (measured on ROCm 7.2: no gain over plain launches)
+    bool capturing = false;
+
     double phase_sec[PH_COUNT] = {0};
-    bool prof_on = false;
+    int prof_on = 0; // 1: the graded kernel only (graphs stay on); 2: every profiled id (plain launches)
     hipEvent_t prof_ev[PR_COUNT][2] = {};
     bool prof_used[PR_COUNT] = {};
     double prof_ms[PR_COUNT] = {0};
     long prof_n[PR_COUNT] = {0};
-    void prof_begin(int id) { if (prof_on) { (void)hipEventRecord(prof_ev[id][0], stream); } }
-    void prof_end(int id) { if (prof_on) { (void)hipEventRecord(prof_ev[id][1], stream); prof_used[id] = true; } }
+    void prof_begin(int id) { if (prof_on && !capturing) { (void)hipEventRecord(prof_ev[id][0], stream); } }
+    void prof_end(int id) { if (prof_on && !capturing) { (void)hipEventRecord(prof_ev[id][1], stream); prof_used[id] = true; } }
     void prof_collect(); // call after the stream has been synchronised
 
     ~Ctx();
 };
+
+// Run `body` (stream launches on c.stream only: kernels, pinned-memory copies, memsets) as segment `seg`:
+// captured into a graph on first use for this batch size, replayed afterwards.
+template <class F>
+int run_segment(Ctx &c, int seg, int n, F &&body)
+{
+    if (!c.use_graphs || c.prof_on == 2) return body();
+    Ctx::SegGraph &g = c.seg[seg];
+    if (g.exec && g.n != n) {
+        (void)hipGraphExecDestroy(g.exec);
+        g.exec = nullptr;
+    }
+    if (!g.exec) {
+        hipError_t e = hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) { c.err = std::string("hipStreamBeginCapture: ") + hipGetErrorString(e); return -1; }
+        c.capturing = true;
+        const int rc = body();
+        c.capturing = false;
+        hipGraph_t graph = nullptr;
+        e = hipStreamEndCapture(c.stream, &graph);
+        if (rc) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        if (e != hipSuccess || !graph) { c.err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return -1; }
+        e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { g.exec = nullptr; c.err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e); return -1; }
+        g.n = n;
+    }
+    const hipError_t e = hipGraphLaunch(g.exec, c.stream);
+    if (e != hipSuccess) { c.err = std::string("hipGraphLaunch: ") + hipGetErrorString(e); return -1; }
+    return 0;
+}
 
 int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &err);
 

@@ -17,9 +17,16 @@
 #include <vector>
 
 #include "kosk_ctx.hpp"
+
+#include <chrono>
 #include "kosk_math.hpp"
 
 namespace kosk {
+
+static double now_sec()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 #define HIPCHK(x)                                                   \
     do {                                                            \
@@ -128,7 +135,6 @@ static int ensure_verify_workspace(Ctx &c)
     HIPCHK(dalloc(&c.d_sec_u1, B * c.n_interp_2d * 256));
     HIPCHK(dalloc(&c.d_sec_u2, B * c.n_interp_2d * 256));
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c.h_Iimg), B * 2 * NOPEN, hipHostMallocDefault));
-    HIPCHK(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming));
     c.verify_ready = true;
     return 0;
 }
@@ -160,12 +166,9 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     const int K = P.K;
     hipStream_t st = c.stream;
 
-    // ---- V0: opened list from the image, validated and expanded on the GPU (no host round trip); the host
-    // only needs the list itself for the final Fiat-Shamir comparison and receives it with the first digests
-    HIPCHK(launch_opened_setup(c.d_proof, c.image_stride, P.off[F_I], c.d_I, c.d_rest, c.d_isort, c.d_hrange, c.sel_stride, c.d_fail, n, st));
-    HIPCHK(hipMemcpy2DAsync(c.h_Iimg, 2 * NOPEN, c.d_proof + P.off[F_I], c.image_stride, 2 * NOPEN, n, hipMemcpyDeviceToHost, st));
-
+    double t0 = now_sec(), t1;
     VerifyArgs va{};
+    OpenedHashArgs oh{};
     va.P = c.d_P;
     va.proof_stride = c.proof_stride;
     va.rm = rm;
@@ -174,12 +177,6 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     va.rest = c.d_rest;
     va.sel_stride = c.sel_stride;
     va.fail = c.d_fail;
-
-    // ---- V1: scatter, gate outputs on opened columns, Tcomm of the opened parties
-    HIPCHK(launch_disassemble(va, c.d_vfields, c.d_vrowtab, c.n_vfields, c.d_proof, c.image_stride, P.off[F_TCOMM],
-                              P.off[F_COMM], c.d_dig1, c.d_dig2, n, st));
-    HIPCHK(launch_gates_opened(va, n, st));
-    OpenedHashArgs oh{};
     oh.proof = c.d_proof;
     oh.image_stride = c.image_stride;
     oh.off_s = (uint32_t)P.off[F_S]; oh.off_e = (uint32_t)P.off[F_E]; oh.off_f = (uint32_t)P.off[F_F];
@@ -191,13 +188,27 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     oh.sel_stride = c.sel_stride;
     oh.prefix = nullptr;
     oh.out = c.d_dig1;
+    if (run_segment(c, Ctx::SEG_V1, n, [&]() -> int {
+    // ---- V0: opened list from the image, validated and expanded on the GPU (no host round trip); the host
+    // only needs the list itself for the final Fiat-Shamir comparison and receives it with the first digests
+    HIPCHK(launch_opened_setup(c.d_proof, c.image_stride, P.off[F_I], c.d_I, c.d_rest, c.d_isort, c.d_hrange, c.sel_stride, c.d_fail, n, st));
+    HIPCHK(hipMemcpy2DAsync(c.h_Iimg, 2 * NOPEN, c.d_proof + P.off[F_I], c.image_stride, 2 * NOPEN, n, hipMemcpyDeviceToHost, st));
+
+
+    // ---- V1: scatter, gate outputs on opened columns, Tcomm of the opened parties
+    HIPCHK(launch_disassemble(va, c.d_vfields, c.d_vrowtab, c.n_vfields, c.d_proof, c.image_stride, P.off[F_TCOMM],
+                              P.off[F_COMM], c.d_dig1, c.d_dig2, n, st));
+    HIPCHK(launch_gates_opened(va, n, st));
     c.prof_begin(PR_V_HASH_TCOMM);
     HIPCHK(launch_opened_hash(oh, K, false, n, st)); // Tcomm of the opened parties, read from the image   :22-35
     c.prof_end(PR_V_HASH_TCOMM);
     HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig1, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
+    return 0;
+    })) return -1;
     HIPCHK(hipEventRecord(c.ev, st));
 
     // ---- alpha-independent GPU work queued behind the copy: interpolation of the unopened shares
+    if (run_segment(c, Ctx::SEG_V1B, n, [&]() -> int {
     InterpArgs ia{};
     ia.rest = c.d_rest;
     ia.isort = c.d_isort;
@@ -265,10 +276,17 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
         const GemmDst xd{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, EXP_OFF};
         if (gemm_modq(c, c.t_expand, xs, xd, c.n_gemm2, n)) return -1;
     }
+    return 0;
+    })) return -1;
 
     // ---- host: alpha while the GPU works
+    t1 = now_sec(); c.phase_sec[PH_V1_ISSUE] = t1 - t0; t0 = t1;
     HIPCHK(hipEventSynchronize(c.ev));
+    t1 = now_sec(); c.phase_sec[PH_V1_WAIT] = t1 - t0; t0 = t1;
     fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool);
+    t1 = now_sec(); c.phase_sec[PH_V_FS_ALPHA] = t1 - t0; t0 = t1;
+    if (run_segment(c, Ctx::SEG_V2, n, [&]() -> int {
+    NttArgs na{};
     HIPCHK(hipMemcpyAsync(c.d_alpha, c.h_alpha, (size_t)n * 80 * 2, hipMemcpyHostToDevice, st));
 
     // ---- V2/V3: beta, gamma, r, NTT_r on the opened columns; reconstruction and NTT check
@@ -305,8 +323,10 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     HIPCHK(launch_ntt(na, st)); // NTT(beta) in place (each block stages its polynomials in LDS first)
     HIPCHK(launch_check_pairs(c.d_sec, c.d_sec + (size_t)NCHK * 256, (size_t)2 * NCHK * 256, NCHK, c.d_fail, FB_BETA_GAMMA, n, st));
     HIPCHK(launch_check_opened(va, n, st));
+    return 0;
+    })) return -1;
 
-    // ---- V10: view hashes of the opened parties
+    // ---- V10: view hashes of the opened parties (plain launch: HIP events can bracket it)
     oh.prefix = c.d_dig1;
     oh.out = c.d_dig2;
     c.prof_begin(PR_V_HASH_VIEW);
@@ -314,7 +334,9 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     c.prof_end(PR_V_HASH_VIEW);
     HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig2, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(c.h_fail, c.d_fail, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st));
+    t1 = now_sec(); c.phase_sec[PH_V2_ISSUE] = t1 - t0; t0 = t1;
     HIPCHK(hipStreamSynchronize(st));
+    t1 = now_sec(); c.phase_sec[PH_V2_WAIT] = t1 - t0; t0 = t1;
     c.prof_collect();
     std::vector<uint16_t> I2((size_t)n * c.sel_stride), rest2((size_t)n * c.sel_stride);
     fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, I2.data(), rest2.data(), c.sel_stride, c.nthreads, c.pool);
@@ -324,6 +346,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
         c.h_fail[b] = f;
         ok[b] = f == 0;
     }
+    c.phase_sec[PH_V_FS_OPEN] = now_sec() - t0;
     return 0;
 }
 
