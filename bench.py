@@ -25,11 +25,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# HIP runtime setting for the multi-slot pipeline (must be in the environment before the runtime starts):
-# with direct dispatch every slot thread writes its own AQL packets and the slots' streams barely overlap on
-# the GPU; with per-queue submission threads (the pre-ROCm-5 default) they do: 0.57 -> 0.46 ms/step measured.
-# INTEGRATION.md lists it as the recommended setting for callers that keep several batches in flight.
-os.environ.setdefault("AMD_DIRECT_DISPATCH", "0")
+# NOTE: do not run this pipeline with AMD_DIRECT_DISPATCH=0.  It looks 20 % faster, but on ROCm 7.2 stream
+# synchronisation then returns before device-to-host copies into pinned memory have landed: the host hashes
+# stale digests and honest proofs get rejected (tools/stress.py reproduces it).  The default (direct dispatch) is correct.
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 

@@ -382,9 +382,8 @@ int prove_resident(Ctx &c, int n)
     HashArgs ha{};
     // ---- offline phase + witness sharing: secrets, randoms, one expansion GEMM
     if (run_segment(c, Ctx::SEG_P1, n, [&]() -> int {
-    HIPCHK(launch_expand_f(c.d_tape, c.tape_stride, c.d_P, c.proof_stride, rm.f, P.M, n, st));
-    HIPCHK(launch_tape_randoms(c.d_tape, c.tape_stride, 64 + 32 * P.M, c.d_fresh_rows, P.nfresh, c.d_P, c.proof_stride, n, st));
-    HIPCHK(launch_witness_secrets(c.d_se, c.se_stride, c.d_P, c.proof_stride, rm, P.eta1, n, st));
+    HIPCHK(launch_prover_pre(c.d_tape, c.tape_stride, c.d_P, c.proof_stride, rm.f, P.M, 64 + 32 * P.M, c.d_fresh_rows, P.nfresh,
+                             c.d_se, c.se_stride, rm, P.eta1, n, st));
     na = NttArgs{};
     na.in = reinterpret_cast<const int16_t *>(c.d_P);
     na.in_gstride = c.proof_stride;

@@ -174,21 +174,20 @@ struct OpenedHashArgs {
     uint8_t *out;          // digest table, written at the party's index
 };
 hipError_t launch_opened_hash(const OpenedHashArgs &a, int K, bool view, int nproofs, hipStream_t st);
+hipError_t launch_check_batch(const VerifyArgs &v, const uint16_t *t_pk, const uint16_t *u1, const uint16_t *u2, int nu, int nproofs,
+                              hipStream_t st);
+hipError_t launch_gather_cols2(const uint16_t *P, size_t proof_stride, const int16_t *rows1, int nrows1, uint16_t *out1,
+                               const int16_t *rows2, int nrows2, uint16_t *out2, const uint16_t *rest, int sel_stride,
+                               const uint16_t *w, int nproofs, hipStream_t st);
 hipError_t launch_gates_opened(const VerifyArgs &v, int nproofs, hipStream_t st);
 hipError_t launch_interp_build(const InterpArgs &a, int nproofs, hipStream_t st);
 // out[b][r][j] = w[b][set][j] * P[b][rows[r]][256 + rest[b][j]]
-hipError_t launch_gather_cols(const uint16_t *P, size_t proof_stride, const int16_t *rows, int nrows, const uint16_t *rest,
-                              int sel_stride, int ncols, int out_cols, const uint16_t *w, int set, uint16_t *out, int nproofs,
-                              hipStream_t st);
 // P[b][dst_rows[r]][k] = node(k) ? P[b][src_rows[r]][256 + rest[node]] : ell[k] * P[b][dst_rows[r]][k],  k < 407
 hipError_t launch_interp_fixup(uint16_t *P, size_t proof_stride, const int16_t *src_rows, const int16_t *dst_rows, int nrows,
                                const InterpArgs &a, int nproofs, hipStream_t st);
-hipError_t launch_check_rest(const VerifyArgs &v, int nproofs, hipStream_t st);
 hipError_t launch_check_opened(const VerifyArgs &v, int nproofs, hipStream_t st);
-hipError_t launch_check_secrets(const VerifyArgs &v, const uint16_t *t_pk, int nproofs, hipStream_t st);
 hipError_t launch_check_pairs(const uint16_t *a, const uint16_t *b, size_t gstride, int nrows, uint32_t *fail, int bit,
                               int nproofs, hipStream_t st);
-hipError_t launch_check_zero(const uint16_t *a, size_t gstride, int nrows, uint32_t *fail, int bit, int nproofs, hipStream_t st);
 
 // ---- key generation (kosk_keygen_kernels.hip) ----
 hipError_t launch_keygen(const uint8_t *tape, size_t tape_stride, uint8_t *seeds, int16_t *A, size_t A_stride, int16_t *se,
@@ -203,12 +202,10 @@ hipError_t launch_sha3_msgs(const uint8_t *in, size_t in_stride, int len, uint8_
                             int outlen, int n, int domain, hipStream_t st);
 hipError_t launch_rows_copy(const uint16_t *src, size_t src_stride, uint16_t *dst, size_t dst_stride, int count,
                             int nrows, hipStream_t st);
-hipError_t launch_expand_f(const uint8_t *tape, size_t tape_stride, uint16_t *P, size_t proof_stride, int row_f,
-                           int M, int nproofs, hipStream_t st);
-hipError_t launch_tape_randoms(const uint8_t *tape, size_t tape_stride, int slice0_off, const int16_t *fresh_rows,
-                               int nfresh, uint16_t *P, size_t proof_stride, int nproofs, hipStream_t st);
-hipError_t launch_witness_secrets(const int16_t *se, size_t se_stride, uint16_t *P, size_t proof_stride,
-                                  const RowMap &rm, int eta1, int nproofs, hipStream_t st);
+// expand_f + tape randoms + witness secrets (the kernels that only read the tape / the key) in one launch
+hipError_t launch_prover_pre(const uint8_t *tape, size_t tape_stride, uint16_t *P, size_t proof_stride, int row_f, int M,
+                             int slice0_off, const int16_t *fresh_rows, int nfresh, const int16_t *se, size_t se_stride,
+                             const RowMap &rm, int eta1, int nproofs, hipStream_t st);
 hipError_t launch_ntt(const NttArgs &a, hipStream_t st);
 hipError_t launch_matvec_ntt(const int16_t *A, size_t A_stride, uint16_t *P, size_t proof_stride, int v_row0, int row0, int K,
                              int nproofs, hipStream_t st);

@@ -5,13 +5,12 @@
 // Kernel <-> reference loop map:
 //   k_commit_hash   K4   mlwe_prover.cpp:116-127, :397-444 ; mlwe_verifier.cpp:23-35, :585-632
 //   k_sha3_msgs          kyber/fips202.c:745-754 on message-major input (tests, generic ABI)
-//   k_expand_f           mlwe_prover.cpp:8-14 (SHAKE256 PRF, BE16 % q)
-//   k_tape_randoms       ss.cpp:5-11
+//   k_prover_pre         mlwe_prover.cpp:8-14 (SHAKE256 PRF, BE16 % q), ss.cpp:5-11 (tape randoms), witness secrets
 //   k_ntt256        K5   kyber/ntt.c:80-95 + poly.c:261-265
 //   k_matvec_ntt    K6   polyvec.c:202-214 + poly.c:307-313
 //   k_rows_to_limbs, k_gemm_modq  K1/K2 ss.cpp:23-32, :44-51, :63-70, :88-97 (+ verifier interpolation apply)
 //   k_lincomb       K3   mlwe_prover.cpp:159-203 ; mlwe_verifier.cpp:68-89, :149-170
-//   k_witness_secrets, k_post_*  K7  ss.cpp:101-136 call sites in prove()
+//   k_post_*        K7   ss.cpp:101-136 call sites in prove()
 //   k_assemble_*    K8   mlwe_prover.cpp:480-537
 #include <hip/hip_runtime.h>
 
@@ -182,15 +181,32 @@ __global__ __launch_bounds__(64) void k_sha3_msgs(const uint8_t *__restrict__ in
 // preprocessing expansions from the randomness tape
 // =========================================================================
 
-// f_i = BE16(SHAKE256(seed_i || i)[2j..2j+1]) % q          mlwe_prover.cpp:8-14
-__global__ __launch_bounds__(64) void k_expand_f(const uint8_t *__restrict__ tape, size_t tape_stride,
-                                                 uint16_t *__restrict__ P, size_t proof_stride, int row_f,
-                                                 int M, int nproofs)
+// The three tape / witness expansions that open the prover, in ONE launch of 64-thread blocks (role by block range):
+//  A  f_i = BE16(SHAKE256(seed_i || i)[2j..2j+1]) % q                          mlwe_prover.cpp:8-14
+//  B  shares of parties 0..150 of every fresh sharing = BE16(tape) % q         ss.cpp:5-11
+//  C  packed secrets that depend only on the witness: s, e, the range constants and the multiplication-gate
+//     chain prod_{m<=k+1} (s - eta_m) (what the reference obtains through recon_secrets_2ddeg, :351-373)
+struct PreArgs {
+    const uint8_t *tape;
+    size_t tape_stride;
+    uint16_t *P;
+    size_t proof_stride;
+    int row_f, M, nproofs;
+    int slice0_off, nfresh;
+    const int16_t *fresh_rows;
+    const int16_t *se;
+    size_t se_stride;
+    RowMap rm;
+    int eta1;
+    int nbA, nbB; // blocks of role A, B (role C: 4 per proof)
+};
+constexpr int PRE_SLICES = 8; // fresh sharings per role-B block
+
+__device__ __forceinline__ void pre_expand_f(const PreArgs &a, int t)
 {
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= M * nproofs) return;
-    const int b = t / M, i = t % M;
-    const uint64_t *seed = reinterpret_cast<const uint64_t *>(tape + (size_t)b * tape_stride + 64 + 32 * i);
+    if (t >= a.M * a.nproofs) return;
+    const int b = t / a.M, i = t % a.M;
+    const uint64_t *seed = reinterpret_cast<const uint64_t *>(a.tape + (size_t)b * a.tape_stride + 64 + 32 * i);
     KState s;
     kstate_zero(s);
 #pragma unroll
@@ -200,7 +216,7 @@ __global__ __launch_bounds__(64) void k_expand_f(const uint8_t *__restrict__ tap
     }
     s.lo[4] = (uint32_t)(uint8_t)i | (0x1Fu << 8);
     s.hi[16] = 0x80000000u;
-    uint16_t *dst = P + (size_t)b * proof_stride + (size_t)(row_f + i) * RS;
+    uint16_t *dst = a.P + (size_t)b * a.proof_stride + (size_t)(a.row_f + i) * RS;
     // 512 bytes = 3 full 136-byte squeezes + 104 bytes
 #pragma unroll 1
     for (int blk = 0; blk < 4; blk++) {
@@ -221,35 +237,34 @@ __global__ __launch_bounds__(64) void k_expand_f(const uint8_t *__restrict__ tap
     }
 }
 
-// shares of parties 0..150 of every fresh sharing = BE16(tape) % q   ss.cpp:5-11
-__global__ __launch_bounds__(192) void k_tape_randoms(const uint8_t *__restrict__ tape, size_t tape_stride, int slice0_off,
-                                                     const int16_t *__restrict__ fresh_rows,
-                                                     uint16_t *__restrict__ P, size_t proof_stride)
+__device__ __forceinline__ void pre_tape_randoms(const PreArgs &a, int idx, int lane)
 {
-    const int t = threadIdx.x;
+    const int part = idx % 3, grp = (idx / 3) % ((a.nfresh + PRE_SLICES - 1) / PRE_SLICES), b = idx / (3 * ((a.nfresh + PRE_SLICES - 1) / PRE_SLICES));
+    const int t = part * 64 + lane;
     if (t > NOPEN) return;
-    const int slice = blockIdx.x, b = blockIdx.y;
-    const uint8_t *src = tape + (size_t)b * tape_stride + slice0_off + 302 * slice + 2 * t;
-    const uint32_t v = (((uint32_t)src[0] << 8) | src[1]) % (uint32_t)Q;
-    P[(size_t)b * proof_stride + (size_t)fresh_rows[slice] * RS + NSEC + t] = (uint16_t)v;
+#pragma unroll
+    for (int q = 0; q < PRE_SLICES; q++) {
+        const int slice = grp * PRE_SLICES + q;
+        if (slice >= a.nfresh) break;
+        const uint8_t *src = a.tape + (size_t)b * a.tape_stride + a.slice0_off + 302 * slice + 2 * t;
+        const uint32_t v = (((uint32_t)src[0] << 8) | src[1]) % (uint32_t)Q;
+        a.P[(size_t)b * a.proof_stride + (size_t)a.fresh_rows[slice] * RS + NSEC + t] = (uint16_t)v;
+    }
 }
 
-// packed secrets that depend only on the witness: s, e, the range constants,
-// and the multiplication-gate chain prod_{m<=k+1} (s - eta_m)  (what the
-// reference obtains through recon_secrets_2ddeg, mlwe_prover.cpp:351-373).
-__global__ __launch_bounds__(256) void k_witness_secrets(const int16_t *__restrict__ se, size_t se_stride,
-                                                        uint16_t *__restrict__ P, size_t proof_stride, RowMap rm, int eta1)
+__device__ __forceinline__ void pre_witness_secrets(const PreArgs &a, int idx, int lane)
 {
-    const int j = threadIdx.x, b = blockIdx.x;
-    uint16_t *Pb = P + (size_t)b * proof_stride;
-    const int16_t *sb = se + (size_t)b * se_stride;
+    const int j = (idx & 3) * 64 + lane, b = idx >> 2;
+    const RowMap &rm = a.rm;
+    uint16_t *Pb = a.P + (size_t)b * a.proof_stride;
+    const int16_t *sb = a.se + (size_t)b * a.se_stride;
     for (int who = 0; who < 2; who++) {
         for (int i = 0; i < rm.K; i++) {
             const uint32_t v = gf_encode(sb[(who * rm.K + i) * 256 + j]);
             Pb[(size_t)((who ? rm.e : rm.s) + i) * RS + j] = (uint16_t)v;
             uint32_t z = 0;
             for (int m = 0; m < rm.E; m++) {
-                const uint32_t c = gf_encode(m - eta1);
+                const uint32_t c = gf_encode(m - a.eta1);
                 Pb[(size_t)((who ? rm.eeta : rm.seta) + i * rm.E + m) * RS + j] = (uint16_t)c;
                 const uint32_t x = gf_sub(v, c);
                 z = (m == 0) ? x : gf_mul(z, x);
@@ -257,6 +272,14 @@ __global__ __launch_bounds__(256) void k_witness_secrets(const int16_t *__restri
             }
         }
     }
+}
+
+__global__ __launch_bounds__(64) void k_prover_pre(PreArgs a)
+{
+    const int blk = blockIdx.x;
+    if (blk < a.nbA) pre_expand_f(a, blk * 64 + threadIdx.x);
+    else if (blk < a.nbA + a.nbB) pre_tape_randoms(a, blk - a.nbA, threadIdx.x);
+    else pre_witness_secrets(a, blk - a.nbA - a.nbB, threadIdx.x);
 }
 
 // =========================================================================
@@ -931,25 +954,18 @@ hipError_t launch_rows_copy(const uint16_t *src, size_t src_stride, uint16_t *ds
     return hipGetLastError();
 }
 
-hipError_t launch_expand_f(const uint8_t *tape, size_t tape_stride, uint16_t *P, size_t proof_stride, int row_f,
-                           int M, int nproofs, hipStream_t st)
+hipError_t launch_prover_pre(const uint8_t *tape, size_t tape_stride, uint16_t *P, size_t proof_stride, int row_f, int M,
+                             int slice0_off, const int16_t *fresh_rows, int nfresh, const int16_t *se, size_t se_stride,
+                             const RowMap &rm, int eta1, int nproofs, hipStream_t st)
 {
-    const int n = M * nproofs;
-    hipLaunchKernelGGL(k_expand_f, dim3((n + 63) / 64), dim3(64), 0, st, tape, tape_stride, P, proof_stride, row_f, M, nproofs);
-    return hipGetLastError();
-}
-
-hipError_t launch_tape_randoms(const uint8_t *tape, size_t tape_stride, int slice0_off, const int16_t *fresh_rows,
-                               int nfresh, uint16_t *P, size_t proof_stride, int nproofs, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_tape_randoms, dim3(nfresh, nproofs), dim3(192), 0, st, tape, tape_stride, slice0_off, fresh_rows, P, proof_stride);
-    return hipGetLastError();
-}
-
-hipError_t launch_witness_secrets(const int16_t *se, size_t se_stride, uint16_t *P, size_t proof_stride,
-                                  const RowMap &rm, int eta1, int nproofs, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_witness_secrets, dim3(nproofs), dim3(256), 0, st, se, se_stride, P, proof_stride, rm, eta1);
+    PreArgs a{};
+    a.tape = tape; a.tape_stride = tape_stride; a.P = P; a.proof_stride = proof_stride;
+    a.row_f = row_f; a.M = M; a.nproofs = nproofs;
+    a.slice0_off = slice0_off; a.nfresh = nfresh; a.fresh_rows = fresh_rows;
+    a.se = se; a.se_stride = se_stride; a.rm = rm; a.eta1 = eta1;
+    a.nbA = (M * nproofs + 63) / 64;
+    a.nbB = 3 * ((nfresh + PRE_SLICES - 1) / PRE_SLICES) * nproofs;
+    hipLaunchKernelGGL(k_prover_pre, dim3(a.nbA + a.nbB + 4 * nproofs), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 

@@ -205,9 +205,12 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig1, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
     return 0;
     })) return -1;
-    HIPCHK(hipEventRecord(c.ev, st));
+    t1 = now_sec(); c.phase_sec[PH_V1_ISSUE] = t1 - t0; t0 = t1;
+    HIPCHK(hipStreamSynchronize(st)); // the opened parties' Tcomm digests are on the host
+    t1 = now_sec(); c.phase_sec[PH_V1_WAIT] = t1 - t0; t0 = t1;
 
-    // ---- alpha-independent GPU work queued behind the copy: interpolation of the unopened shares
+    // ---- alpha-independent GPU work, issued before the host hashes so that it runs meanwhile: interpolation of
+    // the unopened shares
     if (run_segment(c, Ctx::SEG_V1B, n, [&]() -> int {
     InterpArgs ia{};
     ia.rest = c.d_rest;
@@ -228,8 +231,8 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     c.prof_begin(PR_V_INTERP_BUILD);
     HIPCHK(launch_interp_build(ia, n, st));
     c.prof_end(PR_V_INTERP_BUILD);
-    HIPCHK(launch_gather_cols(c.d_P, c.proof_stride, c.d_rows_isrc, c.n_interp_d, c.d_rest, c.sel_stride, DEG + 1, 416, c.d_w, 0, c.d_gather, n, st));
-    HIPCHK(launch_gather_cols(c.d_P, c.proof_stride, c.d_rows_u, c.n_interp_2d, c.d_rest, c.sel_stride, DEG2 + 1, 832, c.d_w, 1, c.d_gather2, n, st));
+    HIPCHK(launch_gather_cols2(c.d_P, c.proof_stride, c.d_rows_isrc, c.n_interp_d, c.d_gather, c.d_rows_u, c.n_interp_2d, c.d_gather2,
+                               c.d_rest, c.sel_stride, c.d_w, n, st));
     { // three independent products in one launch: values at points 0..406 of every interpolated sharing (:201-219 etc.),
       // the 813-node Cauchy sums of the u shares at the packed positions (:523-543), and recon_secrets_2ddeg of the
       // merged u rows (:555-556)
@@ -253,10 +256,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
         if (gemm_modq(c, c.t_expand, xs, xd, c.n_interp_d, n)) return -1; // recompute_share_secrets_ddeg   :224-225, :351, :441-442
         c.prof_end(PR_V_GEMM_EXPAND);
     }
-    HIPCHK(launch_check_rest(va, n, st));
-    HIPCHK(launch_check_secrets(va, c.d_t, n, st));
-    HIPCHK(launch_check_zero(c.d_sec_u1, (size_t)c.n_interp_2d * 256, c.n_interp_2d, c.d_fail, FB_U_INTERP, n, st));
-    HIPCHK(launch_check_zero(c.d_sec_u2, (size_t)c.n_interp_2d * 256, c.n_interp_2d, c.d_fail, FB_U_RECON, n, st));
+    HIPCHK(launch_check_batch(va, c.d_t, c.d_sec_u1, c.d_sec_u2, c.n_interp_2d, n, st));
     // NTT(s+r), NTT(e+r), A(s+r) and their re-sharing depend only on the interpolated rows   :257-271, :287-301
     NttArgs na{};
     na.in = reinterpret_cast<const int16_t *>(c.d_P);
@@ -280,9 +280,6 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     })) return -1;
 
     // ---- host: alpha while the GPU works
-    t1 = now_sec(); c.phase_sec[PH_V1_ISSUE] = t1 - t0; t0 = t1;
-    HIPCHK(hipEventSynchronize(c.ev));
-    t1 = now_sec(); c.phase_sec[PH_V1_WAIT] = t1 - t0; t0 = t1;
     fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool);
     t1 = now_sec(); c.phase_sec[PH_V_FS_ALPHA] = t1 - t0; t0 = t1;
     if (run_segment(c, Ctx::SEG_V2, n, [&]() -> int {

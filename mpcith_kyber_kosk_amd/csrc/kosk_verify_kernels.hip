@@ -274,19 +274,23 @@ __global__ __launch_bounds__(256) void k_interp_cauchy(InterpArgs a)
     *reinterpret_cast<uint4 *>(d + 1024) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
 }
 
-// out[b][r][j] = w[b][set][j] * P[b][rows[r]][256 + rest[b][j]] for j < ncols, zero padded to out_cols
-__global__ __launch_bounds__(256) void k_gather_cols(const uint16_t *__restrict__ P, size_t proof_stride,
-                                                     const int16_t *__restrict__ rows, int nrows,
-                                                     const uint16_t *__restrict__ rest, int sel_stride, int ncols,
-                                                     int out_cols, const uint16_t *__restrict__ w, int set,
-                                                     uint16_t *__restrict__ out)
+
+// out[b][r][j] = w[b][set][j] * P[b][rows[r]][256 + rest[b][j]] for j < ncols, zero padded to out_cols;
+// both gathers of the verifier (degree-d rows, then the u rows of degree 2d) in one launch: blockIdx.y < nrows1 -> set 0
+__global__ __launch_bounds__(256) void k_gather_cols2(const uint16_t *__restrict__ P, size_t proof_stride,
+                                                      const int16_t *__restrict__ rows1, int nrows1, uint16_t *__restrict__ out1,
+                                                      const int16_t *__restrict__ rows2, int nrows2, uint16_t *__restrict__ out2,
+                                                      const uint16_t *__restrict__ rest, int sel_stride, const uint16_t *__restrict__ w)
 {
-    const int r = blockIdx.y, b = blockIdx.z;
-    const uint16_t *src = P + (size_t)b * proof_stride + (size_t)rows[r] * RS + NSEC;
+    const int set = (int)blockIdx.y >= nrows1, b = blockIdx.z;
+    const int r = set ? blockIdx.y - nrows1 : blockIdx.y;
+    const int ncols = set ? DEG2 + 1 : DEG + 1, out_cols = set ? 832 : 416, nrows = set ? nrows2 : nrows1;
+    const uint16_t *src = P + (size_t)b * proof_stride + (size_t)(set ? rows2 : rows1)[r] * RS + NSEC;
     const uint16_t *wb = w + ((size_t)b * 2 + set) * 832;
-    uint16_t *dst = out + ((size_t)b * nrows + r) * out_cols;
+    const uint16_t *rb = rest + (size_t)b * sel_stride;
+    uint16_t *dst = (set ? out2 : out1) + ((size_t)b * nrows + r) * out_cols;
     for (int j = blockIdx.x * 256 + threadIdx.x; j < out_cols; j += gridDim.x * 256)
-        dst[j] = j < ncols ? (uint16_t)gf_mul(wb[j], src[rest[(size_t)b * sel_stride + j]]) : (uint16_t)0;
+        dst[j] = j < ncols ? (uint16_t)gf_mul(wb[j], src[rb[j]]) : (uint16_t)0;
 }
 
 __global__ __launch_bounds__(448) void k_interp_fixup(uint16_t *__restrict__ P, size_t proof_stride,
@@ -304,19 +308,6 @@ __global__ __launch_bounds__(448) void k_interp_fixup(uint16_t *__restrict__ P, 
 
 // ---- checks ---------------------------------------------------------------------
 // recomputed s+r / e+r shares against the unopened ones in the proof   mlwe_verifier.cpp:232-246
-__global__ __launch_bounds__(256) void k_check_rest(VerifyArgs v)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (i >= NREST) return;
-    const RowMap &rm = v.rm;
-    const uint16_t *Pb = v.P + (size_t)b * v.proof_stride + NSEC + v.rest[(size_t)b * v.sel_stride + i];
-    bool bad = false;
-    for (int r = 0; r < rm.K; r++) {
-        bad |= Pb[(size_t)(rm.sr + r) * RS] != Pb[(size_t)(rm.sr_in + r) * RS];
-        bad |= Pb[(size_t)(rm.er + r) * RS] != Pb[(size_t)(rm.er_in + r) * RS];
-    }
-    if (bad) atomicOr(&v.fail[b], 1u << FB_SR_ER_SHARES);
-}
 
 // relation checks on the opened columns   mlwe_verifier.cpp:273-284, :304-312, :365-376, :447-466
 __global__ __launch_bounds__(192) void k_check_opened(VerifyArgs v)
@@ -341,22 +332,6 @@ __global__ __launch_bounds__(192) void k_check_opened(VerifyArgs v)
 }
 
 // interpolated packed secrets: t against the public key, range constants   mlwe_verifier.cpp:354-363, :418-429
-__global__ __launch_bounds__(256) void k_check_secrets(VerifyArgs v, const uint16_t *__restrict__ t_pk)
-{
-    const int k = threadIdx.x, b = blockIdx.x;
-    const RowMap &rm = v.rm;
-    const uint16_t *Pb = v.P + (size_t)b * v.proof_stride + k;
-    uint32_t bits = 0;
-    for (int i = 0; i < rm.K; i++) {
-        if (Pb[(size_t)(rm.t + i) * RS] != t_pk[((size_t)b * rm.K + i) * 256 + k]) bits |= 1u << FB_T_PK;
-        for (int m = 0; m < rm.E; m++) {
-            const uint32_t c = gf_encode(m - v.eta1);
-            if (Pb[(size_t)(rm.seta + i * rm.E + m) * RS] != c) bits |= 1u << FB_ETA_CONST;
-            if (Pb[(size_t)(rm.eeta + i * rm.E + m) * RS] != c) bits |= 1u << FB_ETA_CONST;
-        }
-    }
-    if (bits) atomicOr(&v.fail[b], bits);
-}
 
 // a[b][r][k] == b[b][r][k] for r < nrows, k < 256
 __global__ __launch_bounds__(256) void k_check_pairs(const uint16_t *__restrict__ x, const uint16_t *__restrict__ y,
@@ -364,11 +339,6 @@ __global__ __launch_bounds__(256) void k_check_pairs(const uint16_t *__restrict_
 {
     const size_t o = (size_t)blockIdx.y * gstride + (size_t)blockIdx.x * 256 + threadIdx.x;
     if (x[o] != y[o]) atomicOr(&fail[blockIdx.y], 1u << bit);
-}
-__global__ __launch_bounds__(256) void k_check_zero(const uint16_t *__restrict__ x, size_t gstride, uint32_t *fail, int bit)
-{
-    const size_t o = (size_t)blockIdx.y * gstride + (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (x[o] != 0) atomicOr(&fail[blockIdx.y], 1u << bit);
 }
 
 // Opened list I of every proof, straight from the image: validated (range, duplicates), its complement
@@ -446,7 +416,59 @@ __global__ __launch_bounds__(256) void k_opened_setup(const uint8_t *__restrict_
     }
 }
 
+// The four checks that follow the interpolation GEMMs in one launch (blockIdx.x selects the role):
+// [0,6) recomputed s+r / e+r shares vs the proof's (:232-246); 6: t vs pk and the eta constants (:303-324);
+// then nu blocks each for the interpolated and the reconstructed u secrets, which must vanish (:523-556).
+__global__ __launch_bounds__(256) void k_check_batch(VerifyArgs v, const uint16_t *__restrict__ t_pk,
+                                                     const uint16_t *__restrict__ u1, const uint16_t *__restrict__ u2, int nu)
+{
+    constexpr int NB_REST = (NREST + 255) / 256;
+    const int role = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const RowMap &rm = v.rm;
+    if (role < NB_REST) {
+        const int i = role * 256 + t;
+        if (i >= NREST) return;
+        const uint16_t *Pb = v.P + (size_t)b * v.proof_stride + NSEC + v.rest[(size_t)b * v.sel_stride + i];
+        bool bad = false;
+        for (int r = 0; r < rm.K; r++) {
+            bad |= Pb[(size_t)(rm.sr + r) * RS] != Pb[(size_t)(rm.sr_in + r) * RS];
+            bad |= Pb[(size_t)(rm.er + r) * RS] != Pb[(size_t)(rm.er_in + r) * RS];
+        }
+        if (bad) atomicOr(&v.fail[b], 1u << FB_SR_ER_SHARES);
+    } else if (role == NB_REST) {
+        const uint16_t *Pb = v.P + (size_t)b * v.proof_stride + t;
+        uint32_t bits = 0;
+        for (int i = 0; i < rm.K; i++) {
+            if (Pb[(size_t)(rm.t + i) * RS] != t_pk[((size_t)b * rm.K + i) * 256 + t]) bits |= 1u << FB_T_PK;
+            for (int m = 0; m < rm.E; m++) {
+                const uint32_t c = gf_encode(m - v.eta1);
+                if (Pb[(size_t)(rm.seta + i * rm.E + m) * RS] != c) bits |= 1u << FB_ETA_CONST;
+                if (Pb[(size_t)(rm.eeta + i * rm.E + m) * RS] != c) bits |= 1u << FB_ETA_CONST;
+            }
+        }
+        if (bits) atomicOr(&v.fail[b], bits);
+    } else {
+        const int q = role - NB_REST - 1; // row of u1 (q < nu) or of u2
+        const uint16_t *x = (q < nu ? u1 : u2) + ((size_t)b * nu + (q < nu ? q : q - nu)) * 256;
+        if (x[t] != 0) atomicOr(&v.fail[b], 1u << (q < nu ? FB_U_INTERP : FB_U_RECON));
+    }
+}
+
 // ---- launchers --------------------------------------------------------------------
+hipError_t launch_check_batch(const VerifyArgs &v, const uint16_t *t_pk, const uint16_t *u1, const uint16_t *u2, int nu, int nproofs,
+                              hipStream_t st)
+{
+    hipLaunchKernelGGL(k_check_batch, dim3((NREST + 255) / 256 + 1 + 2 * nu, nproofs), dim3(256), 0, st, v, t_pk, u1, u2, nu);
+    return hipGetLastError();
+}
+hipError_t launch_gather_cols2(const uint16_t *P, size_t proof_stride, const int16_t *rows1, int nrows1, uint16_t *out1,
+                               const int16_t *rows2, int nrows2, uint16_t *out2, const uint16_t *rest, int sel_stride,
+                               const uint16_t *w, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_gather_cols2, dim3(2, nrows1 + nrows2, nproofs), dim3(256), 0, st, P, proof_stride, rows1, nrows1, out1, rows2,
+                       nrows2, out2, rest, sel_stride, w);
+    return hipGetLastError();
+}
 hipError_t launch_opened_setup(const uint8_t *proof, size_t image_stride, size_t off_I, uint16_t *I, uint16_t *rest, uint16_t *isort,
                                uint16_t *hrange, size_t sel_stride, uint32_t *fail, int nproofs, hipStream_t st)
 {
@@ -474,24 +496,10 @@ hipError_t launch_interp_build(const InterpArgs &a, int nproofs, hipStream_t st)
     hipLaunchKernelGGL(k_interp_cauchy, dim3((mp + 63) / 64, ks, nproofs * 2), dim3(256), 0, st, a);
     return hipGetLastError();
 }
-hipError_t launch_gather_cols(const uint16_t *P, size_t proof_stride, const int16_t *rows, int nrows, const uint16_t *rest,
-                              int sel_stride, int ncols, int out_cols, const uint16_t *w, int set, uint16_t *out, int nproofs,
-                              hipStream_t st)
-{
-    if (nrows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_gather_cols, dim3((out_cols + 255) / 256, nrows, nproofs), dim3(256), 0, st, P, proof_stride, rows, nrows,
-                       rest, sel_stride, ncols, out_cols, w, set, out);
-    return hipGetLastError();
-}
 hipError_t launch_interp_fixup(uint16_t *P, size_t proof_stride, const int16_t *src_rows, const int16_t *dst_rows, int nrows,
                                const InterpArgs &a, int nproofs, hipStream_t st)
 {
     hipLaunchKernelGGL(k_interp_fixup, dim3(nrows, nproofs), dim3(448), 0, st, P, proof_stride, src_rows, dst_rows, a);
-    return hipGetLastError();
-}
-hipError_t launch_check_rest(const VerifyArgs &v, int nproofs, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_check_rest, dim3((NREST + 255) / 256, nproofs), dim3(256), 0, st, v);
     return hipGetLastError();
 }
 hipError_t launch_check_opened(const VerifyArgs &v, int nproofs, hipStream_t st)
@@ -499,20 +507,10 @@ hipError_t launch_check_opened(const VerifyArgs &v, int nproofs, hipStream_t st)
     hipLaunchKernelGGL(k_check_opened, dim3(nproofs), dim3(192), 0, st, v);
     return hipGetLastError();
 }
-hipError_t launch_check_secrets(const VerifyArgs &v, const uint16_t *t_pk, int nproofs, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_check_secrets, dim3(nproofs), dim3(256), 0, st, v, t_pk);
-    return hipGetLastError();
-}
 hipError_t launch_check_pairs(const uint16_t *a, const uint16_t *b, size_t gstride, int nrows, uint32_t *fail, int bit,
                               int nproofs, hipStream_t st)
 {
     hipLaunchKernelGGL(k_check_pairs, dim3(nrows, nproofs), dim3(256), 0, st, a, b, gstride, fail, bit);
-    return hipGetLastError();
-}
-hipError_t launch_check_zero(const uint16_t *a, size_t gstride, int nrows, uint32_t *fail, int bit, int nproofs, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_check_zero, dim3(nrows, nproofs), dim3(256), 0, st, a, gstride, fail, bit);
     return hipGetLastError();
 }
 

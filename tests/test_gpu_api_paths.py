@@ -86,3 +86,36 @@ def test_larger_batch_and_bench_shape(oracle, torch_cuda):
         assert (pks[b], sks[b], pis[b]) == (opk, osk, opi)
     assert len(set(pis)) == n
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_pipeline_slots_stress(torch_cuda):
+    """Three contexts proving and verifying concurrently from three host threads (bench.py's pipeline slots):
+    every honest proof must verify and the proof bytes must not depend on what the other slots are doing."""
+    import hashlib
+    import threading
+    from mpcith_kyber_kosk_amd import api
+    S, B, N = 3, 12, 25
+    slots = [api.Kosk(kyber_k=3, max_batch=B, device=0) for _ in range(S)]
+    ref = []
+    for si, c in enumerate(slots):
+        tapes = [hashlib.shake_256(b"kosk-tape-v1:%d" % (si * B + i)).digest(c.tape_bytes) for i in range(B)]
+        c.stage_prover_inputs(tapes)
+        c.prove_resident(B)
+        assert all(c.verify_resident(B))
+        ref.append(hashlib.sha3_256(b"".join(c.fetch_proofs(B))).hexdigest())
+    bad = []
+
+    def work(si):
+        c = slots[si]
+        for it in range(N):
+            c.prove_resident(B)
+            ok = c.verify_resident(B)
+            if not all(ok):
+                bad.append((si, it, ok.count(False), c.fail_masks(B)))
+        if hashlib.sha3_256(b"".join(c.fetch_proofs(B))).hexdigest() != ref[si]:
+            bad.append((si, "proof bytes changed"))
+    th = [threading.Thread(target=work, args=(si,)) for si in range(S)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not bad, bad

@@ -23,7 +23,7 @@ for s, e, n in ev:
         cur_e = max(cur_e, e)
 union += cur_e - cur_s
 wall = hi - lo
-steps = sum(1 for e in ev if "k_expand_f" in e[2])
+steps = sum(1 for e in ev if "k_prover_pre" in e[2])
 print("window %.1f ms, %d prove steps -> %.1f us/step wall" % (wall / 1e6, steps, wall / 1e3 / steps))
 print("GPU non-idle %.1f %% of wall; sum of kernel durations %.0f us/step; avg concurrency while busy %.2f" % (100.0 * union / wall, tot / 1e3 / steps, tot / union))
 for n, d in per.most_common(int(sys.argv[2]) if len(sys.argv) > 2 else 14):
