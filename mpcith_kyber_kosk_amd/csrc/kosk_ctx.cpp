@@ -377,66 +377,70 @@ int prove_resident(Ctx &c, int n)
     const int K = P.K;
     hipStream_t st = c.stream;
     double t0 = now_sec(), t1;
+    const size_t a_gstride = (size_t)(1792 / 16) * 2 * 2048; // limb matrix of one proof's f (or NTT f) rows, transposed
 
-    NttArgs na{};
     HashArgs ha{};
-    // ---- offline phase + witness sharing: secrets, randoms, one expansion GEMM
-    if (run_segment(c, Ctx::SEG_P1, n, [&]() -> int {
-    HIPCHK(launch_prover_pre(c.d_tape, c.tape_stride, c.d_P, c.proof_stride, rm.f, P.M, 64 + 32 * P.M, c.d_fresh_rows, P.nfresh,
-                             c.d_se, c.se_stride, rm, P.eta1, n, st));
-    na = NttArgs{};
-    na.in = reinterpret_cast<const int16_t *>(c.d_P);
-    na.in_gstride = c.proof_stride;
-    na.src_off = c.d_off + c.off_ntt1_src;     // NTT(f_i) -> Tf_i secrets (mlwe_prover.cpp:17-26) and NTT(s_i) (:256)
-    na.out = reinterpret_cast<int16_t *>(c.d_P);
-    na.out_gstride = c.proof_stride;
-    na.dst_off = c.d_off + c.off_ntt1_dst;
-    na.npg = c.n_ntt1;
-    na.npoly = c.n_ntt1 * n;
-    na.out_canonical = 1;
-    c.prof_begin(PR_NTT_F);
-    HIPCHK(launch_ntt(na, st));
-    c.prof_end(PR_NTT_F);
-    HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_P, c.proof_stride, rm.shat, rm.nttas, K, n, st)); // :284-285
-
-    const GemmSrc xsrc{c.d_P, c.proof_stride, c.d_gemm1_rows, RS, 0, XLEN};
-    const GemmDst xdst{c.d_P, c.proof_stride, c.d_gemm1_rows, RS, EXP_OFF};
-    c.prof_begin(PR_GEMM_EXPAND1);
-    if (gemm_modq(c, c.t_expand, xsrc, xdst, c.n_gemm1, n)) return -1;
-    c.prof_end(PR_GEMM_EXPAND1);
-    HIPCHK(launch_post_gates(c.d_P, c.proof_stride, rm, n, st));
-
-    ha = HashArgs{};
     ha.rows = c.d_P;
     ha.group_stride = c.proof_stride;
     ha.row_stride = RS;
     ha.col_off = NSEC;
     ha.lanes_per_group = NPARTY;
     ha.lane_map = nullptr;
-    ha.prefix = nullptr;
-    ha.out = c.d_dig1;
     ha.out_lanes_per_group = NPARTY;
-    c.prof_begin(PR_HASH_TCOMM);
-    HIPCHK(launch_commit_hash(ha, n, K, false, st));
-    c.prof_end(PR_HASH_TCOMM);
-    HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig1, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
-    return 0;
+
+    // ---- P1: offline phase + witness sharing (secrets, randoms, one expansion GEMM), Tcomm of every party
+    if (run_segment(c, Ctx::SEG_P1, n, [&]() -> int {
+        HIPCHK(launch_prover_pre(c.d_tape, c.tape_stride, c.d_P, c.proof_stride, rm.f, P.M, 64 + 32 * P.M, c.d_fresh_rows, P.nfresh,
+                                 c.d_se, c.se_stride, rm, P.eta1, n, st));
+        NttArgs na{};
+        na.in = reinterpret_cast<const int16_t *>(c.d_P);
+        na.in_gstride = c.proof_stride;
+        na.src_off = c.d_off + c.off_ntt1_src; // NTT(f_i) -> Tf_i secrets (mlwe_prover.cpp:17-26) and NTT(s_i) (:256)
+        na.out = reinterpret_cast<int16_t *>(c.d_P);
+        na.out_gstride = c.proof_stride;
+        na.dst_off = c.d_off + c.off_ntt1_dst;
+        na.npg = c.n_ntt1;
+        na.npoly = c.n_ntt1 * n;
+        na.out_canonical = 1;
+        c.prof_begin(PR_NTT_F);
+        HIPCHK(launch_ntt(na, st));
+        c.prof_end(PR_NTT_F);
+        HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_P, c.proof_stride, rm.shat, rm.nttas, K, n, st)); // :284-285
+        const GemmSrc xsrc{c.d_P, c.proof_stride, c.d_gemm1_rows, RS, 0, XLEN};
+        const GemmDst xdst{c.d_P, c.proof_stride, c.d_gemm1_rows, RS, EXP_OFF};
+        c.prof_begin(PR_GEMM_EXPAND1);
+        if (gemm_modq(c, c.t_expand, xsrc, xdst, c.n_gemm1, n)) return -1;
+        c.prof_end(PR_GEMM_EXPAND1);
+        HashArgs h1 = ha;
+        h1.prefix = nullptr;
+        h1.out = c.d_dig1;
+        c.prof_begin(PR_HASH_TCOMM);
+        HIPCHK(launch_commit_hash(h1, n, K, false, st));
+        c.prof_end(PR_HASH_TCOMM);
+        HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig1, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
+        return 0;
     })) return -1;
     c.phase_sec[PH_P1_ISSUE] = now_sec() - t0;
     HIPCHK(hipStreamSynchronize(st));
     t1 = now_sec(); c.phase_sec[PH_GPU_COMMIT] = t1 - t0; t0 = t1;
 
+    // ---- P1B: what neither Tcomm nor alpha needs is issued now and runs while the host hashes: the multiplication
+    // gates on the expanded shares (:338-381) and the transposed limb form of the f rows for the beta/gamma product
+    if (run_segment(c, Ctx::SEG_P1B, n, [&]() -> int {
+        HIPCHK(launch_post_gates(c.d_P, c.proof_stride, rm, n, st));
+        HIPCHK(launch_cols_to_limbs(c.d_P, c.proof_stride, rm.f, rm.tf, P.M, c.d_linA, a_gstride, n, st));
+        return 0;
+    })) return -1;
+
     // ---- Fiat-Shamir round 1 on the host
     fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool);
     t1 = now_sec(); c.phase_sec[PH_FS_ALPHA] = t1 - t0; t0 = t1;
-    if (run_segment(c, Ctx::SEG_P2, n, [&]() -> int {
-    HIPCHK(hipMemcpyAsync(c.d_alpha, c.h_alpha, (size_t)n * 80 * 2, hipMemcpyHostToDevice, st));
 
-    // ---- online relation phase
-    { // beta, gamma, r, NTT_r on every evaluation point: per proof a [J x M] x [M x 1710] product mod q   :159-203
-        const size_t a_gstride = (size_t)(1792 / 16) * 2 * 2048;
+    // ---- P2: beta, gamma, r, NTT_r on every evaluation point (per proof a [J x M] x [M x 1710] product mod q, :159-203),
+    // s + r / e + r (:222-245), then the view commitments, which read nothing else of the relation phase
+    if (run_segment(c, Ctx::SEG_P2, n, [&]() -> int {
+        HIPCHK(hipMemcpyAsync(c.d_alpha, c.h_alpha, (size_t)n * 80 * 2, hipMemcpyHostToDevice, st));
         c.prof_begin(PR_LINCOMB);
-        HIPCHK(launch_cols_to_limbs(c.d_P, c.proof_stride, rm.f, rm.tf, P.M, c.d_linA, a_gstride, n, st));
         HIPCHK(launch_coef_limbs(c.d_alpha, P.J, P.M, c.d_coef, n, st));
         GemmArgs ga{};
         ga.A = c.d_linA; ga.a_gstride = a_gstride; ga.Mpad = 1792; ga.M = NPTS; ga.KS = 2;
@@ -445,36 +449,10 @@ int prove_resident(Ctx &c, int n)
         ga.npg = P.J; ga.npg_pad = 128; ga.ngroups = 2 * n; ga.grouped = 1; ga.c_gdiv = 2; ga.c_rows_gstride = 128;
         HIPCHK(launch_gemm(ga, st));
         c.prof_end(PR_LINCOMB);
-    }
-    HIPCHK(launch_post_open(c.d_P, c.proof_stride, rm, n, st));
-    na.in = reinterpret_cast<const int16_t *>(c.d_P);
-    na.in_gstride = c.proof_stride;
-    na.src_off = c.d_off + c.off_sr_er;        // NTT of the opened s+r, e+r     :260-277
-    na.npg = 2 * K;
-    na.npoly = 2 * K * n;
-    na.out = reinterpret_cast<int16_t *>(c.d_P);
-    na.out_gstride = c.proof_stride;
-    na.dst_off = c.d_off + c.off_nttsr_er;
-    na.out_canonical = 1;
-    HIPCHK(launch_ntt(na, st));
-    HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_P, c.proof_stride, rm.nttsr, rm.nttasr, K, n, st)); // :287-288
-    HIPCHK(launch_copy_tails(c.d_P, c.proof_stride, rm, n, st));
-    const GemmSrc x2src{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, 0, XLEN};
-    const GemmDst x2dst{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, EXP_OFF};
-    c.prof_begin(PR_GEMM_EXPAND2);
-    if (gemm_modq(c, c.t_expand, x2src, x2dst, c.n_gemm2, n)) return -1; // recompute_share_secrets_ddeg x 3K   :298-299,:315
-    c.prof_end(PR_GEMM_EXPAND2);
-    HIPCHK(launch_post_relation(c.d_P, c.proof_stride, rm, n, st));
-    return 0;
+        HIPCHK(launch_post_open(c.d_P, c.proof_stride, rm, n, st));
+        return 0;
     })) return -1;
     // the graded kernel stays a plain launch so that HIP events can bracket it inside the timed region
-    ha.rows = c.d_P;
-    ha.group_stride = c.proof_stride;
-    ha.row_stride = RS;
-    ha.col_off = NSEC;
-    ha.lanes_per_group = NPARTY;
-    ha.lane_map = nullptr;
-    ha.out_lanes_per_group = NPARTY;
     ha.prefix = c.d_dig1;
     ha.out = c.d_dig2;
     c.prof_begin(PR_HASH_VIEW);
@@ -485,29 +463,53 @@ int prove_resident(Ctx &c, int n)
     HIPCHK(hipStreamSynchronize(st));
     t1 = now_sec(); c.phase_sec[PH_GPU_RELATION] = t1 - t0; t0 = t1;
 
+    // ---- P2B: the NTT-domain half of the relation is not hashed, only opened; it runs while the host derives I
+    if (run_segment(c, Ctx::SEG_P2B, n, [&]() -> int {
+        NttArgs na{};
+        na.in = reinterpret_cast<const int16_t *>(c.d_P);
+        na.in_gstride = c.proof_stride;
+        na.src_off = c.d_off + c.off_sr_er; // NTT of the opened s+r, e+r     :260-277
+        na.npg = 2 * K;
+        na.npoly = 2 * K * n;
+        na.out = reinterpret_cast<int16_t *>(c.d_P);
+        na.out_gstride = c.proof_stride;
+        na.dst_off = c.d_off + c.off_nttsr_er;
+        na.out_canonical = 1;
+        HIPCHK(launch_ntt(na, st));
+        HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_P, c.proof_stride, rm.nttsr, rm.nttasr, K, n, st)); // :287-288
+        HIPCHK(launch_copy_tails(c.d_P, c.proof_stride, rm, n, st));
+        const GemmSrc x2src{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, 0, XLEN};
+        const GemmDst x2dst{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, EXP_OFF};
+        c.prof_begin(PR_GEMM_EXPAND2);
+        if (gemm_modq(c, c.t_expand, x2src, x2dst, c.n_gemm2, n)) return -1; // recompute_share_secrets_ddeg x 3K   :298-299,:315
+        c.prof_end(PR_GEMM_EXPAND2);
+        HIPCHK(launch_post_relation(c.d_P, c.proof_stride, rm, n, st));
+        return 0;
+    })) return -1;
+
     // ---- Fiat-Shamir round 2 on the host
     fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, c.h_I, c.h_rest, c.sel_stride, c.nthreads, c.pool);
     t1 = now_sec(); c.phase_sec[PH_FS_OPEN] = t1 - t0; t0 = t1;
-    if (run_segment(c, Ctx::SEG_P3, n, [&]() -> int {
-    HIPCHK(hipMemcpyAsync(c.d_I, c.h_I, ((size_t)c.max_batch + n) * c.sel_stride * 2, hipMemcpyHostToDevice, st)); // I and its complement
 
-    // ---- wire image
-    AssembleArgs aa{};
-    aa.P = c.d_P;
-    aa.proof_stride = c.proof_stride;
-    aa.fields = c.d_fields;
-    aa.rowtab = c.d_rowtab;
-    aa.opened = c.d_I;
-    aa.rest = c.d_rest;
-    aa.sel_stride = c.sel_stride;
-    aa.dig1 = c.d_dig1;
-    aa.dig2 = c.d_dig2;
-    aa.proof = c.d_proof;
-    aa.image_stride = c.image_stride;
-    c.prof_begin(PR_ASSEMBLE);
-    HIPCHK(launch_assemble(aa, c.nfields, P.off[F_TCOMM], P.off[F_COMM], P.off[F_I], n, st));
-    c.prof_end(PR_ASSEMBLE);
-    return 0;
+    // ---- P3: wire image
+    if (run_segment(c, Ctx::SEG_P3, n, [&]() -> int {
+        HIPCHK(hipMemcpyAsync(c.d_I, c.h_I, ((size_t)c.max_batch + n) * c.sel_stride * 2, hipMemcpyHostToDevice, st)); // I and its complement
+        AssembleArgs aa{};
+        aa.P = c.d_P;
+        aa.proof_stride = c.proof_stride;
+        aa.fields = c.d_fields;
+        aa.rowtab = c.d_rowtab;
+        aa.opened = c.d_I;
+        aa.rest = c.d_rest;
+        aa.sel_stride = c.sel_stride;
+        aa.dig1 = c.d_dig1;
+        aa.dig2 = c.d_dig2;
+        aa.proof = c.d_proof;
+        aa.image_stride = c.image_stride;
+        c.prof_begin(PR_ASSEMBLE);
+        HIPCHK(launch_assemble(aa, c.nfields, P.off[F_TCOMM], P.off[F_COMM], P.off[F_I], n, st));
+        c.prof_end(PR_ASSEMBLE);
+        return 0;
     })) return -1;
     c.phase_sec[PH_P3_ISSUE] = now_sec() - t0;
     HIPCHK(hipStreamSynchronize(st));

@@ -116,7 +116,7 @@ struct Ctx {
 
     // hipGraph per pipeline segment (the launches between two host Fiat-Shamir rounds), captured once per
     // batch size and replayed: one API call instead of ~15 launches of kernels that run 3-6 us each.
-    enum SegId { SEG_P1 = 0, SEG_P2, SEG_P3, SEG_V1, SEG_V1B, SEG_V2, SEG_COUNT };
+    enum SegId { SEG_P1 = 0, SEG_P1B, SEG_P2, SEG_P2B, SEG_P3, SEG_V1, SEG_V1B, SEG_V2, SEG_V2B, SEG_COUNT };
     struct SegGraph {
         hipGraphExec_t exec = nullptr;
         int n = 0;

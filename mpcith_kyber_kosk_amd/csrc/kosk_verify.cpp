@@ -300,6 +300,24 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     c.prof_begin(PR_V_LINCOMB);
     HIPCHK(launch_lincomb(la, n, st));
     c.prof_end(PR_V_LINCOMB);
+    return 0;
+    })) return -1;
+
+    // ---- V10: view hashes of the opened parties (plain launch: HIP events can bracket it)
+    oh.prefix = c.d_dig1;
+    oh.out = c.d_dig2;
+    c.prof_begin(PR_V_HASH_VIEW);
+    HIPCHK(launch_opened_hash(oh, K, true, n, st));
+    c.prof_end(PR_V_HASH_VIEW);
+    HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig2, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
+    t1 = now_sec(); c.phase_sec[PH_V2_ISSUE] = t1 - t0; t0 = t1;
+    HIPCHK(hipStreamSynchronize(st));
+    t1 = now_sec(); c.phase_sec[PH_V2_WAIT] = t1 - t0; t0 = t1;
+
+    // ---- V2B: the checks that feed no hash run while the host derives the opened set: reconstruction of the 140
+    // beta/gamma secrets with the NTT comparison (:106-131) and the relation checks on the opened columns
+    if (run_segment(c, Ctx::SEG_V2B, n, [&]() -> int {
+    NttArgs na{};
     {
         const GemmSrc gs{c.d_P, c.proof_stride, c.d_rows_bg, RS, NSEC, XLEN};
         const GemmDst gd{c.d_sec, (size_t)2 * NCHK * 256, nullptr, 256, 0};
@@ -320,23 +338,14 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     HIPCHK(launch_ntt(na, st)); // NTT(beta) in place (each block stages its polynomials in LDS first)
     HIPCHK(launch_check_pairs(c.d_sec, c.d_sec + (size_t)NCHK * 256, (size_t)2 * NCHK * 256, NCHK, c.d_fail, FB_BETA_GAMMA, n, st));
     HIPCHK(launch_check_opened(va, n, st));
+    HIPCHK(hipMemcpyAsync(c.h_fail, c.d_fail, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st));
     return 0;
     })) return -1;
 
-    // ---- V10: view hashes of the opened parties (plain launch: HIP events can bracket it)
-    oh.prefix = c.d_dig1;
-    oh.out = c.d_dig2;
-    c.prof_begin(PR_V_HASH_VIEW);
-    HIPCHK(launch_opened_hash(oh, K, true, n, st));
-    c.prof_end(PR_V_HASH_VIEW);
-    HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig2, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(c.h_fail, c.d_fail, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st));
-    t1 = now_sec(); c.phase_sec[PH_V2_ISSUE] = t1 - t0; t0 = t1;
-    HIPCHK(hipStreamSynchronize(st));
-    t1 = now_sec(); c.phase_sec[PH_V2_WAIT] = t1 - t0; t0 = t1;
-    c.prof_collect();
     std::vector<uint16_t> I2((size_t)n * c.sel_stride), rest2((size_t)n * c.sel_stride);
     fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, I2.data(), rest2.data(), c.sel_stride, c.nthreads, c.pool);
+    HIPCHK(hipStreamSynchronize(st)); // fail masks of V2B
+    c.prof_collect();
     for (int b = 0; b < n; b++) {
         uint32_t f = c.h_fail[b];
         if (memcmp(&I2[(size_t)b * c.sel_stride], c.h_Iimg + (size_t)b * NOPEN, sizeof(uint16_t) * NOPEN) != 0) f |= 1u << FB_OPENED_SET;
