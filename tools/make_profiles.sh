@@ -1,0 +1,49 @@
+#!/bin/bash
+# Regenerates the files under profiles/ (run on the MI355X box from the repo root; outputs under gpurun_out/prof).
+# usage: tools/make_profiles.sh <tag>        e.g. r01b
+set -o pipefail
+tag=${1:-r01}
+out=gpurun_out/prof
+rm -rf $out; mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+# 1. kernel stats of the bench command itself
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 60 --warmup 6 --no-cpu-baseline > $out/bench_under_rocprof.log 2>&1
+cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_kernel_stats.csv
+tail -1 $out/bench_under_rocprof.log > $out/${tag}_bench_under_rocprof.json
+echo "stats done"
+# 2. one slot: GPU-busy per step
+tools/gpu_busy.sh $out/busy 80 > $out/${tag}_gpu_busy_1slot.txt 2>&1
+echo "busy done"
+# 3. PMC passes (separate, no other tracing domains)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_f -- python3 tools/pmc_workload.py > /dev/null 2>&1
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_w -- python3 tools/pmc_workload.py > /dev/null 2>&1
+echo "write done"
+python3 - $out $tag <<'PY'
+import csv, sys, glob, collections, json
+out, tag = sys.argv[1], sys.argv[2]
+def load(d, name):
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    acc = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != name: continue
+        k = (r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Grid_Size"]))
+        a = acc.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += float(r["Counter_Value"])
+    return acc
+F, W = load(out + "/pmc_f", "FETCH_SIZE"), load(out + "/pmc_w", "WRITE_SIZE")
+with open("%s/%s_pmc_fetch_write.csv" % (out, tag), "w") as fo:
+    fo.write("kernel,grid_threads,dispatches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg\n")
+    for k, (n, v) in F.items():
+        w = W.get(k, [1, 0.0])
+        fo.write("%s,%d,%d,%.0f,%.0f\n" % (k[0], k[1], n, v / n, w[1] / max(1, w[0])))
+# in-pipeline view hash: the k_commit_hash<16,220,...> dispatch with 46 proofs (grid 1472 x 46 threads)
+hv = [(k, v) for k, v in F.items() if "k_commit_hash<16, 220" in k[0] and k[1] == 1472 * 46]
+if hv:
+    k, (n, v) = hv[0]
+    w = W[k]
+    traffic = int(round((2 * v / n + w[1] / w[0]) * 1024))
+    json.dump({"source": "profiles/%s_pmc_fetch_write.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md, calibrated on k_ntt256)" % tag,
+               "hash_view_hbm_bytes_per_launch": traffic, "hash_view_algorithmic_bytes_per_launch": 46 * 1454 * 504}, open(out + "/traffic.json", "w"), indent=1)
+    print("view hash traffic per launch:", traffic, "algorithmic", 46 * 1454 * 504)
+PY
+echo "pmc done"
