@@ -233,6 +233,7 @@ static int build_tables(Ctx &c)
     add(F_US, 1, K * Z, [&](int e) { return rm.us(e / Z, e % Z); });
     add(F_UE, 1, K * Z, [&](int e) { return rm.ue(e / Z, e % Z); });
     c.nfields = (int)c.h_fields.size();
+    c.pplan = make_field_plan(c.h_fields.data(), c.nfields);
     if (upload_vec(c, &c.d_fields, c.h_fields)) return -1;
     if (upload_vec(c, &c.d_rowtab, c.h_rowtab)) return -1;
     return 0;
@@ -489,6 +490,14 @@ int prove_resident(Ctx &c, int n)
 
     // ---- Fiat-Shamir round 2 on the host
     fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, c.h_I, c.h_rest, c.sel_stride, c.nthreads, c.pool);
+    for (int b = 0; b < n; b++) { // complement entries owned by each aligned 64-party window (k_assemble_fields)
+        const uint16_t *rest = c.h_rest + (size_t)b * c.sel_stride;
+        uint16_t *win = c.h_I + (size_t)b * c.sel_stride + SEL_WIN;
+        for (int w = 0, j = 0; w <= NWIN; w++) {
+            while (j < NREST && rest[j] < 64 * w) j++;
+            win[w] = (uint16_t)j;
+        }
+    }
     t1 = now_sec(); c.phase_sec[PH_FS_OPEN] = t1 - t0; t0 = t1;
 
     // ---- P3: wire image
@@ -506,6 +515,7 @@ int prove_resident(Ctx &c, int n)
         aa.dig2 = c.d_dig2;
         aa.proof = c.d_proof;
         aa.image_stride = c.image_stride;
+        aa.plan = c.pplan;
         c.prof_begin(PR_ASSEMBLE);
         HIPCHK(launch_assemble(aa, c.nfields, P.off[F_TCOMM], P.off[F_COMM], P.off[F_I], n, st));
         c.prof_end(PR_ASSEMBLE);

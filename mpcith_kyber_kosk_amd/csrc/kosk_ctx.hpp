@@ -93,6 +93,7 @@ struct Ctx {
     FieldDesc *d_vfields = nullptr;  // proof image -> rows (verifier row assignment)
     int16_t *d_vrowtab = nullptr;
     int n_vfields = 0;
+    FieldPlan vplan{}, pplan{}; // block -> (field, chunk) maps of the disassemble / assemble kernels
     int16_t *d_rows_bg = nullptr;    // beta_0..69, gamma_0..69
     int16_t *d_rows_isrc = nullptr, *d_rows_idst = nullptr; // degree-d interpolations: given rows -> recomputed rows
     int16_t *d_rows_u = nullptr;     // us / ue rows (degree 2d)

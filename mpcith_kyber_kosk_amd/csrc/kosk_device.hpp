@@ -105,6 +105,22 @@ struct FieldDesc {
     int rowtab_off;
 };
 
+// which (field, chunk) a block of the assemble / disassemble kernels works on: blocks [0, nrest * NWIN) walk the
+// fields of unopened parties window by window, the rest the fields of opened parties in chunks of 64
+struct FieldPlan {
+    uint8_t rest_ids[NFIELDS], open_ids[NFIELDS];
+    int nrest, nopen;
+};
+inline FieldPlan make_field_plan(const FieldDesc *fields, int nfields)
+{
+    FieldPlan p{};
+    for (int f = 0; f < nfields; f++) {
+        if (fields[f].sel) p.rest_ids[p.nrest++] = (uint8_t)f;
+        else p.open_ids[p.nopen++] = (uint8_t)f;
+    }
+    return p;
+}
+
 struct AssembleArgs {
     const uint16_t *P;
     size_t proof_stride;
@@ -115,6 +131,7 @@ struct AssembleArgs {
     const uint8_t *dig1, *dig2; // [proof][NPARTY][32]
     uint8_t *proof;
     size_t image_stride;
+    FieldPlan plan;
 };
 
 // ---- verifier (kosk_verify_kernels.hip) ----
@@ -156,7 +173,7 @@ struct InterpArgs {
 // opened list from the image -> I, complement, sorted I, hole ranges, MALFORMED bit (overwrites fail[])
 hipError_t launch_opened_setup(const uint8_t *proof, size_t image_stride, size_t off_I, uint16_t *I, uint16_t *rest, uint16_t *isort,
                                uint16_t *hrange, size_t sel_stride, uint32_t *fail, int nproofs, hipStream_t st);
-hipError_t launch_disassemble(const VerifyArgs &v, const FieldDesc *fields, const int16_t *rowtab, int nfields,
+hipError_t launch_disassemble(const VerifyArgs &v, const FieldDesc *fields, const FieldPlan &plan, const int16_t *rowtab,
                               const uint8_t *proof, size_t image_stride, size_t off_tcomm, size_t off_comm,
                               uint8_t *dig1, uint8_t *dig2, int nproofs, hipStream_t st);
 // Tcomm / view hash of the OPENED parties straight from the proof image (mlwe_verifier.cpp:23-35, :585-632):

@@ -37,6 +37,9 @@ constexpr int XLEN = DEG + 1;         // 407 expansion inputs
 constexpr int EXP_OFF = 384;          // first point written by the expand GEMM (party 128)
 constexpr int EXP_M = RS - EXP_OFF;   // 1344 = 21 x 64 outputs per row
 constexpr int NFIELDS = 24;
+// an opened-list row [proof][sel_stride] holds I in [0,150) and, from SEL_WIN on, for each aligned window of 64
+// parties w = 0..23 the number of unopened parties below 64w (so window w owns complement entries [win[w], win[w+1]))
+constexpr int SEL_WIN = 160, NWIN = (NPARTY + 63) / 64;
 constexpr int MAXK = 4, MAXM = 79, MAXJ = NCHK + 2 * MAXK;
 
 struct Params {

@@ -98,6 +98,7 @@ static int ensure_verify_workspace(Ctx &c)
     add(F_US, 1, K * Z, [&](int e) { return rm.us(e / Z, e % Z); });
     add(F_UE, 1, K * Z, [&](int e) { return rm.ue(e / Z, e % Z); });
     c.n_vfields = (int)vf.size();
+    c.vplan = make_field_plan(vf.data(), c.n_vfields);
     if (upload_vec(c, &c.d_vfields, vf)) return -1;
     if (upload_vec(c, &c.d_vrowtab, rt)) return -1;
 
@@ -196,7 +197,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
 
 
     // ---- V1: scatter, gate outputs on opened columns, Tcomm of the opened parties
-    HIPCHK(launch_disassemble(va, c.d_vfields, c.d_vrowtab, c.n_vfields, c.d_proof, c.image_stride, P.off[F_TCOMM],
+    HIPCHK(launch_disassemble(va, c.d_vfields, c.vplan, c.d_vrowtab, c.d_proof, c.image_stride, P.off[F_TCOMM],
                               P.off[F_COMM], c.d_dig1, c.d_dig2, n, st));
     HIPCHK(launch_gates_opened(va, n, st));
     c.prof_begin(PR_V_HASH_TCOMM);

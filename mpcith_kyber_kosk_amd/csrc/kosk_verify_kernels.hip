@@ -19,36 +19,62 @@ constexpr int DIS_TILE = 64 * 80;
 // inverse of k_assemble_fields: proof image -> rows at the listed party columns.
 // Non-canonical values (>= q) can never be produced by an honest prover; they are
 // folded mod q to keep arithmetic bounded and the proof is marked malformed.
-__global__ __launch_bounds__(256) void k_disassemble_fields(VerifyArgs v, const FieldDesc *__restrict__ fields,
-                                                           const int16_t *__restrict__ rowtab,
-                                                           const uint8_t *__restrict__ proof, size_t image_stride)
+__global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const FieldDesc *__restrict__ fields, FieldPlan plan,
+                                                          const int16_t *__restrict__ rowtab,
+                                                          const uint8_t *__restrict__ proof, size_t image_stride)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t tile[DIS_TILE]; // image order, filled by 4-byte copies
-    const FieldDesc fd = fields[blockIdx.y];
-    const int b = blockIdx.z;
-    const int np = fd.sel ? NREST : NOPEN;
-    const int i0 = blockIdx.x * 64;
-    if (i0 >= np) return;
-    const int cnt = min(64, np - i0);
-    const uint32_t *in = reinterpret_cast<const uint32_t *>(proof + (size_t)b * image_stride + fd.off + (size_t)i0 * fd.width * 2);
-    uint32_t *t32 = reinterpret_cast<uint32_t *>(tile);
-    const int words = cnt * fd.width / 2;
-    bool bad = false;
-    for (int q = threadIdx.x; q < words; q += 256) {
-        uint32_t x = in[q];
-        uint32_t lo = x & 0xFFFFu, hi = x >> 16;
-        if (lo >= (uint32_t)Q || hi >= (uint32_t)Q) { bad = true; lo %= Q; hi %= Q; x = lo | (hi << 16); }
-        t32[q] = x;
+    __shared__ __attribute__((aligned(16))) uint16_t tile[DIS_TILE]; // image order
+    const int b = blockIdx.y, x = blockIdx.x, lane = threadIdx.x;
+    const bool kind = x < plan.nrest * NWIN; // unopened parties of one aligned window (see k_assemble_fields)
+    const uint16_t *orow = v.opened + (size_t)b * v.sel_stride;
+    int i0, cnt, f;
+    if (kind) {
+        const int win = x % NWIN;
+        f = plan.rest_ids[x / NWIN];
+        i0 = orow[SEL_WIN + win];
+        cnt = (int)orow[SEL_WIN + win + 1] - i0;
+    } else {
+        const int y = x - plan.nrest * NWIN, nch = (NOPEN + 63) / 64;
+        f = plan.open_ids[y / nch];
+        i0 = (y % nch) * 64;
+        cnt = min(64, NOPEN - i0);
     }
-    __syncthreads();
-    const uint16_t *sel = (fd.sel ? v.rest : v.opened) + (size_t)b * v.sel_stride;
-    uint16_t *Pb = v.P + (size_t)b * v.proof_stride;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (cnt <= 0) return;
+    const FieldDesc fd = fields[f];
+    const uint16_t *in = reinterpret_cast<const uint16_t *>(proof + (size_t)b * image_stride + fd.off) + (size_t)i0 * fd.width;
+    const int n16 = cnt * fd.width;
+    const int head = (int)((reinterpret_cast<uintptr_t>(in) >> 1) & 1);
+    const int body = (n16 - head) >> 1;
+    bool bad = false;
+    auto canon = [&](uint32_t x_) { if (x_ >= (uint32_t)Q) { bad = true; x_ %= Q; } return (uint16_t)x_; };
+    if (lane == 0 && head) tile[0] = canon(in[0]);
+    const uint32_t *in32 = reinterpret_cast<const uint32_t *>(in + head);
+    for (int q0 = 0; q0 < body; q0 += 64 * 8) { // eight independent loads in flight per lane
+        uint32_t xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = q0 + u * 64 + lane;
+            xv[u] = q < body ? in32[q] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = q0 + u * 64 + lane;
+            if (q < body) {
+                tile[head + 2 * q] = canon(xv[u] & 0xFFFFu);
+                tile[head + 2 * q + 1] = canon(xv[u] >> 16);
+            }
+        }
+    }
+    if (lane == 1 && head + 2 * body < n16) tile[n16 - 1] = canon(in[n16 - 1]);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const uint16_t *sel = kind ? v.rest + (size_t)b * v.sel_stride : orow;
     if (lane < cnt) {
-        uint16_t *dst = Pb + NSEC + sel[i0 + lane];
+        uint16_t *dst = v.P + (size_t)b * v.proof_stride + NSEC + sel[i0 + lane];
         const int16_t *rt = rowtab + fd.rowtab_off;
         const uint16_t *t = tile + lane * fd.width;
-        for (int e = w; e < fd.width; e += 4) dst[(size_t)rt[e] * RS] = t[e];
+#pragma unroll 8
+        for (int e = 0; e < fd.width; e++) dst[(size_t)rt[e] * RS] = t[e];
     }
     if (bad) atomicOr(&v.fail[b], 1u << FB_MALFORMED);
 }
@@ -393,6 +419,7 @@ __global__ __launch_bounds__(256) void k_opened_setup(const uint8_t *__restrict_
     for (int k = 0; k < 6; k++) {
         const int p = 6 * t + k;
         if (p >= NPARTY) break;
+        if ((p & 63) == 0) I[(size_t)b * sel_stride + SEL_WIN + (p >> 6)] = (uint16_t)(p - used_before); // unopened below window p/64
         if (u[k]) {
             isort[(size_t)b * sel_stride + used_before] = (uint16_t)p;
             used_before++;
@@ -413,6 +440,7 @@ __global__ __launch_bounds__(256) void k_opened_setup(const uint8_t *__restrict_
         hr[2] = (uint16_t)node[0];
         hr[3] = (uint16_t)(node[2] - DEG2);
         fail[b] = malformed ? 1u << FB_MALFORMED : 0u;
+        I[(size_t)b * sel_stride + SEL_WIN + NWIN] = (uint16_t)NREST;
     }
 }
 
@@ -475,11 +503,11 @@ hipError_t launch_opened_setup(const uint8_t *proof, size_t image_stride, size_t
     hipLaunchKernelGGL(k_opened_setup, dim3(nproofs), dim3(256), 0, st, proof, image_stride, (uint32_t)off_I, I, rest, isort, hrange, sel_stride, fail);
     return hipGetLastError();
 }
-hipError_t launch_disassemble(const VerifyArgs &v, const FieldDesc *fields, const int16_t *rowtab, int nfields,
+hipError_t launch_disassemble(const VerifyArgs &v, const FieldDesc *fields, const FieldPlan &plan, const int16_t *rowtab,
                               const uint8_t *proof, size_t image_stride, size_t off_tcomm, size_t off_comm,
                               uint8_t *dig1, uint8_t *dig2, int nproofs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_disassemble_fields, dim3((NREST + 63) / 64, nfields, nproofs), dim3(256), 0, st, v, fields, rowtab, proof, image_stride);
+    hipLaunchKernelGGL(k_disassemble_fields, dim3(plan.nrest * NWIN + plan.nopen * ((NOPEN + 63) / 64), nproofs), dim3(64), 0, st, v, fields, plan, rowtab, proof, image_stride);
     hipLaunchKernelGGL(k_disassemble_digests, dim3((NREST * 16 + 255) / 256, nproofs), dim3(256), 0, st, proof, image_stride,
                        off_tcomm, off_comm, v.rest, v.sel_stride, dig1, dig2);
     return hipGetLastError();
