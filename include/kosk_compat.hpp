@@ -47,6 +47,42 @@ typedef struct {
     uint8_t sk[KYBER_SECRETKEYBYTES];
 } kyber_keypair; /* kosk.hpp:13-16 */
 
+/* ---- second-level types (ss.hpp:33-37, mlwe_prover.hpp:39-75): same members, same layout ---- */
+typedef struct {
+    size_t len;
+    uint16_t share_x[MPCITH_N];
+    uint16_t share_y[MPCITH_N];
+} share_vec;
+typedef struct {
+    uint16_t f[MPCITH_K + MPCITH_V + 1][KYBER_N];
+    uint16_t NTT_f[MPCITH_K + MPCITH_V + 1][KYBER_N];
+    share_vec f_shares[MPCITH_K + MPCITH_V + 1];
+    share_vec NTT_f_shares[MPCITH_K + MPCITH_V + 1];
+} mpcith_randomness;
+typedef struct {
+    share_vec s_eta_shares[KYBER_K][KYBER_ETA1 * 2 + 1];
+    share_vec e_eta_shares[KYBER_K][KYBER_ETA1 * 2 + 1];
+} mpcith_range_proof;
+typedef struct {
+    uint16_t f_shares[MPCITH_T][MPCITH_K + MPCITH_V + 1], NTT_f_shares[MPCITH_T][MPCITH_K + MPCITH_V + 1];
+    uint16_t beta_shares[MPCITH_N - MPCITH_T][MPCITH_K], gamma_shares[MPCITH_N - MPCITH_T][MPCITH_K];
+    uint8_t Tcomm[MPCITH_N - MPCITH_T][KYBER_SYMBYTES];
+    uint16_t I[MPCITH_T];
+    uint16_t s_shares[MPCITH_T][KYBER_K], e_shares[MPCITH_T][KYBER_K], t_shares[MPCITH_N - MPCITH_T][KYBER_K];
+    uint16_t NTT_s_shares[MPCITH_T][KYBER_K], NTT_e_shares[MPCITH_T][KYBER_K];
+    uint16_t NTT_Ar_shares[MPCITH_T][KYBER_K], NTT_As_shares[MPCITH_T][KYBER_K];
+    uint16_t sr_shares[MPCITH_N - MPCITH_T][KYBER_K], er_shares[MPCITH_N - MPCITH_T][KYBER_K];
+    uint16_t s_eta_shares[MPCITH_N - MPCITH_T][KYBER_K][KYBER_ETA1 * 2 + 1], e_eta_shares[MPCITH_N - MPCITH_T][KYBER_K][KYBER_ETA1 * 2 + 1];
+    uint16_t s_sub_eta_shares[MPCITH_T][KYBER_K][KYBER_ETA1 * 2 + 1], e_sub_eta_shares[MPCITH_T][KYBER_K][KYBER_ETA1 * 2 + 1];
+    uint16_t z_s_ddeg_shares[MPCITH_T][KYBER_K][KYBER_ETA1 * 2], z_e_ddeg_shares[MPCITH_T][KYBER_K][KYBER_ETA1 * 2];
+    uint16_t u_s_2ddeg_shares[MPCITH_N - MPCITH_T][KYBER_K][KYBER_ETA1 * 2], u_e_2ddeg_shares[MPCITH_N - MPCITH_T][KYBER_K][KYBER_ETA1 * 2];
+    uint8_t comm[MPCITH_N - MPCITH_T][KYBER_SYMBYTES];
+} mpcith_proof;
+static_assert(sizeof(mpcith_proof) == MPCITH_PROOF_SIZE, "mpcith_proof must be the wire image (mlwe_prover.cpp:540-543)");
+static_assert(sizeof(share_vec) == 8 + 4 * MPCITH_N, "share_vec layout");
+static_assert(sizeof(mlwe_inst) == (size_t)(KYBER_K * KYBER_K + 3 * KYBER_K) * 512, "mlwe_inst layout");
+#define MPCITH_PRE_RANDOMNESS_SIZE (sizeof(mpcith_randomness) + sizeof(mpcith_range_proof)) /* mlwe_prover.hpp:31 */
+
 extern "C" void randombytes(uint8_t *out, size_t outlen); /* kyber/randombytes.h:7: supplied by the caller's link line */
 
 namespace kosk_compat {
@@ -97,6 +133,57 @@ inline bool kyber_kosk_verify(const uint8_t *pi, const uint8_t *pk)
         abort();
     }
     return ok == 1;
+}
+
+
+/* ---- second-level entry points, used directly by main.cpp:21-47 ---- */
+namespace kosk_compat {
+inline void must(int rc, const char *what)
+{
+    if (rc) {
+        fprintf(stderr, "%s: %s\n", what, kosk_last_error(ctx()));
+        abort();
+    }
+}
+} // namespace kosk_compat
+/* mlwe_prover.hpp:77 */
+inline void prepare_randomness(mpcith_randomness *rand)
+{
+    kosk_compat::must(kosk_prepare_randomness(kosk_compat::ctx(), 1, nullptr, 0, reinterpret_cast<uint8_t *>(rand)), "prepare_randomness");
+}
+/* mlwe_prover.hpp:78 */
+inline void prepare_range_proof(mpcith_range_proof *eta_shares)
+{
+    kosk_compat::must(kosk_prepare_range_proof(kosk_compat::ctx(), 1, nullptr, 0, reinterpret_cast<uint8_t *>(eta_shares)), "prepare_range_proof");
+}
+/* mlwe_prover.hpp:96-99 */
+inline void prove(mpcith_proof *pi, const mlwe_inst *mlwe, const mpcith_randomness *rand, const mpcith_range_proof *eta_share)
+{
+    kosk_compat::must(kosk_prove_prepared(kosk_compat::ctx(), 1, reinterpret_cast<const uint8_t *>(mlwe),
+                                          reinterpret_cast<const uint8_t *>(rand), reinterpret_cast<const uint8_t *>(eta_share),
+                                          nullptr, 0, reinterpret_cast<uint8_t *>(pi)), "prove");
+}
+/* mlwe_verifier.hpp:14-15 */
+inline bool verify(const mpcith_proof *pi, const mlwe_inst *mlwe)
+{
+    uint8_t ok = 0;
+    kosk_compat::must(kosk_verify_inst(kosk_compat::ctx(), 1, reinterpret_cast<const uint8_t *>(pi),
+                                       reinterpret_cast<const uint8_t *>(mlwe), &ok), "verify");
+    return ok == 1;
+}
+/* mlwe_prover.hpp:72-75; the struct IS the wire image (mlwe_prover.cpp:540-543) */
+inline void encode_mpcith_proof(uint8_t *buf, const mpcith_proof *pi) { memcpy(buf, pi, sizeof(mpcith_proof)); }
+inline void decode_mpcith_proof(mpcith_proof *pi, const uint8_t *buf) { memcpy(pi, buf, sizeof(mpcith_proof)); }
+/* mlwe_prover.hpp:50-55.  The reference's decode forgets eta_shares (mlwe_prover.cpp:70-79); this one restores both. */
+inline void encode_preprocessed_randomness(uint8_t *buf, const mpcith_randomness *rand, const mpcith_range_proof *eta_shares)
+{
+    memcpy(buf, rand, sizeof(mpcith_randomness));
+    memcpy(buf + sizeof(mpcith_randomness), eta_shares, sizeof(mpcith_range_proof));
+}
+inline void decode_preprocessed_randomness(mpcith_randomness *rand, mpcith_range_proof *eta_shares, const uint8_t *buf)
+{
+    memcpy(rand, buf, sizeof(mpcith_randomness));
+    memcpy(eta_shares, buf + sizeof(mpcith_randomness), sizeof(mpcith_range_proof));
 }
 
 #endif // KOSK_COMPAT_HPP

@@ -57,6 +57,29 @@ int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, siz
 int kosk_verify_batch(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk, uint8_t *ok);
 int kosk_verify_fail_masks(const kosk_ctx *ctx, uint32_t *masks, int n);
 
+/* ---- Second-level entry points of the reference (mlwe_prover.hpp:77-99, mlwe_verifier.hpp:14-15; used directly by
+ * main.cpp:21-47) on n instances at a time.  The buffers are arrays of the reference's structs for this kyber_k, byte for
+ * byte (little-endian, no padding):
+ *   share_vec          { uint64 len = 1454; u16 share_x[1454] (= 256 + party); u16 share_y[1454]; }      ss.hpp:33-37
+ *   mpcith_randomness  { u16 f[M][256]; u16 NTT_f[M][256]; share_vec f_shares[M]; share_vec NTT_f_shares[M]; }   M = 71 + 2K
+ *   mpcith_range_proof { share_vec s_eta_shares[K][2 eta1 + 1]; share_vec e_eta_shares[K][2 eta1 + 1]; }
+ *   mlwe_inst          { i16 A[K][K][256] (NTT domain); i16 t[K][256]; i16 s[K][256]; i16 e[K][256]; }   = kosk_keygen's outputs
+ * Randomness: `tapes` = per instance exactly the bytes the reference would draw in that call, in its order
+ * (prepare_randomness: M x 32 then 2M x 302; prepare_range_proof: 2K(2 eta1 + 1) x 302; prove: (3K + 4K eta1) x 302),
+ * tape_stride apart; NULL = the randombytes callback / OS entropy with the reference's call sequence. */
+size_t kosk_randomness_bytes(int kyber_k);  /* sizeof(mpcith_randomness)  */
+size_t kosk_range_proof_bytes(int kyber_k); /* sizeof(mpcith_range_proof) */
+size_t kosk_mlwe_inst_bytes(int kyber_k);   /* sizeof(mlwe_inst)          */
+/* prepare_randomness, mlwe_prover.cpp:4-39 */
+int kosk_prepare_randomness(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *rand_out);
+/* prepare_range_proof, mlwe_prover.cpp:41-59 */
+int kosk_prepare_range_proof(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *range_out);
+/* prove + encode_mpcith_proof, mlwe_prover.cpp:81-543: pi receives n proof images */
+int kosk_prove_prepared(kosk_ctx *ctx, int n, const uint8_t *inst, const uint8_t *rand_in, const uint8_t *range_in,
+                        const uint8_t *tapes, size_t tape_stride, uint8_t *pi);
+/* decode_mpcith_proof + verify, mlwe_verifier.cpp:4-686, with A and t from the instance (s, e are not read) */
+int kosk_verify_inst(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *inst, uint8_t *ok);
+
 /* Device-resident split of the two calls above, for callers that keep inputs
  * and proofs in HBM (and for bench.py: the timed region is *_resident only). */
 int kosk_stage_prover_inputs(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk);

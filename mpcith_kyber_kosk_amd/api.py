@@ -33,6 +33,13 @@ def _load():
         "kosk_verifiable_keygen_batch": (C.c_int, [vp, C.c_int, vp, sz, vp, vp, vp]),
         "kosk_verify_batch": (C.c_int, [vp, C.c_int, vp, vp, vp]),
         "kosk_verify_fail_masks": (C.c_int, [vp, vp, C.c_int]),
+        "kosk_randomness_bytes": (sz, [C.c_int]),
+        "kosk_range_proof_bytes": (sz, [C.c_int]),
+        "kosk_mlwe_inst_bytes": (sz, [C.c_int]),
+        "kosk_prepare_randomness": (C.c_int, [vp, C.c_int, vp, sz, vp]),
+        "kosk_prepare_range_proof": (C.c_int, [vp, C.c_int, vp, sz, vp]),
+        "kosk_prove_prepared": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, sz, vp]),
+        "kosk_verify_inst": (C.c_int, [vp, C.c_int, vp, vp, vp]),
         "kosk_stage_prover_inputs": (C.c_int, [vp, C.c_int, vp, sz, vp, vp]),
         "kosk_prove_resident": (C.c_int, [vp, C.c_int]),
         "kosk_fetch_proofs": (C.c_int, [vp, C.c_int, vp]),
@@ -70,7 +77,8 @@ def _load():
 lib = _load()
 EXPORTS = ["kosk_pk_bytes", "kosk_sk_bytes", "kosk_proof_bytes", "kosk_tape_bytes", "kosk_proof_field", "kosk_create",
            "kosk_destroy", "kosk_last_error", "kosk_set_randombytes", "kosk_verifiable_keygen_batch", "kosk_verify_batch",
-           "kosk_verify_fail_masks", "kosk_stage_prover_inputs", "kosk_prove_resident", "kosk_fetch_proofs",
+           "kosk_verify_fail_masks", "kosk_randomness_bytes", "kosk_range_proof_bytes", "kosk_mlwe_inst_bytes",
+           "kosk_prepare_randomness", "kosk_prepare_range_proof", "kosk_prove_prepared", "kosk_verify_inst", "kosk_stage_prover_inputs", "kosk_prove_resident", "kosk_fetch_proofs",
            "kosk_stage_verifier_inputs", "kosk_verify_resident", "kosk_phase_seconds", "kosk_sha3_256_batch",
            "kosk_shake256_batch", "kosk_commit_hash_lanes", "kosk_ntt256_batch", "kosk_lagrange_expand",
            "kosk_recon_secrets", "kosk_profile_enable", "kosk_profile_read", "kosk_stream_timer_start", "kosk_stream_timer_stop", "kosk_device_synchronize", "kosk_streams", "kosk_resident_proofs", "kosk_keygen", "kosk_fs_alpha",
@@ -202,6 +210,37 @@ class Kosk:
         m = (C.c_uint32 * n)()
         self._chk(lib.kosk_verify_fail_masks(self._h, m, n), "fail_masks")
         return list(m)
+
+    # second-level entry points (reference structs as bytes; see include/kosk_mi355x.h)
+    def prepare_randomness(self, tapes=None, n=None):
+        n = len(tapes) if tapes is not None else n
+        size = lib.kosk_randomness_bytes(self.k)
+        out = C.create_string_buffer(size * n)
+        blob = b"".join(tapes) if tapes is not None else None
+        self._chk(lib.kosk_prepare_randomness(self._h, n, blob, len(tapes[0]) if tapes is not None else 0, out), "prepare_randomness")
+        return [out.raw[i * size:(i + 1) * size] for i in range(n)]
+
+    def prepare_range_proof(self, tapes=None, n=None):
+        n = len(tapes) if tapes is not None else n
+        size = lib.kosk_range_proof_bytes(self.k)
+        out = C.create_string_buffer(size * n)
+        blob = b"".join(tapes) if tapes is not None else None
+        self._chk(lib.kosk_prepare_range_proof(self._h, n, blob, len(tapes[0]) if tapes is not None else 0, out), "prepare_range_proof")
+        return [out.raw[i * size:(i + 1) * size] for i in range(n)]
+
+    def prove_prepared(self, insts, rands, ranges, tapes=None):
+        n = len(insts)
+        pi = C.create_string_buffer(self.proof_bytes * n)
+        blob = b"".join(tapes) if tapes is not None else None
+        self._chk(lib.kosk_prove_prepared(self._h, n, b"".join(insts), b"".join(rands), b"".join(ranges), blob,
+                                          len(tapes[0]) if tapes is not None else 0, pi), "prove_prepared")
+        return [pi.raw[i * self.proof_bytes:(i + 1) * self.proof_bytes] for i in range(n)]
+
+    def verify_inst(self, proofs, insts):
+        n = len(proofs)
+        ok = (C.c_uint8 * n)()
+        self._chk(lib.kosk_verify_inst(self._h, n, b"".join(proofs), b"".join(insts), ok), "verify_inst")
+        return [bool(x) for x in ok]
 
     # resident split (bench)
     def stage_prover_inputs(self, tapes):

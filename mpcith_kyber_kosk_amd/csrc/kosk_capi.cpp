@@ -195,6 +195,66 @@ int kosk_verify_batch(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk
     return 0;
 }
 
+// ---- second-level entry points (kosk_split.cpp) -----------------------------------------------------------
+size_t kosk_randomness_bytes(int k) { Params p; return make_params(k, p) ? randomness_bytes(p) : 0; }
+size_t kosk_range_proof_bytes(int k) { Params p; return make_params(k, p) ? range_proof_bytes(p) : 0; }
+size_t kosk_mlwe_inst_bytes(int k) { Params p; return make_params(k, p) ? mlwe_inst_bytes(p) : 0; }
+
+int kosk_prepare_randomness(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *rand_out)
+{
+    if (!ctx || n < 0 || !rand_out) return -1;
+    Ctx &c = *ctx->c;
+    ctx->err.clear();
+    for (int done = 0; done < n;) {
+        const int m = (n - done) < c.max_batch ? (n - done) : c.max_batch;
+        if (prepare_randomness(c, m, tapes ? tapes + (size_t)done * tape_stride : nullptr, tape_stride,
+                               rand_out + (size_t)done * randomness_bytes(c.P))) return -1;
+        done += m;
+    }
+    return 0;
+}
+int kosk_prepare_range_proof(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *range_out)
+{
+    if (!ctx || n < 0 || !range_out) return -1;
+    Ctx &c = *ctx->c;
+    ctx->err.clear();
+    for (int done = 0; done < n;) {
+        const int m = (n - done) < c.max_batch ? (n - done) : c.max_batch;
+        if (prepare_range_proof(c, m, tapes ? tapes + (size_t)done * tape_stride : nullptr, tape_stride,
+                                range_out + (size_t)done * range_proof_bytes(c.P))) return -1;
+        done += m;
+    }
+    return 0;
+}
+int kosk_prove_prepared(kosk_ctx *ctx, int n, const uint8_t *inst, const uint8_t *rand_in, const uint8_t *range_in,
+                        const uint8_t *tapes, size_t tape_stride, uint8_t *pi)
+{
+    if (!ctx || n < 0 || !inst || !rand_in || !range_in || !pi) return -1;
+    Ctx &c = *ctx->c;
+    ctx->err.clear();
+    for (int done = 0; done < n;) {
+        const int m = (n - done) < c.max_batch ? (n - done) : c.max_batch;
+        if (prove_prepared(c, m, inst + (size_t)done * mlwe_inst_bytes(c.P), rand_in + (size_t)done * randomness_bytes(c.P),
+                           range_in + (size_t)done * range_proof_bytes(c.P), tapes ? tapes + (size_t)done * tape_stride : nullptr,
+                           tape_stride, pi + (size_t)done * c.P.proof_bytes)) return -1;
+        done += m;
+    }
+    return 0;
+}
+int kosk_verify_inst(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *inst, uint8_t *ok)
+{
+    if (!ctx || n < 0 || !pi || !inst || !ok) return -1;
+    Ctx &c = *ctx->c;
+    ctx->err.clear();
+    for (int done = 0; done < n;) {
+        const int m = (n - done) < c.max_batch ? (n - done) : c.max_batch;
+        if (stage_verifier_inst(c, m, pi + (size_t)done * c.P.proof_bytes, inst + (size_t)done * mlwe_inst_bytes(c.P))) return -1;
+        if (verify_resident(c, m, ok + done)) return -1;
+        done += m;
+    }
+    return 0;
+}
+
 int kosk_verify_fail_masks(const kosk_ctx *ctx, uint32_t *masks, int n)
 {
     if (!ctx || n < 0 || n > ctx->max_batch) return -1;

@@ -369,7 +369,47 @@ int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride,
     return 0;
 }
 
-int prove_resident(Ctx &c, int n)
+// The sharing front of the prover for the fresh sharings [s0, s1) of the tape order: tape / witness expansion, NTTs,
+// A*NTT(s), and the Lagrange expansion of exactly those rows.  FRONT_FULL is what kyber_verifiable_keygen needs;
+// the other three are the reference's separate entry points (mlwe_prover.cpp:4-39, :41-59, and the sharing part of :81-).
+int issue_sharing_front(Ctx &c, int n, FrontPart part)
+{
+    const Params &P = c.P;
+    const RowMap &rm = c.rm;
+    const int K = P.K, noff_f = 2 * P.M, noff = 2 * P.M + 2 * K * P.E;
+    hipStream_t st = c.stream;
+    int s0 = 0, s1 = P.nfresh, witness = 1, ntt_first = 0, ntt_count = c.n_ntt1;
+    bool expand = true, matvec = true;
+    if (part == FRONT_RANDOMNESS) { s1 = noff_f; witness = 0; ntt_count = P.M; matvec = false; }
+    else if (part == FRONT_RANGE) { s0 = noff_f; s1 = noff; witness = 2; ntt_count = 0; expand = false; matvec = false; }
+    else if (part == FRONT_ONLINE) { s0 = noff; expand = false; ntt_first = P.M; ntt_count = K; }
+    HIPCHK(launch_prover_pre(c.d_tape, c.tape_stride, c.d_P, c.proof_stride, rm.f, P.M, 64 + 32 * P.M, c.d_fresh_rows, s0, s1, expand,
+                             witness, c.d_se, c.se_stride, rm, P.eta1, n, st));
+    if (ntt_count > 0) {
+        NttArgs na{};
+        na.in = reinterpret_cast<const int16_t *>(c.d_P);
+        na.in_gstride = c.proof_stride;
+        na.src_off = c.d_off + c.off_ntt1_src + ntt_first; // NTT(f_i) -> Tf_i secrets (mlwe_prover.cpp:17-26) and NTT(s_i) (:256)
+        na.out = reinterpret_cast<int16_t *>(c.d_P);
+        na.out_gstride = c.proof_stride;
+        na.dst_off = c.d_off + c.off_ntt1_dst + ntt_first;
+        na.npg = ntt_count;
+        na.npoly = ntt_count * n;
+        na.out_canonical = 1;
+        c.prof_begin(PR_NTT_F);
+        HIPCHK(launch_ntt(na, st));
+        c.prof_end(PR_NTT_F);
+    }
+    if (matvec) HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_P, c.proof_stride, rm.shat, rm.nttas, K, n, st)); // :284-285
+    const GemmSrc xsrc{c.d_P, c.proof_stride, c.d_gemm1_rows + s0, RS, 0, XLEN};
+    const GemmDst xdst{c.d_P, c.proof_stride, c.d_gemm1_rows + s0, RS, EXP_OFF};
+    c.prof_begin(PR_GEMM_EXPAND1);
+    if (gemm_modq(c, c.t_expand, xsrc, xdst, s1 - s0, n)) return -1;
+    c.prof_end(PR_GEMM_EXPAND1);
+    return 0;
+}
+
+int prove_resident(Ctx &c, int n, bool online_only)
 {
     if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
     HIPCHK(hipSetDevice(c.device));
@@ -390,28 +430,8 @@ int prove_resident(Ctx &c, int n)
     ha.out_lanes_per_group = NPARTY;
 
     // ---- P1: offline phase + witness sharing (secrets, randoms, one expansion GEMM), Tcomm of every party
-    if (run_segment(c, Ctx::SEG_P1, n, [&]() -> int {
-        HIPCHK(launch_prover_pre(c.d_tape, c.tape_stride, c.d_P, c.proof_stride, rm.f, P.M, 64 + 32 * P.M, c.d_fresh_rows, P.nfresh,
-                                 c.d_se, c.se_stride, rm, P.eta1, n, st));
-        NttArgs na{};
-        na.in = reinterpret_cast<const int16_t *>(c.d_P);
-        na.in_gstride = c.proof_stride;
-        na.src_off = c.d_off + c.off_ntt1_src; // NTT(f_i) -> Tf_i secrets (mlwe_prover.cpp:17-26) and NTT(s_i) (:256)
-        na.out = reinterpret_cast<int16_t *>(c.d_P);
-        na.out_gstride = c.proof_stride;
-        na.dst_off = c.d_off + c.off_ntt1_dst;
-        na.npg = c.n_ntt1;
-        na.npoly = c.n_ntt1 * n;
-        na.out_canonical = 1;
-        c.prof_begin(PR_NTT_F);
-        HIPCHK(launch_ntt(na, st));
-        c.prof_end(PR_NTT_F);
-        HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_P, c.proof_stride, rm.shat, rm.nttas, K, n, st)); // :284-285
-        const GemmSrc xsrc{c.d_P, c.proof_stride, c.d_gemm1_rows, RS, 0, XLEN};
-        const GemmDst xdst{c.d_P, c.proof_stride, c.d_gemm1_rows, RS, EXP_OFF};
-        c.prof_begin(PR_GEMM_EXPAND1);
-        if (gemm_modq(c, c.t_expand, xsrc, xdst, c.n_gemm1, n)) return -1;
-        c.prof_end(PR_GEMM_EXPAND1);
+    if (run_segment(c, online_only ? -1 : (int)Ctx::SEG_P1, n, [&]() -> int {
+        if (issue_sharing_front(c, n, online_only ? FRONT_ONLINE : FRONT_FULL)) return -1;
         HashArgs h1 = ha;
         h1.prefix = nullptr;
         h1.out = c.d_dig1;

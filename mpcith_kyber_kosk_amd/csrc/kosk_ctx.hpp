@@ -144,7 +144,7 @@ struct Ctx {
 template <class F>
 int run_segment(Ctx &c, int seg, int n, F &&body)
 {
-    if (!c.use_graphs || c.prof_on == 2) return body();
+    if (seg < 0 || !c.use_graphs || c.prof_on == 2) return body();
     Ctx::SegGraph &g = c.seg[seg];
     if (g.exec && g.n != n) {
         (void)hipGraphExecDestroy(g.exec);
@@ -189,7 +189,20 @@ inline int gemm_modq(Ctx &c, const GemmTable &t, const GemmSrc &s, const GemmDst
 // host tapes -> pk/sk on host, tape + key material resident in HBM
 int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk);
 // everything from resident inputs to resident proof images (two host Fiat-Shamir round trips)
-int prove_resident(Ctx &c, int n);
+enum FrontPart { FRONT_FULL = 0, FRONT_RANDOMNESS, FRONT_RANGE, FRONT_ONLINE };
+int issue_sharing_front(Ctx &c, int n, FrontPart part);
+// online_only: the offline material (f, NTT f, eta sharings) is already in the row matrix (prove_prepared)
+int prove_resident(Ctx &c, int n, bool online_only = false);
+// the reference's second-level entry points on host structs (kosk_split.cpp); struct layouts in include/kosk_mi355x.h
+size_t randomness_bytes(const Params &P);
+size_t range_proof_bytes(const Params &P);
+size_t mlwe_inst_bytes(const Params &P);
+int prepare_randomness(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *rand_out);
+int prepare_range_proof(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *range_out);
+int prove_prepared(Ctx &c, int n, const uint8_t *inst, const uint8_t *rand_in, const uint8_t *range_in, const uint8_t *tapes,
+                   size_t tape_stride, uint8_t *pi);
+int stage_verifier_inst(Ctx &c, int n, const uint8_t *pi, const uint8_t *inst);
+int ensure_verify_workspace(Ctx &c);
 int fetch_proofs(Ctx &c, int n, uint8_t *pi);
 
 int stage_verifier_inputs(Ctx &c, int n, const uint8_t *pi, const uint8_t *pk);

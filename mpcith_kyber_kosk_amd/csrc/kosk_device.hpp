@@ -221,8 +221,9 @@ hipError_t launch_rows_copy(const uint16_t *src, size_t src_stride, uint16_t *ds
                             int nrows, hipStream_t st);
 // expand_f + tape randoms + witness secrets (the kernels that only read the tape / the key) in one launch
 hipError_t launch_prover_pre(const uint8_t *tape, size_t tape_stride, uint16_t *P, size_t proof_stride, int row_f, int M,
-                             int slice0_off, const int16_t *fresh_rows, int nfresh, const int16_t *se, size_t se_stride,
-                             const RowMap &rm, int eta1, int nproofs, hipStream_t st);
+                             int slice0_off, const int16_t *fresh_rows, int slice_begin, int slice_end, bool expand_f,
+                             int witness_mode, const int16_t *se, size_t se_stride, const RowMap &rm, int eta1, int nproofs,
+                             hipStream_t st);
 hipError_t launch_ntt(const NttArgs &a, hipStream_t st);
 hipError_t launch_matvec_ntt(const int16_t *A, size_t A_stride, uint16_t *P, size_t proof_stride, int v_row0, int row0, int K,
                              int nproofs, hipStream_t st);

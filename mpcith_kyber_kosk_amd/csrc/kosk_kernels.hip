@@ -192,7 +192,8 @@ struct PreArgs {
     uint16_t *P;
     size_t proof_stride;
     int row_f, M, nproofs;
-    int slice0_off, nfresh;
+    int slice0_off, slice_begin, slice_end; // fresh sharings [slice_begin, slice_end) of the tape order are drawn
+    int witness_mode;                       // 0 none, 1 everything, 2 only the range constants (prepare_range_proof)
     const int16_t *fresh_rows;
     const int16_t *se;
     size_t se_stride;
@@ -239,13 +240,14 @@ __device__ __forceinline__ void pre_expand_f(const PreArgs &a, int t)
 
 __device__ __forceinline__ void pre_tape_randoms(const PreArgs &a, int idx, int lane)
 {
-    const int part = idx % 3, grp = (idx / 3) % ((a.nfresh + PRE_SLICES - 1) / PRE_SLICES), b = idx / (3 * ((a.nfresh + PRE_SLICES - 1) / PRE_SLICES));
+    const int ngrp = (a.slice_end - a.slice_begin + PRE_SLICES - 1) / PRE_SLICES;
+    const int part = idx % 3, grp = (idx / 3) % ngrp, b = idx / (3 * ngrp);
     const int t = part * 64 + lane;
     if (t > NOPEN) return;
 #pragma unroll
     for (int q = 0; q < PRE_SLICES; q++) {
-        const int slice = grp * PRE_SLICES + q;
-        if (slice >= a.nfresh) break;
+        const int slice = a.slice_begin + grp * PRE_SLICES + q;
+        if (slice >= a.slice_end) break;
         const uint8_t *src = a.tape + (size_t)b * a.tape_stride + a.slice0_off + 302 * slice + 2 * t;
         const uint32_t v = (((uint32_t)src[0] << 8) | src[1]) % (uint32_t)Q;
         a.P[(size_t)b * a.proof_stride + (size_t)a.fresh_rows[slice] * RS + NSEC + t] = (uint16_t)v;
@@ -260,6 +262,11 @@ __device__ __forceinline__ void pre_witness_secrets(const PreArgs &a, int idx, i
     const int16_t *sb = a.se + (size_t)b * a.se_stride;
     for (int who = 0; who < 2; who++) {
         for (int i = 0; i < rm.K; i++) {
+            if (a.witness_mode == 2) { // mlwe_prover.cpp:41-59: the constants -eta1..eta1, replicated over the 256 positions
+                for (int m = 0; m < rm.E; m++)
+                    Pb[(size_t)((who ? rm.eeta : rm.seta) + i * rm.E + m) * RS + j] = (uint16_t)gf_encode(m - a.eta1);
+                continue;
+            }
             const uint32_t v = gf_encode(sb[(who * rm.K + i) * 256 + j]);
             Pb[(size_t)((who ? rm.e : rm.s) + i) * RS + j] = (uint16_t)v;
             uint32_t z = 0;
@@ -972,17 +979,21 @@ hipError_t launch_rows_copy(const uint16_t *src, size_t src_stride, uint16_t *ds
 }
 
 hipError_t launch_prover_pre(const uint8_t *tape, size_t tape_stride, uint16_t *P, size_t proof_stride, int row_f, int M,
-                             int slice0_off, const int16_t *fresh_rows, int nfresh, const int16_t *se, size_t se_stride,
-                             const RowMap &rm, int eta1, int nproofs, hipStream_t st)
+                             int slice0_off, const int16_t *fresh_rows, int slice_begin, int slice_end, bool expand_f,
+                             int witness_mode, const int16_t *se, size_t se_stride, const RowMap &rm, int eta1, int nproofs,
+                             hipStream_t st)
 {
     PreArgs a{};
     a.tape = tape; a.tape_stride = tape_stride; a.P = P; a.proof_stride = proof_stride;
     a.row_f = row_f; a.M = M; a.nproofs = nproofs;
-    a.slice0_off = slice0_off; a.nfresh = nfresh; a.fresh_rows = fresh_rows;
+    a.slice0_off = slice0_off; a.slice_begin = slice_begin; a.slice_end = slice_end; a.fresh_rows = fresh_rows;
+    a.witness_mode = witness_mode;
     a.se = se; a.se_stride = se_stride; a.rm = rm; a.eta1 = eta1;
-    a.nbA = (M * nproofs + 63) / 64;
-    a.nbB = 3 * ((nfresh + PRE_SLICES - 1) / PRE_SLICES) * nproofs;
-    hipLaunchKernelGGL(k_prover_pre, dim3(a.nbA + a.nbB + 4 * nproofs), dim3(64), 0, st, a);
+    a.nbA = expand_f ? (M * nproofs + 63) / 64 : 0;
+    a.nbB = 3 * ((slice_end - slice_begin + PRE_SLICES - 1) / PRE_SLICES) * nproofs;
+    const int nb = a.nbA + a.nbB + (witness_mode ? 4 * nproofs : 0);
+    if (nb <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_prover_pre, dim3(nb), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 

@@ -47,7 +47,7 @@ static int upload_vec(Ctx &c, T **d, const std::vector<T> &v)
     return 0;
 }
 
-static int ensure_verify_workspace(Ctx &c)
+int ensure_verify_workspace(Ctx &c)
 {
     if (c.verify_ready) return 0;
     const Params &P = c.P;

@@ -102,3 +102,63 @@ def recon(shares, two_d=False):
 def table(which):
     fn, shape = [(lib.ko_table_share_ddeg, (1303, 407)), (lib.ko_table_recon_ddeg, (256, 407)), (lib.ko_table_recon_2ddeg, (256, 813))][which]
     return np.ctypeslib.as_array(fn(), shape=shape).copy()
+
+
+class Mlwe(C.Structure):  # ko_mlwe, oracle/kosk_oracle.h
+    _fields_ = [("A", C.c_int16 * (4 * 4 * 256)), ("t", C.c_int16 * (4 * 256)), ("s", C.c_int16 * (4 * 256)), ("e", C.c_int16 * (4 * 256))]
+
+
+lib.ko_pre_alloc.restype = C.c_void_p
+lib.ko_pre_free.argtypes = [C.c_void_p]
+for _n in ("ko_pre_f", "ko_pre_ntt_f", "ko_pre_f_shares", "ko_pre_ntt_f_shares"):
+    getattr(lib, _n).restype = C.POINTER(C.c_uint16)
+    getattr(lib, _n).argtypes = [C.c_void_p, C.c_int]
+for _n in ("ko_pre_s_eta_shares", "ko_pre_e_eta_shares"):
+    getattr(lib, _n).restype = C.POINTER(C.c_uint16)
+    getattr(lib, _n).argtypes = [C.c_void_p, C.c_int, C.c_int]
+lib.ko_prepare_randomness.argtypes = lib.ko_prepare_range_proof.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+lib.ko_prove.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+lib.ko_keygen.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+lib.ko_verify.argtypes = [C.c_int, C.c_char_p, C.c_void_p, C.c_char_p, C.c_size_t]
+
+
+def mlwe_inst_bytes(k, raw):
+    """ko_mlwe -> the reference's mlwe_inst image for KYBER_K = k: A[K][K][256], t, s, e (mlwe_prover.hpp:34-37)"""
+    A = np.ctypeslib.as_array(raw.A).reshape(4, 4, 256)[:k, :k]
+    parts = [A] + [np.ctypeslib.as_array(getattr(raw, f)).reshape(4, 256)[:k] for f in ("t", "s", "e")]
+    return b"".join(np.ascontiguousarray(x, dtype=np.int16).tobytes() for x in parts)
+
+
+def main_order(k, tape):
+    """The call order of the reference's main.cpp:21-47 on one tape: prepare_randomness, prepare_range_proof, kyber_keygen,
+    prove, verify.  Returns the offline material in the reference's struct layouts, the raw instance, the proof, and how
+    many tape bytes each call consumed."""
+    p = params(k)
+    t = Tape(tape, len(tape), 0, 0, 0)
+    pre = lib.ko_pre_alloc()
+    used = []
+    lib.ko_prepare_randomness(k, C.byref(t), pre); used.append(t.pos)
+    lib.ko_prepare_range_proof(k, C.byref(t), pre); used.append(t.pos)
+    raw = Mlwe()
+    pk = C.create_string_buffer(p.pk_bytes); sk = C.create_string_buffer(p.sk_bytes)
+    lib.ko_keygen(k, C.byref(t), pk, sk, C.byref(raw)); used.append(t.pos)
+    pi = C.create_string_buffer(p.proof_bytes)
+    lib.ko_prove(k, C.byref(t), pi, C.byref(raw), pre, None); used.append(t.pos)
+    assert not t.overrun
+    why = C.create_string_buffer(256)
+    ok = bool(lib.ko_verify(k, pi.raw, C.byref(raw), why, 256))
+    M, E = p.M, p.E
+
+    def share_vec(ptr):
+        y = np.ctypeslib.as_array(ptr, shape=(1454,)).astype(np.uint16)
+        return (1454).to_bytes(8, "little") + (np.arange(1454, dtype=np.uint16) + 256).tobytes() + y.tobytes()
+    f = b"".join(np.ctypeslib.as_array(lib.ko_pre_f(pre, i), shape=(256,)).tobytes() for i in range(M))
+    nf = b"".join(np.ctypeslib.as_array(lib.ko_pre_ntt_f(pre, i), shape=(256,)).tobytes() for i in range(M))
+    fs = b"".join(share_vec(lib.ko_pre_f_shares(pre, i)) for i in range(M))
+    nfs = b"".join(share_vec(lib.ko_pre_ntt_f_shares(pre, i)) for i in range(M))
+    rand = f + nf + fs + nfs
+    rng = b"".join(share_vec(lib.ko_pre_s_eta_shares(pre, i, j)) for i in range(k) for j in range(E)) + \
+        b"".join(share_vec(lib.ko_pre_e_eta_shares(pre, i, j)) for i in range(k) for j in range(E))
+    lib.ko_pre_free(pre)
+    return {"rand": rand, "range": rng, "inst": mlwe_inst_bytes(k, raw), "pk": pk.raw, "sk": sk.raw, "pi": pi.raw, "verify": ok,
+            "used": used}

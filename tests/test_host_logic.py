@@ -149,3 +149,14 @@ def test_compat_header_proof_size_macro(api):
                                    "-Wl,-rpath," + os.path.join(ROOT, "mpcith_kyber_kosk_amd"), "-o", exe])
             out = subprocess.check_output([exe], text=True).split()
             assert [int(x) for x in out] == [api.proof_bytes(k), api.pk_bytes(k), api.sk_bytes(k)]
+
+
+def test_second_level_struct_sizes():
+    """sizeof(mpcith_randomness), sizeof(mpcith_range_proof), sizeof(mlwe_inst) per KYBER_K."""
+    from mpcith_kyber_kosk_amd import api
+    want = {2: (950400, 163072, 5120), 3: (975744, 174720, 9216), 4: (1001088, 232960, 14336)}
+    for k, (r, g, i) in want.items():
+        assert api.lib.kosk_randomness_bytes(k) == r
+        assert api.lib.kosk_range_proof_bytes(k) == g
+        assert api.lib.kosk_mlwe_inst_bytes(k) == i
+    assert api.lib.kosk_randomness_bytes(5) == 0

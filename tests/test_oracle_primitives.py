@@ -134,3 +134,22 @@ def test_sharing_round_trips(oracle):
     out = np.zeros(407, np.uint16)
     oracle.lib.ko_interp_eval(out.ctypes.data_as(C.c_void_p), 407, xs.ctypes.data_as(C.c_void_p), ys.ctypes.data_as(C.c_void_p), 407)
     assert np.array_equal(out, full[:407])
+
+
+def test_oracle_main_cpp_call_order(oracle):
+    """main.cpp:21-47 order (prepare_randomness, prepare_range_proof, kyber_keygen, prove, verify): the whole tape is
+    consumed in the documented pieces, the proof verifies, and the struct images have the reference's sizes."""
+    for k, sizes in ((2, (950400, 163072, 5120)), (3, (975744, 174720, 9216))):
+        p = oracle.params(k)
+        r = oracle.main_order(k, oracle.tape_bytes_for(k, 7))
+        assert r["verify"]
+        a = 32 * p.M + 2 * p.M * 302
+        b = a + 2 * k * p.E * 302
+        assert r["used"] == [a, b, b + 64, p.tape_bytes]
+        assert (len(r["rand"]), len(r["range"]), len(r["inst"])) == sizes
+        # f -> NTT f inside the randomness struct
+        import numpy as np
+        f0 = np.frombuffer(r["rand"][:512], np.uint16).astype(np.int32)
+        f0 = np.where(f0 > 1664, f0 - 3329, f0).astype(np.int16)
+        ntt0 = np.frombuffer(r["rand"][p.M * 512:p.M * 512 + 512], np.uint16)
+        assert np.array_equal(np.mod(oracle.poly_ntt(f0).astype(np.int32), 3329).astype(np.uint16), ntt0)
