@@ -119,3 +119,24 @@ def test_pipeline_slots_stress(torch_cuda):
     [t.start() for t in th]
     [t.join() for t in th]
     assert not bad, bad
+
+
+def test_graph_replay_path_gives_identical_proofs(oracle, torch_cuda, monkeypatch):
+    """KOSK_GRAPHS=1: every pipeline segment captured once and replayed as a hipGraph (also across a batch-size change,
+    which forces a re-capture); proofs must not differ from the plain-launch path or the oracle."""
+    from mpcith_kyber_kosk_amd import api
+    k = 3
+    tapes = [oracle.tape_bytes_for(k, 60 + i) for i in range(3)]
+    plain = api.Kosk(kyber_k=k, max_batch=3)
+    want = plain.verifiable_keygen(tapes)
+    monkeypatch.setenv("KOSK_GRAPHS", "1")
+    g = api.Kosk(kyber_k=k, max_batch=3)
+    monkeypatch.delenv("KOSK_GRAPHS")
+    for rep in range(3):  # first call captures, later calls replay
+        got = g.verifiable_keygen(tapes)
+        assert got == want
+        assert g.verify(got[2], got[0]) == [True, True, True]
+    got2 = g.verifiable_keygen(tapes[:2])  # different batch size: segments are re-captured
+    assert got2[2] == want[2][:2]
+    assert g.verify(got2[2], got2[0]) == [True, True]
+    assert want[2][0] == oracle.verifiable_keygen(k, tapes[0])[2]
