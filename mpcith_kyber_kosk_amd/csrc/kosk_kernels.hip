@@ -298,41 +298,18 @@ __global__ __launch_bounds__(64) void k_prover_pre(PreArgs a)
 __constant__ static const ZetaTable kZetasDev = ZetaTable();
 
 constexpr int NTT_PPB = 16;
+constexpr int NTT_LSTRIDE = 256 + 16; // int16 per polynomial in LDS (32-byte pad: conflict-free stride reads)
 
-// Butterflies in PACKED FP32 (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two coefficients per full-rate instruction).
-// The integer form costs ~44 SIMD cycles per butterfly on this chip (its 24/32-bit multiplies are half / quarter rate)
-// and made the kernel VALU-bound at 37 % of HBM peak; here a pair of butterflies is six packed instructions (24 cycles).
-// Exactness: all values are integers below 2^24 in magnitude, so products and sums are exact; the reduction
-//   t = p - rint(p / q) * q   (rint by the 1.5 * 2^23 trick, the last step one FMA)
-// returns the residue within +-(q/2 + 2) exactly.  With the zetas as plain roots (not Montgomery form) the residues are
-// those of ntt.c:80-95 followed by poly_reduce (poly.c:261-265); the final step picks the reference's representative.
-typedef float v2f __attribute__((ext_vector_type(2)));
-constexpr float NTT_QF = (float)Q, NTT_QINVF = 1.0f / (float)Q, NTT_MAGIC = 12582912.0f; // 1.5 * 2^23
-
-__device__ __forceinline__ v2f ntt_red(v2f p) // |p| < 2^24 -> residue in [-q/2 - 2, q/2 + 2]
-{
-    const v2f k = (p * NTT_QINVF + NTT_MAGIC) - NTT_MAGIC;
-    return p - k * NTT_QF;
-}
-#define KOSK_BFLY2(lo, hi, zv)                 \
-    {                                          \
-        const v2f t_ = ntt_red((hi) * (zv));   \
-        (hi) = (lo) - t_;                      \
-        (lo) = (lo) + t_;                      \
+#define KOSK_BFLY(lo, hi, z)                 \
+    {                                        \
+        const int32_t t_ = fqmul((z), (hi)); \
+        (hi) = (lo) - t_;                    \
+        (lo) = (lo) + t_;                    \
     }
-
-// Input contract as for the reference's int16 ntt(): |coefficient| < 2^12 (canonical or centred values; int16
-// arithmetic would already overflow beyond that).  Bounds: values grow by <= q/2 + 2 per layer, so with one reduction
-// at the transposition every product stays below 2^24.
-// Data flow: 16-byte coalesced loads -> LDS (int16) -> stride-16 register layout, layers 128..16 -> LDS as fp32 (no
-// conversions at the transposition) -> contiguous layout, layers 8..2 -> canonical u16 -> 16-byte stores.
-constexpr int NTT_FSTRIDE = 16 * 20 + 16; // floats per polynomial in the fp32 transposition buffer: rows of 16 padded to 20
-                                         // (the 64-byte row reads of 16 lanes spread over the banks), polynomials 16 banks apart
 
 __global__ __launch_bounds__(256) void k_ntt256(NttArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float ldsf[NTT_PPB * NTT_FSTRIDE];
-    int16_t *lds16 = reinterpret_cast<int16_t *>(ldsf); // the int16 staging image lives in the same memory (first quarter)
+    __shared__ __attribute__((aligned(16))) int16_t lds[NTT_PPB * NTT_LSTRIDE];
     const int tid = threadIdx.x;
     const int p0 = blockIdx.x * NTT_PPB;
 
@@ -341,100 +318,75 @@ __global__ __launch_bounds__(256) void k_ntt256(NttArgs a)
         if (p < a.npoly) {
             const int g = p / a.npg, i = p - g * a.npg;
             const size_t off = (size_t)g * a.in_gstride + (a.src_off ? (size_t)a.src_off[i] : (size_t)i * 256);
-            *reinterpret_cast<uint4 *>(lds16 + pl * 2 * NTT_FSTRIDE + ch * 8) = *reinterpret_cast<const uint4 *>(a.in + off + ch * 8);
+            *reinterpret_cast<uint4 *>(lds + pl * NTT_LSTRIDE + ch * 8) =
+                *reinterpret_cast<const uint4 *>(a.in + off + ch * 8);
         }
     }
     __syncthreads();
 
     const int pl = tid >> 4, l = tid & 15;
-    const int16_t *mine16 = lds16 + pl * 2 * NTT_FSTRIDE;
-    // P[q] = (r[2q], r[2q+1]); coefficient index of r[i] is j = l + 16 i
-    v2f P[8];
+    int16_t *mine = lds + pl * NTT_LSTRIDE;
+    int32_t r[16];
 #pragma unroll
-    for (int q = 0; q < 8; q++) P[q] = (v2f){(float)mine16[l + 32 * q], (float)mine16[l + 32 * q + 16]};
-    __syncthreads(); // the fp32 image overwrites the staging bytes
+    for (int i = 0; i < 16; i++) r[i] = mine[l + 16 * i];
 
-    // len = 128, 64, 32 <-> register distance 8, 4, 2 (= pair distance 4, 2, 1), one zeta for both halves of a pair
-    {
-        const v2f z = {kZetasDev.zf[1], kZetasDev.zf[1]};
+    // coefficient index j = l + 16 i : len = 128, 64, 32, 16 <-> register distance 8, 4, 2, 1
 #pragma unroll
-        for (int q = 0; q < 4; q++) KOSK_BFLY2(P[q], P[q + 4], z);
-    }
+    for (int i = 0; i < 8; i++) KOSK_BFLY(r[i], r[i + 8], (int32_t)kZetasDev.z[1]);
 #pragma unroll
-    for (int blk = 0; blk < 2; blk++) {
-        const v2f z = {kZetasDev.zf[2 + blk], kZetasDev.zf[2 + blk]};
+    for (int blk = 0; blk < 2; blk++)
 #pragma unroll
-        for (int q = 0; q < 2; q++) KOSK_BFLY2(P[4 * blk + q], P[4 * blk + q + 2], z);
-    }
+        for (int i = 0; i < 4; i++) KOSK_BFLY(r[8 * blk + i], r[8 * blk + i + 4], (int32_t)kZetasDev.z[2 + blk]);
 #pragma unroll
-    for (int blk = 0; blk < 4; blk++) {
-        const v2f z = {kZetasDev.zf[4 + blk], kZetasDev.zf[4 + blk]};
-        KOSK_BFLY2(P[2 * blk], P[2 * blk + 1], z);
-    }
-    // len = 16 <-> the two halves of one pair: regroup two pairs into (lo, lo') and (hi, hi') with their own zetas
-    float *minef = ldsf + pl * NTT_FSTRIDE;
+    for (int blk = 0; blk < 4; blk++)
 #pragma unroll
-    for (int m = 0; m < 4; m++) {
-        v2f lo = {P[2 * m].x, P[2 * m + 1].x}, hi = {P[2 * m].y, P[2 * m + 1].y};
-        const v2f z = {kZetasDev.zf[8 + 2 * m], kZetasDev.zf[8 + 2 * m + 1]};
-        KOSK_BFLY2(lo, hi, z);
-        lo = ntt_red(lo); // the one mid-way reduction (see the bounds above)
-        hi = ntt_red(hi);
-        // r[4m] = lo.x, r[4m+1] = hi.x, r[4m+2] = lo.y, r[4m+3] = hi.y ; coefficient of r[i] is l + 16 i
-        minef[l + 20 * (4 * m)] = lo.x;
-        minef[l + 20 * (4 * m + 1)] = hi.x;
-        minef[l + 20 * (4 * m + 2)] = lo.y;
-        minef[l + 20 * (4 * m + 3)] = hi.y;
-    }
+        for (int i = 0; i < 2; i++) KOSK_BFLY(r[4 * blk + i], r[4 * blk + i + 2], (int32_t)kZetasDev.z[4 + blk]);
+#pragma unroll
+    for (int blk = 0; blk < 8; blk++) KOSK_BFLY(r[2 * blk], r[2 * blk + 1], (int32_t)kZetasDev.z[8 + blk]);
+
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) mine[l + 16 * i] = (int16_t)r[i];
     __syncthreads();
     {
-        const float4 *src = reinterpret_cast<const float4 *>(minef + 20 * l);
+        const uint4 v0 = *reinterpret_cast<const uint4 *>(mine + 16 * l);
+        const uint4 v1 = *reinterpret_cast<const uint4 *>(mine + 16 * l + 8);
+        const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 v = src[q];
-            P[2 * q] = (v2f){v.x, v.y};
-            P[2 * q + 1] = (v2f){v.z, v.w};
+        for (int q = 0; q < 8; q++) {
+            r[2 * q] = (int16_t)(w[q] & 0xFFFF);
+            r[2 * q + 1] = (int16_t)(w[q] >> 16);
         }
     }
-    // coefficient index j = 16 l + c with P[q] = (c = 2q, 2q + 1): zeta index = 128/len + j/(2 len)
+    // coefficient index j = 16 l + c : zeta index = 128/len + j/(2 len)
     {
-        const v2f z8 = {kZetasDev.zf[16 + l], kZetasDev.zf[16 + l]};
+        const int32_t z8 = kZetasDev.z[16 + l];
 #pragma unroll
-        for (int q = 0; q < 4; q++) KOSK_BFLY2(P[q], P[q + 4], z8);
-        const v2f z4a = {kZetasDev.zf[32 + 2 * l], kZetasDev.zf[32 + 2 * l]}, z4b = {kZetasDev.zf[33 + 2 * l], kZetasDev.zf[33 + 2 * l]};
+        for (int c = 0; c < 8; c++) KOSK_BFLY(r[c], r[c + 8], z8);
+        const int32_t z4a = kZetasDev.z[32 + 2 * l], z4b = kZetasDev.z[33 + 2 * l];
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            KOSK_BFLY2(P[q], P[q + 2], z4a);
-            KOSK_BFLY2(P[4 + q], P[6 + q], z4b);
+        for (int c = 0; c < 4; c++) {
+            KOSK_BFLY(r[c], r[c + 4], z4a);
+            KOSK_BFLY(r[8 + c], r[12 + c], z4b);
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const v2f z2 = {kZetasDev.zf[64 + 4 * l + q], kZetasDev.zf[64 + 4 * l + q]};
-            KOSK_BFLY2(P[2 * q], P[2 * q + 1], z2);
+            const int32_t z2 = kZetasDev.z[64 + 4 * l + q];
+            KOSK_BFLY(r[4 * q], r[4 * q + 2], z2);
+            KOSK_BFLY(r[4 * q + 1], r[4 * q + 3], z2);
         }
     }
     const int p = p0 + pl;
     if (p < a.npoly) {
         uint32_t w[8];
-        if (a.out_canonical) {
-            // floor instead of rint: k = rint(x/q - 1/2 + 1/(2q)) = floor(x/q) for every integer x (the residues sit 1/q
-            // apart, far above the fp32 error at |x| < 2^14), so x - kq is the canonical value in [0, q) directly
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const v2f y = P[q] * NTT_QINVF + (0.5f / (float)Q - 0.5f);
-                const v2f k = (y + NTT_MAGIC) - NTT_MAGIC;
-                const v2f rr = P[q] - k * NTT_QF;
-                w[q] = ((uint32_t)(int32_t)rr.x) | ((uint32_t)(int32_t)rr.y << 16);
+        for (int q = 0; q < 8; q++) {
+            int32_t x0 = barrett_reduce((int16_t)r[2 * q]), x1 = barrett_reduce((int16_t)r[2 * q + 1]);
+            if (a.out_canonical) {
+                x0 = (int32_t)gf_encode(x0);
+                x1 = (int32_t)gf_encode(x1);
             }
-        } else { // the centred representative of poly_reduce: [-(q-1)/2, (q-1)/2]
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const v2f rr = ntt_red(P[q]);
-                int32_t x0 = (int32_t)rr.x, x1 = (int32_t)rr.y;
-                x0 += x0 < -(Q / 2) ? Q : (x0 > Q / 2 ? -Q : 0);
-                x1 += x1 < -(Q / 2) ? Q : (x1 > Q / 2 ? -Q : 0);
-                w[q] = ((uint32_t)x0 & 0xFFFFu) | ((uint32_t)x1 << 16);
-            }
+            w[q] = ((uint32_t)x0 & 0xFFFFu) | ((uint32_t)x1 << 16);
         }
         const int g = p / a.npg, i = p - g * a.npg;
         const size_t off = (size_t)g * a.out_gstride + (a.dst_off ? (size_t)a.dst_off[i] : (size_t)i * 256);

@@ -23,60 +23,24 @@ KOSK_HD inline uint32_t gf_encode(int32_t a) { return (uint32_t)(a < 0 ? a + Q :
 constexpr int32_t QINV = -3327; // q^-1 mod 2^16
 
 // reduce.c:16-23; a in (-q*2^15, q*2^15), result in (-q, q)
-// On the device every product is written as a 24-bit multiply (v_mul_i32_i24 / v_mad_i32_i24, half rate) instead of the
-// quarter-rate v_mul_lo_u32 the plain C form compiles to: the low 16 bits of a*QINV depend only on the low 16 bits of a.
 KOSK_HD inline int32_t montgomery_reduce(int32_t a)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int32_t t = (int16_t)__mul24(a, QINV);
-    return (a - __mul24(t, Q)) >> 16;
-#else
     int32_t t = (int16_t)((int16_t)a * (int16_t)QINV);
     return (a - t * Q) >> 16;
-#endif
 }
 // reduce.c:35-42; centred representative of an int16-range value
 KOSK_HD inline int32_t barrett_reduce(int32_t a)
 {
     constexpr int32_t v = ((1 << 26) + Q / 2) / Q;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int32_t t = (__mul24(v, a) + (1 << 25)) >> 26; // |a| < 2^15, v < 2^15
-    return a - __mul24(t, Q);
-#else
     int32_t t = (v * a + (1 << 25)) >> 26;
     return a - t * Q;
-#endif
 }
-// operands of Kyber's fqmul are a zeta / matrix coefficient (|.| < 2^12) and a coefficient of int16 range
-KOSK_HD inline int32_t fqmul(int32_t a, int32_t b)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return montgomery_reduce(__mul24(a, b));
-#else
-    return montgomery_reduce(a * b);
-#endif
-}
-
-// a * z * 2^-16 mod q with the zeta's companion zq = z * q^-1 mod 2^16: the two products are independent and both are
-// 24-bit multiplies; equals fqmul(z, a) bit for bit (the low 16 bits of a*z*q^-1 are those of a*zq)
-KOSK_HD inline int32_t fqmul_zeta(int32_t a, int32_t z, int32_t zq)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int32_t p = __mul24(a, z);
-    const int32_t t = (int16_t)__mul24(a, zq);
-    return (p - __mul24(t, Q)) >> 16;
-#else
-    (void)zq;
-    return fqmul(z, a);
-#endif
-}
+KOSK_HD inline int32_t fqmul(int32_t a, int32_t b) { return montgomery_reduce(a * b); }
 
 // zetas[k] = 17^bitrev7(k) * 2^16 mod q, centred (recipe of ntt.c:7-37)
 struct ZetaTable {
     int16_t z[128];
-    int16_t zq[128]; // z * q^-1 mod 2^16 (the second factor of the split Montgomery product, as in Kyber's AVX2 code)
-    float zf[128];   // the plain root 17^bitrev7(k), centred, as fp32 (for the packed-fp32 butterflies of k_ntt256)
-    constexpr ZetaTable() : z(), zq(), zf()
+    constexpr ZetaTable() : z()
     {
         int32_t pw[128] = {};
         pw[0] = 1;
@@ -87,10 +51,6 @@ struct ZetaTable {
             int32_t v = pw[br] * 2285 % Q;
             if (v > Q / 2) v -= Q;
             z[i] = (int16_t)v;
-            zq[i] = (int16_t)(uint16_t)((uint32_t)(v * QINV) & 0xFFFFu);
-            int32_t pl = pw[br];
-            if (pl > Q / 2) pl -= Q;
-            zf[i] = (float)pl;
         }
     }
 };

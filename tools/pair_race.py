@@ -11,6 +11,14 @@ ca.lagrange_expand(y.data_ptr(), o.data_ptr(), rows); ca.synchronize(); ref = o.
 bad = {"k448": 0, other: 0}
 stop = False
 def loop_a():
+    if len(sys.argv) > 3 and sys.argv[3] == "pipeline":   # load generator: the whole prove+verify pipeline on 46 proofs
+        cc = api.Kosk(kyber_k=3, max_batch=46, device=0)
+        tp = [hashlib.shake_256(b"kosk-tape-v1:%d" % i).digest(cc.tape_bytes) for i in range(46)]
+        cc.stage_prover_inputs(tp)
+        for it in range(N):
+            cc.prove_resident(46)
+            if not all(cc.verify_resident(46)): bad["k448"] += 1
+        return
     for it in range(N):
         o.zero_(); torch.cuda.synchronize()
         ca.lagrange_expand(y.data_ptr(), o.data_ptr(), rows); ca.synchronize()
