@@ -95,7 +95,7 @@ def test_pipeline_slots_stress(torch_cuda):
     import hashlib
     import threading
     from mpcith_kyber_kosk_amd import api
-    S, B, N = 3, 12, 25
+    S, B, N = 3, 46, 120  # 360 prove+verify steps: a kernel that misbehaves once per 1 000 launches under load shows up
     slots = [api.Kosk(kyber_k=3, max_batch=B, device=0) for _ in range(S)]
     ref = []
     for si, c in enumerate(slots):
