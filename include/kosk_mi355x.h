@@ -87,6 +87,18 @@ int kosk_prove_resident(kosk_ctx *ctx, int n);
 int kosk_fetch_proofs(kosk_ctx *ctx, int n, uint8_t *pi);
 int kosk_stage_verifier_inputs(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk);
 int kosk_verify_resident(kosk_ctx *ctx, int n, uint8_t *ok);
+/* ---- Compact wire format (no reference counterpart: the reference ships the raw image of
+ * mpcith_proof, mlwe_prover.cpp:540-543).  Same 24 fields in the same order, every u16 field packed two values into
+ * three bytes (12 bits each, the bit order of Kyber's poly_tobytes, kyber/poly.c:128-147), the two digest fields raw,
+ * every field on a 16-byte boundary: 664 340 / 680 980 / 744 148 -> 78 % of that.  Lossless for images whose u16
+ * values are below 4096 (compression fails otherwise).  The resident variants pack / unpack on the GPU so that PCIe
+ * carries the compact bytes. */
+size_t kosk_compact_proof_bytes(int kyber_k);
+int kosk_proof_compress(int kyber_k, const uint8_t *pi, uint8_t *out);   /* host codec; -1 if a value >= 4096 */
+int kosk_proof_decompress(int kyber_k, const uint8_t *in, uint8_t *pi);
+int kosk_fetch_proofs_compact(kosk_ctx *ctx, int n, uint8_t *out);        /* like kosk_fetch_proofs */
+int kosk_stage_verifier_inputs_compact(kosk_ctx *ctx, int n, const uint8_t *in, const uint8_t *pk); /* like kosk_stage_verifier_inputs */
+
 /* wall seconds of the phases of the last prove / verify on this context (16 values: host_pre, gpu_commit,
  * fs_alpha, gpu_relation, fs_open, gpu_assemble, d2h, then the host time spent issuing the prover's three
  * segments, and the verifier's issue1, wait1, fs_alpha, issue2, wait2, fs_open) */

@@ -40,6 +40,11 @@ def _load():
         "kosk_prepare_range_proof": (C.c_int, [vp, C.c_int, vp, sz, vp]),
         "kosk_prove_prepared": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, sz, vp]),
         "kosk_verify_inst": (C.c_int, [vp, C.c_int, vp, vp, vp]),
+        "kosk_compact_proof_bytes": (sz, [C.c_int]),
+        "kosk_proof_compress": (C.c_int, [C.c_int, vp, vp]),
+        "kosk_proof_decompress": (C.c_int, [C.c_int, vp, vp]),
+        "kosk_fetch_proofs_compact": (C.c_int, [vp, C.c_int, vp]),
+        "kosk_stage_verifier_inputs_compact": (C.c_int, [vp, C.c_int, vp, vp]),
         "kosk_stage_prover_inputs": (C.c_int, [vp, C.c_int, vp, sz, vp, vp]),
         "kosk_prove_resident": (C.c_int, [vp, C.c_int]),
         "kosk_fetch_proofs": (C.c_int, [vp, C.c_int, vp]),
@@ -78,7 +83,8 @@ lib = _load()
 EXPORTS = ["kosk_pk_bytes", "kosk_sk_bytes", "kosk_proof_bytes", "kosk_tape_bytes", "kosk_proof_field", "kosk_create",
            "kosk_destroy", "kosk_last_error", "kosk_set_randombytes", "kosk_verifiable_keygen_batch", "kosk_verify_batch",
            "kosk_verify_fail_masks", "kosk_randomness_bytes", "kosk_range_proof_bytes", "kosk_mlwe_inst_bytes",
-           "kosk_prepare_randomness", "kosk_prepare_range_proof", "kosk_prove_prepared", "kosk_verify_inst", "kosk_stage_prover_inputs", "kosk_prove_resident", "kosk_fetch_proofs",
+           "kosk_prepare_randomness", "kosk_prepare_range_proof", "kosk_prove_prepared", "kosk_verify_inst", "kosk_compact_proof_bytes",
+           "kosk_proof_compress", "kosk_proof_decompress", "kosk_fetch_proofs_compact", "kosk_stage_verifier_inputs_compact", "kosk_stage_prover_inputs", "kosk_prove_resident", "kosk_fetch_proofs",
            "kosk_stage_verifier_inputs", "kosk_verify_resident", "kosk_phase_seconds", "kosk_sha3_256_batch",
            "kosk_shake256_batch", "kosk_commit_hash_lanes", "kosk_ntt256_batch", "kosk_lagrange_expand",
            "kosk_recon_secrets", "kosk_profile_enable", "kosk_profile_read", "kosk_stream_timer_start", "kosk_stream_timer_stop", "kosk_device_synchronize", "kosk_streams", "kosk_resident_proofs", "kosk_keygen", "kosk_fs_alpha",
@@ -210,6 +216,16 @@ class Kosk:
         m = (C.c_uint32 * n)()
         self._chk(lib.kosk_verify_fail_masks(self._h, m, n), "fail_masks")
         return list(m)
+
+    # compact wire format
+    def fetch_proofs_compact(self, n):
+        size = lib.kosk_compact_proof_bytes(self.k)
+        out = C.create_string_buffer(size * n)
+        self._chk(lib.kosk_fetch_proofs_compact(self._h, n, out), "fetch_proofs_compact")
+        return [out.raw[i * size:(i + 1) * size] for i in range(n)]
+
+    def stage_verifier_inputs_compact(self, blobs, pks):
+        self._chk(lib.kosk_stage_verifier_inputs_compact(self._h, len(blobs), b"".join(blobs), b"".join(pks)), "stage_verifier_inputs_compact")
 
     # second-level entry points (reference structs as bytes; see include/kosk_mi355x.h)
     def prepare_randomness(self, tapes=None, n=None):

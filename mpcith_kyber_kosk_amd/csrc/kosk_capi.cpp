@@ -255,6 +255,37 @@ int kosk_verify_inst(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *ins
     return 0;
 }
 
+// ---- compact wire format (kosk_compact.hip) ------------------------------------------------------------------
+size_t kosk_compact_proof_bytes(int k) { Params p; return make_params(k, p) ? make_compact_plan(p).bytes : 0; }
+int kosk_proof_compress(int k, const uint8_t *pi, uint8_t *out)
+{
+    Params p;
+    if (!make_params(k, p) || !pi || !out) return -1;
+    return compact_encode(p, pi, out);
+}
+int kosk_proof_decompress(int k, const uint8_t *in, uint8_t *pi)
+{
+    Params p;
+    if (!make_params(k, p) || !pi || !in) return -1;
+    compact_decode(p, in, pi);
+    return 0;
+}
+int kosk_fetch_proofs_compact(kosk_ctx *ctx, int n, uint8_t *out)
+{
+    if (!ctx || n < 0 || n > ctx->max_batch || !out) return -1;
+    const size_t cb = make_compact_plan(ctx->c->P).bytes;
+    return ctx->run(n, [&](Ctx &c, int first, int count) { return fetch_proofs_compact(c, count, out + (size_t)first * cb); });
+}
+int kosk_stage_verifier_inputs_compact(kosk_ctx *ctx, int n, const uint8_t *in, const uint8_t *pk)
+{
+    if (!ctx || n < 0 || n > ctx->max_batch || !in || !pk) return -1;
+    const Params &P = ctx->c->P;
+    const size_t cb = make_compact_plan(P).bytes;
+    return ctx->run(n, [&](Ctx &c, int first, int count) {
+        return stage_verifier_inputs_compact(c, count, in + (size_t)first * cb, pk + (size_t)first * P.pk_bytes);
+    });
+}
+
 int kosk_verify_fail_masks(const kosk_ctx *ctx, uint32_t *masks, int n)
 {
     if (!ctx || n < 0 || n > ctx->max_batch) return -1;

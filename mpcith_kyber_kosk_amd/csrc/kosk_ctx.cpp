@@ -72,6 +72,10 @@ Ctx::~Ctx()
     void *host[] = {h_tape, h_dig, h_proof, h_alpha, h_I, h_fail, h_Iimg, h_seeds, h_pk, h_sb};
     for (void *p : host)
         if (p) (void)hipHostFree(p);
+    if (d_compact) (void)hipFree(d_compact);
+    if (d_compact_bad) (void)hipFree(d_compact_bad);
+    if (h_compact) (void)hipHostFree(h_compact);
+    if (h_compact_bad) (void)hipHostFree(h_compact_bad);
     if (pool) pool_destroy(pool);
     if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);

@@ -43,6 +43,19 @@ struct GemmDst {
     int rstride, off;
 };
 
+// compact wire format (kosk_compact.hip)
+struct CompactField {
+    uint32_t src_off, dst_off, n; // image offset, compact offset, u16 values (or bytes when raw)
+    int raw;
+};
+struct CompactPlan {
+    CompactField f[NFIELDS];
+    size_t bytes;
+};
+CompactPlan make_compact_plan(const Params &P);
+int compact_encode(const Params &P, const uint8_t *img, uint8_t *out); // -1: a value >= 4096
+void compact_decode(const Params &P, const uint8_t *in, uint8_t *img);
+
 struct Ctx {
     int device = 0;
     Params P{};
@@ -109,6 +122,11 @@ struct Ctx {
     uint32_t *d_fail = nullptr;      // [proof] bit mask of failed checks (FailBit)
     uint16_t *h_Iimg = nullptr;      // I fields as read from the proof images
     hipEvent_t ev = nullptr;
+    // compact wire format staging (allocated on first use)
+    CompactPlan cplan{};
+    size_t compact_stride = 0;
+    uint8_t *d_compact = nullptr, *h_compact = nullptr;
+    uint32_t *d_compact_bad = nullptr, *h_compact_bad = nullptr;
 
     // pinned host staging
     uint8_t *h_tape = nullptr, *h_dig = nullptr, *h_proof = nullptr;
@@ -203,6 +221,8 @@ int prove_prepared(Ctx &c, int n, const uint8_t *inst, const uint8_t *rand_in, c
                    size_t tape_stride, uint8_t *pi);
 int stage_verifier_inst(Ctx &c, int n, const uint8_t *pi, const uint8_t *inst);
 int ensure_verify_workspace(Ctx &c);
+int fetch_proofs_compact(Ctx &c, int n, uint8_t *out);
+int stage_verifier_inputs_compact(Ctx &c, int n, const uint8_t *in, const uint8_t *pk);
 int fetch_proofs(Ctx &c, int n, uint8_t *pi);
 
 int stage_verifier_inputs(Ctx &c, int n, const uint8_t *pi, const uint8_t *pk);

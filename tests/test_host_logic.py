@@ -160,3 +160,22 @@ def test_second_level_struct_sizes():
         assert api.lib.kosk_range_proof_bytes(k) == g
         assert api.lib.kosk_mlwe_inst_bytes(k) == i
     assert api.lib.kosk_randomness_bytes(5) == 0
+
+
+def test_compact_codec_roundtrip_on_oracle_proof(oracle):
+    """Host codec of the compact wire format: sizes, lossless on a real proof, values >= 4096 refused."""
+    import ctypes as C
+    from mpcith_kyber_kosk_amd import api
+    want = {2: 664340, 3: 680980, 4: 744148}
+    for k in (2, 3, 4):
+        cb = api.lib.kosk_compact_proof_bytes(k)
+        assert cb % 16 == 0 and 0.77 * want[k] < cb < 0.79 * want[k]
+    k = 2
+    pi = oracle.verifiable_keygen(k, oracle.tape_bytes_for(k, 3))[2]
+    out = C.create_string_buffer(api.lib.kosk_compact_proof_bytes(k))
+    assert api.lib.kosk_proof_compress(k, pi, out) == 0
+    back = C.create_string_buffer(len(pi))
+    assert api.lib.kosk_proof_decompress(k, out, back) == 0
+    assert back.raw == pi
+    bad = bytearray(pi); bad[1] = 0x10
+    assert api.lib.kosk_proof_compress(k, bytes(bad), out) == -1
