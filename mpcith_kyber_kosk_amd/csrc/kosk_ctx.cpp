@@ -263,6 +263,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     c.nthreads = hc ? (int)(hc > 8 ? 8 : hc) : 1; // per context; several contexts (pipeline slots) share the host
     if (const char *e = getenv("KOSK_HOST_THREADS")) c.nthreads = atoi(e) > 0 ? atoi(e) : c.nthreads;
     if (const char *e = getenv("KOSK_GRAPHS")) c.use_graphs = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_LINCOMB_FUSED")) c.lincomb_fused = atoi(e) != 0;
 
     auto body = [&]() -> int {
         HIPCHK(hipSetDevice(device));
@@ -453,7 +454,7 @@ int prove_resident(Ctx &c, int n, bool online_only)
     // gates on the expanded shares (:338-381) and the transposed limb form of the f rows for the beta/gamma product
     if (run_segment(c, Ctx::SEG_P1B, n, [&]() -> int {
         HIPCHK(launch_post_gates(c.d_P, c.proof_stride, rm, n, st));
-        HIPCHK(launch_cols_to_limbs(c.d_P, c.proof_stride, rm.f, rm.tf, P.M, c.d_linA, a_gstride, n, st));
+        if (!c.lincomb_fused) HIPCHK(launch_cols_to_limbs(c.d_P, c.proof_stride, rm.f, rm.tf, P.M, c.d_linA, a_gstride, n, st));
         return 0;
     })) return -1;
 
@@ -467,12 +468,16 @@ int prove_resident(Ctx &c, int n, bool online_only)
         HIPCHK(hipMemcpyAsync(c.d_alpha, c.h_alpha, (size_t)n * 80 * 2, hipMemcpyHostToDevice, st));
         c.prof_begin(PR_LINCOMB);
         HIPCHK(launch_coef_limbs(c.d_alpha, P.J, P.M, c.d_coef, n, st));
-        GemmArgs ga{};
-        ga.A = c.d_linA; ga.a_gstride = a_gstride; ga.Mpad = 1792; ga.M = NPTS; ga.KS = 2;
-        ga.B = c.d_coef; ga.BRT = 2 * n * 8;
-        ga.C = c.d_P; ga.c_gstride = c.proof_stride; ga.c_rows = c.d_lin_rows; ga.c_rstride = RS; ga.c_off = 0;
-        ga.npg = P.J; ga.npg_pad = 128; ga.ngroups = 2 * n; ga.grouped = 1; ga.c_gdiv = 2; ga.c_rows_gstride = 128;
-        HIPCHK(launch_gemm(ga, st));
+        if (c.lincomb_fused) {
+            HIPCHK(launch_lincomb_fused(c.d_P, c.proof_stride, rm.f, rm.tf, P.M, c.d_coef, c.d_P, c.d_lin_rows, P.J, n, st));
+        } else {
+            GemmArgs ga{};
+            ga.A = c.d_linA; ga.a_gstride = a_gstride; ga.Mpad = 1792; ga.M = NPTS; ga.KS = 2;
+            ga.B = c.d_coef; ga.BRT = 2 * n * 8;
+            ga.C = c.d_P; ga.c_gstride = c.proof_stride; ga.c_rows = c.d_lin_rows; ga.c_rstride = RS; ga.c_off = 0;
+            ga.npg = P.J; ga.npg_pad = 128; ga.ngroups = 2 * n; ga.grouped = 1; ga.c_gdiv = 2; ga.c_rows_gstride = 128;
+            HIPCHK(launch_gemm(ga, st));
+        }
         c.prof_end(PR_LINCOMB);
         HIPCHK(launch_post_open(c.d_P, c.proof_stride, rm, n, st));
         return 0;

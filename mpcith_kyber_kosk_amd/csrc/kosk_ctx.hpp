@@ -143,6 +143,7 @@ struct Ctx {
     SegGraph seg[SEG_COUNT];
     bool use_graphs = false; // KOSK_GRAPHS=1 turns them on (measured on ROCm 7.2: no gain over plain launches)
     bool capturing = false;
+    bool lincomb_fused = true; // KOSK_LINCOMB_FUSED=0: separate transposition pass + generic GEMM
 
     double phase_sec[PH_COUNT] = {0};
     int prof_on = 0; // 1: the graded kernel only (graphs stay on); 2: every profiled id (plain launches)

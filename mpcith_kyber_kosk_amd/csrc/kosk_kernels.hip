@@ -676,6 +676,112 @@ __global__ __launch_bounds__(256) void k_cols_to_limbs(const uint16_t *__restric
     *reinterpret_cast<uint4 *>(d + 1024) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
 }
 
+// ---- K3 (prover) fused: the f rows are transposed and limb-split INSIDE the product's staging -------------------
+// One workgroup = (proof, f | NTT f, 128 evaluation points): the 77 x 128 input values are read row-wise (coalesced
+// 2-byte gathers, 64 per thread, all in flight), written to LDS as the [point][k] limb tiles the MFMA A operand wants,
+// the coefficient limb matrix (k_coef_limbs) of the proof is copied next to it, and 128 x 128 x 128 is multiplied in
+// two column halves.  Replaces k_cols_to_limbs + k_gemm_modq<true> and their 90 MB round trip through HBM.
+constexpr int LF_A_BYTES = 2 * 8 * 2048, LF_B_BYTES = 2 * 8 * 2048; // 2 k-steps x 8 row tiles x (2 limbs x 1 KiB)
+__global__ __launch_bounds__(256) void k_lincomb_fused(const uint16_t *P, size_t proof_stride, int row_f, int row_tf, int M,
+                                                       const uint8_t *__restrict__ coef, int BRT, uint16_t *C,
+                                                       const int16_t *__restrict__ lin_rows, int J)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LF_A_BYTES + LF_B_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w & 1, wn = w >> 1;
+    const int g = blockIdx.y, b = g >> 1, which = g & 1;
+    const int m0 = blockIdx.x * 128;
+    // B: this group's coefficient tiles, 2 k-steps x 16 KiB contiguous each
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(coef + ((size_t)ks * BRT + (size_t)g * 8) * 2048) + tid;
+        uint4 *dst = reinterpret_cast<uint4 *>(lds + LF_A_BYTES + ks * 16384) + tid;
+#pragma unroll
+        for (int q = 0; q < 4; q++) dst[256 * q] = src[256 * q];
+    }
+    // A: thread -> (point pair x = m0 + 2 (pidx & 63), 16-row chunk ch = pidx >> 6) for pidx = tid + 256 i: one 4-byte
+    // load per row brings two points (rows are 4-byte aligned, m0 is even; NPTS is even, so a pair is live or dead as one)
+    const uint16_t *src0 = P + (size_t)b * proof_stride + (size_t)(which ? row_tf : row_f) * RS + m0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int pidx = tid + 256 * i, xl = (pidx & 63) * 2, ch = pidx >> 6;
+        const bool live = m0 + xl < NPTS;
+        uint32_t v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int k = ch * 16 + q;
+            v[q] = (live && k < M) ? *reinterpret_cast<const uint32_t *>(src0 + (size_t)k * RS + xl) : 0u;
+        }
+#pragma unroll
+        for (int pt = 0; pt < 2; pt++) {
+            uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                int c0, c1;
+                limb_split(gf_center(pt ? v[q] >> 16 : v[q] & 0xFFFFu), c0, c1);
+                lo[q >> 2] |= ((uint32_t)c0 & 0xFFu) << (8 * (q & 3));
+                hi[q >> 2] |= ((uint32_t)c1 & 0xFFu) << (8 * (q & 3));
+            }
+            const int x = xl + pt;
+            uint8_t *d = lds + ((ch >> 2) * 8 + (x >> 4)) * 2048 + (x & 15) * 64 + (((ch & 3) ^ limb_swz(x & 15)) << 4);
+            *reinterpret_cast<uint4 *>(d) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            *reinterpret_cast<uint4 *>(d + 1024) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        }
+    }
+    __syncthreads();
+    const int frag = (lane & 15) * 64 + (((lane >> 4) ^ limb_swz(lane & 15)) << 4);
+    uint16_t *Cb = C + (size_t)b * proof_stride;
+#pragma unroll 1
+    for (int nh = 0; nh < 2; nh++) { // output columns j = nh * 64 + wn * 32 + ...
+        if (nh * 64 + wn * 32 >= J) break;
+        v4i s0[4][2], s1[4][2], s2[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) { s0[i][j] = (v4i){0, 0, 0, 0}; s1[i][j] = s0[i][j]; s2[i][j] = s0[i][j]; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const uint8_t *la = lds + (ks * 8 + wm * 4) * 2048 + frag;
+            const uint8_t *lb = lds + LF_A_BYTES + (ks * 8 + nh * 4 + wn * 2) * 2048 + frag;
+            v4i a0[4], a1[4], b0[2], b1[2];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                a0[i] = *reinterpret_cast<const v4i *>(la + i * 2048);
+                a1[i] = *reinterpret_cast<const v4i *>(la + i * 2048 + 1024);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                b0[j] = *reinterpret_cast<const v4i *>(lb + j * 2048);
+                b1[j] = *reinterpret_cast<const v4i *>(lb + j * 2048 + 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    s0[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[i], b0[j], s0[i][j], 0, 0, 0);
+                    s1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[i], b1[j], s1[i][j], 0, 0, 0);
+                    s1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[i], b0[j], s1[i][j], 0, 0, 0);
+                    s2[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[i], b1[j], s2[i][j], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int jo = nh * 64 + wn * 32 + j * 16 + (lane & 15);
+            if (jo >= J) continue;
+            uint16_t *crow = Cb + (size_t)lin_rows[which * 128 + jo] * RS;
+#pragma unroll
+            for (int ib = 0; ib < 4; ib++) {
+                const int m = m0 + wm * 64 + ib * 16 + (lane >> 4) * 4;
+                if (m >= NPTS) continue;
+                uint32_t v[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = gf_from_i32(s0[ib][j][r] + 64 * s1[ib][j][r] + 767 * s2[ib][j][r]);
+                *reinterpret_cast<uint2 *>(crow + m) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+            }
+        }
+    }
+}
+
 // "B" operand: Coef[j][k] = alpha_j^k for the 70 check rows; for the r rows (j >= 70) the constant term is
 // f_71 instead of f_0 (mlwe_prover.cpp:187,196): Coef[j][0] = 0 and Coef[j][71] = alpha_j^71 + 1.
 // Written for both groups (f and NTT f) of the proof.  One thread per (j, 16-k chunk).
@@ -1048,6 +1154,13 @@ hipError_t launch_cols_to_limbs(const uint16_t *P, size_t proof_stride, int row_
                                 int nproofs, hipStream_t st)
 {
     hipLaunchKernelGGL(k_cols_to_limbs, dim3(LIN_MPAD / 64, LIN_K / 64, 2 * nproofs), dim3(256), 0, st, P, proof_stride, row_f, row_tf, M, A, a_gstride);
+    return hipGetLastError();
+}
+hipError_t launch_lincomb_fused(const uint16_t *P, size_t proof_stride, int row_f, int row_tf, int M, const uint8_t *coef, uint16_t *C,
+                                const int16_t *lin_rows, int J, int nproofs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_lincomb_fused, dim3((NPTS + 127) / 128, 2 * nproofs), dim3(256), 0, st, P, proof_stride, row_f, row_tf, M, coef,
+                       2 * nproofs * 8, C, lin_rows, J);
     return hipGetLastError();
 }
 hipError_t launch_coef_limbs(const uint16_t *alpha, int J, int M, uint8_t *B, int nproofs, hipStream_t st)
