@@ -305,7 +305,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
         // data operand of the largest GEMM: every fresh sharing of every proof (<= 256 per proof), 13 k-steps
         c.limb_cap = ((B * 256 + 63) / 64 * 64 / 16) * (size_t)13 * 2048;
         HIPCHK(dalloc(&c.d_limbs, c.limb_cap));
-        HIPCHK(dalloc(&c.d_linA, B * 2 * (size_t)(1792 / 16) * 2 * 2048));
+        if (!c.lincomb_fused) HIPCHK(dalloc(&c.d_linA, B * 2 * (size_t)(1792 / 16) * 2 * 2048)); // only the unfused path stores the transposed f rows
         HIPCHK(dalloc(&c.d_coef, B * 2 * (size_t)8 * 2 * 2048));
         HIPCHK(dalloc(&c.d_fail, B));
         HIPCHK(halloc(&c.h_tape, B * c.tape_stride));
