@@ -505,9 +505,7 @@ int prove_resident(Ctx &c, int n, bool online_only)
         na.out_gstride = c.proof_stride;
         na.dst_off = c.d_off + c.off_nttsr_er;
         na.out_canonical = 1;
-        HIPCHK(launch_ntt(na, st));
-        HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_P, c.proof_stride, rm.nttsr, rm.nttasr, K, n, st)); // :287-288
-        HIPCHK(launch_copy_tails(c.d_P, c.proof_stride, rm, n, st));
+        HIPCHK(launch_relation_ntt(na, c.d_A, c.key_stride, c.d_P, c.proof_stride, rm, n, st)); // NTT, A o NTT(s+r) (:287-288), tails
         const GemmSrc x2src{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, 0, XLEN};
         const GemmDst x2dst{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, EXP_OFF};
         c.prof_begin(PR_GEMM_EXPAND2);

@@ -225,6 +225,9 @@ hipError_t launch_prover_pre(const uint8_t *tape, size_t tape_stride, uint16_t *
                              int witness_mode, const int16_t *se, size_t se_stride, const RowMap &rm, int eta1, int nproofs,
                              hipStream_t st);
 hipError_t launch_ntt(const NttArgs &a, hipStream_t st);
+// k_ntt256 (this proof's na.npg = 2K polynomials) + k_matvec_ntt(nttsr -> nttasr) + k_copy_tails in one launch
+hipError_t launch_relation_ntt(const NttArgs &na, const int16_t *A, size_t A_stride, uint16_t *P, size_t proof_stride, const RowMap &rm,
+                               int nproofs, hipStream_t st);
 hipError_t launch_matvec_ntt(const int16_t *A, size_t A_stride, uint16_t *P, size_t proof_stride, int v_row0, int row0, int K,
                              int nproofs, hipStream_t st);
 // several independent products in ONE launch (the small ones are latency-bound: run them side by side)

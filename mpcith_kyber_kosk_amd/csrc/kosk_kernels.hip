@@ -307,11 +307,10 @@ constexpr int NTT_LSTRIDE = 256 + 16; // int16 per polynomial in LDS (32-byte pa
         (lo) = (lo) + t_;                    \
     }
 
-__global__ __launch_bounds__(256) void k_ntt256(NttArgs a)
+// one tile of up to 16 polynomials p0 .. p0+15 by a 256-thread workgroup (all threads must call it)
+__device__ __forceinline__ void ntt256_tile(const NttArgs &a, const int p0, int16_t *__restrict__ lds)
 {
-    __shared__ __attribute__((aligned(16))) int16_t lds[NTT_PPB * NTT_LSTRIDE];
     const int tid = threadIdx.x;
-    const int p0 = blockIdx.x * NTT_PPB;
 
     for (int c = tid; c < NTT_PPB * 32; c += 256) {
         const int pl = c >> 5, ch = c & 31, p = p0 + pl;
@@ -396,12 +395,17 @@ __global__ __launch_bounds__(256) void k_ntt256(NttArgs a)
     }
 }
 
+__global__ __launch_bounds__(256) void k_ntt256(NttArgs a)
+{
+    __shared__ __attribute__((aligned(16))) int16_t lds[NTT_PPB * NTT_LSTRIDE];
+    ntt256_tile(a, blockIdx.x * NTT_PPB, lds);
+}
+
 // K6  r_i = tomont(Barrett(sum_l basemul(A[i][l], v[l])))      polyvec.c:202-214, poly.c:307-313
 // one thread per degree-1 factor (pair of coefficients); output canonical u16
-__global__ __launch_bounds__(128) void k_matvec_ntt(const int16_t *__restrict__ A, size_t A_stride,
-                                                    uint16_t *__restrict__ P, size_t proof_stride, int v_row0, int row0, int K)
+__device__ __forceinline__ void matvec_ntt_item(const int16_t *__restrict__ A, size_t A_stride, uint16_t *P, size_t proof_stride,
+                                                int v_row0, int row0, int K, const int t, const int i, const int b)
 {
-    const int t = threadIdx.x, i = blockIdx.x, b = blockIdx.y;
     const int32_t zeta = (t & 1) ? -(int32_t)kZetasDev.z[64 + (t >> 1)] : (int32_t)kZetasDev.z[64 + (t >> 1)];
     const int16_t *Ai = A + (size_t)b * A_stride + (size_t)i * K * 256;
     // the vector operand is the canonical NTT image stored in the packed-secret part of K consecutive rows
@@ -425,6 +429,37 @@ __global__ __launch_bounds__(128) void k_matvec_ntt(const int16_t *__restrict__ 
     r1 = montgomery_reduce(barrett_reduce(r1) * f);
     uint16_t *dst = P + (size_t)b * proof_stride + (size_t)(row0 + i) * RS;
     *reinterpret_cast<uint32_t *>(dst + 2 * t) = gf_from_i32(r0) | (gf_from_i32(r1) << 16);
+}
+
+__global__ __launch_bounds__(128) void k_matvec_ntt(const int16_t *__restrict__ A, size_t A_stride,
+                                                    uint16_t *__restrict__ P, size_t proof_stride, int v_row0, int row0, int K)
+{
+    matvec_ntt_item(A, A_stride, P, proof_stride, v_row0, row0, K, threadIdx.x, blockIdx.x, blockIdx.y);
+}
+
+// NTT(s + r), NTT(e + r), A o NTT(s + r) and the tails of their re-sharing inputs for ONE proof per workgroup: the three
+// launches k_ntt256 -> k_matvec_ntt -> k_copy_tails (each 4-5 us of mostly launch latency) in one.   mlwe_prover.cpp:260-288
+__global__ __launch_bounds__(256) void k_relation_ntt(NttArgs na, const int16_t *__restrict__ A, size_t A_stride, uint16_t *P,
+                                                      size_t proof_stride, RowMap rm)
+{
+    __shared__ __attribute__((aligned(16))) int16_t lds[NTT_PPB * NTT_LSTRIDE];
+    const int b = blockIdx.x, K = rm.K, tid = threadIdx.x;
+    NttArgs a = na; // this proof's 2K polynomials as a group of their own
+    a.in += (size_t)b * na.in_gstride;
+    a.out += (size_t)b * na.out_gstride;
+    a.npoly = a.npg;
+    ntt256_tile(a, 0, lds);
+    __syncthreads(); // the NTT images (global, written by this workgroup) are the matvec's vector operand
+    for (int idx = tid; idx < K * 128; idx += 256) matvec_ntt_item(A, A_stride, P, proof_stride, rm.nttsr, rm.nttasr, K, idx & 127, idx >> 7, b);
+    if (tid <= NOPEN) { // sr_rnd / er_rnd / ntt_Asr_rnd tails, as k_copy_tails
+        uint16_t *Pb = P + (size_t)b * proof_stride + NSEC + tid;
+        for (int i = 0; i < K; i++) {
+            const uint16_t sv = Pb[(size_t)(rm.sr + i) * RS], ev = Pb[(size_t)(rm.er + i) * RS];
+            Pb[(size_t)(rm.nttsr + i) * RS] = sv;
+            Pb[(size_t)(rm.nttasr + i) * RS] = sv;
+            Pb[(size_t)(rm.ntter + i) * RS] = ev;
+        }
+    }
 }
 
 // =========================================================================
@@ -1107,6 +1142,14 @@ hipError_t launch_ntt(const NttArgs &a, hipStream_t st)
 {
     if (a.npoly <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_ntt256, dim3((a.npoly + NTT_PPB - 1) / NTT_PPB), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_relation_ntt(const NttArgs &na, const int16_t *A, size_t A_stride, uint16_t *P, size_t proof_stride, const RowMap &rm,
+                               int nproofs, hipStream_t st)
+{
+    if (na.npg > NTT_PPB) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_relation_ntt, dim3(nproofs), dim3(256), 0, st, na, A, A_stride, P, proof_stride, rm);
     return hipGetLastError();
 }
 

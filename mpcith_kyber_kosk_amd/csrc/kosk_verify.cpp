@@ -269,9 +269,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     na.out_gstride = c.proof_stride;
     na.dst_off = c.d_off + c.off_nttsr_er;
     na.out_canonical = 1;
-    HIPCHK(launch_ntt(na, st));
-    HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_P, c.proof_stride, rm.nttsr, rm.nttasr, K, n, st));
-    HIPCHK(launch_copy_tails(c.d_P, c.proof_stride, rm, n, st));
+    HIPCHK(launch_relation_ntt(na, c.d_A, c.key_stride, c.d_P, c.proof_stride, rm, n, st));
     {
         const GemmSrc xs{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, 0, XLEN};
         const GemmDst xd{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, EXP_OFF};
