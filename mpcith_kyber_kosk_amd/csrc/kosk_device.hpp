@@ -30,6 +30,10 @@ struct NttArgs {
     int npg;   // polynomials per group
     int npoly; // total
     int out_canonical; // 1: [0,q) (encode_to_gf3329), 0: centred int16 (poly_ntt)
+    // compare mode (cmp_fail != null): nothing is stored; the result is compared with the polynomial cmp_delta u16 after its
+    // output position and bit cmp_bit of cmp_fail[group] is set on a mismatch (NTT(beta_j) == gamma_j, mlwe_verifier.cpp:110-124)
+    uint32_t *cmp_fail;
+    int cmp_delta, cmp_bit;
 };
 
 // ---- "limb matrix": the MFMA operand format of the mod-q GEMM -------------------------------
@@ -203,8 +207,6 @@ hipError_t launch_interp_build(const InterpArgs &a, int nproofs, hipStream_t st)
 hipError_t launch_interp_fixup(uint16_t *P, size_t proof_stride, const int16_t *src_rows, const int16_t *dst_rows, int nrows,
                                const InterpArgs &a, int nproofs, hipStream_t st);
 hipError_t launch_check_opened(const VerifyArgs &v, int nproofs, hipStream_t st);
-hipError_t launch_check_pairs(const uint16_t *a, const uint16_t *b, size_t gstride, int nrows, uint32_t *fail, int bit,
-                              int nproofs, hipStream_t st);
 
 // ---- key generation (kosk_keygen_kernels.hip) ----
 hipError_t launch_keygen(const uint8_t *tape, size_t tape_stride, uint8_t *seeds, int16_t *A, size_t A_stride, int16_t *se,

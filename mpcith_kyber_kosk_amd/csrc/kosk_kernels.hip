@@ -390,8 +390,14 @@ __device__ __forceinline__ void ntt256_tile(const NttArgs &a, const int p0, int1
         const int g = p / a.npg, i = p - g * a.npg;
         const size_t off = (size_t)g * a.out_gstride + (a.dst_off ? (size_t)a.dst_off[i] : (size_t)i * 256);
         uint4 *o = reinterpret_cast<uint4 *>(a.out + off + 16 * l);
-        o[0] = make_uint4(w[0], w[1], w[2], w[3]);
-        o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        if (a.cmp_fail) {
+            const uint4 c0 = o[a.cmp_delta / 8], c1 = o[a.cmp_delta / 8 + 1];
+            if (c0.x != w[0] || c0.y != w[1] || c0.z != w[2] || c0.w != w[3] || c1.x != w[4] || c1.y != w[5] || c1.z != w[6] || c1.w != w[7])
+                atomicOr(&a.cmp_fail[g], 1u << a.cmp_bit);
+        } else {
+            o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
     }
 }
 

@@ -334,8 +334,10 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     na.npg = NCHK;
     na.npoly = NCHK * n;
     na.out_canonical = 1;
-    HIPCHK(launch_ntt(na, st)); // NTT(beta) in place (each block stages its polynomials in LDS first)
-    HIPCHK(launch_check_pairs(c.d_sec, c.d_sec + (size_t)NCHK * 256, (size_t)2 * NCHK * 256, NCHK, c.d_fail, FB_BETA_GAMMA, n, st));
+    na.cmp_fail = c.d_fail; // NTT(beta_j) is compared with gamma_j (70 polynomials further) as it is produced
+    na.cmp_delta = NCHK * 256;
+    na.cmp_bit = FB_BETA_GAMMA;
+    HIPCHK(launch_ntt(na, st));
     HIPCHK(launch_check_opened(va, n, st));
     HIPCHK(hipMemcpyAsync(c.h_fail, c.d_fail, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st));
     return 0;

@@ -359,13 +359,6 @@ __global__ __launch_bounds__(192) void k_check_opened(VerifyArgs v)
 
 // interpolated packed secrets: t against the public key, range constants   mlwe_verifier.cpp:354-363, :418-429
 
-// a[b][r][k] == b[b][r][k] for r < nrows, k < 256
-__global__ __launch_bounds__(256) void k_check_pairs(const uint16_t *__restrict__ x, const uint16_t *__restrict__ y,
-                                                     size_t gstride, uint32_t *fail, int bit)
-{
-    const size_t o = (size_t)blockIdx.y * gstride + (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (x[o] != y[o]) atomicOr(&fail[blockIdx.y], 1u << bit);
-}
 
 // Opened list I of every proof, straight from the image: validated (range, duplicates), its complement
 // (the unopened parties ascending), the opened parties ascending, and for the two interpolations how many
@@ -533,12 +526,6 @@ hipError_t launch_interp_fixup(uint16_t *P, size_t proof_stride, const int16_t *
 hipError_t launch_check_opened(const VerifyArgs &v, int nproofs, hipStream_t st)
 {
     hipLaunchKernelGGL(k_check_opened, dim3(nproofs), dim3(192), 0, st, v);
-    return hipGetLastError();
-}
-hipError_t launch_check_pairs(const uint16_t *a, const uint16_t *b, size_t gstride, int nrows, uint32_t *fail, int bit,
-                              int nproofs, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_check_pairs, dim3(nrows, nproofs), dim3(256), 0, st, a, b, gstride, fail, bit);
     return hipGetLastError();
 }
 
