@@ -1016,8 +1016,23 @@ constexpr int ASM_TILE = 64 * 80; // u16 per tile: 64 parties x the widest field
 // One wave per (field, 64 parties): for the fields of unopened parties the 64 parties are those of one ALIGNED window of
 // 64 party columns (a single 128-byte line per row read, PMC: 125 -> 35 MB fetched), for opened fields 64 entries of I.
 // No workgroup barrier: the wave gathers its whole tile (independent loads), then streams it out.
-__global__ __launch_bounds__(64) void k_assemble_fields(AssembleArgs a)
+__global__ __launch_bounds__(64) void k_assemble_fields(AssembleArgs a, uint32_t off_tcomm, uint32_t off_comm, uint32_t off_I)
 {
+    { // blocks past the field tiles: Tcomm / comm of the unopened parties and the list I itself (64 u16 per block)
+        const int nfield_blocks = a.plan.nrest * NWIN + a.plan.nopen * ((NOPEN + 63) / 64);
+        if ((int)blockIdx.x >= nfield_blocks) {
+            const int q = ((int)blockIdx.x - nfield_blocks) * 64 + threadIdx.x, b = blockIdx.y;
+            uint8_t *img = a.proof + (size_t)b * a.image_stride;
+            if (q < NREST * 16) {
+                const int i = q >> 4, w = q & 15;
+                const size_t src = ((size_t)b * NPARTY + a.rest[(size_t)b * a.sel_stride + i]) * 32 + 2 * w;
+                reinterpret_cast<uint16_t *>(img + off_tcomm)[q] = *reinterpret_cast<const uint16_t *>(a.dig1 + src);
+                reinterpret_cast<uint16_t *>(img + off_comm)[q] = *reinterpret_cast<const uint16_t *>(a.dig2 + src);
+            }
+            if (q < NOPEN) reinterpret_cast<uint16_t *>(img + off_I)[q] = a.opened[(size_t)b * a.sel_stride + q];
+            return;
+        }
+    }
     // the tile is kept in IMAGE order (party-major, no padding): the second phase is a straight copy.
     __shared__ __attribute__((aligned(16))) uint16_t tile[ASM_TILE];
     const int b = blockIdx.y, x = blockIdx.x, lane = threadIdx.x;
@@ -1056,20 +1071,6 @@ __global__ __launch_bounds__(64) void k_assemble_fields(AssembleArgs a)
     uint32_t *out32 = reinterpret_cast<uint32_t *>(out + head);
     for (int q = lane; q < body; q += 64) out32[q] = (uint32_t)tile[head + 2 * q] | ((uint32_t)tile[head + 2 * q + 1] << 16);
     if (lane == 1 && head + 2 * body < n16) out[n16 - 1] = tile[n16 - 1];
-}
-
-// Tcomm / comm of the unopened parties and the list I itself
-__global__ __launch_bounds__(256) void k_assemble_digests(AssembleArgs a, size_t off_tcomm, size_t off_comm, size_t off_I)
-{
-    const int q = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    uint8_t *img = a.proof + (size_t)b * a.image_stride;
-    if (q < NREST * 16) {
-        const int i = q >> 4, w = q & 15;
-        const size_t src = ((size_t)b * NPARTY + a.rest[(size_t)b * a.sel_stride + i]) * 32 + 2 * w;
-        reinterpret_cast<uint16_t *>(img + off_tcomm)[q] = *reinterpret_cast<const uint16_t *>(a.dig1 + src);
-        reinterpret_cast<uint16_t *>(img + off_comm)[q] = *reinterpret_cast<const uint16_t *>(a.dig2 + src);
-    }
-    if (q < NOPEN) reinterpret_cast<uint16_t *>(img + off_I)[q] = a.opened[(size_t)b * a.sel_stride + q];
 }
 
 // plain strided row copy (kernel-level ABI helpers): dst[r][0..count) = src[r][0..count)
@@ -1257,8 +1258,8 @@ hipError_t launch_post_relation(uint16_t *P, size_t proof_stride, const RowMap &
 hipError_t launch_assemble(const AssembleArgs &a, int nfields, size_t off_tcomm, size_t off_comm, size_t off_I,
                            int nproofs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_assemble_fields, dim3(a.plan.nrest * NWIN + a.plan.nopen * ((NOPEN + 63) / 64), nproofs), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(k_assemble_digests, dim3((NREST * 16 + 255) / 256, nproofs), dim3(256), 0, st, a, off_tcomm, off_comm, off_I);
+    hipLaunchKernelGGL(k_assemble_fields, dim3(a.plan.nrest * NWIN + a.plan.nopen * ((NOPEN + 63) / 64) + (NREST * 16 + 63) / 64, nproofs), dim3(64),
+                       0, st, a, (uint32_t)off_tcomm, (uint32_t)off_comm, (uint32_t)off_I);
     return hipGetLastError();
 }
 

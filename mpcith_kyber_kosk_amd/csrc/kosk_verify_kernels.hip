@@ -21,8 +21,22 @@ constexpr int DIS_TILE = 64 * 80;
 // folded mod q to keep arithmetic bounded and the proof is marked malformed.
 __global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const FieldDesc *__restrict__ fields, FieldPlan plan,
                                                           const int16_t *__restrict__ rowtab,
-                                                          const uint8_t *__restrict__ proof, size_t image_stride)
+                                                          const uint8_t *__restrict__ proof, size_t image_stride, uint32_t off_tcomm,
+                                                          uint32_t off_comm, uint8_t *__restrict__ dig1, uint8_t *__restrict__ dig2)
 {
+    { // blocks past the field tiles: Tcomm / comm of the unopened parties into the two digest tables  mlwe_verifier.cpp:36-38, :645-647
+        const int nfield_blocks = plan.nrest * NWIN + plan.nopen * ((NOPEN + 63) / 64);
+        if ((int)blockIdx.x >= nfield_blocks) {
+            const int q = ((int)blockIdx.x - nfield_blocks) * 64 + threadIdx.x, b = blockIdx.y;
+            if (q >= NREST * 16) return;
+            const uint8_t *img = proof + (size_t)b * image_stride;
+            const int i = q >> 4, w = q & 15;
+            const size_t dst = ((size_t)b * NPARTY + v.rest[(size_t)b * v.sel_stride + i]) * 32 + 2 * w;
+            *reinterpret_cast<uint16_t *>(dig1 + dst) = reinterpret_cast<const uint16_t *>(img + off_tcomm)[q];
+            *reinterpret_cast<uint16_t *>(dig2 + dst) = reinterpret_cast<const uint16_t *>(img + off_comm)[q];
+            return;
+        }
+    }
     __shared__ __attribute__((aligned(16))) uint16_t tile[DIS_TILE]; // image order
     const int b = blockIdx.y, x = blockIdx.x, lane = threadIdx.x;
     const bool kind = x < plan.nrest * NWIN; // unopened parties of one aligned window (see k_assemble_fields)
@@ -79,19 +93,6 @@ __global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const F
     if (bad) atomicOr(&v.fail[b], 1u << FB_MALFORMED);
 }
 
-// Tcomm / comm of the unopened parties into the two digest tables  mlwe_verifier.cpp:36-38, :645-647
-__global__ __launch_bounds__(256) void k_disassemble_digests(const uint8_t *__restrict__ proof, size_t image_stride,
-                                                            size_t off_tcomm, size_t off_comm, const uint16_t *__restrict__ rest,
-                                                            int sel_stride, uint8_t *__restrict__ dig1, uint8_t *__restrict__ dig2)
-{
-    const int q = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (q >= NREST * 16) return;
-    const uint8_t *img = proof + (size_t)b * image_stride;
-    const int i = q >> 4, w = q & 15;
-    const size_t dst = ((size_t)b * NPARTY + rest[(size_t)b * sel_stride + i]) * 32 + 2 * w;
-    *reinterpret_cast<uint16_t *>(dig1 + dst) = reinterpret_cast<const uint16_t *>(img + off_tcomm)[q];
-    *reinterpret_cast<uint16_t *>(dig2 + dst) = reinterpret_cast<const uint16_t *>(img + off_comm)[q];
-}
 
 // ---- SHA3-256 of the opened parties' Tcomm / view messages, one opened party per thread ---------------
 // word w (u16) of opened party i's message, K / VIEW compile-time so that every source is resolved statically
@@ -500,9 +501,8 @@ hipError_t launch_disassemble(const VerifyArgs &v, const FieldDesc *fields, cons
                               const uint8_t *proof, size_t image_stride, size_t off_tcomm, size_t off_comm,
                               uint8_t *dig1, uint8_t *dig2, int nproofs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_disassemble_fields, dim3(plan.nrest * NWIN + plan.nopen * ((NOPEN + 63) / 64), nproofs), dim3(64), 0, st, v, fields, plan, rowtab, proof, image_stride);
-    hipLaunchKernelGGL(k_disassemble_digests, dim3((NREST * 16 + 255) / 256, nproofs), dim3(256), 0, st, proof, image_stride,
-                       off_tcomm, off_comm, v.rest, v.sel_stride, dig1, dig2);
+    hipLaunchKernelGGL(k_disassemble_fields, dim3(plan.nrest * NWIN + plan.nopen * ((NOPEN + 63) / 64) + (NREST * 16 + 63) / 64, nproofs), dim3(64), 0, st, v, fields, plan,
+                       rowtab, proof, image_stride, (uint32_t)off_tcomm, (uint32_t)off_comm, dig1, dig2);
     return hipGetLastError();
 }
 hipError_t launch_gates_opened(const VerifyArgs &v, int nproofs, hipStream_t st)
