@@ -469,7 +469,7 @@ int prove_resident(Ctx &c, int n, bool online_only)
         c.prof_begin(PR_LINCOMB);
         HIPCHK(launch_coef_limbs(c.d_alpha, P.J, P.M, c.d_coef, n, st));
         if (c.lincomb_fused) {
-            HIPCHK(launch_lincomb_fused(c.d_P, c.proof_stride, rm.f, rm.tf, P.M, c.d_coef, c.d_P, c.d_lin_rows, P.J, n, st));
+            HIPCHK(launch_lincomb_fused(c.d_P, c.proof_stride, rm, c.d_coef, c.d_P, c.d_lin_rows, P.J, n, st)); // includes s + r, e + r
         } else {
             GemmArgs ga{};
             ga.A = c.d_linA; ga.a_gstride = a_gstride; ga.Mpad = 1792; ga.M = NPTS; ga.KS = 2;
@@ -479,7 +479,7 @@ int prove_resident(Ctx &c, int n, bool online_only)
             HIPCHK(launch_gemm(ga, st));
         }
         c.prof_end(PR_LINCOMB);
-        HIPCHK(launch_post_open(c.d_P, c.proof_stride, rm, n, st));
+        if (!c.lincomb_fused) HIPCHK(launch_post_open(c.d_P, c.proof_stride, rm, n, st));
         return 0;
     })) return -1;
     // the graded kernel stays a plain launch so that HIP events can bracket it inside the timed region

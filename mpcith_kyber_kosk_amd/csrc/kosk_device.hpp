@@ -244,7 +244,8 @@ hipError_t launch_gemm(const GemmArgs &a, hipStream_t st);
 // K3 on the matrix cores (prover): transposed f / NTT-f rows and the alpha-power coefficient matrix as limb matrices
 hipError_t launch_cols_to_limbs(const uint16_t *P, size_t proof_stride, int row_f, int row_tf, int M, uint8_t *A, size_t a_gstride,
                                 int nproofs, hipStream_t st);
-hipError_t launch_lincomb_fused(const uint16_t *P, size_t proof_stride, int row_f, int row_tf, int M, const uint8_t *coef, uint16_t *C,
+// beta/gamma/r/NTT_r rows of every proof from its f / NTT f rows, plus s + r and e + r (the k_post_open step) in the epilogue
+hipError_t launch_lincomb_fused(const uint16_t *P, size_t proof_stride, const RowMap &rm, const uint8_t *coef, uint16_t *C,
                                 const int16_t *lin_rows, int J, int nproofs, hipStream_t st);
 hipError_t launch_coef_limbs(const uint16_t *alpha, int J, int M, uint8_t *B, int nproofs, hipStream_t st);
 hipError_t launch_pow_table(const uint16_t *alpha, int J, int M, int32_t *pwT, int nproofs, hipStream_t st);

@@ -725,7 +725,8 @@ __global__ __launch_bounds__(256) void k_cols_to_limbs(const uint16_t *__restric
 constexpr int LF_A_BYTES = 2 * 8 * 2048, LF_B_BYTES = 2 * 8 * 2048; // 2 k-steps x 8 row tiles x (2 limbs x 1 KiB)
 __global__ __launch_bounds__(256) void k_lincomb_fused(const uint16_t *P, size_t proof_stride, int row_f, int row_tf, int M,
                                                        const uint8_t *__restrict__ coef, int BRT, uint16_t *C,
-                                                       const int16_t *__restrict__ lin_rows, int J)
+                                                       const int16_t *__restrict__ lin_rows, int J, int K, int row_s, int row_e,
+                                                       int row_sr, int row_er)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[LF_A_BYTES + LF_B_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -818,6 +819,14 @@ __global__ __launch_bounds__(256) void k_lincomb_fused(const uint16_t *P, size_t
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = gf_from_i32(s0[ib][j][r] + 64 * s1[ib][j][r] + 767 * s2[ib][j][r]);
                 *reinterpret_cast<uint2 *>(crow + m) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+                if (which == 0 && jo >= NCHK) { // r rows: s + r_i, e + r_{K+i} on the spot (mlwe_prover.cpp:222-245)
+                    const int idx = jo - NCHK;
+                    const int src_row = idx < K ? row_s + idx : row_e + (idx - K), dst_row = idx < K ? row_sr + idx : row_er + (idx - K);
+                    const uint2 sv = *reinterpret_cast<const uint2 *>(Cb + (size_t)src_row * RS + m);
+                    const uint32_t a0 = gf_add(sv.x & 0xFFFFu, v[0]), a1 = gf_add(sv.x >> 16, v[1]);
+                    const uint32_t a2 = gf_add(sv.y & 0xFFFFu, v[2]), a3 = gf_add(sv.y >> 16, v[3]);
+                    *reinterpret_cast<uint2 *>(Cb + (size_t)dst_row * RS + m) = make_uint2(a0 | (a1 << 16), a2 | (a3 << 16));
+                }
             }
         }
     }
@@ -1206,11 +1215,11 @@ hipError_t launch_cols_to_limbs(const uint16_t *P, size_t proof_stride, int row_
     hipLaunchKernelGGL(k_cols_to_limbs, dim3(LIN_MPAD / 64, LIN_K / 64, 2 * nproofs), dim3(256), 0, st, P, proof_stride, row_f, row_tf, M, A, a_gstride);
     return hipGetLastError();
 }
-hipError_t launch_lincomb_fused(const uint16_t *P, size_t proof_stride, int row_f, int row_tf, int M, const uint8_t *coef, uint16_t *C,
+hipError_t launch_lincomb_fused(const uint16_t *P, size_t proof_stride, const RowMap &rm, const uint8_t *coef, uint16_t *C,
                                 const int16_t *lin_rows, int J, int nproofs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_lincomb_fused, dim3((NPTS + 127) / 128, 2 * nproofs), dim3(256), 0, st, P, proof_stride, row_f, row_tf, M, coef,
-                       2 * nproofs * 8, C, lin_rows, J);
+    hipLaunchKernelGGL(k_lincomb_fused, dim3((NPTS + 127) / 128, 2 * nproofs), dim3(256), 0, st, P, proof_stride, rm.f, rm.tf, rm.M, coef,
+                       2 * nproofs * 8, C, lin_rows, J, rm.K, rm.s, rm.e, rm.sr, rm.er);
     return hipGetLastError();
 }
 hipError_t launch_coef_limbs(const uint16_t *alpha, int J, int M, uint8_t *B, int nproofs, hipStream_t st)
