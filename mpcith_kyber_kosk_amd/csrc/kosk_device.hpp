@@ -144,6 +144,11 @@ enum FailBit {
     FB_ETA_CONST, FB_SUB_ETA, FB_U_INTERP, FB_U_RECON, FB_OPENED_SET
 };
 
+// image offsets of the opened parties' s - eta, e - eta, z_s, z_e records (fields 17-20 of mpcith_proof)
+struct GateOffsets {
+    uint32_t ssub, esub, zs, ze;
+};
+
 struct VerifyArgs {
     uint16_t *P;
     size_t proof_stride;
@@ -179,7 +184,7 @@ hipError_t launch_opened_setup(const uint8_t *proof, size_t image_stride, size_t
                                uint16_t *hrange, size_t sel_stride, uint32_t *fail, int nproofs, hipStream_t st);
 hipError_t launch_disassemble(const VerifyArgs &v, const FieldDesc *fields, const FieldPlan &plan, const int16_t *rowtab,
                               const uint8_t *proof, size_t image_stride, size_t off_tcomm, size_t off_comm,
-                              uint8_t *dig1, uint8_t *dig2, int nproofs, hipStream_t st);
+                              uint8_t *dig1, uint8_t *dig2, const GateOffsets &go, int nproofs, hipStream_t st);
 // Tcomm / view hash of the OPENED parties straight from the proof image (mlwe_verifier.cpp:23-35, :585-632):
 // s, e, f, NTT f, z_s, z_e are contiguous per party there; only beta, gamma, s+r, e+r, u come from rows.
 struct OpenedHashArgs {
@@ -200,7 +205,6 @@ hipError_t launch_check_batch(const VerifyArgs &v, const uint16_t *t_pk, const u
 hipError_t launch_gather_cols2(const uint16_t *P, size_t proof_stride, const int16_t *rows1, int nrows1, uint16_t *out1,
                                const int16_t *rows2, int nrows2, uint16_t *out2, const uint16_t *rest, int sel_stride,
                                const uint16_t *w, int nproofs, hipStream_t st);
-hipError_t launch_gates_opened(const VerifyArgs &v, int nproofs, hipStream_t st);
 hipError_t launch_interp_build(const InterpArgs &a, int nproofs, hipStream_t st);
 // out[b][r][j] = w[b][set][j] * P[b][rows[r]][256 + rest[b][j]]
 // P[b][dst_rows[r]][k] = node(k) ? P[b][src_rows[r]][256 + rest[node]] : ell[k] * P[b][dst_rows[r]][k],  k < 407

@@ -197,9 +197,9 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
 
 
     // ---- V1: scatter, gate outputs on opened columns, Tcomm of the opened parties
+    const GateOffsets go{(uint32_t)P.off[F_SSUB], (uint32_t)P.off[F_ESUB], (uint32_t)P.off[F_ZS], (uint32_t)P.off[F_ZE]};
     HIPCHK(launch_disassemble(va, c.d_vfields, c.vplan, c.d_vrowtab, c.d_proof, c.image_stride, P.off[F_TCOMM],
-                              P.off[F_COMM], c.d_dig1, c.d_dig2, n, st));
-    HIPCHK(launch_gates_opened(va, n, st));
+                              P.off[F_COMM], c.d_dig1, c.d_dig2, go, n, st)); // + digests + gate outputs of the opened parties
     c.prof_begin(PR_V_HASH_TCOMM);
     HIPCHK(launch_opened_hash(oh, K, false, n, st)); // Tcomm of the opened parties, read from the image   :22-35
     c.prof_end(PR_V_HASH_TCOMM);

@@ -22,8 +22,35 @@ constexpr int DIS_TILE = 64 * 80;
 __global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const FieldDesc *__restrict__ fields, FieldPlan plan,
                                                           const int16_t *__restrict__ rowtab,
                                                           const uint8_t *__restrict__ proof, size_t image_stride, uint32_t off_tcomm,
-                                                          uint32_t off_comm, uint8_t *__restrict__ dig1, uint8_t *__restrict__ dig2)
+                                                          uint32_t off_comm, uint8_t *__restrict__ dig1, uint8_t *__restrict__ dig2,
+                                                          GateOffsets go)
 {
+    { // last blocks: multiplication-gate outputs u = z_2d - z_d of the OPENED parties (mlwe_verifier.cpp:468-502), read from
+      // the party-major image records (30 + 24 contiguous bytes per party) instead of 54 scattered matrix columns
+        const int nfb = plan.nrest * NWIN + plan.nopen * ((NOPEN + 63) / 64) + (NREST * 16 + 63) / 64;
+        if ((int)blockIdx.x >= nfb) {
+            const int t = ((int)blockIdx.x - nfb) * 64 + threadIdx.x, b = blockIdx.y;
+            if (t >= NOPEN) return;
+            const RowMap &rm = v.rm;
+            const uint8_t *img = proof + (size_t)b * image_stride;
+            uint16_t *Pc = v.P + (size_t)b * v.proof_stride + NSEC + v.opened[(size_t)b * v.sel_stride + t];
+            bool bad = false;
+            auto rd = [&](uint32_t off, int idx) { uint32_t x_ = reinterpret_cast<const uint16_t *>(img + off)[idx]; if (x_ >= (uint32_t)Q) { bad = true; x_ %= Q; } return x_; };
+            for (int who = 0; who < 2; who++)
+                for (int i = 0; i < rm.K; i++) {
+                    const uint32_t osub = who ? go.esub : go.ssub, oz = who ? go.ze : go.zs;
+                    uint32_t prev = rd(osub, (t * rm.K + i) * rm.E);
+                    for (int j = 0; j < rm.Z; j++) {
+                        const uint32_t z2 = gf_mul(prev, rd(osub, (t * rm.K + i) * rm.E + j + 1));
+                        const uint32_t zd = rd(oz, (t * rm.K + i) * rm.Z + j);
+                        Pc[(size_t)(who ? rm.ue(i, j) : rm.us(i, j)) * RS] = (uint16_t)gf_sub(z2, zd);
+                        prev = zd;
+                    }
+                }
+            (void)bad; // the same values are range-checked by the scatter blocks
+            return;
+        }
+    }
     { // blocks past the field tiles: Tcomm / comm of the unopened parties into the two digest tables  mlwe_verifier.cpp:36-38, :645-647
         const int nfield_blocks = plan.nrest * NWIN + plan.nopen * ((NOPEN + 63) / 64);
         if ((int)blockIdx.x >= nfield_blocks) {
@@ -196,27 +223,6 @@ hipError_t launch_opened_hash(const OpenedHashArgs &a, int K, bool view, int npr
     return hipGetLastError();
 }
 
-// u = z2d - z_d on the opened columns from the opened gate inputs   mlwe_verifier.cpp:469-495
-__global__ __launch_bounds__(192) void k_gates_opened(VerifyArgs v)
-{
-    const int t = threadIdx.x, b = blockIdx.x;
-    if (t >= NOPEN) return;
-    const RowMap &rm = v.rm;
-    uint16_t *Pb = v.P + (size_t)b * v.proof_stride + NSEC + v.opened[(size_t)b * v.sel_stride + t];
-#pragma unroll
-    for (int who = 0; who < 2; who++)
-#pragma unroll 4
-        for (int i = 0; i < rm.K; i++) {
-            const int sub0 = (who ? rm.esub : rm.ssub) + i * rm.E;
-            uint32_t prev = Pb[(size_t)sub0 * RS];
-            for (int j = 0; j < rm.Z; j++) {
-                const uint32_t z2 = gf_mul(prev, Pb[(size_t)(sub0 + j + 1) * RS]);
-                const uint32_t zd = Pb[(size_t)(who ? rm.ze(i, j) : rm.zs(i, j)) * RS];
-                Pb[(size_t)(who ? rm.ue(i, j) : rm.us(i, j)) * RS] = (uint16_t)gf_sub(z2, zd);
-                prev = zd;
-            }
-        }
-}
 
 // ---- interpolation operators over the nodes x_j = 256 + rest[j] (see InterpArgs) ---------------
 __device__ __forceinline__ uint32_t gf_neg_if(uint32_t v, int odd) { return (odd & 1) && v ? (uint32_t)Q - v : v; }
@@ -499,15 +505,10 @@ hipError_t launch_opened_setup(const uint8_t *proof, size_t image_stride, size_t
 }
 hipError_t launch_disassemble(const VerifyArgs &v, const FieldDesc *fields, const FieldPlan &plan, const int16_t *rowtab,
                               const uint8_t *proof, size_t image_stride, size_t off_tcomm, size_t off_comm,
-                              uint8_t *dig1, uint8_t *dig2, int nproofs, hipStream_t st)
+                              uint8_t *dig1, uint8_t *dig2, const GateOffsets &go, int nproofs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_disassemble_fields, dim3(plan.nrest * NWIN + plan.nopen * ((NOPEN + 63) / 64) + (NREST * 16 + 63) / 64, nproofs), dim3(64), 0, st, v, fields, plan,
-                       rowtab, proof, image_stride, (uint32_t)off_tcomm, (uint32_t)off_comm, dig1, dig2);
-    return hipGetLastError();
-}
-hipError_t launch_gates_opened(const VerifyArgs &v, int nproofs, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_gates_opened, dim3(nproofs), dim3(192), 0, st, v);
+    hipLaunchKernelGGL(k_disassemble_fields, dim3(plan.nrest * NWIN + plan.nopen * ((NOPEN + 63) / 64) + (NREST * 16 + 63) / 64 + (NOPEN + 63) / 64, nproofs), dim3(64), 0,
+                       st, v, fields, plan, rowtab, proof, image_stride, (uint32_t)off_tcomm, (uint32_t)off_comm, dig1, dig2, go);
     return hipGetLastError();
 }
 hipError_t launch_interp_build(const InterpArgs &a, int nproofs, hipStream_t st)
