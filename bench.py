@@ -211,7 +211,7 @@ def main():
     ap.add_argument("--cpu-proofs", type=int, default=12, help="bounded CPU baseline sample (about 13 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
-    ap.add_argument("--slots", type=int, default=int(os.environ.get("KOSK_BENCH_SLOTS", "6")),
+    ap.add_argument("--slots", type=int, default=int(os.environ.get("KOSK_BENCH_SLOTS", "7")),
                     help="independent batches kept in flight per GPU (own HIP stream + host threads each); "
                          "steps are dealt round-robin to the slots")
     args = ap.parse_args()
