@@ -204,8 +204,8 @@ def extras(api, torch, k, B, tapes):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--kyber-k", type=int, default=3)
     ap.add_argument("--batch", type=int, default=46, help="proofs per GPU per step (46 x 1454 = 66 884 party lanes)")
     ap.add_argument("--cpu-proofs", type=int, default=12, help="bounded CPU baseline sample (about 13 s)")
