@@ -477,6 +477,13 @@ void pack_limb_table(const std::vector<uint16_t> &A, int M, int Kdim, int Mpad, 
 // -------------------------------------------------------------------- misc --
 // Persistent worker pool: Fiat-Shamir rounds arrive in short bursts between GPU phases, so the
 // workers spin briefly on a generation counter before they block.
+//
+// Every parallel_for publishes its own Job object (index counter, completion counter, bounds, function): nothing a
+// worker can touch is ever reset for the next job, so a worker that wakes late for job N either finds no job
+// (cur_ == nullptr) or helps with job N+1 -- both are valid.  A Job lives on run()'s stack; run() retires it
+// (cur_ = nullptr) and then waits until no worker is inside the pick-up window (inside_ == 0).  inside_++ / load cur_
+// on the worker and store cur_ / load inside_ in run() are sequentially consistent (Dekker pattern): either the worker
+// sees the job retired or run() sees the worker inside.
 class Pool {
 public:
     static Pool &get() { static Pool p; return p; }
@@ -485,7 +492,7 @@ public:
     {
         {
             std::lock_guard<std::mutex> lk(mu_);
-            stop_ = true;
+            stop_.store(true);
             gen_.fetch_add(1);
         }
         cv_.notify_all();
@@ -493,40 +500,44 @@ public:
     }
     void run(int n, int nthreads, const std::function<void(int)> &fn)
     {
-        std::lock_guard<std::mutex> job(job_mu_);
+        std::lock_guard<std::mutex> job_lock(job_mu_);
         grow(nthreads - 1);
-        fn_ = &fn;
-        n_ = n;
-        next_.store(0, std::memory_order_relaxed);
-        done_.store(0, std::memory_order_relaxed);
-        want_ = std::min<int>((int)th_.size(), nthreads - 1);
+        Job job{&fn, n, std::min<int>((int)th_.size(), nthreads - 1)};
+        cur_.store(&job);
         {
             std::lock_guard<std::mutex> lk(mu_);
-            gen_.fetch_add(1, std::memory_order_release);
+            gen_.fetch_add(1);
         }
         cv_.notify_all();
-        work();
-        while (done_.load(std::memory_order_acquire) < n) __builtin_ia32_pause();
-        // workers may still be inside work() looking for an index: wait until they have left fn_
-        while (inside_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+        work(job);
+        while (job.done.load(std::memory_order_acquire) < n) __builtin_ia32_pause();
+        cur_.store(nullptr);
+        // a worker may still hold &job between its pick-up and its first (failing) index fetch
+        while (inside_.load() != 0) __builtin_ia32_pause();
     }
 
 private:
+    struct Job {
+        const std::function<void(int)> *fn;
+        int n, want;
+        std::atomic<int> next{0}, done{0};
+        Job(const std::function<void(int)> *f, int n_, int w) : fn(f), n(n_), want(w) {}
+    };
     void grow(int want)
     {
         while ((int)th_.size() < want && th_.size() < 255) {
             const int id = (int)th_.size();
-            const uint64_t g = gen_.load(std::memory_order_acquire); // never pick up a job published before we existed
+            const uint64_t g = gen_.load(); // never pick up a job published before we existed
             th_.emplace_back([this, id, g] { loop(id, g); });
         }
     }
-    void work()
+    static void work(Job &j)
     {
         for (;;) {
-            const int i = next_.fetch_add(1, std::memory_order_relaxed);
-            if (i >= n_) break;
-            (*fn_)(i);
-            done_.fetch_add(1, std::memory_order_release);
+            const int i = j.next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= j.n) break;
+            (*j.fn)(i);
+            j.done.fetch_add(1, std::memory_order_release);
         }
     }
     static int spin_us()
@@ -550,23 +561,20 @@ private:
                 __builtin_ia32_pause();
             }
             seen = gen_.load(std::memory_order_acquire);
-            if (stop_) return;
-            if (id < want_) {
-                inside_.fetch_add(1, std::memory_order_acq_rel);
-                // the job may already be over (n_ exhausted); work() then returns at once
-                work();
-                inside_.fetch_sub(1, std::memory_order_acq_rel);
-            }
+            if (stop_.load()) return;
+            inside_.fetch_add(1);
+            if (Job *j = cur_.load())
+                if (id < j->want) work(*j);
+            inside_.fetch_sub(1);
         }
     }
     std::vector<std::thread> th_;
     std::mutex job_mu_, mu_;
     std::condition_variable cv_;
     std::atomic<uint64_t> gen_{0};
-    std::atomic<int> next_{0}, done_{0}, inside_{0};
-    const std::function<void(int)> *fn_ = nullptr;
-    int n_ = 0, want_ = 0;
-    bool stop_ = false;
+    std::atomic<int> inside_{0};
+    std::atomic<Job *> cur_{nullptr};
+    std::atomic<bool> stop_{false};
 };
 
 Pool *pool_create() { return new Pool(); }

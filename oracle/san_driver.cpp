@@ -1,0 +1,183 @@
+// san_driver.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// CPU sanitizer target (the reference's CMakeLists.txt:6-7 has none; its probe build ran clean
+// under ASan+UBSan).  Built by `make -C oracle asan` (-fsanitize=address,undefined) and `make -C oracle tsan`
+// (-fsanitize=thread) from the oracle (kosk_oracle.c) and the product's host file (csrc/kosk_host.cpp: sponge,
+// multi-buffer SHA3, keygen, Fiat-Shamir batches, Lagrange rows, thread pool); run by tests/test_sanitizers.py.
+//
+//   san_driver full  : K = 2,3,4: oracle keygen + prove + verify (+ one tampered proof), host code against the oracle
+//   san_driver pool  : back-to-back small parallel_for calls (the hand-off race of ADVICE r1) + batched Fiat-Shamir
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "kosk_oracle.h"
+#include "../mpcith_kyber_kosk_amd/csrc/kosk_host.hpp"
+
+static int fails = 0;
+#define CHECK(cond, ...)                   \
+    do {                                   \
+        if (!(cond)) {                     \
+            fails++;                       \
+            fprintf(stderr, "FAIL: ");     \
+            fprintf(stderr, __VA_ARGS__);  \
+            fprintf(stderr, "\n");         \
+        }                                  \
+    } while (0)
+
+static std::vector<uint8_t> tape_for(int K, int idx)
+{
+    ko_params P;
+    ko_get_params(K, &P);
+    char seed[64];
+    const int n = snprintf(seed, sizeof seed, "kosk-tape-v1:%d", idx);
+    std::vector<uint8_t> t(P.tape_bytes);
+    ko_shake256(t.data(), t.size(), (const uint8_t *)seed, (size_t)n);
+    return t;
+}
+
+static void pool_hammer(int rounds)
+{
+    kosk::Pool *pool = kosk::pool_create();
+    std::vector<int> hit(64);
+    long total = 0;
+    for (int r = 0; r < rounds; r++) {
+        const int n = 2 + r % 13, nt = 2 + r % 5;
+        std::fill(hit.begin(), hit.end(), 0);
+        kosk::parallel_for(pool, n, nt, [&](int i) { hit[i]++; });
+        for (int i = 0; i < n; i++) {
+            CHECK(hit[i] == 1, "pool: index %d ran %d times in round %d", i, hit[i], r);
+            total += hit[i];
+        }
+    }
+    kosk::pool_destroy(pool);
+    printf("pool: %d back-to-back jobs, %ld indices\n", rounds, total);
+}
+
+static void host_vs_oracle(int K)
+{
+    ko_params OP;
+    ko_get_params(K, &OP);
+    kosk::Params P;
+    kosk::make_params(K, P);
+    CHECK(P.proof_bytes == OP.proof_bytes && P.tape_bytes == OP.tape_bytes, "params K=%d", K);
+
+    std::vector<uint8_t> tape = tape_for(K, 0);
+    std::vector<uint8_t> pk(OP.pk_bytes), sk(OP.sk_bytes), pi(OP.proof_bytes);
+    ko_tape t;
+    ko_tape_init(&t, tape.data(), tape.size());
+    ko_trace *tr = new ko_trace();
+    ko_verifiable_keygen(K, &t, pk.data(), sk.data(), pi.data(), tr);
+    CHECK(!t.overrun && t.pos == OP.tape_bytes, "tape consumption K=%d", K);
+    char why[128] = {0};
+    CHECK(ko_kosk_verify(K, pi.data(), pk.data(), why, sizeof why) == 1, "oracle rejects its own proof K=%d: %s", K, why);
+    std::vector<uint8_t> bad = pi;
+    bad[OP.off[KO_F_SR] + 3] ^= 1;
+    CHECK(ko_kosk_verify(K, bad.data(), pk.data(), why, sizeof why) == 0, "oracle accepts a tampered proof K=%d", K);
+
+    // host keygen (kosk.cpp:4-70) against the oracle's
+    std::vector<uint8_t> pk2(P.pk_bytes), sk2(P.sk_bytes);
+    kosk::HostKey *key = new kosk::HostKey();
+    kosk::host_keygen(P, tape.data(), pk2.data(), sk2.data(), *key);
+    CHECK(pk2 == pk && sk2 == sk, "host_keygen differs from the oracle K=%d", K);
+    delete key;
+
+    // Fiat-Shamir rounds (mlwe_prover.cpp:130-153, :445-474), single and batched (multi-buffer SHA3 + pool)
+    uint16_t alpha[kosk::MAXJ] = {0};
+    kosk::fs_alpha(P, &tr->tcomm[0][0], alpha);
+    CHECK(memcmp(alpha, tr->alpha, sizeof(uint16_t) * P.J) == 0, "fs_alpha K=%d", K);
+    uint16_t I[kosk::NOPEN], rest[kosk::NREST];
+    kosk::fs_opened(&tr->view_digest[0][0], I, rest);
+    CHECK(memcmp(I, pi.data() + OP.off[KO_F_I], sizeof I) == 0, "fs_opened K=%d", K);
+    const int nb = 11;
+    std::vector<uint8_t> digs((size_t)nb * KO_PARTIES * 32);
+    for (int b = 0; b < nb; b++) {
+        memcpy(&digs[(size_t)b * KO_PARTIES * 32], &tr->view_digest[0][0], (size_t)KO_PARTIES * 32);
+        digs[(size_t)b * KO_PARTIES * 32 + 5] ^= (uint8_t)b; // b = 0 stays the real table
+    }
+    kosk::Pool *pool = kosk::pool_create();
+    std::vector<uint16_t> Ib((size_t)nb * 1312), rb((size_t)nb * 1312), al((size_t)nb * 80);
+    kosk::fs_opened_batch(nb, digs.data(), (size_t)KO_PARTIES * 32, Ib.data(), rb.data(), 1312, 3, pool);
+    kosk::fs_alpha_batch(P, nb, digs.data(), (size_t)KO_PARTIES * 32, al.data(), 80, 3, pool);
+    CHECK(memcmp(Ib.data(), I, sizeof I) == 0, "fs_opened_batch K=%d", K);
+    for (int b = 0; b < nb; b++) {
+        uint16_t I1[kosk::NOPEN], r1[kosk::NREST], a1[kosk::MAXJ];
+        kosk::fs_opened(&digs[(size_t)b * KO_PARTIES * 32], I1, r1);
+        kosk::fs_alpha(P, &digs[(size_t)b * KO_PARTIES * 32], a1);
+        CHECK(memcmp(&Ib[(size_t)b * 1312], I1, sizeof I1) == 0 && memcmp(&rb[(size_t)b * 1312], r1, sizeof r1) == 0, "fs_opened_batch[%d] K=%d", b, K);
+        CHECK(memcmp(&al[(size_t)b * 80], a1, sizeof(uint16_t) * P.J) == 0, "fs_alpha_batch[%d] K=%d", b, K);
+    }
+    kosk::pool_destroy(pool);
+    delete tr;
+    printf("K=%d: oracle prove/verify/tamper, host keygen and Fiat-Shamir rounds ok\n", K);
+}
+
+static void primitives()
+{
+    // sponge against the oracle's on ragged lengths around the rate boundaries
+    std::vector<uint8_t> msg(700);
+    for (size_t i = 0; i < msg.size(); i++) msg[i] = (uint8_t)(i * 131 + 7);
+    for (size_t len : {0u, 1u, 135u, 136u, 137u, 271u, 272u, 273u, 320u, 472u, 524u, 700u}) {
+        uint8_t a[64], b[64];
+        kosk::sha3_256(a, msg.data(), len);
+        ko_sha3_256(b, msg.data(), len);
+        CHECK(memcmp(a, b, 32) == 0, "sha3_256 len %zu", len);
+        kosk::sha3_512(a, msg.data(), len);
+        ko_sha3_512(b, msg.data(), len);
+        CHECK(memcmp(a, b, 64) == 0, "sha3_512 len %zu", len);
+        uint8_t x[300], y[300];
+        kosk::shake256(x, sizeof x, msg.data(), len);
+        ko_shake256(y, sizeof y, msg.data(), len);
+        CHECK(memcmp(x, y, sizeof x) == 0, "shake256 len %zu", len);
+        kosk::shake128(x, sizeof x, msg.data(), len);
+        ko_shake128(y, sizeof y, msg.data(), len);
+        CHECK(memcmp(x, y, sizeof x) == 0, "shake128 len %zu", len);
+    }
+    // multi-buffer SHA3 on 1..9 messages (exercises the partial last group)
+    for (int count = 1; count <= 9; count++) {
+        std::vector<const uint8_t *> in(count);
+        for (int i = 0; i < count; i++) in[i] = msg.data() + i;
+        std::vector<uint8_t> out((size_t)count * 32);
+        kosk::sha3_256_multi(out.data(), in.data(), 472, count);
+        for (int i = 0; i < count; i++) {
+            uint8_t b[32];
+            ko_sha3_256(b, in[i], 472);
+            CHECK(memcmp(&out[(size_t)i * 32], b, 32) == 0, "sha3_256_multi %d/%d", i, count);
+        }
+    }
+    // Lagrange rows against the oracle's tables (first, middle, last row of each)
+    const uint16_t *ts = ko_table_share_ddeg(), *tr = ko_table_recon_ddeg(), *t2 = ko_table_recon_2ddeg();
+    std::vector<uint16_t> row(KO_DEG2 + 1);
+    for (int x : {0, 651, 1302}) {
+        kosk::lagrange_row(row.data(), KO_DEG + 1, 0, KO_DEG + 1 + x);
+        CHECK(memcmp(row.data(), ts + (size_t)x * (KO_DEG + 1), 2 * (KO_DEG + 1)) == 0, "share table row %d", x);
+    }
+    for (int i : {0, 100, 255}) {
+        kosk::lagrange_row(row.data(), KO_DEG + 1, KO_NSEC, i);
+        CHECK(memcmp(row.data(), tr + (size_t)i * (KO_DEG + 1), 2 * (KO_DEG + 1)) == 0, "recon table row %d", i);
+        kosk::lagrange_row(row.data(), KO_DEG2 + 1, KO_NSEC, i);
+        CHECK(memcmp(row.data(), t2 + (size_t)i * (KO_DEG2 + 1), 2 * (KO_DEG2 + 1)) == 0, "recon 2d table row %d", i);
+    }
+    printf("primitives ok\n");
+}
+
+int main(int argc, char **argv)
+{
+    const char *mode = argc > 1 ? argv[1] : "full";
+    if (!strcmp(mode, "pool")) {
+        pool_hammer(argc > 2 ? atoi(argv[2]) : 20000);
+        host_vs_oracle(2);
+    } else {
+        primitives();
+        for (int K = 2; K <= 4; K++) host_vs_oracle(K);
+        pool_hammer(2000);
+    }
+    if (fails) {
+        fprintf(stderr, "%d check(s) failed\n", fails);
+        return 1;
+    }
+    printf("san_driver %s: ok\n", mode);
+    return 0;
+}

@@ -1,6 +1,9 @@
-"""Oracle primitives against oracle/_ref: the reference's OWN kyber/*.c and utils/gf3329.c compiled in
-place (oracle/Makefile).  Skipped when that build is absent (it cannot be rebuilt without /root/reference,
-but the prebuilt .so travels to the GPU box)."""
+"""Oracle (and product layouts) against oracle/_ref: the reference's OWN sources compiled in place (oracle/Makefile).
+  libkyber_ref_k*.so : kyber/*.c + utils/gf3329.c                       -> L0/L1 primitives
+  libkosk_ref_k*.so  : + ss.cpp + mlwe_prover.cpp + our sizeof/offsetof probe (oracle/ref_layout.cpp); the generated
+                       utils/precomputed_kyber.c is not mounted, so get_precomputed_* are unresolved and the library is
+                       loaded with RTLD_LAZY: only functions that never reach them are called here.
+Skipped when that build is absent (it cannot be rebuilt without /root/reference; oracle/_ref is git-ignored)."""
 import ctypes as C
 import os
 
@@ -100,3 +103,163 @@ def test_fips202_and_gf3329(oracle):
             assert ref.gf3329_mul(a, b) == oracle.lib.ko_gf_mul(a, b)
     for a in range(-1664, 1665, 7):
         assert ref.encode_to_gf3329(a) == oracle.lib.ko_gf_encode(a)
+
+
+# ---- L2/L3 pieces of the reference that compile without the unmounted Lagrange tables -----------------------------
+
+def _kosk_ref(k):
+    path = os.path.join(ROOT, "oracle", "_ref", "libkosk_ref_k%d.so" % k)
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    return C.CDLL(path, mode=os.RTLD_LAZY)  # get_precomputed_* stay unresolved (see the module docstring)
+
+
+def _layout(k):
+    ref = _kosk_ref(k)
+    ref.ref_layout_name.restype = C.c_char_p
+    ref.ref_layout_value.restype = C.c_size_t
+    return {ref.ref_layout_name(i).decode(): ref.ref_layout_value(i) for i in range(ref.ref_layout_count())}
+
+
+FIELD_NAMES = ["f_shares", "NTT_f_shares", "beta_shares", "gamma_shares", "Tcomm", "I", "s_shares", "e_shares", "t_shares",
+               "NTT_s_shares", "NTT_e_shares", "NTT_Ar_shares", "NTT_As_shares", "sr_shares", "er_shares", "s_eta_shares",
+               "e_eta_shares", "s_sub_eta_shares", "e_sub_eta_shares", "z_s_ddeg_shares", "z_e_ddeg_shares",
+               "u_s_2ddeg_shares", "u_e_2ddeg_shares", "comm"]
+
+
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_struct_layouts_of_the_reference_headers(k, oracle):
+    """sizeof / offsetof straight out of mlwe_prover.hpp:34-94, ss.hpp:33-42, kosk.hpp:13-16 against the oracle's
+    parameter block, the product library's (kosk_proof_field etc.) and the struct images the tests build."""
+    L = _layout(k)
+    p = oracle.params(k)
+    assert (L["KYBER_K"], L["KYBER_ETA1"], L["MPCITH_N"], L["MPCITH_T"], L["MPCITH_K"], L["MPCITH_V"]) == (k, p.eta1, 1454, 150, 70, p.V)
+    assert (L["DEG_D"], L["DEG_2D"]) == (406, 812)
+    assert L["sizeof mpcith_proof"] == L["MPCITH_PROOF_SIZE"] == p.proof_bytes
+    offs = [L["offsetof mpcith_proof." + n] for n in FIELD_NAMES]
+    assert offs == list(p.off)
+    assert [b - a for a, b in zip(offs, offs[1:] + [p.proof_bytes])] == list(p.size)  # no padding anywhere
+    assert L["sizeof kyber_keypair"] == p.pk_bytes + p.sk_bytes and L["offsetof kyber_keypair.sk"] == p.pk_bytes
+    assert (L["sizeof share_vec"], L["offsetof share_vec.share_x"], L["offsetof share_vec.share_y"]) == (5824, 8, 8 + 2908)
+    assert (L["sizeof secret_vec"], L["offsetof secret_vec.secret"]) == (520, 8)
+    M, E = p.M, p.E
+    assert L["sizeof mlwe_inst"] == 512 * (k * k + 3 * k)
+    assert [L["offsetof mlwe_inst." + m] for m in "Atse"] == [0, 512 * k * k, 512 * (k * k + k), 512 * (k * k + 2 * k)]
+    assert L["sizeof mpcith_randomness"] == 2 * M * 512 + 2 * M * 5824
+    assert [L["offsetof mpcith_randomness." + m] for m in ("f", "NTT_f", "f_shares", "NTT_f_shares")] == [0, M * 512, 2 * M * 512, 2 * M * 512 + M * 5824]
+    assert L["sizeof mpcith_range_proof"] == 2 * k * E * 5824 and L["offsetof mpcith_range_proof.e_eta_shares"] == k * E * 5824
+    assert L["MPCITH_PRE_RANDOMNESS_SIZE"] == L["sizeof mpcith_randomness"] + L["sizeof mpcith_range_proof"]
+    Z = p.Z
+    assert L["sizeof mpcith_vp_state"] == 32 + 2 * (4 * k + 2 * M + 140 + 4 * k * Z)
+    # the struct images the oracle-side helpers build for the split API have exactly these sizes
+    img = oracle.main_order(k, oracle.tape_bytes_for(k, 0))
+    assert len(img["rand"]) == L["sizeof mpcith_randomness"] and len(img["range"]) == L["sizeof mpcith_range_proof"]
+    assert len(img["inst"]) == L["sizeof mlwe_inst"]
+    # and the product library reports the same wire layout
+    so = os.path.join(ROOT, "mpcith_kyber_kosk_amd", "libkosk_mi355x.so")
+    if os.path.exists(so):
+        lib = C.CDLL(so)
+        for f in ("kosk_proof_bytes", "kosk_randomness_bytes", "kosk_range_proof_bytes", "kosk_mlwe_inst_bytes"):
+            getattr(lib, f).restype = C.c_size_t
+        assert lib.kosk_proof_bytes(k) == L["sizeof mpcith_proof"]
+        assert lib.kosk_randomness_bytes(k) == L["sizeof mpcith_randomness"]
+        assert lib.kosk_range_proof_bytes(k) == L["sizeof mpcith_range_proof"]
+        assert lib.kosk_mlwe_inst_bytes(k) == L["sizeof mlwe_inst"]
+        for i in range(24):
+            o, z = C.c_size_t(), C.c_size_t()
+            assert lib.kosk_proof_field(k, i, C.byref(o), C.byref(z)) == 0
+            assert (o.value, z.value) == (offs[i], p.size[i])
+
+
+class ShareVec(C.Structure):  # ss.hpp:33-37
+    _fields_ = [("len", C.c_size_t), ("share_x", C.c_uint16 * 1454), ("share_y", C.c_uint16 * 1454)]
+
+
+def test_shares_add_sub_mul(oracle):
+    """ss.cpp:101-136 (compiled reference) against the oracle's lane ops, including the x-mismatch error return."""
+    ref = _kosk_ref(3)
+    rng = np.random.default_rng(5)
+    oracle.lib.ko_gf_add.restype = oracle.lib.ko_gf_sub.restype = oracle.lib.ko_gf_mul.restype = C.c_uint16
+    for trial in range(4):
+        a, b, r = ShareVec(), ShareVec(), ShareVec()
+        ya = rng.integers(0, 3329, 1454).astype(np.uint16); yb = rng.integers(0, 3329, 1454).astype(np.uint16)
+        if trial == 0:
+            ya[:4] = [0, 3328, 1, 3328]; yb[:4] = [0, 3328, 3328, 1]
+        for v, y in ((a, ya), (b, yb)):
+            v.share_x[:] = list(range(256, 256 + 1454)); v.share_y[:] = y.tolist()
+        # C++ linkage in the reference (ss.hpp declares them outside extern "C")
+        for name, fn in (("_Z10shares_addP9share_vecPKS_S2_", oracle.lib.ko_gf_add), ("_Z10shares_subP9share_vecPKS_S2_", oracle.lib.ko_gf_sub),
+                         ("_Z10shares_mulP9share_vecPKS_S2_", oracle.lib.ko_gf_mul)):
+            assert getattr(ref, name)(C.byref(r), C.byref(a), C.byref(b)) == 0
+            exp = [fn(int(x), int(y)) for x, y in zip(ya, yb)]
+            assert list(r.share_y) == exp and list(r.share_x) == list(a.share_x)
+    b.share_x[700] += 1
+    assert ref._Z10shares_addP9share_vecPKS_S2_(C.byref(r), C.byref(a), C.byref(b)) == -1  # error convention: -1 on mismatching x
+
+
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_decode_and_encode_mpcith_proof(k, oracle):
+    """mlwe_prover.cpp:540-630: decode copies field by field at the struct's offsets, encode is the struct image.  An
+    oracle proof must survive decode -> encode unchanged, i.e. the oracle's wire layout is the reference's."""
+    ref = _kosk_ref(k)
+    _, _, pi, _, _ = oracle.verifiable_keygen(k, oracle.tape_bytes_for(k, 1))
+    st = C.create_string_buffer(len(pi))
+    ref._Z19decode_mpcith_proofP12mpcith_proofPKh(st, C.c_char_p(pi))
+    assert st.raw == pi
+    out = C.create_string_buffer(len(pi))
+    ref._Z19encode_mpcith_proofPhPK12mpcith_proof(out, st)
+    assert out.raw == pi
+    # every field on its own: a buffer that holds 0x00.. except one field decodes to the same
+    p = oracle.params(k)
+    for i in (0, 4, 5, 8, 15, 21, 23):
+        buf = bytearray(len(pi)); buf[p.off[i]:p.off[i] + p.size[i]] = pi[p.off[i]:p.off[i] + p.size[i]]
+        ref._Z19decode_mpcith_proofP12mpcith_proofPKh(st, C.c_char_p(bytes(buf)))
+        assert st.raw == bytes(buf)
+
+
+def test_lagrange_tables_against_the_reference_interpolation(oracle):
+    """The reference's generated table file is not mounted, but its own Lagrange code is (ss.cpp:138-264: interpolate,
+    poly_eval_from_points): table . y must equal the reference's interpolation of y evaluated at the table's points,
+    for the three node sets (ss.cpp:26-27, :47, :66)."""
+    ref = _kosk_ref(2)
+    fn = ref._Z21poly_eval_from_pointsPtPKtS1_tS1_t
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint16, C.c_void_p, C.c_uint16]
+    rng = np.random.default_rng(11)
+    vp = C.c_void_p
+    cases = [(0, np.arange(407), 407 + np.arange(1303)), (1, 256 + np.arange(407), np.arange(256)), (2, 256 + np.arange(813), np.arange(256))]
+    for which, nodes, evalx in cases:
+        T = oracle.table(which).astype(np.int64)
+        nodes = nodes.astype(np.uint16); evalx = evalx.astype(np.uint16)
+        ys = [rng.integers(0, 3329, len(nodes)).astype(np.uint16) for _ in range(2)]
+        e = np.zeros(len(nodes), np.uint16); e[len(nodes) // 3] = 1   # one unit vector = one full table column
+        for y in ys + [e]:
+            res = np.zeros(len(evalx), np.uint16)
+            fn(res.ctypes.data_as(vp), nodes.ctypes.data_as(vp), y.ctypes.data_as(vp), len(nodes) - 1, evalx.ctypes.data_as(vp), len(evalx))
+            assert np.array_equal(res.astype(np.int64), (T @ y.astype(np.int64)) % 3329)
+    # and the oracle's replacement for NTL interpolate + eval agrees with the reference's interpolation on an I-like node set
+    nodes = np.sort(rng.choice(np.arange(256, 1710), 407, replace=False)).astype(np.uint16)
+    y = rng.integers(0, 3329, 407).astype(np.uint16)
+    evalx = np.arange(407, dtype=np.uint16)
+    r1, r2 = np.zeros(407, np.uint16), np.zeros(407, np.uint16)
+    fn(r1.ctypes.data_as(vp), nodes.ctypes.data_as(vp), y.ctypes.data_as(vp), 406, evalx.ctypes.data_as(vp), 407)
+    oracle.lib.ko_interp_eval(r2.ctypes.data_as(vp), 407, nodes.ctypes.data_as(vp), y.ctypes.data_as(vp), 407)
+    assert np.array_equal(r1, r2)
+
+
+@pytest.mark.parametrize("k", [2, 3])
+def test_preprocessed_randomness_codec(k, oracle):
+    """mlwe_prover.cpp:61-79: encode is two memcpys; decode restores `rand` but forgets `eta_shares` (the quirk the
+    product's decoder fixes)."""
+    ref = _kosk_ref(k)
+    img = oracle.main_order(k, oracle.tape_bytes_for(k, 2))
+    buf = C.create_string_buffer(len(img["rand"]) + len(img["range"]))
+    ref._Z30encode_preprocessed_randomnessPhPK17mpcith_randomnessPK18mpcith_range_proof(buf, C.c_char_p(img["rand"]), C.c_char_p(img["range"]))
+    assert buf.raw == img["rand"] + img["range"]
+    r2 = C.create_string_buffer(len(img["rand"])); e2 = C.create_string_buffer(b"\xAA" * len(img["range"]), len(img["range"]))
+    ref._Z30decode_preprocessed_randomnessP17mpcith_randomnessP18mpcith_range_proofPKh(r2, e2, buf)
+    exp = bytearray(img["rand"])  # the decoder copies f, NTT_f, share_x, share_y -- not the (unused) share_vec.len words
+    M = oracle.params(k).M
+    for i in range(2 * M):
+        exp[2 * M * 512 + i * 5824: 2 * M * 512 + i * 5824 + 8] = bytes(8)
+    assert r2.raw == bytes(exp)
+    assert e2.raw == b"\xAA" * len(img["range"])  # untouched: the reference's decoder never writes eta_shares
