@@ -1,16 +1,31 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Kyber-768 KOSK proofs/s (prove + verify) on N MI355X.
+"""Headline benchmark: Kyber KOSK proofs/s (key generation + prove + verify) on N MI355X.
 
-One "step" = one pass of the hot path over one batch of synthetic input per GPU:
-B = 46 independent Kyber-768 verifiable-keygen proofs (46 x 1454 = 66 884 party
-lanes >= the 65 536 of BASELINE.json configs[2]) are PROVED and then VERIFIED, with the
-randomness tapes, key material and (for verify) proof images already resident in HBM.
-Several whole batches are kept in flight per GPU (--slots, one HIP stream each): the protocol has
-two host Fiat-Shamir round trips per prove and per verify, and a slot's host phase hides under
-another slot's kernels.  Every step is still a complete prove + verify of its own 46 proofs.
-Ranks shard by proof (independent units, no data-path collective): scaling = weak.
+One "step" = one pass of the hot path over one batch of synthetic input per GPU, through the two reference calls as
+resident library calls:
+    kosk_verifiable_keygen_resident   kyber_verifiable_keygen  (kosk.cpp:72-86): GPU key generation, offline + online
+                                      prover; pk/sk come back to the host, the proofs stay in HBM
+    kosk_verify_resident_pk           kyber_kosk_verify        (kosk.cpp:88-117): pk decoding + gen_matrix, verifier
+Inputs (randomness tapes) are resident in HBM when the timed region starts; every step reads a different tape set
+(--tape-sets per slot, rotated).  Every verify bit of every step is asserted.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+--config picks the BASELINE.json workload (1-based, as VERDICT/SURVEY number them; configs[c-1] of BASELINE.json):
+    2  Kyber-512,  46 proofs  = 66 884 party lanes per GPU per step
+    3  Kyber-768,  46 proofs  = 66 884 party lanes per GPU per step            (default: the metric's configuration)
+    4  Kyber-1024, 91 proofs  = 132 314 party lanes per GPU per step (2^20 lanes over 8 GPUs, proof-aligned), with the
+       Tcomm and view-commitment digest tables all-gathered (RCCL) from HBM after each commitment round
+    5  Kyber-768, 512 proofs per GPU per step (4096 keygens over 8 GPUs, throughput mode): proofs/s, batch latency,
+       batch-of-1 latency
+
+Several whole batches are kept in flight per GPU (--slots, one library context = one HIP stream + host threads each):
+the protocol has two host Fiat-Shamir round trips per prove and per verify, and a slot's host phase hides under another
+slot's kernels.  Timing: the slots run continuously; W warm-up steps, then EXACTLY K steps are timed from the completion
+of step W to the completion of step W+K (a steady-state window: the pipeline is full on both edges), then S more steps
+drain untimed.  barrier + torch.cuda.synchronize() bracket the whole run; `drained_run` reports the same run timed
+from the first issue to the last completion (fill and drain included).  MAX over ranks; ranks shard by proof (no
+data-path collective): scaling = weak.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 """
@@ -19,24 +34,31 @@ import ctypes as C
 import hashlib
 import json
 import os
+import socket
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# Four host threads per pipeline slot hash as fast as eight here (the 46 proofs are six AVX-512 groups and six slots
-# interleave) and leave more of the node's cores to the other ranks of an N-GPU run.
-os.environ.setdefault("KOSK_HOST_THREADS", "4")
-
-# NOTE: do not run this pipeline with AMD_DIRECT_DISPATCH=0.  It looks 20 % faster, but on ROCm 7.2 stream
-# synchronisation then returns before device-to-host copies into pinned memory have landed: the host hashes
-# stale digests and honest proofs get rejected (tools/stress.py reproduces it).  The default (direct dispatch) is correct.
+# NOTE: the library refuses AMD_DIRECT_DISPATCH=0 (stream synchronisation does not cover D2H copies in that mode on
+# ROCm 7.2: the host would hash stale digests; tools/stress.py reproduces it).
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 
+CONFIGS = {  # 1-based config number -> (kyber_k, proofs per GPU per step, default slots, host threads per slot)
+    2: dict(k=2, batch=46, slots=6, threads=4, what="Kyber-512 (KYBER_K=2), 46 proofs = 66 884 party lanes per GPU per step"),
+    3: dict(k=3, batch=46, slots=6, threads=4, what="Kyber-768 (KYBER_K=3), 46 proofs = 66 884 party lanes per GPU per step"),
+    4: dict(k=4, batch=91, slots=3, threads=6, what="Kyber-1024 (KYBER_K=4), 91 proofs = 132 314 party lanes per GPU per step "
+                                                    "(2^20 lanes over 8 GPUs, proof-aligned), digest tables all-gathered after each commitment round"),
+    5: dict(k=3, batch=512, slots=3, threads=8, what="Kyber-768 (KYBER_K=3), 512 verifiable keygens per GPU per step (4096 over 8 GPUs, throughput mode)"),
+}
+VIEW_MSG = {2: 452, 3: 472, 4: 524}
+TCOMM_MSG = {2: 308, 3: 320, 4: 332}
 
-def tapes_for(k, first, count, nbytes):
+
+def tapes_for(first, count, nbytes):
     return [hashlib.shake_256(("kosk-tape-v1:%d" % (first + b)).encode()).digest(nbytes) for b in range(count)]
 
 
@@ -54,17 +76,15 @@ def cpu_baseline(k, tapes, nproofs):
         raise RuntimeError("oracle rejected its own proofs")
     tot = tp.value + tv.value
     return {"value": nproofs / tot, "unit": "proofs/s", "cores": 1, "kind": "port",
-            "sample": "%d of the batch's proofs (same tapes), kyber_verifiable_keygen + kyber_kosk_verify, "
-                      "single thread, clock(): prove %.2f s + verify %.2f s; host has %d cores"
-                      % (nproofs, tp.value, tv.value, os.cpu_count())}
+            "sample": "%d of the first batch's proofs (same tapes), kyber_verifiable_keygen + kyber_kosk_verify, "
+                      "single thread, clock(): prove %.2f s + verify %.2f s; host reports %d cores, %d usable by this process"
+                      % (nproofs, tp.value, tv.value, os.cpu_count(), len(os.sched_getaffinity(0)))}
 
 
 def kernel_microbench(ctx, torch, k, lanes=65536, reps=20):
-    """Graded kernels at exactly `lanes` lanes (BASELINE.json configs[2]); hipEvent pairs on the ctx stream."""
-    import numpy as np
-    from mpcith_kyber_kosk_amd import api
+    """Graded kernels at exactly `lanes` lanes (BASELINE.json configs[1..2]); hipEvent pairs on the ctx stream."""
     out = {}
-    tc_words = api.lib.kosk_pk_bytes(k) * 0 + {2: 154, 3: 160, 4: 166}[k]
+    tc_words = {2: 154, 3: 160, 4: 166}[k]
     vw_words = {2: 210, 3: 220, 4: 246}[k]
     g = torch.Generator(device="cuda"); g.manual_seed(1)
     rows = torch.randint(0, 3329, (vw_words, lanes), dtype=torch.int16, device="cuda", generator=g)
@@ -83,8 +103,7 @@ def kernel_microbench(ctx, torch, k, lanes=65536, reps=20):
         perms = lanes * ((2 * words + 32 * wp) // 136 + 1)
         out[name] = {"lanes": lanes, "msg_bytes": 2 * words + 32 * wp, "us": ms * 1e3, "GBps": nbytes / ms / 1e6,
                      "frac_hbm_peak": nbytes / ms / 1e6 / HBM_PEAK_GBS, "keccak_f_per_s": perms / ms * 1e3}
-    # the same view-hash kernel with enough lanes to give every SIMD >= 4 waves (its saturated rate)
-    for big in (262144, 1048576):
+    for big in (262144, 1048576):  # the same view-hash kernel with several waves per SIMD (its saturated rate)
         rows_b = torch.randint(0, 3329, (vw_words, big), dtype=torch.int16, device="cuda", generator=g)
         pre_b = torch.randint(0, 256, (big, 32), dtype=torch.uint8, device="cuda", generator=g)
         dig_b = torch.zeros((big, 32), dtype=torch.uint8, device="cuda")
@@ -98,7 +117,7 @@ def kernel_microbench(ctx, torch, k, lanes=65536, reps=20):
         ms = ctx.timer_stop_ms() / 5
         nbytes = big * (2 * vw_words + 64)
         out["sha3_view_%d_lanes" % big] = {"us": ms * 1e3, "GBps": nbytes / ms / 1e6, "frac_hbm_peak": nbytes / ms / 1e6 / HBM_PEAK_GBS,
-                                           "keccak_f_per_s": big * 4 / ms * 1e3}
+                                           "keccak_f_per_s": big * ((2 * vw_words + 32) // 136 + 1) / ms * 1e3}
         del rows_b, pre_b, dig_b
     polys = torch.randint(0, 3329, (lanes, 256), dtype=torch.int16, device="cuda", generator=g)
     outp = torch.zeros_like(polys)
@@ -114,18 +133,16 @@ def kernel_microbench(ctx, torch, k, lanes=65536, reps=20):
     return out
 
 
-def extras(api, torch, k, B, tapes):
-    """Untimed-region extras for DESIGN.md: PCIe-inclusive end-to-end rate and a throughput-mode sample."""
+def pcie_inclusive(api, k, B, tapes):
+    """For DESIGN.md only (never `value`): the two top-level ABI calls on HOST buffers, one caller thread."""
     out = {}
-    import ctypes as C
     c = api.Kosk(kyber_k=k, max_batch=B)
     blob = C.create_string_buffer(b"".join(tapes), c.tape_bytes * B)
     pk = C.create_string_buffer(c.pk_bytes * B); sk = C.create_string_buffer(c.sk_bytes * B)
     pi = C.create_string_buffer(c.proof_bytes * B); okb = C.create_string_buffer(B)
     lib, h = api.lib, c.handle
 
-    def once():
-        # the two top-level ABI calls on HOST buffers: host keygen, tape H2D, proof D2H (31 MB), proof/pk H2D for verify
+    def once():  # tape H2D, proofs D2H (B x 0.68 MB), proofs + pk H2D for verify
         assert lib.kosk_verifiable_keygen_batch(h, B, blob, c.tape_bytes, pk, sk, pi) == 0
         assert lib.kosk_verify_batch(h, B, pi, pk, okb) == 0 and okb.raw == b"\x01" * B
     once()
@@ -134,13 +151,11 @@ def extras(api, torch, k, B, tapes):
     for _ in range(reps):
         once()
     out["pcie_inclusive_proofs_per_s"] = reps * B / (time.perf_counter() - t0)
-    # the same with the compact wire format: proofs cross PCIe at 78 % of the image size, packed / unpacked on the GPU
     cb = lib.kosk_compact_proof_bytes(k)
     blobs = C.create_string_buffer(cb * B)
 
-    def once_compact():
-        assert lib.kosk_stage_prover_inputs(h, B, blob, c.tape_bytes, pk, sk) == 0
-        assert lib.kosk_prove_resident(h, B) == 0
+    def once_compact():  # the same with the compact wire format: 78 % of the image size over PCIe
+        assert lib.kosk_verifiable_keygen_resident(h, B, blob, c.tape_bytes, pk, sk) == 0
         assert lib.kosk_fetch_proofs_compact(h, B, blobs) == 0
         assert lib.kosk_stage_verifier_inputs_compact(h, B, blobs, pk) == 0
         assert lib.kosk_verify_resident(h, B, okb) == 0 and okb.raw == b"\x01" * B
@@ -151,73 +166,85 @@ def extras(api, torch, k, B, tapes):
     out["pcie_inclusive_compact_proofs_per_s"] = reps * B / (time.perf_counter() - t0)
     out["compact_proof_bytes"] = cb
     c.close()
-    import threading
-    # the host-buffer calls from three caller threads with a context each (how a host application reaches throughput:
-    # one context's PCIe copies and host hashing hide under another's kernels)
-    SP = 3
-    ctxs = [api.Kosk(kyber_k=k, max_batch=B) for _ in range(SP)]
-    bufs = [(C.create_string_buffer(cc.pk_bytes * B), C.create_string_buffer(cc.sk_bytes * B), C.create_string_buffer(cc.proof_bytes * B),
-             C.create_string_buffer(B)) for cc in ctxs]
-
-    def host_calls(i, n):
-        cc, (pk_, sk_, pi_, ok_) = ctxs[i], bufs[i]
-        for _ in range(n):
-            assert lib.kosk_verifiable_keygen_batch(cc.handle, B, blob, cc.tape_bytes, pk_, sk_, pi_) == 0
-            assert lib.kosk_verify_batch(cc.handle, B, pi_, pk_, ok_) == 0 and ok_.raw == b"\x01" * B
-    for i in range(SP):
-        host_calls(i, 1)
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=host_calls, args=(i, reps)) for i in range(SP)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    out["pcie_inclusive_3_callers_proofs_per_s"] = SP * reps * B / (time.perf_counter() - t0)
-    for cc in ctxs:
-        cc.close()
-    BT, ST, steps = 512, 2, 3
-    slots = [api.Kosk(kyber_k=k, max_batch=BT) for _ in range(ST)]
-    for si, sc in enumerate(slots):
-        sc.stage_prover_inputs(tapes_for(k, 1000 + si * BT, BT, sc.tape_bytes))
-
-    def work(sc):
-        for _ in range(steps):
-            sc.prove_resident(BT)
-            assert all(sc.verify_resident(BT))
-    for sc in slots:
-        work_warm = threading.Thread(target=lambda s_=sc: (s_.prove_resident(BT), s_.verify_resident(BT)))
-        work_warm.start(); work_warm.join()
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=work, args=(sc,)) for sc in slots]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dtt = time.perf_counter() - t0
-    out["throughput_mode"] = {"proofs_per_batch": BT, "slots": ST, "proofs_per_s": ST * steps * BT / dtt,
-                              "batch_latency_ms": dtt / steps * 1e3, "note": "BASELINE configs[4] per-GPU share: 512 Kyber-768 keygens in one batch"}
-    for sc in slots:
-        sc.close()
     return out
+
+
+class Slot:
+    """One pipeline slot: a library context with its tape bank in HBM (and, for config 4, its own process group)."""
+
+    def __init__(self, api, torch, k, B, device, first_tape, nsets):
+        self.c = api.Kosk(kyber_k=k, max_batch=B, device=device)
+        self.B, self.nsets = B, nsets
+        self.stride = (self.c.tape_bytes + 63) // 64 * 64
+        import numpy as np
+        host = np.zeros((nsets, B, self.stride), np.uint8)
+        self.first_tapes = None
+        for s in range(nsets):
+            tp = tapes_for(first_tape + s * B, B, self.c.tape_bytes)
+            if s == 0:
+                self.first_tapes = tp
+            for b, t in enumerate(tp):
+                host[s, b, :len(t)] = np.frombuffer(t, np.uint8)
+        self.bank = torch.from_numpy(host).to("cuda:%d" % device)  # randomness resident in HBM
+        self.gather = None  # config 4: (dist, group, [out0, out1], world)
+        self.pending = []
+        self.steps_done = 0
+
+    def step(self, torch, index):
+        c, B = self.c, self.B
+        ptr = self.bank[index % self.nsets].data_ptr()
+        c.verifiable_keygen_resident(ptr, n=B, tape_stride=self.stride)
+        if self.pending:
+            # the verifier reuses the digest tables: the all-gathers that read them must have completed
+            for w in self.pending:
+                w.wait()
+            torch.cuda.current_stream().synchronize()
+            self.pending = []
+        ok = c.verify_resident_pk(B)
+        if not all(ok):
+            raise RuntimeError("verifier rejected %d of %d honest proofs (masks %s)" % (ok.count(False), B, c.fail_masks(B)[:8]))
+        self.steps_done += 1
+
+    def enable_gather(self, api, torch, dist, group, world):
+        B = self.B
+        # concatenation form [world * B][1454][32] (rank-major = global proof order of the contiguous partition)
+        outs = [torch.empty((world * B, 1454, 32), dtype=torch.uint8, device=self.bank.device) for _ in range(2)]
+        self.gather = (dist, group, outs, world)
+
+        def hook(role, rnd, ptr, nbytes):
+            if role != 0:
+                return  # the verifier's tables are the prover's again (opened digests recomputed, the rest from the proof)
+            assert nbytes == B * 1454 * 32
+            src = torch.as_tensor(api.DeviceView(ptr, (B, 1454, 32)), device=self.bank.device)
+            self.pending.append(dist.all_gather_into_tensor(outs[rnd], src, group=group, async_op=True))
+        self.c.set_round_hook(hook)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--kyber-k", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=46, help="proofs per GPU per step (46 x 1454 = 66 884 party lanes)")
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS), help="BASELINE.json workload, 1-based (see the module docstring)")
+    ap.add_argument("--kyber-k", type=int, default=0, help="override the configuration's KYBER_K")
+    ap.add_argument("--batch", type=int, default=0, help="override the configuration's proofs per GPU per step")
+    ap.add_argument("--slots", type=int, default=int(os.environ.get("KOSK_BENCH_SLOTS", "0")),
+                    help="independent batches kept in flight per GPU (own HIP stream + host threads each); 0 = the configuration's "
+                         "default.  Never depends on --steps.")
+    ap.add_argument("--tape-sets", type=int, default=4, help="distinct resident tape sets per slot, rotated step by step")
     ap.add_argument("--cpu-proofs", type=int, default=12, help="bounded CPU baseline sample (about 13 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernels", action="store_true")
-    ap.add_argument("--slots", type=int, default=int(os.environ.get("KOSK_BENCH_SLOTS", "0")),
-                    help="independent batches kept in flight per GPU (own HIP stream + host threads each); steps are dealt "
-                         "round-robin to the slots.  0 = by run length: 7 for >= 200 timed steps, else 3 (a short run never "
-                         "reaches the steady interleaving of many slots: K=20 gives 70 k proofs/s with 3 slots, 38 k with 7)")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the 65 536-lane kernel leg and the PCIe-inclusive extras")
     args = ap.parse_args()
-    if args.slots <= 0:
-        args.slots = 7 if args.steps >= 200 else 3
+    cfg = dict(CONFIGS[args.config])
+    if args.kyber_k:
+        cfg["k"] = args.kyber_k
+    if args.batch:
+        cfg["batch"] = args.batch
+    custom = bool(args.kyber_k or args.batch)
+    k, B = cfg["k"], cfg["batch"]
+    S = args.slots if args.slots > 0 else cfg["slots"]
+    os.environ.setdefault("KOSK_HOST_THREADS", str(cfg["threads"]))
 
     import torch
     if not torch.cuda.is_available():
@@ -233,179 +260,244 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    want_gather = args.config == 4 and not custom
+    if world > 1 or want_gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:  # plain `python bench.py --config 4`: a one-rank RCCL job
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from mpcith_kyber_kosk_amd import api
-    import threading
-    k, B, S = args.kyber_k, args.batch, max(1, args.slots)
-    # S pipeline slots: each owns a context (HIP stream, HBM workspace, host worker threads) and a resident
-    # batch of B proofs' inputs.  While one slot waits for a host Fiat-Shamir round, the GPU runs another's kernels.
-    slots = [api.Kosk(kyber_k=k, max_batch=B, device=local_rank) for _ in range(S)]
-    ctx = slots[0]
-    tapes = None
-    for si, c in enumerate(slots):
-        t = tapes_for(k, (rank * S + si) * B, B, c.tape_bytes)
-        if si == 0:
-            tapes = t
-        c.stage_prover_inputs(t)  # randomness tapes + key material -> HBM (outside the timed region)
-        # setup, not a benchmark step: first use allocates the verifier workspace and builds its tables
-        c.prove_resident(B)
-        assert all(c.verify_resident(B))
+    from mpcith_kyber_kosk_amd import api, sharding
+    slots = [Slot(api, torch, k, B, local_rank, ((rank * S + si) * args.tape_sets) * B, args.tape_sets) for si in range(S)]
+    ctx = slots[0].c
+    tapes = slots[0].first_tapes
+    if want_gather:
+        if rehearse:
+            raise SystemExit("config 4 gathers device tensors over RCCL: no gloo rehearsal")
+        for sl in slots:  # one communicator per slot: each slot issues its collectives in its own fixed order
+            sl.enable_gather(api, torch, dist, dist.new_group(list(range(world))), world)
+    for sl in slots:  # setup, not a benchmark step: first use allocates the verifier workspace and builds its tables
+        sl.step(torch, 0)
 
-    def step(c):
-        c.prove_resident(B)
-        ok = c.verify_resident(B)
-        if not all(ok):
-            raise RuntimeError("rank %d: verifier rejected %d of %d honest proofs" % (rank, ok.count(False), B))
+    W, K = max(0, args.warmup), max(1, args.steps)
+    D = S  # untimed drain: the window's last steps finish with the pipeline still full
+    total = W + K + D
+    state = {"next": 0, "limit": 0, "err": None}
+    lock = threading.Lock()
+    done_t = []
+    lat = []
+    static = want_gather  # collectives: every rank must run the same steps on the same slot
 
-    # one persistent worker thread per slot (created once: a thread's first HIP call pays thread-local set-up)
-    import queue
-    jobs = [queue.Queue() for _ in range(S)]
-    done = queue.Queue()
+    def take(si, nth):
+        """index of slot si's nth step of this run, or None when the run is over"""
+        if static:
+            i = si + nth * S
+            return i if i < state["limit"] and state["err"] is None else None
+        with lock:
+            i = state["next"]
+            if i >= state["limit"] or state["err"] is not None:
+                return None
+            state["next"] = i + 1
+            return i
 
-    def worker(si):
+    def worker(si, go, fin):
+        sl = slots[si]
         while True:
-            n_my = jobs[si].get()
-            if n_my is None:
+            go.wait(); go.clear()
+            if state["limit"] < 0:
                 return
-            err = None
             try:
-                for _ in range(n_my):
-                    step(slots[si])
+                nth = 0
+                while True:
+                    i = take(si, nth)
+                    if i is None:
+                        break
+                    nth += 1
+                    t_a = time.perf_counter()
+                    sl.step(torch, i)
+                    t_b = time.perf_counter()
+                    with lock:
+                        done_t.append(t_b)
+                        lat.append(t_b - t_a)
             except Exception as e:  # noqa: BLE001
-                err = e
-            done.put(err)
-    workers = [threading.Thread(target=worker, args=(si,), daemon=True) for si in range(S)]
+                with lock:
+                    state["err"] = e
+            fin.set()
+    gos = [threading.Event() for _ in range(S)]
+    fins = [threading.Event() for _ in range(S)]
+    workers = [threading.Thread(target=worker, args=(si, gos[si], fins[si]), daemon=True) for si in range(S)]
     for wt in workers:
         wt.start()
 
-    def run_steps(nsteps):
-        """deal nsteps whole batches round-robin to the slots; returns when all are proved and verified"""
-        for si in range(S):
-            jobs[si].put(len(range(si, nsteps, S)))
-        errs = [done.get() for _ in range(S)]
-        for e in errs:
-            if e is not None:
-                raise e
-
-    run_steps(S)  # setup: every worker thread touches the GPU once before anything is timed
-    # conditioning (setup, untimed, independent of --warmup): a freshly started process measures 3 ms per step for its
-    # first dozens of steps (GPU clocks, runtime and worker threads still ramping); a driver that asks for a handful of
-    # steps should time the machine in its working state, so run the pipeline for ~0.25 s first
-    t_cond = time.perf_counter()
-    while time.perf_counter() - t_cond < float(os.environ.get("KOSK_BENCH_CONDITION_S", "0.25")):
-        run_steps(4 * S)
+    def run(nsteps):
+        """nsteps whole steps through the S slots, back to back; returns (start time, completion times, step latencies)"""
+        with lock:
+            state["next"], state["limit"] = 0, nsteps
+            del done_t[:]
+            del lat[:]
+        t_s = time.perf_counter()
+        for g_ in gos:
+            g_.set()
+        for f_ in fins:
+            f_.wait(); f_.clear()
+        if state["err"] is not None:
+            raise state["err"]
+        return t_s, sorted(done_t), list(lat)
 
     def barrier():
         torch.cuda.synchronize()
-        for c in slots:
-            c.synchronize()
+        for sl in slots:
+            sl.c.synchronize()
         if dist is not None:
             dist.barrier()
 
-    run_steps(args.warmup)
-    for c in slots:
-        c.profile_enable(True)
+    # conditioning (setup, untimed, independent of --warmup/--steps): clocks, runtime and worker threads of a fresh
+    # process ramp for a few hundred milliseconds
+    t_cond = time.perf_counter()
+    if static:
+        for _ in range(3):  # a fixed count: every rank must issue the same collectives
+            run(2 * S)
+    else:
+        while time.perf_counter() - t_cond < float(os.environ.get("KOSK_BENCH_CONDITION_S", "0.3")):
+            run(2 * S)
+    for sl in slots:
+        sl.c.profile_enable(True)
     import resource
     barrier()
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
-    t0 = time.perf_counter()
-    run_steps(args.steps)
+    t_s, comp, lats = run(total)
     barrier()
-    dt = time.perf_counter() - t0
+    t_e = time.perf_counter()
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    t0 = comp[W - 1] if W > 0 else t_s
+    t1 = comp[W + K - 1]
+    dt = t1 - t0
+    dt_drained = t_e - t_s
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     prof = {}
-    for c in slots:
-        for name, (ms, cnt_) in c.profile_read().items():
+    for sl in slots:
+        for name, (ms, cnt_) in sl.c.profile_read().items():
             a, b = prof.get(name, (0.0, 0))
             prof[name] = (a + ms, b + cnt_)
-        c.profile_enable(False)
+        sl.c.profile_enable(False)
     phases = ctx.phase_seconds()
+    gather_info = None
+    if want_gather:
+        # the gathered tables: this rank's block must be its own digest table (the verifier rebuilt the same table)
+        sl = slots[0]
+        _, _, outs, _ = sl.gather
+        for w_ in sl.pending:
+            w_.wait()
+        torch.cuda.synchronize()
+        same = all(bool(torch.equal(outs[r].view(world, B, 1454, 32)[rank], torch.as_tensor(sl.c.resident_digests(r, B), device=outs[r].device))) for r in (0, 1))
+        if not same:
+            raise RuntimeError("all-gathered digest table differs from the resident one")
+        gather_info = {"collective": "all_gather_into_tensor (RCCL)", "tables_per_step": 2, "bytes_per_rank_per_table": B * 1454 * 32,
+                       "gathered_shape": list(outs[0].shape), "own_block_matches_resident_table": True}
     if dist is not None:
         cdev = "cpu" if rehearse else "cuda"
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        t = torch.tensor([dt, dt_drained], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        # result gather: how many proofs verified across the job (not part of the timed data path)
-        cnt = torch.tensor([B * args.steps], dtype=torch.int64, device=cdev)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        total = int(cnt.item())
-        # and a digest per rank over its last batch of proofs, all-gathered (RCCL over xGMI on a real node)
-        from mpcith_kyber_kosk_amd import sharding
-        pr = slots[0].fetch_proofs(B)
-        mine = torch.frombuffer(bytearray(hashlib.sha3_256(b"".join(pr)).digest()), dtype=torch.uint8).reshape(1, 32).to(cdev)
-        table = sharding.allgather_digest_table(mine, world, dist)
-        assert table.shape == (world, 32) and bytes(table[rank].tolist()) == bytes(mine[0].tolist())
-    else:
-        total = B * args.steps
+        dt, dt_drained = float(t[0].item()), float(t[1].item())
+        if not want_gather:
+            # result gather (not on the data path): one digest per rank over its last batch of proofs
+            pr = slots[0].c.fetch_proofs(B)
+            mine = torch.frombuffer(bytearray(hashlib.sha3_256(b"".join(pr)).digest()), dtype=torch.uint8).reshape(1, 32).to(cdev)
+            table = sharding.allgather_digest_table(mine, world, dist)
+            assert table.shape == (world, 32) and bytes(table[rank].tolist()) == bytes(mine[0].tolist())
 
     if rank == 0:
-        p_view = {2: 452, 3: 472, 4: 524}[k]
-        p_tcomm = {2: 308, 3: 320, 4: 332}[k]
         kern = {}
         for name, (ms, cnt_) in prof.items():
             if cnt_:
                 kern[name] = {"avg_us": ms / cnt_ * 1e3, "launches": cnt_, "total_ms": ms}
-        # graded kernel: the SHA3-256 view commitment (K4); algorithmic bytes = message + digest per party lane.
-        # A step's lanes are spread over `streams` launches (one per sub-batch), so bytes/launch = total/launches.
+        # graded kernel: the SHA3-256 view commitment (K4); algorithmic bytes = message + digest per party lane
         hv = kern.get("hash_view")
         roof = None
-        lanes_total = args.steps * B * 1454
         if hv:
-            nbytes = lanes_total * (p_view + 32) / hv["launches"]
+            lanes_per_launch = B * 1454
+            nbytes = lanes_per_launch * (VIEW_MSG[k] + 32)
             ach = nbytes / (hv["avg_us"] * 1e-6) / 1e9
-            traffic = None
+            traffic, tsrc = None, None
             tfile = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tfile):
-                traffic = json.load(open(tfile)).get("hash_view_hbm_bytes_per_launch")
-            roof = {"kernel": "k_commit_hash<16,220> (SHA3-256 view commitment, one party lane per thread)",
+            if os.path.exists(tfile) and k == 3 and B == 46:
+                tj = json.load(open(tfile))
+                traffic, tsrc = tj.get("hash_view_hbm_bytes_per_launch"), tj.get("source")
+            roof = {"kernel": "k_commit_hash (SHA3-256 view commitment, prover, %d party lanes per launch)" % lanes_per_launch,
                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": hv["avg_us"],
-                    "lanes_per_launch": lanes_total / hv["launches"]}
+                    "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": hv["avg_us"],
+                    "lanes_per_launch": lanes_per_launch,
+                    "note": "HIP events on the slot's stream inside the run; %d slots share the GPU, so a launch's duration includes "
+                            "co-running kernels of other slots" % S}
             ht = kern.get("hash_tcomm")
             if ht:
-                ht["GBps"] = lanes_total * (p_tcomm + 32) / (ht["total_ms"] * 1e-3) / 1e9
+                ht["GBps"] = B * 1454 * (TCOMM_MSG[k] + 32) / (ht["avg_us"] * 1e-6) / 1e9
             hv["GBps"] = ach
         g1 = kern.get("gemm_expand1")
         if g1:
             rows = {2: 214 - 6, 3: 226 - 9, 4: 254 - 12}[k]
-            g1["useful_GMACps"] = args.steps * B * rows * 1303 * 407 / (g1["total_ms"] * 1e-3) / 1e9
+            g1["useful_GMACps"] = B * rows * 1303 * 407 / (g1["avg_us"] * 1e-6) / 1e9
+        lats.sort()
         line = {
             "metric": "kyber768_kosk_proofs_per_sec_prove_plus_verify" if k == 3 else "kyber%d_kosk_proofs_per_sec_prove_plus_verify" % (256 * k),
-            "value": total / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": world * K * B / dt, "unit": "proofs/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
-            "config": {"workload": "Kyber-768 (KYBER_K=3), 46 proofs = 66 884 party lanes per GPU per step, "
-                                   "prove (offline+online) + verify, inputs resident in HBM" if k == 3 and B == 46 else
-                                   "KYBER_K=%d, %d proofs per GPU per step, prove + verify" % (k, B),
-                       "kyber_k": k, "proofs_per_gpu": B, "party_lanes_per_gpu": B * 1454, "sharding": "by proof",
-                       "pipeline_slots_per_gpu": S, "host_threads_per_slot": os.environ.get("KOSK_HOST_THREADS", "4")},
+            "config": {"workload": (cfg["what"] if not custom else "KYBER_K=%d, %d proofs per GPU per step" % (k, B)) +
+                                   ": kyber_verifiable_keygen (GPU key generation + offline + online prover) + kyber_kosk_verify (pk decoding + "
+                                   "verifier), randomness tapes resident in HBM, a different tape set every step",
+                       "baseline_config": "configs[%d]" % (args.config - 1), "kyber_k": k, "proofs_per_gpu": B, "party_lanes_per_gpu": B * 1454,
+                       "sharding": "by proof", "pipeline_slots_per_gpu": S, "tape_sets_per_slot": args.tape_sets,
+                       "host_threads_per_slot": os.environ.get("KOSK_HOST_THREADS"),
+                       "timing": "steady-state window: completion of step W to completion of step W+K, slots running continuously"},
+            "drained_run": {"steps": total, "ms_per_step": dt_drained / total * 1e3, "value": world * total * B / dt_drained,
+                            "note": "the same run from first issue to last completion, barrier + synchronize on both sides (fill and drain included)"},
+            "step_latency_ms": {"median": lats[len(lats) // 2] * 1e3, "p90": lats[int(len(lats) * 0.9)] * 1e3,
+                                "note": "one slot's keygen + prove + verify of its %d proofs while the other slots run" % B},
             "roofline": roof,
-            "host_cpu_cores_busy": round(host_cpu_s / (time.perf_counter() - t0), 2) if False else round(host_cpu_s / max(dt, 1e-9), 2),
+            "host_cpu_cores_busy": round(host_cpu_s / max(dt_drained, 1e-9), 2),
+            "host_cpus_usable": len(os.sched_getaffinity(0)),
             "kernels_in_pipeline": kern,
+            "profiled_kernel_ms_per_step": round(sum(v["total_ms"] for v in kern.values()) / max(1, sum(sl.steps_done for sl in slots) - S), 4),
             "prove_phase_ms": dict(zip(["host_pre", "gpu_commit", "fs_alpha_host", "gpu_relation", "fs_open_host", "gpu_assemble", "d2h"],
                                        [round(x * 1e3, 3) for x in phases])),
         }
-        if world == 1 and not args.no_kernels:
+        if gather_info:
+            line["digest_allgather"] = gather_info
+        if args.config == 5 and not custom:
+            # batch-of-1 latency: one verifiable keygen + verify alone on an idle GPU
+            c1 = api.Kosk(kyber_k=k, max_batch=1, device=local_rank)
+            t1s = []
+            tp1 = tapes_for(10 ** 6, 12, c1.tape_bytes)
+            for i in range(12):
+                ta = time.perf_counter()
+                c1.verifiable_keygen_resident([tp1[i]])
+                assert c1.verify_resident_pk(1) == [True]
+                t1s.append(time.perf_counter() - ta)
+            t1s = sorted(t1s[2:])
+            c1.close()
+            line["latency"] = {"batch_of_512_ms_median": lats[len(lats) // 2] * 1e3, "batch_of_1_ms_median": t1s[len(t1s) // 2] * 1e3,
+                               "per_proof_us_at_throughput": dt / K / B * 1e6}
+        if world == 1 and not args.no_kernels and args.config in (2, 3) and not custom:
             line["kernels_65536_lanes"] = kernel_microbench(ctx, torch, k)
-            line["extras"] = extras(api, torch, k, B, tapes)
+            line["extras"] = pcie_inclusive(api, k, B, tapes)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(k, tapes, min(args.cpu_proofs, B))
         print(json.dumps(line))
+    state["limit"] = -1
+    for g_ in gos:
+        g_.set()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    for q in jobs:
-        q.put(None)
-    for c in slots:
-        c.close()
+    for sl in slots:
+        sl.c.close()
 
 
 if __name__ == "__main__":

@@ -87,6 +87,15 @@ int kosk_prove_resident(kosk_ctx *ctx, int n);
 int kosk_fetch_proofs(kosk_ctx *ctx, int n, uint8_t *pi);
 int kosk_stage_verifier_inputs(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk);
 int kosk_verify_resident(kosk_ctx *ctx, int n, uint8_t *ok);
+/* The two reference calls as ONE resident call each (what bench.py times):
+ * kyber_verifiable_keygen (kosk.cpp:72-86) -- key generation (kosk.cpp:4-70) runs on the device at the head of the
+ * prover's first segment, pk / sk are written to the HOST buffers, the proofs stay in HBM.  `tapes` may be host or DEVICE
+ * memory (a device buffer whose base and tape_stride are multiples of 8 is read in place) or NULL (randombytes callback).
+ * kyber_kosk_verify (kosk.cpp:88-117) on the resident proofs -- polyvec_frombytes(t) + gen_matrix (kosk.cpp:94-99) run at
+ * the head of the verifier's first segment from `pk` (host or device memory), or, with pk == NULL, from the pk bytes the
+ * key generation left in HBM. */
+int kosk_verifiable_keygen_resident(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk);
+int kosk_verify_resident_pk(kosk_ctx *ctx, int n, const uint8_t *pk, uint8_t *ok);
 /* ---- Compact wire format (no reference counterpart: the reference ships the raw image of
  * mpcith_proof, mlwe_prover.cpp:540-543).  Same 24 fields in the same order, every u16 field packed two values into
  * three bytes (12 bits each, the bit order of Kyber's poly_tobytes, kyber/poly.c:128-147), the two digest fields raw,
@@ -146,6 +155,16 @@ int kosk_streams(const kosk_ctx *ctx);
 /* device pointer / stride of the resident proof images of sub-batch 0, for callers chaining work in HBM
  * (with KOSK_STREAMS=1 this is the whole batch) */
 int kosk_resident_proofs(kosk_ctx *ctx, void **d_proofs, size_t *stride);
+/* The per-party commitment digests in HBM: round 0 = Tcomm[1454][32] of every proof of the last batch
+ * (mlwe_prover.cpp:116-127, the input of sha3_256(Tcomm[0..N)) at :130-135), round 1 = the view commitments
+ * (:397-444, input of :445-449); `stride` = bytes per proof (1454 * 32).  This is what a multi-GPU job all-gathers
+ * (RCCL) after each commitment round (BASELINE.json configs[3]).  Needs KOSK_STREAMS=1. */
+int kosk_resident_digests(kosk_ctx *ctx, int round, void **d_digests, size_t *stride);
+/* Called on the calling thread as soon as a round's table is complete in HBM and the context's stream is idle
+ * (role 0 prover / 1 verifier; round as above; bytes = n * 1454 * 32): the place to start that all-gather so that it
+ * overlaps the host's Fiat-Shamir hashing.  fn == NULL removes the hook. */
+typedef void (*kosk_round_fn)(void *user, int role, int round, const void *d_digests, size_t bytes);
+int kosk_set_round_hook(kosk_ctx *ctx, kosk_round_fn fn, void *user);
 
 /* ---- host-only pieces of the path (no device needed) ------------------------ */
 

@@ -50,6 +50,10 @@ def _load():
         "kosk_fetch_proofs": (C.c_int, [vp, C.c_int, vp]),
         "kosk_stage_verifier_inputs": (C.c_int, [vp, C.c_int, vp, vp]),
         "kosk_verify_resident": (C.c_int, [vp, C.c_int, vp]),
+        "kosk_verifiable_keygen_resident": (C.c_int, [vp, C.c_int, vp, sz, vp, vp]),
+        "kosk_verify_resident_pk": (C.c_int, [vp, C.c_int, vp, vp]),
+        "kosk_resident_digests": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(sz)]),
+        "kosk_set_round_hook": (C.c_int, [vp, vp, vp]),
         "kosk_phase_seconds": (C.c_int, [vp, C.POINTER(C.c_double), C.c_int]),
         "kosk_sha3_256_batch": (C.c_int, [vp, vp, sz, sz, vp, C.c_int]),
         "kosk_shake256_batch": (C.c_int, [vp, vp, sz, sz, vp, sz, C.c_int]),
@@ -85,7 +89,8 @@ EXPORTS = ["kosk_pk_bytes", "kosk_sk_bytes", "kosk_proof_bytes", "kosk_tape_byte
            "kosk_verify_fail_masks", "kosk_randomness_bytes", "kosk_range_proof_bytes", "kosk_mlwe_inst_bytes",
            "kosk_prepare_randomness", "kosk_prepare_range_proof", "kosk_prove_prepared", "kosk_verify_inst", "kosk_compact_proof_bytes",
            "kosk_proof_compress", "kosk_proof_decompress", "kosk_fetch_proofs_compact", "kosk_stage_verifier_inputs_compact", "kosk_stage_prover_inputs", "kosk_prove_resident", "kosk_fetch_proofs",
-           "kosk_stage_verifier_inputs", "kosk_verify_resident", "kosk_phase_seconds", "kosk_sha3_256_batch",
+           "kosk_stage_verifier_inputs", "kosk_verify_resident", "kosk_verifiable_keygen_resident", "kosk_verify_resident_pk",
+           "kosk_resident_digests", "kosk_set_round_hook", "kosk_phase_seconds", "kosk_sha3_256_batch",
            "kosk_shake256_batch", "kosk_commit_hash_lanes", "kosk_ntt256_batch", "kosk_lagrange_expand",
            "kosk_recon_secrets", "kosk_profile_enable", "kosk_profile_read", "kosk_stream_timer_start", "kosk_stream_timer_stop", "kosk_device_synchronize", "kosk_streams", "kosk_resident_proofs", "kosk_keygen", "kosk_fs_alpha",
            "kosk_fs_opened", "kosk_host_sha3_256", "kosk_host_shake256", "kosk_host_sha3_256_multi", "kosk_lagrange_table"]
@@ -135,6 +140,13 @@ def host_shake256(data, outlen):
     return out.raw
 
 
+class DeviceView:
+    """A window on library-owned HBM for torch (torch.as_tensor(view, device="cuda") is zero-copy): uint8, C-contiguous."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "|u1", "data": (int(ptr), False), "version": 2, "strides": None}
+
+
 class Kosk:
     """One library context = one GPU, one parameter set, up to max_batch proofs in flight.
 
@@ -152,6 +164,8 @@ class Kosk:
         self.pk_bytes, self.sk_bytes = pk_bytes(kyber_k), sk_bytes(kyber_k)
         self.proof_bytes, self.tape_bytes = proof_bytes(kyber_k), tape_bytes(kyber_k)
         self._cb = None
+        self._hook = None
+        self._pk = self._sk = None
 
     def close(self):
         if self._h:
@@ -278,6 +292,51 @@ class Kosk:
         pi = C.create_string_buffer(self.proof_bytes * n)
         self._chk(lib.kosk_fetch_proofs(self._h, n, pi), "fetch_proofs")
         return [pi.raw[i * self.proof_bytes:(i + 1) * self.proof_bytes] for i in range(n)]
+
+    def verifiable_keygen_resident(self, tapes, n=None, tape_stride=None):
+        """kyber_verifiable_keygen as one resident call: key generation + prove, pk/sk returned, proofs stay in HBM.
+        tapes: list of bytes, or an int DEVICE pointer (with n and tape_stride), or None (callback / OS entropy, with n)."""
+        if isinstance(tapes, int):
+            tp, stride = C.c_void_p(tapes), tape_stride
+        elif tapes is None:
+            tp, stride = None, 0
+        else:
+            n = len(tapes)
+            blob = b"".join(t[:self.tape_bytes] for t in tapes)
+            tp, stride = C.c_char_p(blob), self.tape_bytes
+        if getattr(self, "_pk", None) is None or len(self._pk) != self.pk_bytes * n:
+            self._pk = C.create_string_buffer(self.pk_bytes * n); self._sk = C.create_string_buffer(self.sk_bytes * n)
+        self._chk(lib.kosk_verifiable_keygen_resident(self._h, n, tp, stride, self._pk, self._sk), "verifiable_keygen_resident")
+        return n
+
+    def keys(self, n):
+        """pk, sk lists of the last stage_prover_inputs / verifiable_keygen_resident"""
+        return ([self._pk.raw[i * self.pk_bytes:(i + 1) * self.pk_bytes] for i in range(n)],
+                [self._sk.raw[i * self.sk_bytes:(i + 1) * self.sk_bytes] for i in range(n)])
+
+    def verify_resident_pk(self, n, pks=None):
+        """kyber_kosk_verify on the resident proofs, pk decoding (polyvec_frombytes + gen_matrix) included; pks None = the
+        pk bytes the key generation left in HBM"""
+        ok = C.create_string_buffer(n)
+        self._chk(lib.kosk_verify_resident_pk(self._h, n, C.c_char_p(b"".join(pks)) if pks is not None else None, ok), "verify_resident_pk")
+        return [b == 1 for b in ok.raw]
+
+    def resident_digests(self, rnd, n):
+        """DeviceView of the round's digest table [n][1454][32] (round 0 Tcomm, 1 view commitments)"""
+        d, stride = C.c_void_p(), C.c_size_t()
+        self._chk(lib.kosk_resident_digests(self._h, rnd, C.byref(d), C.byref(stride)), "resident_digests")
+        assert stride.value == 1454 * 32
+        return DeviceView(d.value, (n, 1454, 32))
+
+    def set_round_hook(self, fn):
+        """fn(role, round, device_ptr, nbytes) on the calling thread when a round's digest table is complete in HBM"""
+        if fn is None:
+            self._hook = None
+            self._chk(lib.kosk_set_round_hook(self._h, None, None), "set_round_hook")
+            return
+        CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t)
+        self._hook = CB(lambda _u, role, rnd, ptr, nbytes: fn(role, rnd, ptr, nbytes))
+        self._chk(lib.kosk_set_round_hook(self._h, C.cast(self._hook, C.c_void_p), None), "set_round_hook")
 
     def phase_seconds(self):
         out = (C.c_double * 16)()

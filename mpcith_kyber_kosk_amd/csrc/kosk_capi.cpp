@@ -28,9 +28,16 @@ struct kosk_ctx {
         count = base + (i < rem ? 1 : 0);
         first = i * base + (i < rem ? i : rem);
     }
+    // every entry point starts from a clean error state (kosk_last_error never reports a stale message)
+    void clear_err()
+    {
+        err.clear();
+        for (Ctx *x : sub) x->err.clear();
+    }
     template <typename F>
     int run(int n, F &&fn)
     {
+        clear_err();
         const int S = (int)sub.size();
         std::vector<int> rc(S, 0);
         std::vector<std::thread> th;
@@ -49,7 +56,7 @@ struct kosk_ctx {
     }
 };
 
-static std::string g_create_err;
+static thread_local std::string g_create_err; // error text of the last failed kosk_create on this thread
 
 #define HIPCHK_C(x)                                                        \
     do {                                                                   \
@@ -78,6 +85,14 @@ int kosk_proof_field(int k, int idx, size_t *offset, size_t *size)
 int kosk_create(kosk_ctx **ctx, int device, int kyber_k, int max_batch)
 {
     if (!ctx) return -1;
+    g_create_err.clear();
+    if (const char *e = getenv("AMD_DIRECT_DISPATCH"))
+        if (atoi(e) == 0 && e[0] != '\0') {
+            // measured on ROCm 7.2 (tools/stress.py): with direct dispatch off, hipStreamSynchronize returned before
+            // device-to-host copies into pinned memory had landed; the host then hashed stale digests
+            g_create_err = "AMD_DIRECT_DISPATCH=0 is not supported: stream synchronisation does not cover D2H copies in that mode";
+            return -1;
+        }
     int S = 1; // KOSK_STREAMS: sub-batches in flight per handle (1 measured best at 46 proofs: kernels sit on latency floors)
     if (const char *e = getenv("KOSK_STREAMS")) S = atoi(e) > 0 ? atoi(e) : S;
     if (S > max_batch) S = max_batch > 0 ? max_batch : 1;
@@ -166,6 +181,56 @@ int kosk_verify_resident(kosk_ctx *ctx, int n, uint8_t *ok)
     return ctx->run(n, [&](Ctx &c, int first, int count) { return verify_resident(c, count, ok + first); });
 }
 
+int kosk_verifiable_keygen_resident(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk)
+{
+    if (!ctx || n < 1 || n > ctx->max_batch || !pk || !sk) return -1;
+    const Params &P = ctx->c->P;
+    if (!tapes && ctx->sub.size() > 1) {
+        // the randombytes callback is stateful: draw sequentially in proof order, then prove the sub-batches in parallel
+        std::vector<uint8_t> drawn((size_t)n * P.tape_bytes);
+        Ctx &c0 = *ctx->c;
+        uint8_t *tp = drawn.data();
+        auto draw = [&](size_t len) { if (c0.rb) c0.rb(c0.rb_user, tp, len); else os_randombytes(tp, len); tp += len; };
+        for (int b = 0; b < n; b++) {
+            draw(64);
+            for (int i = 0; i < P.M; i++) draw(32);
+            for (int i = 0; i < P.nfresh; i++) draw(302);
+        }
+        return ctx->run(n, [&](Ctx &c, int first, int count) {
+            const KeygenIn kg{drawn.data() + (size_t)first * P.tape_bytes, P.tape_bytes, pk + (size_t)first * P.pk_bytes, sk + (size_t)first * P.sk_bytes};
+            return prove_resident(c, count, false, &kg);
+        });
+    }
+    return ctx->run(n, [&](Ctx &c, int first, int count) {
+        const KeygenIn kg{tapes ? tapes + (size_t)first * tape_stride : nullptr, tape_stride, pk + (size_t)first * P.pk_bytes,
+                          sk + (size_t)first * P.sk_bytes};
+        return prove_resident(c, count, false, &kg);
+    });
+}
+int kosk_verify_resident_pk(kosk_ctx *ctx, int n, const uint8_t *pk, uint8_t *ok)
+{
+    if (!ctx || n < 1 || n > ctx->max_batch || !ok) return -1;
+    const Params &P = ctx->c->P;
+    return ctx->run(n, [&](Ctx &c, int first, int count) {
+        return verify_resident(c, count, ok + first, pk ? 1 : 2, pk ? pk + (size_t)first * P.pk_bytes : nullptr);
+    });
+}
+int kosk_set_round_hook(kosk_ctx *ctx, kosk_round_fn fn, void *user)
+{
+    if (!ctx) return -1;
+    if (fn && ctx->sub.size() > 1) { ctx->err = "kosk_set_round_hook needs KOSK_STREAMS=1 (one digest table per round)"; return -1; }
+    for (Ctx *c : ctx->sub) { c->round_hook = fn; c->round_user = user; }
+    return 0;
+}
+int kosk_resident_digests(kosk_ctx *ctx, int round, void **d_digests, size_t *stride)
+{
+    if (!ctx || round < 0 || round > 1) return -1;
+    if (ctx->sub.size() > 1) { ctx->err = "kosk_resident_digests needs KOSK_STREAMS=1 (sub-batches keep separate tables)"; return -1; }
+    if (d_digests) *d_digests = round ? ctx->c->d_dig2 : ctx->c->d_dig1;
+    if (stride) *stride = (size_t)NPARTY * 32;
+    return 0;
+}
+
 int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride,
                                  uint8_t *pk, uint8_t *sk, uint8_t *pi)
 {
@@ -204,7 +269,7 @@ int kosk_prepare_randomness(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t t
 {
     if (!ctx || n < 0 || !rand_out) return -1;
     Ctx &c = *ctx->c;
-    ctx->err.clear();
+    ctx->clear_err();
     for (int done = 0; done < n;) {
         const int m = (n - done) < c.max_batch ? (n - done) : c.max_batch;
         if (prepare_randomness(c, m, tapes ? tapes + (size_t)done * tape_stride : nullptr, tape_stride,
@@ -217,7 +282,7 @@ int kosk_prepare_range_proof(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t 
 {
     if (!ctx || n < 0 || !range_out) return -1;
     Ctx &c = *ctx->c;
-    ctx->err.clear();
+    ctx->clear_err();
     for (int done = 0; done < n;) {
         const int m = (n - done) < c.max_batch ? (n - done) : c.max_batch;
         if (prepare_range_proof(c, m, tapes ? tapes + (size_t)done * tape_stride : nullptr, tape_stride,
@@ -231,7 +296,7 @@ int kosk_prove_prepared(kosk_ctx *ctx, int n, const uint8_t *inst, const uint8_t
 {
     if (!ctx || n < 0 || !inst || !rand_in || !range_in || !pi) return -1;
     Ctx &c = *ctx->c;
-    ctx->err.clear();
+    ctx->clear_err();
     for (int done = 0; done < n;) {
         const int m = (n - done) < c.max_batch ? (n - done) : c.max_batch;
         if (prove_prepared(c, m, inst + (size_t)done * mlwe_inst_bytes(c.P), rand_in + (size_t)done * randomness_bytes(c.P),
@@ -245,7 +310,7 @@ int kosk_verify_inst(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *ins
 {
     if (!ctx || n < 0 || !pi || !inst || !ok) return -1;
     Ctx &c = *ctx->c;
-    ctx->err.clear();
+    ctx->clear_err();
     for (int done = 0; done < n;) {
         const int m = (n - done) < c.max_batch ? (n - done) : c.max_batch;
         if (stage_verifier_inst(c, m, pi + (size_t)done * c.P.proof_bytes, inst + (size_t)done * mlwe_inst_bytes(c.P))) return -1;
@@ -288,7 +353,7 @@ int kosk_stage_verifier_inputs_compact(kosk_ctx *ctx, int n, const uint8_t *in, 
 
 int kosk_verify_fail_masks(const kosk_ctx *ctx, uint32_t *masks, int n)
 {
-    if (!ctx || n < 0 || n > ctx->max_batch) return -1;
+    if (!ctx || !masks || n < 0 || n > ctx->max_batch) return -1;
     for (int i = 0; i < (int)ctx->sub.size(); i++) {
         int first, count;
         ctx->split(n, i, first, count);
@@ -325,23 +390,26 @@ int kosk_profile_read(const kosk_ctx *ctx, int id, double *total_ms, long *launc
     return 0;
 }
 
-static hipEvent_t g_t0 = nullptr, g_t1 = nullptr;
 int kosk_stream_timer_start(kosk_ctx *ctx)
 {
     if (!ctx) return -1;
     Ctx &c = *ctx->c;
-    if (!g_t0) { HIPCHK_C(hipEventCreate(&g_t0)); HIPCHK_C(hipEventCreate(&g_t1)); }
-    HIPCHK_C(hipEventRecord(g_t0, c.stream));
+    ctx->clear_err();
+    HIPCHK_C(hipSetDevice(c.device));
+    if (!c.timer_ev[0]) { HIPCHK_C(hipEventCreate(&c.timer_ev[0])); HIPCHK_C(hipEventCreate(&c.timer_ev[1])); }
+    HIPCHK_C(hipEventRecord(c.timer_ev[0], c.stream));
     return 0;
 }
 int kosk_stream_timer_stop(kosk_ctx *ctx, double *ms)
 {
-    if (!ctx || !g_t0) return -1;
+    if (!ctx || !ctx->c->timer_ev[0]) return -1;
     Ctx &c = *ctx->c;
-    HIPCHK_C(hipEventRecord(g_t1, c.stream));
-    HIPCHK_C(hipEventSynchronize(g_t1));
+    ctx->clear_err();
+    HIPCHK_C(hipSetDevice(c.device));
+    HIPCHK_C(hipEventRecord(c.timer_ev[1], c.stream));
+    HIPCHK_C(hipEventSynchronize(c.timer_ev[1]));
     float f = 0;
-    HIPCHK_C(hipEventElapsedTime(&f, g_t0, g_t1));
+    HIPCHK_C(hipEventElapsedTime(&f, c.timer_ev[0], c.timer_ev[1]));
     if (ms) *ms = f;
     return 0;
 }
@@ -349,8 +417,10 @@ int kosk_stream_timer_stop(kosk_ctx *ctx, double *ms)
 int kosk_device_synchronize(kosk_ctx *ctx)
 {
     if (!ctx) return -1;
+    ctx->clear_err();
     for (Ctx *cp : ctx->sub) {
         Ctx &c = *cp;
+        HIPCHK_C(hipSetDevice(c.device));
         HIPCHK_C(hipStreamSynchronize(c.stream));
     }
     return 0;
@@ -360,6 +430,7 @@ int kosk_streams(const kosk_ctx *ctx) { return ctx ? (int)ctx->sub.size() : -1; 
 int kosk_resident_proofs(kosk_ctx *ctx, void **d_proofs, size_t *stride)
 {
     if (!ctx) return -1;
+    if (ctx->sub.size() > 1) { ctx->err = "kosk_resident_proofs needs KOSK_STREAMS=1 (sub-batches keep separate images)"; return -1; }
     if (d_proofs) *d_proofs = ctx->c->d_proof;
     if (stride) *stride = ctx->c->image_stride;
     return 0;
@@ -371,6 +442,8 @@ int kosk_sha3_256_batch(kosk_ctx *ctx, const uint8_t *d_in, size_t in_stride, si
 {
     if (!ctx) return -1;
     Ctx &c = *ctx->c;
+    ctx->clear_err();
+    HIPCHK_C(hipSetDevice(c.device));
     HIPCHK_C(launch_sha3_msgs(d_in, in_stride, (int)inlen, d_out, 32, 32, n, 0x06, c.stream));
     return 0;
 }
@@ -378,6 +451,8 @@ int kosk_shake256_batch(kosk_ctx *ctx, const uint8_t *d_in, size_t in_stride, si
 {
     if (!ctx) return -1;
     Ctx &c = *ctx->c;
+    ctx->clear_err();
+    HIPCHK_C(hipSetDevice(c.device));
     HIPCHK_C(launch_sha3_msgs(d_in, in_stride, (int)inlen, d_out, outlen, (int)outlen, n, 0x1F, c.stream));
     return 0;
 }
@@ -387,6 +462,8 @@ int kosk_commit_hash_lanes(kosk_ctx *ctx, const uint16_t *d_rows, size_t row_str
 {
     if (!ctx) return -1;
     Ctx &c = *ctx->c;
+    ctx->clear_err();
+    HIPCHK_C(hipSetDevice(c.device));
     HashArgs ha{};
     ha.rows = d_rows;
     ha.group_stride = 0;
@@ -405,6 +482,8 @@ int kosk_ntt256_batch(kosk_ctx *ctx, const int16_t *d_in, int16_t *d_out, int n)
 {
     if (!ctx) return -1;
     Ctx &c = *ctx->c;
+    ctx->clear_err();
+    HIPCHK_C(hipSetDevice(c.device));
     NttArgs na{};
     na.in = d_in;
     na.out = d_out;
@@ -419,6 +498,8 @@ int kosk_lagrange_expand(kosk_ctx *ctx, const uint16_t *d_y407, uint16_t *d_shar
 {
     if (!ctx) return -1;
     Ctx &c = *ctx->c;
+    ctx->clear_err();
+    HIPCHK_C(hipSetDevice(c.device));
     const int cap_rows = c.max_batch * c.rm.nrows; // the row matrix doubles as scratch
     const int cap = std::min<long>(cap_rows, (long)(c.limb_cap / (7 * 128)) - 64);
     for (int done = 0; done < n;) {
@@ -437,6 +518,8 @@ int kosk_recon_secrets(kosk_ctx *ctx, const uint16_t *d_shares, uint16_t *d_secr
 {
     if (!ctx) return -1;
     Ctx &c = *ctx->c;
+    ctx->clear_err();
+    HIPCHK_C(hipSetDevice(c.device));
     const GemmTable &t = two_d ? c.t_recon_2d : c.t_recon_d;
     const int cap_rows = c.max_batch * c.rm.nrows;
     const int cap = std::min<long>(cap_rows, (long)(c.limb_cap / ((size_t)t.KS * 128)) - 64);

@@ -78,6 +78,8 @@ Ctx::~Ctx()
     if (h_compact_bad) (void)hipHostFree(h_compact_bad);
     if (pool) pool_destroy(pool);
     if (ev) (void)hipEventDestroy(ev);
+    for (auto e : timer_ev)
+        if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -324,12 +326,32 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     return 0;
 }
 
-int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk)
+static bool is_device_pointer(const void *p)
 {
-    if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
-    HIPCHK(hipSetDevice(c.device));
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError(); // plain host memory: not an error
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice;
+}
+
+int upload_tapes(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride)
+{
     const Params &P = c.P;
-    const double t0 = now_sec();
+    if (tapes && tape_stride < P.tape_bytes) { c.err = "tape_stride smaller than kosk_tape_bytes"; return -1; }
+    if (tapes && is_device_pointer(tapes)) {
+        // the caller keeps its randomness in HBM: use it in place when the kernels' 8-byte loads are aligned, else one D2D copy
+        if (tape_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(tapes) & 7) == 0) {
+            c.tape_cur = tapes;
+            c.tape_cur_stride = tape_stride;
+            return 0;
+        }
+        HIPCHK(hipMemcpy2DAsync(c.d_tape, c.tape_stride, tapes, tape_stride, P.tape_bytes, n, hipMemcpyDeviceToDevice, c.stream));
+        c.tape_cur = c.d_tape;
+        c.tape_cur_stride = c.tape_stride;
+        return 0;
+    }
     if (!tapes) {
         // draw through the randombytes callback in the reference's call order and
         // lengths (kosk.cpp:12, mlwe_prover.cpp:9, ss.cpp:5), proof after proof
@@ -344,13 +366,21 @@ int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride,
             for (int i = 0; i < P.M; i++) draw(32);
             for (int i = 0; i < P.nfresh; i++) draw(302);
         }
-    }
-    if (tapes)
+    } else {
         parallel_for(c.pool, n, c.nthreads, [&](int b) { memcpy(c.h_tape + (size_t)b * c.tape_stride, tapes + (size_t)b * tape_stride, P.tape_bytes); });
+    }
     HIPCHK(hipMemcpyAsync(c.d_tape, c.h_tape, (size_t)n * c.tape_stride, hipMemcpyHostToDevice, c.stream));
-    // kyber_keygen on the device (kosk.cpp:4-70): A, s, e never leave HBM; only pk, NTT(s) bytes and the seeds come back
+    c.tape_cur = c.d_tape;
+    c.tape_cur_stride = c.tape_stride;
+    return 0;
+}
+
+// kyber_keygen on the device (kosk.cpp:4-70): A, s, e never leave HBM; only pk, NTT(s) bytes and the seeds come back
+int issue_keygen(Ctx &c, int n)
+{
+    const Params &P = c.P;
     const int K = P.K;
-    HIPCHK(launch_keygen(c.d_tape, c.tape_stride, c.d_seeds, c.d_A, c.key_stride, c.d_se, c.se_stride, K, P.eta1, n, c.stream));
+    HIPCHK(launch_keygen(c.tape_cur, c.tape_cur_stride, c.d_seeds, c.d_A, c.key_stride, c.d_se, c.se_stride, K, P.eta1, n, c.stream));
     NttArgs na{};
     na.in = c.d_se; na.in_gstride = c.se_stride; na.src_off = nullptr;
     na.out = c.d_sehat; na.out_gstride = c.se_stride; na.dst_off = nullptr;
@@ -361,7 +391,12 @@ int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride,
     HIPCHK(hipMemcpyAsync(c.h_pk, c.d_pk, (size_t)n * c.pk_stride, hipMemcpyDeviceToHost, c.stream));
     HIPCHK(hipMemcpyAsync(c.h_sb, c.d_sb, (size_t)n * c.sb_stride, hipMemcpyDeviceToHost, c.stream));
     HIPCHK(hipMemcpyAsync(c.h_seeds, c.d_seeds, (size_t)n * 64, hipMemcpyDeviceToHost, c.stream));
-    HIPCHK(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+void finish_keygen_host(Ctx &c, int n, uint8_t *pk, uint8_t *sk)
+{
+    const Params &P = c.P;
     parallel_for(c.pool, n, c.nthreads, [&](int b) { // sk = NTT(s) bytes || pk || H(pk) || z, z = noise seed   kosk.cpp:62-69
         uint8_t *pkb = pk + (size_t)b * P.pk_bytes, *skb = sk + (size_t)b * P.sk_bytes;
         memcpy(pkb, c.h_pk + (size_t)b * c.pk_stride, P.pk_bytes);
@@ -370,6 +405,18 @@ int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride,
         sha3_256(skb + P.sk_bytes - 64, pkb, P.pk_bytes);
         memcpy(skb + P.sk_bytes - 32, c.h_seeds + (size_t)b * 64 + 32, 32);
     });
+}
+
+int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk)
+{
+    if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
+    if (!pk || !sk) { c.err = "pk / sk output buffers are required"; return -1; }
+    HIPCHK(hipSetDevice(c.device));
+    const double t0 = now_sec();
+    if (upload_tapes(c, n, tapes, tape_stride)) return -1;
+    if (issue_keygen(c, n)) return -1;
+    HIPCHK(hipStreamSynchronize(c.stream));
+    finish_keygen_host(c, n, pk, sk);
     c.phase_sec[PH_HOST_PRE] = now_sec() - t0;
     return 0;
 }
@@ -388,7 +435,7 @@ int issue_sharing_front(Ctx &c, int n, FrontPart part)
     if (part == FRONT_RANDOMNESS) { s1 = noff_f; witness = 0; ntt_count = P.M; matvec = false; }
     else if (part == FRONT_RANGE) { s0 = noff_f; s1 = noff; witness = 2; ntt_count = 0; expand = false; matvec = false; }
     else if (part == FRONT_ONLINE) { s0 = noff; expand = false; ntt_first = P.M; ntt_count = K; }
-    HIPCHK(launch_prover_pre(c.d_tape, c.tape_stride, c.d_P, c.proof_stride, rm.f, P.M, 64 + 32 * P.M, c.d_fresh_rows, s0, s1, expand,
+    HIPCHK(launch_prover_pre(c.tape_cur, c.tape_cur_stride, c.d_P, c.proof_stride, rm.f, P.M, 64 + 32 * P.M, c.d_fresh_rows, s0, s1, expand,
                              witness, c.d_se, c.se_stride, rm, P.eta1, n, st));
     if (ntt_count > 0) {
         NttArgs na{};
@@ -414,9 +461,11 @@ int issue_sharing_front(Ctx &c, int n, FrontPart part)
     return 0;
 }
 
-int prove_resident(Ctx &c, int n, bool online_only)
+int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
 {
     if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
+    if (keygen && (!keygen->pk || !keygen->sk)) { c.err = "pk / sk output buffers are required"; return -1; }
+    if (!keygen && !c.tape_cur) { c.err = "no resident prover inputs: call kosk_stage_prover_inputs first"; return -1; }
     HIPCHK(hipSetDevice(c.device));
     const Params &P = c.P;
     const RowMap &rm = c.rm;
@@ -434,8 +483,13 @@ int prove_resident(Ctx &c, int n, bool online_only)
     ha.lane_map = nullptr;
     ha.out_lanes_per_group = NPARTY;
 
+    // ---- key generation at the head of P1 (tape pointers may change from call to call: never part of a captured graph)
+    if (keygen) {
+        if (upload_tapes(c, n, keygen->tapes, keygen->tape_stride)) return -1;
+        if (issue_keygen(c, n)) return -1;
+    }
     // ---- P1: offline phase + witness sharing (secrets, randoms, one expansion GEMM), Tcomm of every party
-    if (run_segment(c, online_only ? -1 : (int)Ctx::SEG_P1, n, [&]() -> int {
+    if (run_segment(c, (online_only || keygen) ? -1 : (int)Ctx::SEG_P1, n, [&]() -> int {
         if (issue_sharing_front(c, n, online_only ? FRONT_ONLINE : FRONT_FULL)) return -1;
         HashArgs h1 = ha;
         h1.prefix = nullptr;
@@ -449,6 +503,7 @@ int prove_resident(Ctx &c, int n, bool online_only)
     c.phase_sec[PH_P1_ISSUE] = now_sec() - t0;
     HIPCHK(hipStreamSynchronize(st));
     t1 = now_sec(); c.phase_sec[PH_GPU_COMMIT] = t1 - t0; t0 = t1;
+    if (c.round_hook) c.round_hook(c.round_user, 0, 0, c.d_dig1, (size_t)n * NPARTY * 32);
 
     // ---- P1B: what neither Tcomm nor alpha needs is issued now and runs while the host hashes: the multiplication
     // gates on the expanded shares (:338-381) and the transposed limb form of the f rows for the beta/gamma product
@@ -458,7 +513,8 @@ int prove_resident(Ctx &c, int n, bool online_only)
         return 0;
     })) return -1;
 
-    // ---- Fiat-Shamir round 1 on the host
+    // ---- Fiat-Shamir round 1 on the host (and the host half of the key generation)
+    if (keygen) finish_keygen_host(c, n, keygen->pk, keygen->sk);
     fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool);
     t1 = now_sec(); c.phase_sec[PH_FS_ALPHA] = t1 - t0; t0 = t1;
 
@@ -492,6 +548,7 @@ int prove_resident(Ctx &c, int n, bool online_only)
     c.phase_sec[PH_P2_ISSUE] = now_sec() - t0;
     HIPCHK(hipStreamSynchronize(st));
     t1 = now_sec(); c.phase_sec[PH_GPU_RELATION] = t1 - t0; t0 = t1;
+    if (c.round_hook) c.round_hook(c.round_user, 0, 1, c.d_dig2, (size_t)n * NPARTY * 32);
 
     // ---- P2B: the NTT-domain half of the relation is not hashed, only opened; it runs while the host derives I
     if (run_segment(c, Ctx::SEG_P2B, n, [&]() -> int {

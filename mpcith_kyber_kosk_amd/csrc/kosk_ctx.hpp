@@ -13,6 +13,16 @@
 namespace kosk {
 
 typedef void (*randombytes_fn)(void *user, uint8_t *out, size_t len);
+// called on the calling thread when a commitment round's digest table [n][1454][32] is complete in HBM (stream idle):
+// role 0 prover / 1 verifier, round 0 Tcomm / 1 view commitments
+typedef void (*round_fn)(void *user, int role, int round, const void *d_digests, size_t bytes);
+
+// key generation folded into the prover's first segment (kyber_verifiable_keygen as ONE resident call)
+struct KeygenIn {
+    const uint8_t *tapes; // host or device memory; nullptr: the randombytes callback
+    size_t tape_stride;
+    uint8_t *pk, *sk;     // host, n records each
+};
 
 enum Phase { PH_HOST_PRE = 0, PH_GPU_COMMIT, PH_FS_ALPHA, PH_GPU_RELATION, PH_FS_OPEN, PH_GPU_ASSEMBLE, PH_D2H,
              // host time spent issuing each segment (part of the GPU phases above) and the verifier's phases
@@ -67,6 +77,8 @@ struct Ctx {
     std::string err;
     randombytes_fn rb = nullptr;
     void *rb_user = nullptr;
+    round_fn round_hook = nullptr;
+    void *round_user = nullptr;
 
     // constant tables (HBM, L2-resident while in use)
     GemmTable t_expand, t_recon_d, t_recon_2d;
@@ -87,6 +99,9 @@ struct Ctx {
     int sel_stride = 0;
     uint16_t *d_P = nullptr;
     uint8_t *d_tape = nullptr, *d_dig1 = nullptr, *d_dig2 = nullptr, *d_proof = nullptr;
+    // the tapes the kernels read: d_tape after an upload, or the caller's own device buffer used in place
+    const uint8_t *tape_cur = nullptr;
+    size_t tape_cur_stride = 0;
     int16_t *d_A = nullptr, *d_se = nullptr;
     // key generation on the device (kosk_keygen_kernels.hip)
     uint8_t *d_seeds = nullptr, *d_pk = nullptr, *d_sb = nullptr; // sha3_512 output, packed pk, packed NTT(s)
@@ -122,6 +137,7 @@ struct Ctx {
     uint32_t *d_fail = nullptr;      // [proof] bit mask of failed checks (FailBit)
     uint16_t *h_Iimg = nullptr;      // I fields as read from the proof images
     hipEvent_t ev = nullptr;
+    hipEvent_t timer_ev[2] = {nullptr, nullptr}; // kosk_stream_timer_start / _stop
     // compact wire format staging (allocated on first use)
     CompactPlan cplan{};
     size_t compact_stride = 0;
@@ -205,13 +221,20 @@ inline int gemm_modq(Ctx &c, const GemmTable &t, const GemmSrc &s, const GemmDst
     return gemm_modq(c, t.d, 0, t.Mpad, t.M, t.KS, s, d, npg, ngroups, false);
 }
 
-// host tapes -> pk/sk on host, tape + key material resident in HBM
+// tapes (host or device memory, nullptr = callback) -> pk/sk on host, tape + key material resident in HBM
 int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk);
+// its three parts: make the tapes resident (async), kyber_keygen on the device + D2H of pk / NTT(s) / seeds (async),
+// and, once the stream has been synchronised, the host half (sk = NTT(s) || pk || H(pk) || z, kosk.cpp:62-69)
+int upload_tapes(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride);
+int issue_keygen(Ctx &c, int n);
+void finish_keygen_host(Ctx &c, int n, uint8_t *pk, uint8_t *sk);
 // everything from resident inputs to resident proof images (two host Fiat-Shamir round trips)
 enum FrontPart { FRONT_FULL = 0, FRONT_RANDOMNESS, FRONT_RANGE, FRONT_ONLINE };
 int issue_sharing_front(Ctx &c, int n, FrontPart part);
 // online_only: the offline material (f, NTT f, eta sharings) is already in the row matrix (prove_prepared)
-int prove_resident(Ctx &c, int n, bool online_only = false);
+// keygen != nullptr: key generation runs at the head of the first segment (no extra synchronisation) and pk / sk are
+// written before the call returns -- the whole kyber_verifiable_keygen, proofs left resident
+int prove_resident(Ctx &c, int n, bool online_only = false, const KeygenIn *keygen = nullptr);
 // the reference's second-level entry points on host structs (kosk_split.cpp); struct layouts in include/kosk_mi355x.h
 size_t randomness_bytes(const Params &P);
 size_t range_proof_bytes(const Params &P);
@@ -227,6 +250,9 @@ int stage_verifier_inputs_compact(Ctx &c, int n, const uint8_t *in, const uint8_
 int fetch_proofs(Ctx &c, int n, uint8_t *pi);
 
 int stage_verifier_inputs(Ctx &c, int n, const uint8_t *pi, const uint8_t *pk);
-int verify_resident(Ctx &c, int n, uint8_t *ok);
+// pk_mode 0: A and t are already resident (stage_verifier_inputs / stage_verifier_inst); 1: decode `pk` (host or
+// device memory, n records of pk_bytes) at the head of the first segment (kosk.cpp:94-99: polyvec_frombytes + gen_matrix);
+// 2: decode the pk bytes the key generation left resident in HBM
+int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode = 0, const uint8_t *pk = nullptr);
 
 } // namespace kosk

@@ -129,6 +129,110 @@ __global__ __launch_bounds__(64) void k_commit_hash(HashArgs a)
     o[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
 }
 
+// The same hash with the message rows staged through LDS by LDS-DMA (global_load_lds_dwordx4): one wave-instruction
+// brings 8 rows x 128 bytes = the 64 lanes' words of 8 message rows as whole cache lines, with no VGPR destination and
+// no per-row address arithmetic on the VALU (the one-lane form issues 220 two-byte gathers and as many 64-bit adds per
+// lane).  A 136-byte block of the 64 lanes is [<=72 rows][64 lanes] u16 = 9 KiB; with NBUF = 2 the next block lands
+// in the other buffer while Keccak-f runs on this one (launches with few waves per SIMD), with NBUF = 1 occupancy
+// hides the landing (many waves per SIMD).  Needs 16-byte aligned row segments and readable padding up to the wave's
+// 64th lane (launch_hash_t checks); lanes beyond lanes_per_group take part in the loads and store nothing.
+template <int PREFIX_WORDS, int NROWS, int NBUF>
+__global__ __launch_bounds__(64) void k_commit_hash_dma(HashArgs a)
+{
+    constexpr int W = PREFIX_WORDS + NROWS; // u16 words in the message
+    constexpr int RATE_W = 68;              // 136-byte rate
+    constexpr int NBLK = W / RATE_W + 1;    // pad10*1 always adds to the last (possibly empty) block
+    constexpr int STAGE_ROWS = 72;          // 9 DMA pieces of 8 rows
+    __shared__ __attribute__((aligned(16))) uint16_t stage[NBUF][STAGE_ROWS * 64];
+
+    const int tl = threadIdx.x;
+    const int lane = blockIdx.x * 64 + tl;
+    const int g = blockIdx.y;
+    const uint16_t *__restrict__ rowbase = a.rows + (size_t)g * a.group_stride + a.col_off + blockIdx.x * 64; // wave-uniform
+    const size_t dig = ((size_t)g * a.out_lanes_per_group + lane) * 32;
+    const bool live = lane < a.lanes_per_group;
+
+    // rows [rlo, rhi) of block b sit in stage rows 0 .. rhi - rlo - 1
+    auto issue = [&](auto blkc, int buf) {
+        constexpr int blk = decltype(blkc)::value;
+        constexpr int rlo = blk * RATE_W > PREFIX_WORDS ? blk * RATE_W - PREFIX_WORDS : 0;
+        constexpr int rhi = (blk + 1) * RATE_W - PREFIX_WORDS < NROWS ? (blk + 1) * RATE_W - PREFIX_WORDS : NROWS;
+        constexpr int cnt = rhi - rlo;
+        if constexpr (cnt > 0) {
+            constexpr int pieces = (cnt + 7) / 8;
+#pragma unroll
+            for (int p = 0; p < pieces; p++) {
+                int r = rlo + p * 8 + (tl >> 3);
+                if (p == pieces - 1 && (cnt & 7)) r = r < rhi ? r : rhi - 1; // the tail piece re-reads the last row
+                const uint16_t *src = rowbase + (size_t)r * a.row_stride + (tl & 7) * 8;
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(stage[buf] + p * 512), 16, 0, 0);
+            }
+        }
+    };
+
+    KState s;
+    kstate_zero(s);
+    issue(std::integral_constant<int, 0>{}, 0);
+    if constexpr (PREFIX_WORDS > 0) {
+        static_assert(PREFIX_WORDS == 16, "the prefix is one 32-byte digest");
+        if (live) {
+            const uint4 *pp = reinterpret_cast<const uint4 *>(a.prefix + dig);
+            const uint4 p0 = pp[0], p1 = pp[1];
+            s.lo[0] = p0.x; s.hi[0] = p0.y; s.lo[1] = p0.z; s.hi[1] = p0.w;
+            s.lo[2] = p1.x; s.hi[2] = p1.y; s.lo[3] = p1.z; s.hi[3] = p1.w;
+        }
+    }
+    auto run = [&]<int... Bs>(std::integer_sequence<int, Bs...>) {
+        (([&] {
+             constexpr int blk = Bs;
+             constexpr int buf = NBUF == 2 ? (blk & 1) : 0;
+             constexpr int rlo = blk * RATE_W > PREFIX_WORDS ? blk * RATE_W - PREFIX_WORDS : 0;
+             if constexpr (NBUF == 2 && blk + 1 < NBLK) {
+                 // the other buffer was consumed one block ago: start the next block's DMA before waiting for this one
+                 issue(std::integral_constant<int, blk + 1>{}, buf ^ 1);
+                 constexpr int nrlo = (blk + 1) * RATE_W - PREFIX_WORDS;
+                 constexpr int nrhi = (blk + 2) * RATE_W - PREFIX_WORDS < NROWS ? (blk + 2) * RATE_W - PREFIX_WORDS : NROWS;
+                 constexpr int npieces = nrhi > nrlo ? (nrhi - nrlo + 7) / 8 : 0;
+                 __builtin_amdgcn_s_waitcnt(0x0F70 | (npieces & 15) | ((npieces >> 4) << 14)); // vmcnt(npieces): this block has landed
+             } else {
+                 __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+             }
+             asm volatile("" ::: "memory");
+             const uint16_t *st = stage[buf];
+#pragma unroll
+             for (int w = 0; w < RATE_W; w += 2) {
+                 const int gw = blk * RATE_W + w; // first of two u16 words forming half a 64-bit lane
+                 if (gw < PREFIX_WORDS || gw >= W) continue;
+                 uint32_t v = st[(gw - PREFIX_WORDS - rlo) * 64 + tl];
+                 if (gw + 1 < W) v |= (uint32_t)st[(gw + 1 - PREFIX_WORDS - rlo) * 64 + tl] << 16;
+                 if ((w & 2) == 0) s.lo[w / 4] ^= v;
+                 else s.hi[w / 4] ^= v;
+             }
+             if constexpr (blk == NBLK - 1) {
+                 constexpr int padbyte = 2 * W - (NBLK - 1) * 136;
+                 constexpr uint32_t padv = 0x06u << (8 * (padbyte % 4));
+                 if constexpr ((padbyte % 8) < 4) s.lo[padbyte / 8] ^= padv;
+                 else s.hi[padbyte / 8] ^= padv;
+                 s.hi[16] ^= 0x80000000u;
+             }
+             if constexpr (NBUF == 1 && blk + 1 < NBLK) {
+                 // single buffer: every LDS read of this block must have returned before the next DMA overwrites it
+                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                 issue(std::integral_constant<int, blk + 1>{}, 0);
+             }
+             asm volatile("" ::: "memory");
+             keccak_f1600_dev(s);
+         }()),
+         ...);
+    };
+    run(std::make_integer_sequence<int, NBLK>{});
+    if (live) {
+        uint4 *o = reinterpret_cast<uint4 *>(a.out + dig);
+        o[0] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
+        o[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
+    }
+}
+
 // SHA3-256 / SHAKE256 of n byte messages of equal length stored message-major.
 __global__ __launch_bounds__(64) void k_sha3_msgs(const uint8_t *__restrict__ in, size_t in_stride, int len,
                                                   uint8_t *__restrict__ out, size_t out_stride, int outlen,
@@ -661,7 +765,13 @@ __device__ __forceinline__ void gemm_modq_block(const GemmArgs &a, const int bx,
             uint32_t v[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) v[r] = gf_from_i32(s0[ib][j][r] + 64 * s1[ib][j][r] + 767 * s2[ib][j][r]); // < 2^31 for k <= 832
-            *reinterpret_cast<uint2 *>(crow + m0) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+            if (m0 + 4 <= a.M) {
+                *reinterpret_cast<uint2 *>(crow + m0) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+            } else { // M % 4 != 0 (the 407-point interpolation operator): never write past the logical output
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (m0 + r < a.M) crow[m0 + r] = (uint16_t)v[r];
+            }
         }
     }
 }
@@ -1094,12 +1204,30 @@ __global__ __launch_bounds__(256) void k_rows_copy(const uint16_t *__restrict__ 
 // =========================================================================
 // host-side launchers
 // =========================================================================
+static bool hash_dma_enabled()
+{
+    static const bool on = !(getenv("KOSK_HASH_DMA") && atoi(getenv("KOSK_HASH_DMA")) == 0);
+    return on;
+}
+
 template <int PW, int NR>
 static void launch_hash_t(const HashArgs &a, int ngroups, hipStream_t st)
 {
     dim3 grid((a.lanes_per_group + 63) / 64, ngroups);
-    // fewer than ~3 waves per SIMD (1024 SIMDs): nothing else hides the row loads -> pipelined variant
     const long waves = (long)grid.x * grid.y;
+    // LDS-DMA staging needs 16-byte aligned 128-byte row segments per wave and readable row padding up to the last
+    // wave's 64th lane (true for the row matrix: RS = 1728 = 256 + 23 * 64)
+    const bool dma_ok = hash_dma_enabled() && !a.lane_map && a.row_stride % 8 == 0 && a.group_stride % 8 == 0 && a.col_off % 8 == 0 &&
+                        (reinterpret_cast<uintptr_t>(a.rows) & 15) == 0 && a.col_off + (int)grid.x * 64 <= a.row_stride &&
+                        (!PW || (reinterpret_cast<uintptr_t>(a.prefix) & 15) == 0);
+    if (dma_ok) {
+        // up to ~2 waves per SIMD the next block's DMA runs under this block's permutation (two buffers, 18 KiB per wave);
+        // beyond that one buffer (4 waves per SIMD fit) and occupancy hides the landing
+        if (waves <= 2 * 1024 + 256) hipLaunchKernelGGL((k_commit_hash_dma<PW, NR, 2>), grid, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_commit_hash_dma<PW, NR, 1>), grid, dim3(64), 0, st, a);
+        return;
+    }
+    // fewer than ~3 waves per SIMD (1024 SIMDs): nothing else hides the row loads -> pipelined variant
     if (waves < 3 * 1024) hipLaunchKernelGGL((k_commit_hash<PW, NR, true>), grid, dim3(64), 0, st, a);
     else hipLaunchKernelGGL((k_commit_hash<PW, NR, false>), grid, dim3(64), 0, st, a);
 }

@@ -58,6 +58,8 @@ static int fill_tape_part(Ctx &c, int n, bool seeds, int s0, int s1, const uint8
         }
     }
     HIPCHK(hipMemcpyAsync(c.d_tape, c.h_tape, (size_t)n * c.tape_stride, hipMemcpyHostToDevice, c.stream));
+    c.tape_cur = c.d_tape;
+    c.tape_cur_stride = c.tape_stride;
     return 0;
 }
 

@@ -157,11 +157,37 @@ int stage_verifier_inputs(Ctx &c, int n, const uint8_t *pi, const uint8_t *pk)
     return 0;
 }
 
-int verify_resident(Ctx &c, int n, uint8_t *ok)
+static bool is_device_pointer(const void *p)
+{
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice;
+}
+
+int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
 {
     if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
+    if (!ok) { c.err = "ok output buffer is required"; return -1; }
+    if (pk_mode == 1 && !pk) { c.err = "pk_mode 1 needs the public keys"; return -1; }
     HIPCHK(hipSetDevice(c.device));
     if (ensure_verify_workspace(c)) return -1;
+    if (pk_mode) {
+        // polyvec_frombytes(t) and gen_matrix(A, seed) on the device (kosk.cpp:94-99), ahead of the first segment on the
+        // same stream: no synchronisation of its own
+        const Params &Pk = c.P;
+        if (pk_mode == 1) {
+            if (is_device_pointer(pk)) {
+                HIPCHK(hipMemcpy2DAsync(c.d_pk, c.pk_stride, pk, Pk.pk_bytes, Pk.pk_bytes, n, hipMemcpyDeviceToDevice, c.stream));
+            } else {
+                for (int b = 0; b < n; b++) memcpy(c.h_pk + (size_t)b * c.pk_stride, pk + (size_t)b * Pk.pk_bytes, Pk.pk_bytes);
+                HIPCHK(hipMemcpyAsync(c.d_pk, c.h_pk, (size_t)n * c.pk_stride, hipMemcpyHostToDevice, c.stream));
+            }
+        }
+        HIPCHK(launch_decode_pk(c.d_pk, c.pk_stride, c.d_t, c.d_A, c.key_stride, Pk.K, n, c.stream));
+    }
     const Params &P = c.P;
     const RowMap &rm = c.rm;
     const int K = P.K;
@@ -209,6 +235,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     t1 = now_sec(); c.phase_sec[PH_V1_ISSUE] = t1 - t0; t0 = t1;
     HIPCHK(hipStreamSynchronize(st)); // the opened parties' Tcomm digests are on the host
     t1 = now_sec(); c.phase_sec[PH_V1_WAIT] = t1 - t0; t0 = t1;
+    if (c.round_hook) c.round_hook(c.round_user, 1, 0, c.d_dig1, (size_t)n * NPARTY * 32);
 
     // ---- alpha-independent GPU work, issued before the host hashes so that it runs meanwhile: interpolation of
     // the unopened shares
@@ -312,6 +339,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok)
     t1 = now_sec(); c.phase_sec[PH_V2_ISSUE] = t1 - t0; t0 = t1;
     HIPCHK(hipStreamSynchronize(st));
     t1 = now_sec(); c.phase_sec[PH_V2_WAIT] = t1 - t0; t0 = t1;
+    if (c.round_hook) c.round_hook(c.round_user, 1, 1, c.d_dig2, (size_t)n * NPARTY * 32);
 
     // ---- V2B: the checks that feed no hash run while the host derives the opened set: reconstruction of the 140
     // beta/gamma secrets with the NTT comparison (:106-131) and the relation checks on the opened columns

@@ -1,0 +1,129 @@
+"""BASELINE.json configs[3] and configs[4] at their per-GPU sizes, and the resident one-call entry points bench.py times
+(kosk_verifiable_keygen_resident / kosk_verify_resident_pk), against the CPU oracle: every verify bit, spot proofs byte
+for byte, the digest tables a multi-GPU job all-gathers (kosk_resident_digests, kosk_set_round_hook)."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU: torch.cuda.is_available() is False")
+    return torch
+
+
+def _device_tapes(torch, tapes, stride):
+    host = np.zeros((len(tapes), stride), np.uint8)
+    for b, t in enumerate(tapes):
+        host[b, :len(t)] = np.frombuffer(t, np.uint8)
+    return torch.from_numpy(host).cuda()
+
+
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_resident_one_call_entry_points(k, oracle, torch_cuda):
+    """kyber_verifiable_keygen / kyber_kosk_verify as one resident call each: tapes from host memory, from device memory
+    used in place (aligned stride) and through a D2D copy (odd stride); pk from HBM, from the host, from device memory."""
+    torch = torch_cuda
+    from mpcith_kyber_kosk_amd import api
+    n = 3
+    ctx = api.Kosk(kyber_k=k, max_batch=n)
+    tapes = [oracle.tape_bytes_for(k, 40 + b) for b in range(n)]
+    ref = [oracle.verifiable_keygen(k, t) for t in tapes]
+    for mode in ("host", "device_inplace", "device_copy"):
+        if mode == "host":
+            ctx.verifiable_keygen_resident(tapes)
+        else:
+            stride = (ctx.tape_bytes + 63) // 64 * 64 if mode == "device_inplace" else ctx.tape_bytes + 3
+            dev = _device_tapes(torch, tapes, stride)
+            ctx.verifiable_keygen_resident(dev.data_ptr(), n=n, tape_stride=stride)
+        pks, sks = ctx.keys(n)
+        pis = ctx.fetch_proofs(n)
+        for b in range(n):
+            assert pks[b] == ref[b][0] and sks[b] == ref[b][1], (mode, b)
+            assert pis[b] == ref[b][2], (mode, b)
+        assert ctx.verify_resident_pk(n) == [True] * n                      # pk bytes left in HBM by the key generation
+    assert ctx.verify_resident_pk(n, pks) == [True] * n                      # pk from host memory
+    dpk = torch.frombuffer(bytearray(b"".join(pks)), dtype=torch.uint8).cuda()
+    ok = C.create_string_buffer(n)
+    assert api.lib.kosk_verify_resident_pk(ctx.handle, n, C.c_void_p(dpk.data_ptr()), ok) == 0 and ok.raw == b"\x01" * n
+    wrong = [pks[1], pks[0], pks[2]]                                         # proofs 0 and 1 against each other's key
+    assert ctx.verify_resident_pk(n, wrong) == [False, False, True]
+    # error paths: missing outputs, batch too large, no resident inputs on a fresh context
+    assert api.lib.kosk_verifiable_keygen_resident(ctx.handle, n, None, 0, None, None) != 0
+    assert api.lib.kosk_verify_resident_pk(ctx.handle, n + 1, None, ok) != 0
+    fresh = api.Kosk(kyber_k=k, max_batch=1)
+    assert api.lib.kosk_prove_resident(fresh.handle, 1) != 0 and b"resident" in api.lib.kosk_last_error(fresh.handle)
+    fresh.close()
+    ctx.close()
+
+
+def _spot_check(ctx, oracle, k, tapes, n, spots):
+    pks, sks = ctx.keys(n)
+    pis = ctx.fetch_proofs(n)
+    p = oracle.params(k)
+    for b in spots:
+        opk, osk, opi, _, _, tr = oracle.verifiable_keygen(k, tapes[b], trace=True)
+        assert pks[b] == opk and sks[b] == osk and pis[b] == opi, b
+        yield b, pis[b], tr, p
+
+
+def test_config4_kyber1024_91_proofs_and_digest_tables(oracle, torch_cuda):
+    """configs[3] per-GPU share: K=4, 91 proofs = 132 314 party lanes in one batch.  The digest tables a multi-GPU job
+    all-gathers after each commitment round are reachable in HBM and hold exactly Tcomm[0..1454) / the view commitments."""
+    torch = torch_cuda
+    from mpcith_kyber_kosk_amd import api
+    k, n = 4, 91
+    ctx = api.Kosk(kyber_k=k, max_batch=n)
+    tapes = [oracle.tape_bytes_for(k, 2000 + b) for b in range(n)]
+    seen = []
+
+    def hook(role, rnd, ptr, nbytes):
+        t = torch.as_tensor(api.DeviceView(ptr, (n, 1454, 32)), device="cuda")
+        seen.append((role, rnd, nbytes, t[[0, 45, 90]].cpu().numpy().copy()))
+    ctx.set_round_hook(hook)
+    ctx.verifiable_keygen_resident(tapes)
+    assert [(s[0], s[1], s[2]) for s in seen] == [(0, 0, n * 1454 * 32), (0, 1, n * 1454 * 32)]
+    tables = [torch.as_tensor(ctx.resident_digests(r, n), device="cuda").cpu().numpy().copy() for r in (0, 1)]
+    assert tables[0].shape == (n, 1454, 32)
+    for j, (b, pi, tr, p) in enumerate(_spot_check(ctx, oracle, k, tapes, n, (0, 45, 90))):
+        tc = np.frombuffer(bytes(tr.tcomm), np.uint8).reshape(1454, 32)
+        vw = np.frombuffer(bytes(tr.view_digest), np.uint8).reshape(1454, 32)
+        assert np.array_equal(tables[0][b], tc) and np.array_equal(tables[1][b], vw)
+        assert np.array_equal(seen[0][3][j], tc) and np.array_equal(seen[1][3][j], vw)   # complete when the hook fires
+        # sha3_256(Tcomm[0..N)) / sha3_256(ch_seeds) of mlwe_prover.cpp:130-135, :445-449 from the gathered bytes
+        assert hashlib.sha3_256(tables[0][b].tobytes()).digest() == bytes(tr.h1)
+        assert hashlib.sha3_256(tables[1][b].tobytes()).digest() == bytes(tr.ch)
+    assert ctx.verify_resident_pk(n) == [True] * n
+    assert [(s[0], s[1]) for s in seen[2:]] == [(1, 0), (1, 1)]
+    # the verifier rebuilds the same tables (opened digests recomputed, the others taken from the proofs)
+    for r in (0, 1):
+        assert np.array_equal(torch.as_tensor(ctx.resident_digests(r, n), device="cuda").cpu().numpy(), tables[r])
+    ctx.set_round_hook(None)
+    ctx.close()
+
+
+def test_config5_kyber768_512_keygens(oracle, torch_cuda):
+    """configs[4] per-GPU share: 512 independent Kyber-768 verifiable keygens in one batch."""
+    from mpcith_kyber_kosk_amd import api
+    k, n = 3, 512
+    ctx = api.Kosk(kyber_k=k, max_batch=n)
+    tapes = [oracle.tape_bytes_for(k, b) for b in range(n)]   # seeds "kosk-tape-v1:0" .. ":511" 
+    ctx.verifiable_keygen_resident(tapes)
+    for _ in _spot_check(ctx, oracle, k, tapes, n, (0, 255, 511)):
+        pass
+    assert hashlib.sha3_256(ctx.fetch_proofs(1)[0]).hexdigest() == "3c8192372ced98f0eb195db9dd2e68afcddddd9762a565baa6fea85504decec1"
+    assert ctx.verify_resident_pk(n) == [True] * n
+    # a tampered proof inside the big batch is the only one rejected
+    pis = ctx.fetch_proofs(n)
+    pks, _ = ctx.keys(n)
+    bad = bytearray(pis[300]); bad[api.proof_field(k, 13)[0] + 7] ^= 2
+    pis[300] = bytes(bad)
+    ok = ctx.verify(pis, pks)
+    assert ok == [i != 300 for i in range(n)]
+    ctx.close()

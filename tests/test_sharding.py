@@ -40,6 +40,17 @@ def _worker(rank, world, port, q):
         r, i = divmod(gl, units)
         if i % 97 == 0:
             ok &= bytes(table[gl].tolist()) == hashlib.sha3_256(str(gl).encode()).digest()
+    # BASELINE configs[3]: the per-GPU digest tables of one commitment round, [91 proofs][1454][32] per rank, gathered the way
+    # bench.py --config 4 gathers them from HBM (all_gather_into_tensor into [world * 91][1454][32], rank-major)
+    tab = torch.full((91, 1454, 32), rank + 1, dtype=torch.uint8)
+    tab[rank * 7, 11, 5] = 200 + rank
+    cat = torch.empty((world * 91, 1454, 32), dtype=torch.uint8)   # concatenation form: valid for gloo and RCCL alike
+    dist.all_gather_into_tensor(cat, tab)
+    out = cat.view(world, 91, 1454, 32)
+    for r in range(world):
+        ok &= int(out[r, 0, 0, 0]) == r + 1 and int(out[r, r * 7, 11, 5]) == 200 + r
+    flat = s.allgather_digest_table(tab.reshape(-1, 32), world, dist)
+    ok &= flat.shape == (world * 91 * 1454, 32) and torch.equal(flat.reshape(world, 91, 1454, 32), out)
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
