@@ -63,7 +63,7 @@ Ctx::~Ctx()
     for (auto &pe : prof_ev)
         for (auto e : pe)
             if (e) (void)hipEventDestroy(e);
-    void *dev[] = {t_expand.d, t_recon_d.d, t_recon_2d.d, d_fresh_rows, d_gemm1_rows, d_gemm2_rows, d_off, d_fields,
+    void *dev[] = {t_expand.d, t_recon_d.d, t_recon_2d.d, t_expand.dfrag, t_recon_d.dfrag, t_recon_2d.dfrag, d_fresh_rows, d_gemm1_rows, d_gemm2_rows, d_off, d_fields,
                    d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_seeds, d_pk, d_sb, d_sehat, d_t, d_alpha, d_I, d_pwT, d_limbs, d_linA, d_coef, d_lin_rows,
                    d_gather, d_gather2, d_W, d_W2, d_w, d_ell, d_sec, d_sec_u1, d_sec_u2, d_fail, d_inv, d_vfields,
                    d_vrowtab, d_rows_bg, d_rows_isrc, d_rows_idst, d_rows_u, d_fact, d_invfact, d_node_of, d_isort, d_hrange};
@@ -93,6 +93,11 @@ static int upload_table(Ctx &c, GemmTable &t, const std::vector<uint16_t> &A, in
     pack_limb_table(A, M, Kdim, t.Mpad, t.KS, pk);
     HIPCHK(dalloc(&t.d, pk.size()));
     HIPCHK(hipMemcpy(t.d, pk.data(), pk.size(), hipMemcpyHostToDevice));
+    if (t.KS == 7) {
+        pack_frag_table(A, M, Kdim, t.Mpad, t.KS, pk);
+        HIPCHK(dalloc(&t.dfrag, pk.size()));
+        HIPCHK(hipMemcpy(t.dfrag, pk.data(), pk.size(), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -109,13 +114,24 @@ GemmArgs gemm_args_small(const uint8_t *A, size_t a_gstride, int Mpad, int M, in
 }
 
 int gemm_modq(Ctx &c, const uint8_t *A, size_t a_gstride, int Mpad, int M, int KS, const GemmSrc &s, const GemmDst &d,
-              int npg, int ngroups, bool grouped)
+              int npg, int ngroups, bool grouped, const uint8_t *Afrag)
 {
     if (npg <= 0 || ngroups <= 0) return 0;
     GemmArgs ga{};
+    ga.Afrag = Afrag;
     ga.A = A; ga.a_gstride = a_gstride; ga.Mpad = Mpad; ga.M = M; ga.KS = KS;
     ga.C = d.C; ga.c_gstride = d.gstride; ga.c_rows = d.rows; ga.c_rstride = d.rstride; ga.c_off = d.off;
     ga.npg = npg; ga.npg_pad = grouped ? (npg + 63) / 64 * 64 : npg; ga.ngroups = ngroups; ga.grouped = grouped ? 1 : 0;
+    if (!grouped && Afrag) {
+        // shared table, 407-wide inputs: data rows resident in LDS, no limb matrix in HBM (k_table_gemm)
+        GemmArgs ta = ga;
+        ta.B = nullptr; ta.BRT = 0;
+        ta.src = s.src; ta.src_gstride = s.gstride; ta.src_rows = s.rows; ta.src_rstride = s.rstride; ta.src_koff = s.koff;
+        if (table_gemm_usable(ta)) {
+            HIPCHK(launch_table_gemm(ta, reinterpret_cast<uint16_t *>(c.d_limbs), c.stream));
+            return 0;
+        }
+    }
     const int rows = ((grouped ? ga.npg_pad * ngroups : npg * ngroups) + 63) / 64 * 64;
     const int mtiles = Mpad / 128;
     if (mtiles >= 4 && rows >= 2048 && (size_t)(rows / 16) * KS * 2048 <= c.limb_cap) {
@@ -376,11 +392,12 @@ int upload_tapes(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride)
 }
 
 // kyber_keygen on the device (kosk.cpp:4-70): A, s, e never leave HBM; only pk, NTT(s) bytes and the seeds come back
-int issue_keygen(Ctx &c, int n)
+int issue_keygen(Ctx &c, int n, bool sampled)
 {
     const Params &P = c.P;
     const int K = P.K;
-    HIPCHK(launch_keygen(c.tape_cur, c.tape_cur_stride, c.d_seeds, c.d_A, c.key_stride, c.d_se, c.se_stride, K, P.eta1, n, c.stream));
+    // `sampled`: seeds, A, s, e were already produced as roles of the prover's first launch (issue_sharing_front)
+    if (!sampled) HIPCHK(launch_keygen(c.tape_cur, c.tape_cur_stride, c.d_seeds, c.d_A, c.key_stride, c.d_se, c.se_stride, K, P.eta1, n, c.stream));
     NttArgs na{};
     na.in = c.d_se; na.in_gstride = c.se_stride; na.src_off = nullptr;
     na.out = c.d_sehat; na.out_gstride = c.se_stride; na.dst_off = nullptr;
@@ -424,7 +441,7 @@ int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride,
 // The sharing front of the prover for the fresh sharings [s0, s1) of the tape order: tape / witness expansion, NTTs,
 // A*NTT(s), and the Lagrange expansion of exactly those rows.  FRONT_FULL is what kyber_verifiable_keygen needs;
 // the other three are the reference's separate entry points (mlwe_prover.cpp:4-39, :41-59, and the sharing part of :81-).
-int issue_sharing_front(Ctx &c, int n, FrontPart part)
+int issue_sharing_front(Ctx &c, int n, FrontPart part, bool with_keygen)
 {
     const Params &P = c.P;
     const RowMap &rm = c.rm;
@@ -435,8 +452,10 @@ int issue_sharing_front(Ctx &c, int n, FrontPart part)
     if (part == FRONT_RANDOMNESS) { s1 = noff_f; witness = 0; ntt_count = P.M; matvec = false; }
     else if (part == FRONT_RANGE) { s0 = noff_f; s1 = noff; witness = 2; ntt_count = 0; expand = false; matvec = false; }
     else if (part == FRONT_ONLINE) { s0 = noff; expand = false; ntt_first = P.M; ntt_count = K; }
+    const KeygenFront kgf{c.d_seeds, c.d_A, c.key_stride, c.d_se, c.se_stride};
     HIPCHK(launch_prover_pre(c.tape_cur, c.tape_cur_stride, c.d_P, c.proof_stride, rm.f, P.M, 64 + 32 * P.M, c.d_fresh_rows, s0, s1, expand,
-                             witness, c.d_se, c.se_stride, rm, P.eta1, n, st));
+                             witness, c.d_se, c.se_stride, rm, P.eta1, n, st, with_keygen ? &kgf : nullptr));
+    if (with_keygen && issue_keygen(c, n, true)) return -1; // NTT(s), NTT(e), t = A o s + e, pk / sk bytes and their D2H
     if (ntt_count > 0) {
         NttArgs na{};
         na.in = reinterpret_cast<const int16_t *>(c.d_P);
@@ -483,14 +502,11 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     ha.lane_map = nullptr;
     ha.out_lanes_per_group = NPARTY;
 
-    // ---- key generation at the head of P1 (tape pointers may change from call to call: never part of a captured graph)
-    if (keygen) {
-        if (upload_tapes(c, n, keygen->tapes, keygen->tape_stride)) return -1;
-        if (issue_keygen(c, n)) return -1;
-    }
+    // ---- key generation rides in the first launch of P1 (tape pointers may change from call to call: never part of a captured graph)
+    if (keygen && upload_tapes(c, n, keygen->tapes, keygen->tape_stride)) return -1;
     // ---- P1: offline phase + witness sharing (secrets, randoms, one expansion GEMM), Tcomm of every party
     if (run_segment(c, (online_only || keygen) ? -1 : (int)Ctx::SEG_P1, n, [&]() -> int {
-        if (issue_sharing_front(c, n, online_only ? FRONT_ONLINE : FRONT_FULL)) return -1;
+        if (issue_sharing_front(c, n, online_only ? FRONT_ONLINE : FRONT_FULL, keygen != nullptr)) return -1;
         HashArgs h1 = ha;
         h1.prefix = nullptr;
         h1.out = c.d_dig1;

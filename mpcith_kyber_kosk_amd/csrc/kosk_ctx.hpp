@@ -36,6 +36,7 @@ enum ProfId { PR_HASH_TCOMM = 0, PR_HASH_VIEW, PR_GEMM_EXPAND1, PR_GEMM_EXPAND2,
 
 struct GemmTable {
     uint8_t *d = nullptr; // limb matrix (kosk_device.hpp)
+    uint8_t *dfrag = nullptr; // the same in fragment-linear tile order (k_table_gemm), tables with Kdim <= 448 only
     int M = 0, Mpad = 0, KS = 0, Kdim = 0;
 };
 
@@ -212,13 +213,13 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
 
 // C[g][rows_d[i]][off + m] = sum_k A[m][k] * src[g][rows_s[i]][koff + k] mod q  (conversion to limbs + MFMA GEMM)
 int gemm_modq(Ctx &c, const uint8_t *A, size_t a_gstride, int Mpad, int M, int KS, const GemmSrc &s, const GemmDst &d,
-              int npg, int ngroups, bool grouped);
+              int npg, int ngroups, bool grouped, const uint8_t *Afrag = nullptr);
 // argument block of a small product (data operand converted inside the kernel), for launch_gemm_batch
 GemmArgs gemm_args_small(const uint8_t *A, size_t a_gstride, int Mpad, int M, int KS, const GemmSrc &s, const GemmDst &d, int npg,
                          int ngroups, bool grouped);
 inline int gemm_modq(Ctx &c, const GemmTable &t, const GemmSrc &s, const GemmDst &d, int npg, int ngroups)
 {
-    return gemm_modq(c, t.d, 0, t.Mpad, t.M, t.KS, s, d, npg, ngroups, false);
+    return gemm_modq(c, t.d, 0, t.Mpad, t.M, t.KS, s, d, npg, ngroups, false, t.dfrag);
 }
 
 // tapes (host or device memory, nullptr = callback) -> pk/sk on host, tape + key material resident in HBM
@@ -226,11 +227,11 @@ int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride,
 // its three parts: make the tapes resident (async), kyber_keygen on the device + D2H of pk / NTT(s) / seeds (async),
 // and, once the stream has been synchronised, the host half (sk = NTT(s) || pk || H(pk) || z, kosk.cpp:62-69)
 int upload_tapes(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride);
-int issue_keygen(Ctx &c, int n);
+int issue_keygen(Ctx &c, int n, bool sampled = false);
 void finish_keygen_host(Ctx &c, int n, uint8_t *pk, uint8_t *sk);
 // everything from resident inputs to resident proof images (two host Fiat-Shamir round trips)
 enum FrontPart { FRONT_FULL = 0, FRONT_RANDOMNESS, FRONT_RANGE, FRONT_ONLINE };
-int issue_sharing_front(Ctx &c, int n, FrontPart part);
+int issue_sharing_front(Ctx &c, int n, FrontPart part, bool with_keygen = false);
 // online_only: the offline material (f, NTT f, eta sharings) is already in the row matrix (prove_prepared)
 // keygen != nullptr: key generation runs at the head of the first segment (no extra synchronisation) and pk / sk are
 // written before the call returns -- the whole kyber_verifiable_keygen, proofs left resident

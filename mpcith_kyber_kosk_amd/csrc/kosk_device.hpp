@@ -71,6 +71,7 @@ struct LimbArgs {
 // C[n][c_off + m] = sum_k A[m][k] * B[n][k] mod q, both operands limb matrices
 struct GemmArgs {
     const uint8_t *A;  // table limb matrix, RT = Mpad/16
+    const uint8_t *Afrag; // the same table with fragment-linear tiles (k_table_gemm), or null
     size_t a_gstride;  // bytes between per-group operands (grouped mode)
     int Mpad, M, KS;   // Mpad multiple of 128; m < M is stored
     const uint8_t *B;  // data operand as a limb matrix, rows n = g*npg_pad + i (null: convert from `src` on the fly)
@@ -226,10 +227,18 @@ hipError_t launch_sha3_msgs(const uint8_t *in, size_t in_stride, int len, uint8_
 hipError_t launch_rows_copy(const uint16_t *src, size_t src_stride, uint16_t *dst, size_t dst_stride, int count,
                             int nrows, hipStream_t st);
 // expand_f + tape randoms + witness secrets (the kernels that only read the tape / the key) in one launch
+// key generation outputs when it runs as roles of the prover's first launch
+struct KeygenFront {
+    uint8_t *seeds;
+    int16_t *A;
+    size_t A_stride;
+    int16_t *se;
+    size_t se_stride;
+};
 hipError_t launch_prover_pre(const uint8_t *tape, size_t tape_stride, uint16_t *P, size_t proof_stride, int row_f, int M,
                              int slice0_off, const int16_t *fresh_rows, int slice_begin, int slice_end, bool expand_f,
                              int witness_mode, const int16_t *se, size_t se_stride, const RowMap &rm, int eta1, int nproofs,
-                             hipStream_t st);
+                             hipStream_t st, const KeygenFront *kg = nullptr);
 hipError_t launch_ntt(const NttArgs &a, hipStream_t st);
 // k_ntt256 (this proof's na.npg = 2K polynomials) + k_matvec_ntt(nttsr -> nttasr) + k_copy_tails in one launch
 hipError_t launch_relation_ntt(const NttArgs &na, const int16_t *A, size_t A_stride, uint16_t *P, size_t proof_stride, const RowMap &rm,
@@ -245,6 +254,9 @@ struct GemmBatch {
 hipError_t launch_gemm_batch(const GemmArgs *list, int count, hipStream_t st);
 hipError_t launch_rows_to_limbs(const LimbArgs &a, hipStream_t st);
 hipError_t launch_gemm(const GemmArgs &a, hipStream_t st);
+// table products (shared table, 407-wide u16 input rows) with the data rows resident in LDS; `sink` = 4 KiB of scratch
+bool table_gemm_usable(const GemmArgs &a);
+hipError_t launch_table_gemm(const GemmArgs &a, uint16_t *sink, hipStream_t st);
 // K3 on the matrix cores (prover): transposed f / NTT-f rows and the alpha-power coefficient matrix as limb matrices
 hipError_t launch_cols_to_limbs(const uint16_t *P, size_t proof_stride, int row_f, int row_tf, int M, uint8_t *A, size_t a_gstride,
                                 int nproofs, hipStream_t st);

@@ -474,6 +474,24 @@ void pack_limb_table(const std::vector<uint16_t> &A, int M, int Kdim, int Mpad, 
         }
 }
 
+// The same limb split in "fragment-linear" order for kernels that load MFMA operands straight from global memory: inside a
+// 1 KiB tile, lane l = 16 (k % 64 / 16) + (m % 16) of v_mfma_i32_16x16x64_i8 finds its 16 bytes at offset 16 l, so a wave
+// reads the tile as one linear, fully coalesced 1 KiB load.
+void pack_frag_table(const std::vector<uint16_t> &A, int M, int Kdim, int Mpad, int KS, std::vector<uint8_t> &out)
+{
+    const int RT = Mpad / 16;
+    out.assign((size_t)KS * RT * 2048, 0);
+    for (int m = 0; m < M; m++)
+        for (int k = 0; k < Kdim; k++) {
+            const int32_t c = gf_center(A[(size_t)m * Kdim + k]);
+            const int c0 = ((c + 32) & 63) - 32, c1 = (c - c0) >> 6;
+            const int ks = k >> 6, kc = (k >> 4) & 3, rr = m & 15;
+            const size_t base = ((size_t)(ks * RT + (m >> 4)) * 2) * 1024 + (size_t)(kc * 16 + rr) * 16 + (k & 15);
+            out[base] = (uint8_t)(int8_t)c0;
+            out[base + 1024] = (uint8_t)(int8_t)c1;
+        }
+}
+
 // -------------------------------------------------------------------- misc --
 // Persistent worker pool: Fiat-Shamir rounds arrive in short bursts between GPU phases, so the
 // workers spin briefly on a generation counter before they block.

@@ -19,6 +19,7 @@
 
 #include "kosk_device.hpp"
 #include "kosk_keccak_dev.hpp"
+#include "kosk_keygen_dev.hpp"
 #include "kosk_math.hpp"
 
 namespace kosk {
@@ -304,6 +305,14 @@ struct PreArgs {
     RowMap rm;
     int eta1;
     int nbA, nbB; // blocks of role A, B (role C: 4 per proof)
+    // key generation as two more roles of the same launch (kosk.cpp:12-20): G one thread per matrix entry A[i][j], N one per
+    // noise polynomial; each hashes d || K itself (one extra permutation) so that no role waits for another
+    int nbG, nbN, K;
+    uint8_t *kg_seeds;   // [proof][64] public seed || noise seed (written by the nonce-0 thread of role N)
+    int16_t *kg_A;       // [proof][K][K][256]
+    size_t kg_A_stride;
+    int16_t *kg_se;      // [proof][2K][256] s then e
+    size_t kg_se_stride;
 };
 constexpr int PRE_SLICES = 8; // fresh sharings per role-B block
 
@@ -385,12 +394,41 @@ __device__ __forceinline__ void pre_witness_secrets(const PreArgs &a, int idx, i
     }
 }
 
+__device__ __forceinline__ void pre_gen_matrix(const PreArgs &a, int t)
+{
+    const int KK = a.K * a.K;
+    if (t >= a.nproofs * KK) return;
+    const int b = t / KK, ij = t - b * KK, i = ij / a.K, j = ij - i * a.K;
+    uint32_t pub[8], noise[8];
+    kg_seed_hash(a.tape + (size_t)b * a.tape_stride, a.K, pub, noise);
+    kg_gen_matrix(pub, i, j, a.kg_A + (size_t)b * a.kg_A_stride + (size_t)ij * 256);
+}
+
+__device__ __forceinline__ void pre_noise(const PreArgs &a, int t)
+{
+    if (t >= a.nproofs * 2 * a.K) return;
+    const int b = t / (2 * a.K), nonce = t - b * 2 * a.K;
+    uint32_t pub[8], noise[8];
+    kg_seed_hash(a.tape + (size_t)b * a.tape_stride, a.K, pub, noise);
+    if (nonce == 0) {
+        uint32_t *o = reinterpret_cast<uint32_t *>(a.kg_seeds + (size_t)b * 64);
+#pragma unroll
+        for (int q = 0; q < 8; q++) { o[q] = pub[q]; o[8 + q] = noise[q]; }
+    }
+    kg_noise(noise, nonce, a.eta1, a.kg_se + (size_t)b * a.kg_se_stride + (size_t)nonce * 256);
+}
+
 __global__ __launch_bounds__(64) void k_prover_pre(PreArgs a)
 {
-    const int blk = blockIdx.x;
-    if (blk < a.nbA) pre_expand_f(a, blk * 64 + threadIdx.x);
-    else if (blk < a.nbA + a.nbB) pre_tape_randoms(a, blk - a.nbA, threadIdx.x);
-    else pre_witness_secrets(a, blk - a.nbA - a.nbB, threadIdx.x);
+    int blk = blockIdx.x;
+    if (blk < a.nbA) return pre_expand_f(a, blk * 64 + threadIdx.x);
+    blk -= a.nbA;
+    if (blk < a.nbB) return pre_tape_randoms(a, blk, threadIdx.x);
+    blk -= a.nbB;
+    if (blk < a.nbG) return pre_gen_matrix(a, blk * 64 + threadIdx.x);
+    blk -= a.nbG;
+    if (blk < a.nbN) return pre_noise(a, blk * 64 + threadIdx.x);
+    pre_witness_secrets(a, blk - a.nbN, threadIdx.x);
 }
 
 // =========================================================================
@@ -781,6 +819,156 @@ __global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[2][GM_A_BYTES + GM_B_BYTES];
     gemm_modq_block<BLIMB>(a, blockIdx.x, blockIdx.y, blockIdx.z, lds);
+}
+
+// ---- table products with the DATA ROWS resident in LDS (k_table_gemm) ------------------------------------------
+// C[n][c_off + m] = sum_k T[m][k] * X[n][k] mod q for a table T shared by every row: the Lagrange expansion
+// (ss.cpp:23-32, :88-97; T = 1344 x 407) and recon_secrets_ddeg (ss.cpp:44-51; T = 256 x 407).
+// The generic kernel above re-streams a 128 x 64 table tile AND a 64-row data tile for every k-step of every output
+// tile (87 MAC per byte staged) and needs the data operand as a limb matrix in HBM, written by one launch and re-read
+// by each of the 11 table tiles.  Here a workgroup owns 48 data rows: they are converted to limbs ONCE, straight from
+// the canonical u16 rows into LDS (42 KiB), and stay there while the workgroup's 8 waves walk the table.  Each wave
+// takes 16-row chunks of the table on its own (no workgroup barrier after the prologue): the chunk's MFMA fragments
+// (7 k-steps x 2 limbs x 16 bytes per lane) are loaded from the L2-resident table limb matrix straight into registers -- a
+// fragment is 16 contiguous bytes of a 1 KiB tile, the wave reads each tile exactly once -- and every register set is
+// re-loaded for the NEXT chunk right after its MFMAs have been issued, so a whole chunk (7 k-steps, ~1350 MFMA cycles)
+// of loads is in flight behind the arithmetic.  After the last k-step the wave reduces mod q and stores 16 x 48 outputs;
+// with two waves per SIMD that epilogue runs under the partner's MFMAs.
+// HBM traffic = the data rows once + the output once + the table once (L2-resident afterwards).
+// In-place use (the expansion writes points >= 384 of the rows it reads points < 448 of): the rows are read in the
+// prologue only; with the table split over several workgroups per row block (msplit) another workgroup may already be
+// writing points 384..447 of the same rows -- points < 407 are rewritten with their own values (identity rows of the
+// table) and points >= 407 meet zero table columns, so any value read there is harmless.
+constexpr int TG_NB = 48, TG_WAVES = 8;
+
+__device__ __forceinline__ uint32_t gf_reduce_pos(uint32_t x) // x < 2^31
+{
+    const uint32_t t = __umulhi(x, 1290167u); // floor(2^32 / q): t in {floor(x/q) - 1, floor(x/q)}
+    uint32_t r = x - t * (uint32_t)Q;
+    r = r >= (uint32_t)Q ? r - Q : r;
+    return r >= (uint32_t)Q ? r - Q : r;
+}
+
+// TG_RT = table row tiles (of 16) per chunk
+template <int KS, int TG_RT>
+__global__ __launch_bounds__(512, 2) void k_table_gemm(GemmArgs a, int nchunks, int chunks_per_block)
+{
+    constexpr int TG_CHUNK = 16 * TG_RT;
+    __shared__ __attribute__((aligned(16))) uint8_t ldsB[KS * 3 * 2048]; // [k-step][row tile][limb][1 KiB]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ntot = a.npg * a.ngroups;
+    const int n0 = blockIdx.x * TG_NB;
+
+    // ---- prologue: this workgroup's data rows, u16 -> limbs, into LDS (every row is read exactly once from HBM);
+    // all loads of a thread are issued before the first conversion
+    constexpr int ITEMS = TG_NB * KS * 4, PER = (ITEMS + 511) / 512;
+    uint4 x0[PER], x1[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const int item = tid + q * 512;
+        const int row_l = item / (KS * 4), kc16 = item - row_l * (KS * 4);
+        const int n = n0 + row_l;
+        x0[q] = make_uint4(0, 0, 0, 0);
+        x1[q] = x0[q];
+        if (item < ITEMS && n < ntot) {
+            const int g = n / a.npg, i = n - g * a.npg;
+            const uint16_t *src = a.src + (size_t)g * a.src_gstride + (size_t)(a.src_rows ? (int)a.src_rows[i] : i) * a.src_rstride + a.src_koff + kc16 * 16;
+            x0[q] = *reinterpret_cast<const uint4 *>(src);
+            x1[q] = *reinterpret_cast<const uint4 *>(src + 8);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const int item = tid + q * 512;
+        if (item < ITEMS) {
+            const int row_l = item / (KS * 4), kc16 = item - row_l * (KS * 4);
+            uint4 lo, hi;
+            gm_split16(x0[q], x1[q], lo, hi);
+            uint8_t *d = ldsB + ((kc16 >> 2) * 3 + (row_l >> 4)) * 2048 + (row_l & 15) * 64 + (((kc16 & 3) ^ limb_swz(row_l & 15)) << 4);
+            *reinterpret_cast<uint4 *>(d) = lo;
+            *reinterpret_cast<uint4 *>(d + 1024) = hi;
+        }
+    }
+
+    const int c_begin = blockIdx.y * chunks_per_block;
+    const int c_end = c_begin + chunks_per_block < nchunks ? c_begin + chunks_per_block : nchunks;
+    const int c_first = c_begin + w;
+    const int nmy = c_first < c_end ? (c_end - c_first + TG_WAVES - 1) / TG_WAVES : 0; // chunks c_first, c_first + 8, ...
+    const int ART = a.Mpad / 16;
+    // fragment address inside a 1 KiB LDS tile: row lane & 15, k-chunk lane >> 4 (swizzled)
+    const int frag = (lane & 15) * 64 + (((lane >> 4) ^ limb_swz(lane & 15)) << 4);
+    // this lane's table fragments of chunk c, k-step ks: tiles (row tile TG_RT c + i, limb) of k-step ks; the table copy
+    // a.Afrag keeps every tile in fragment order, so the wave's load of a tile is one linear 1 KiB read
+    v4i fa[KS][2 * TG_RT];
+    auto load_chunk_ks = [&](int c, int ks, v4i (&dst)[2 * TG_RT]) {
+        const uint8_t *src = a.Afrag + ((size_t)(ks * ART + TG_RT * c) * 2) * 1024 + lane * 16;
+#pragma unroll
+        for (int q = 0; q < 2 * TG_RT; q++) dst[q] = *reinterpret_cast<const v4i *>(src + q * 1024);
+    };
+    if (nmy > 0) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) load_chunk_ks(c_first, ks, fa[ks]);
+    }
+    __syncthreads(); // the only workgroup barrier: from here on the waves run independently
+    if (nmy == 0) return;
+
+    // output rows of this lane's three columns (n = n0 + 16 j + (lane & 15))
+    uint16_t *crow[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int n = n0 + j * 16 + (lane & 15);
+        crow[j] = nullptr;
+        if (n < ntot) {
+            const int g = n / a.npg, i = n - g * a.npg;
+            crow[j] = a.C + (size_t)g * a.c_gstride + (size_t)(a.c_rows ? (int)a.c_rows[i] : i) * a.c_rstride + a.c_off + (lane >> 4) * 4;
+        }
+    }
+
+    v4i s0[TG_RT][3], s1[TG_RT][3], s2[TG_RT][3];
+#pragma unroll
+    for (int i = 0; i < TG_RT; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) { s0[i][j] = (v4i){0, 0, 0, 0}; s1[i][j] = s0[i][j]; s2[i][j] = s0[i][j]; }
+
+    for (int ci = 0; ci < nmy; ci++) {
+        const int c = c_first + ci * TG_WAVES;
+        const int cn = ci + 1 < nmy ? c + TG_WAVES : c; // the chunk to prefetch (the last one re-loads itself: harmless)
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const uint8_t *lb = ldsB + ks * 3 * 2048 + frag;
+            v4i b0[3], b1[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                b0[j] = *reinterpret_cast<const v4i *>(lb + j * 2048);
+                b1[j] = *reinterpret_cast<const v4i *>(lb + j * 2048 + 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < TG_RT; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    s0[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i], b0[j], s0[i][j], 0, 0, 0);
+                    s1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i], b1[j], s1[i][j], 0, 0, 0);
+                    s1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i + 1], b0[j], s1[i][j], 0, 0, 0);
+                    s2[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i + 1], b1[j], s2[i][j], 0, 0, 0);
+                }
+            load_chunk_ks(cn, ks, fa[ks]); // in flight for a whole chunk of arithmetic before it is used
+            __builtin_amdgcn_sched_barrier(0); // keep the k-steps apart: hoisting every LDS read of the chunk costs 150 VGPRs
+        }
+        // epilogue of the chunk: D[row = m: 4 (lane >> 4) + r][col = n: lane & 15] -> four consecutive m per lane, one 8-byte
+        // store per block.  |S0 + 64 S1 + 767 S2| < 2^29 for k <= 448, so adding 90 000 q makes it a positive u32.
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int i = 0; i < TG_RT; i++) {
+                uint32_t v[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    v[r] = gf_reduce_pos((uint32_t)(s0[i][j][r] + 64 * s1[i][j][r] + 767 * s2[i][j][r] + 90000 * Q));
+                    s0[i][j][r] = 0; s1[i][j][r] = 0; s2[i][j][r] = 0;
+                }
+                if (crow[j]) *reinterpret_cast<uint2 *>(crow[j] + c * TG_CHUNK + i * 16) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+            }
+    }
 }
 
 // up to three independent products (data operand as u16 rows) side by side in one launch
@@ -1266,7 +1454,7 @@ hipError_t launch_rows_copy(const uint16_t *src, size_t src_stride, uint16_t *ds
 hipError_t launch_prover_pre(const uint8_t *tape, size_t tape_stride, uint16_t *P, size_t proof_stride, int row_f, int M,
                              int slice0_off, const int16_t *fresh_rows, int slice_begin, int slice_end, bool expand_f,
                              int witness_mode, const int16_t *se, size_t se_stride, const RowMap &rm, int eta1, int nproofs,
-                             hipStream_t st)
+                             hipStream_t st, const KeygenFront *kg)
 {
     PreArgs a{};
     a.tape = tape; a.tape_stride = tape_stride; a.P = P; a.proof_stride = proof_stride;
@@ -1274,11 +1462,38 @@ hipError_t launch_prover_pre(const uint8_t *tape, size_t tape_stride, uint16_t *
     a.slice0_off = slice0_off; a.slice_begin = slice_begin; a.slice_end = slice_end; a.fresh_rows = fresh_rows;
     a.witness_mode = witness_mode;
     a.se = se; a.se_stride = se_stride; a.rm = rm; a.eta1 = eta1;
+    a.K = rm.K;
     a.nbA = expand_f ? (M * nproofs + 63) / 64 : 0;
     a.nbB = 3 * ((slice_end - slice_begin + PRE_SLICES - 1) / PRE_SLICES) * nproofs;
-    const int nb = a.nbA + a.nbB + (witness_mode ? 4 * nproofs : 0);
+    const int nbC = witness_mode ? 4 * nproofs : 0;
+    if (kg) {
+        // the witness secrets (role C) read s and e, which role N of this launch produces: they follow in a launch of their own
+        a.kg_seeds = kg->seeds; a.kg_A = kg->A; a.kg_A_stride = kg->A_stride; a.kg_se = kg->se; a.kg_se_stride = kg->se_stride;
+        a.nbG = (nproofs * rm.K * rm.K + 63) / 64;
+        a.nbN = (nproofs * 2 * rm.K + 63) / 64;
+        hipLaunchKernelGGL(k_prover_pre, dim3(a.nbA + a.nbB + a.nbG + a.nbN), dim3(64), 0, st, a);
+        if (nbC) {
+            a.nbA = a.nbB = a.nbG = a.nbN = 0;
+            hipLaunchKernelGGL(k_prover_pre, dim3(nbC), dim3(64), 0, st, a);
+        }
+        return hipGetLastError();
+    }
+    const int nb = a.nbA + a.nbB + nbC;
     if (nb <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_prover_pre, dim3(nb), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+// key generation alone (kosk_stage_prover_inputs): roles G and N of the same kernel
+hipError_t launch_keygen(const uint8_t *tape, size_t tape_stride, uint8_t *seeds, int16_t *A, size_t A_stride, int16_t *se,
+                         size_t se_stride, int K, int eta1, int n, hipStream_t st)
+{
+    PreArgs a{};
+    a.tape = tape; a.tape_stride = tape_stride; a.nproofs = n; a.eta1 = eta1; a.K = K;
+    a.kg_seeds = seeds; a.kg_A = A; a.kg_A_stride = A_stride; a.kg_se = se; a.kg_se_stride = se_stride;
+    a.nbG = (n * K * K + 63) / 64;
+    a.nbN = (n * 2 * K + 63) / 64;
+    hipLaunchKernelGGL(k_prover_pre, dim3(a.nbG + a.nbN), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 
@@ -1324,6 +1539,34 @@ hipError_t launch_gemm_batch(const GemmArgs *list, int count, hipStream_t st)
     }
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_gemm_modq_batch, dim3(total), dim3(256), 0, st, bt);
+    return hipGetLastError();
+}
+
+// the table-product kernel: shared table, KS == 7 (407-wide inputs), aligned u16 rows
+static bool table_gemm_ok(const GemmArgs &a)
+{
+    static const bool on = !(getenv("KOSK_TABLE_GEMM") && atoi(getenv("KOSK_TABLE_GEMM")) == 0);
+    return on && a.Afrag && !a.grouped && !a.B && a.KS == 7 && a.M % 32 == 0 && a.c_gdiv <= 1 && a.src_koff % 8 == 0 && a.src_rstride % 8 == 0 &&
+           a.src_gstride % 8 == 0 && (reinterpret_cast<uintptr_t>(a.src) & 15) == 0 && a.c_off % 4 == 0 && a.c_rstride % 4 == 0 &&
+           a.c_gstride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C) & 7) == 0;
+}
+
+bool table_gemm_usable(const GemmArgs &a) { return table_gemm_ok(a); }
+
+hipError_t launch_table_gemm(const GemmArgs &a, uint16_t *sink, hipStream_t st)
+{
+    const int ntot = a.npg * a.ngroups;
+    if (ntot <= 0) return hipSuccess;
+    static const int rt = getenv("KOSK_TG_RT") ? atoi(getenv("KOSK_TG_RT")) : 1;
+    const int nchunks = a.M / (rt == 2 ? 32 : 16), nblk = (ntot + TG_NB - 1) / TG_NB;
+    // few data rows: split the table over several workgroups per row block so that the launch still covers the chip
+    int msplit = nblk >= 160 ? 1 : (256 + nblk - 1) / nblk;
+    if (msplit > nchunks) msplit = nchunks;
+    const int cpb = (nchunks + msplit - 1) / msplit;
+    msplit = (nchunks + cpb - 1) / cpb;
+    (void)sink;
+    if (rt == 2) hipLaunchKernelGGL((k_table_gemm<7, 2>), dim3(nblk, msplit), dim3(512), 0, st, a, nchunks, cpb);
+    else hipLaunchKernelGGL((k_table_gemm<7, 1>), dim3(nblk, msplit), dim3(512), 0, st, a, nchunks, cpb);
     return hipGetLastError();
 }
 

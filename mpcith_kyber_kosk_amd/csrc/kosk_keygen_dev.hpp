@@ -1,0 +1,152 @@
+// Device functions of Kyber key generation (kosk.cpp:4-70), one sponge per thread, usable from any kernel so that the
+// prover front can run them as extra block ranges of its first launch (kosk_kernels.hip: k_prover_pre).
+// The squeezed blocks are parsed straight from the state registers (static lane indices after unrolling): no per-thread
+// LDS byte buffer, no dependent LDS reads inside the rejection loop.
+//   kg_seed_hash     sha3_512(d || K) -> public seed || noise seed               kosk.cpp:12-14
+//   kg_gen_matrix    SHAKE128(seed || j || i) + rej_uniform                       indcpa.c:124-145, :168-193
+//   kg_noise         SHAKE256(noise seed || nonce) + cbd2 / cbd3                  poly.c:225-230, cbd.c:58-107
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kosk_keccak_dev.hpp"
+#include "kosk_math.hpp"
+
+namespace kosk {
+
+// dword w of the sponge state seen as a little-endian byte string (w = 2 * lane + half)
+template <int WIDX>
+__device__ __forceinline__ uint32_t kdword(const KState &s)
+{
+    return (WIDX & 1) ? s.hi[WIDX >> 1] : s.lo[WIDX >> 1];
+}
+
+// fresh state = pad(seed32 || extra[0..nextra) || dom) for a sponge of `rate` bytes; seed32 as 8 dwords
+__device__ __forceinline__ void kg_absorb(KState &s, const uint32_t (&seed)[8], uint32_t extra, int nextra, int rate, uint32_t dom)
+{
+    kstate_zero(s);
+#pragma unroll
+    for (int l = 0; l < 4; l++) { s.lo[l] = seed[2 * l]; s.hi[l] = seed[2 * l + 1]; }
+    s.lo[4] = (extra & ((1u << (8 * nextra)) - 1u)) | (dom << (8 * nextra)); // nextra <= 2
+    const int last = rate / 8 - 1;
+#pragma unroll
+    for (int l = 0; l < 25; l++)
+        if (l == last) s.hi[l] ^= 0x80000000u;
+}
+
+__device__ __forceinline__ void kg_load_seed(uint32_t (&seed)[8], const uint8_t *p)
+{
+    if ((reinterpret_cast<uintptr_t>(p) & 3) == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) seed[i] = reinterpret_cast<const uint32_t *>(p)[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) seed[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
+    }
+}
+
+// buf = sha3_512(d[32] || K): dwords 0..7 public seed, 8..15 noise seed   (kosk.cpp:12-14: the reference hashes d || K)
+__device__ __forceinline__ void kg_seed_hash(const uint8_t *d32, int K, uint32_t (&pub)[8], uint32_t (&noise)[8])
+{
+    uint32_t d[8];
+    kg_load_seed(d, d32);
+    KState s;
+    kg_absorb(s, d, (uint32_t)K, 1, 72, 0x06);
+    keccak_f1600_dev(s);
+#pragma unroll
+    for (int l = 0; l < 4; l++) { pub[2 * l] = s.lo[l]; pub[2 * l + 1] = s.hi[l]; noise[2 * l] = s.lo[4 + l]; noise[2 * l + 1] = s.hi[4 + l]; }
+}
+
+// the 24 bits at bit offset 24 * T of the squeezed block
+template <int T>
+__device__ __forceinline__ uint32_t kg_triple(const KState &s)
+{
+    constexpr int k = (3 * T) / 4, sh = (24 * T) % 32;
+    if constexpr (sh == 0) return kdword<k>(s) & 0xFFFFFFu;
+    else if constexpr (sh == 8) return kdword<k>(s) >> 8;
+    else return __builtin_amdgcn_alignbit(kdword<k + 1>(s), kdword<k>(s), sh) & 0xFFFFFFu;
+}
+
+// A[i][j] (canonical, 256 coefficients at r) from the public seed; XOF input seed || j || i (gen_matrix, transposed == 0)
+__device__ __forceinline__ void kg_gen_matrix(const uint32_t (&pub)[8], int i, int j, int16_t *__restrict__ r)
+{
+    KState s;
+    kg_absorb(s, pub, (uint32_t)j | ((uint32_t)i << 8), 2, 168, 0x1F);
+    int ctr = 0;
+#pragma unroll 1
+    for (int blk = 0; blk < 32 && ctr < 256; blk++) { // 3 blocks suffice with probability 1 - 2^-40; bounded anyway
+        keccak_f1600_dev(s);
+        auto parse = [&]<int... Ts>(std::integer_sequence<int, Ts...>) {
+            (([&] {
+                 const uint32_t x = kg_triple<Ts>(s);
+                 const uint32_t v0 = x & 0xFFFu, v1 = x >> 12;
+                 if (v0 < (uint32_t)Q && ctr < 256) r[ctr++] = (int16_t)v0;
+                 if (v1 < (uint32_t)Q && ctr < 256) r[ctr++] = (int16_t)v1;
+             }()),
+             ...);
+        };
+        parse(std::make_integer_sequence<int, 56>{}); // 168 bytes = 56 triples
+    }
+}
+
+// 8 cbd2 coefficients from 32 bits / 4 cbd3 coefficients from 24 bits (cbd.c:58-107)
+__device__ __forceinline__ uint4 kg_cbd2_word(uint32_t x)
+{
+    const uint32_t d = (x & 0x55555555u) + ((x >> 1) & 0x55555555u);
+    uint32_t o[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int32_t c0 = (int32_t)((d >> (8 * q)) & 3) - (int32_t)((d >> (8 * q + 2)) & 3);
+        const int32_t c1 = (int32_t)((d >> (8 * q + 4)) & 3) - (int32_t)((d >> (8 * q + 6)) & 3);
+        o[q] = ((uint32_t)c0 & 0xFFFFu) | ((uint32_t)c1 << 16);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ uint2 kg_cbd3_triple(uint32_t x)
+{
+    const uint32_t d = (x & 0x00249249u) + ((x >> 1) & 0x00249249u) + ((x >> 2) & 0x00249249u);
+    uint32_t o[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int32_t c0 = (int32_t)((d >> (12 * q)) & 7) - (int32_t)((d >> (12 * q + 3)) & 7);
+        const int32_t c1 = (int32_t)((d >> (12 * q + 6)) & 7) - (int32_t)((d >> (12 * q + 9)) & 7);
+        o[q] = ((uint32_t)c0 & 0xFFFFu) | ((uint32_t)c1 << 16);
+    }
+    return make_uint2(o[0], o[1]);
+}
+
+// poly_getnoise_eta1(r, noise seed, nonce): 256 small signed coefficients at r (16-byte aligned)
+__device__ __forceinline__ void kg_noise(const uint32_t (&noise)[8], int nonce, int eta1, int16_t *__restrict__ r)
+{
+    KState s;
+    kg_absorb(s, noise, (uint32_t)nonce, 1, 136, 0x1F);
+    keccak_f1600_dev(s);
+    if (eta1 == 2) { // 128 bytes = 32 dwords, 8 coefficients each
+        auto go = [&]<int... Ws>(std::integer_sequence<int, Ws...>) {
+            ((reinterpret_cast<uint4 *>(r)[Ws] = kg_cbd2_word(kdword<Ws>(s))), ...);
+        };
+        go(std::make_integer_sequence<int, 32>{});
+    } else { // 192 bytes = 64 triples of 4 coefficients: 136 bytes of this block (45 triples + 1 byte), the rest from the next
+        auto go1 = [&]<int... Ts>(std::integer_sequence<int, Ts...>) {
+            ((reinterpret_cast<uint2 *>(r)[Ts] = kg_cbd3_triple(kg_triple<Ts>(s))), ...);
+        };
+        go1(std::make_integer_sequence<int, 45>{});
+        const uint32_t carry = kdword<33>(s) >> 24; // byte 135
+        keccak_f1600_dev(s);
+        // triple 45 = byte 135 of block 1 and bytes 0, 1 of block 2; triples 46.. start at byte 2 of block 2
+        reinterpret_cast<uint2 *>(r)[45] = kg_cbd3_triple(carry | ((kdword<0>(s) & 0xFFFFu) << 8));
+        auto go2 = [&]<int... Us>(std::integer_sequence<int, Us...>) {
+            (([&] {
+                 constexpr int bit = 16 + 24 * Us, k = bit / 32, sh = bit % 32; // bit offset inside block 2
+                 uint32_t x;
+                 if constexpr (sh == 0) x = kdword<k>(s) & 0xFFFFFFu;
+                 else if constexpr (sh == 8) x = kdword<k>(s) >> 8;
+                 else x = __builtin_amdgcn_alignbit(kdword<k + 1>(s), kdword<k>(s), sh) & 0xFFFFFFu;
+                 reinterpret_cast<uint2 *>(r)[46 + Us] = kg_cbd3_triple(x);
+             }()),
+             ...);
+        };
+        go2(std::make_integer_sequence<int, 18>{});
+    }
+}
+
+} // namespace kosk

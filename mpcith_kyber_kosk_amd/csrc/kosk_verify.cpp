@@ -175,8 +175,6 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     HIPCHK(hipSetDevice(c.device));
     if (ensure_verify_workspace(c)) return -1;
     if (pk_mode) {
-        // polyvec_frombytes(t) and gen_matrix(A, seed) on the device (kosk.cpp:94-99), ahead of the first segment on the
-        // same stream: no synchronisation of its own
         const Params &Pk = c.P;
         if (pk_mode == 1) {
             if (is_device_pointer(pk)) {
@@ -186,7 +184,8 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
                 HIPCHK(hipMemcpyAsync(c.d_pk, c.h_pk, (size_t)n * c.pk_stride, hipMemcpyHostToDevice, c.stream));
             }
         }
-        HIPCHK(launch_decode_pk(c.d_pk, c.pk_stride, c.d_t, c.d_A, c.key_stride, Pk.K, n, c.stream));
+        // the decoding itself (polyvec_frombytes + gen_matrix) is issued with segment V1B: nothing before needs A or t, and
+        // there it runs while the host hashes instead of in front of the first digests
     }
     const Params &P = c.P;
     const RowMap &rm = c.rm;
@@ -240,6 +239,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     // ---- alpha-independent GPU work, issued before the host hashes so that it runs meanwhile: interpolation of
     // the unopened shares
     if (run_segment(c, Ctx::SEG_V1B, n, [&]() -> int {
+    if (pk_mode) HIPCHK(launch_decode_pk(c.d_pk, c.pk_stride, c.d_t, c.d_A, c.key_stride, K, n, st)); // kosk.cpp:94-99
     InterpArgs ia{};
     ia.rest = c.d_rest;
     ia.isort = c.d_isort;

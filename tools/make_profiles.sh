@@ -2,14 +2,14 @@
 # Regenerates the files under profiles/ (run on the MI355X box from the repo root; outputs under gpurun_out/prof).
 # usage: tools/make_profiles.sh <tag>        e.g. r01b
 set -o pipefail
-tag=${1:-r01}
+tag=${1:-r02}
 out=gpurun_out/prof
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # 1. kernel stats of the bench command itself
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 60 --warmup 6 --no-cpu-baseline > $out/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 60 --warmup 6 --no-cpu-baseline --no-kernels > $out/bench_under_rocprof.log 2>&1
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_kernel_stats.csv
-tail -1 $out/bench_under_rocprof.log > $out/${tag}_bench_under_rocprof.json
+grep -a '^{"metric"' $out/bench_under_rocprof.log | tail -1 > $out/${tag}_bench_under_rocprof.json
 echo "stats done"
 # 2. one slot: GPU-busy per step
 tools/gpu_busy.sh $out/busy 80 > $out/${tag}_gpu_busy_1slot.txt 2>&1
@@ -37,7 +37,7 @@ with open("%s/%s_pmc_fetch_write.csv" % (out, tag), "w") as fo:
         w = W.get(k, [1, 0.0])
         fo.write("%s,%d,%d,%.0f,%.0f\n" % (k[0], k[1], n, v / n, w[1] / max(1, w[0])))
 # in-pipeline view hash: the k_commit_hash<16,220,...> dispatch with 46 proofs (grid 1472 x 46 threads)
-hv = [(k, v) for k, v in F.items() if "k_commit_hash<16, 220" in k[0] and k[1] == 1472 * 46]
+hv = [(k, v) for k, v in F.items() if "k_commit_hash" in k[0] and "<16, 220" in k[0] and k[1] == 1472 * 46]
 if hv:
     k, (n, v) = hv[0]
     w = W[k]

@@ -7,10 +7,9 @@ from mpcith_kyber_kosk_amd import api
 k, B = 3, 46
 ctx = api.Kosk(kyber_k=k, max_batch=B)
 tapes = [hashlib.shake_256(("kosk-tape-v1:%d" % b).encode()).digest(ctx.tape_bytes) for b in range(B)]
-ctx.stage_prover_inputs(tapes)
 for _ in range(2):
-    ctx.prove_resident(B)
-    assert all(ctx.verify_resident(B))
+    ctx.verifiable_keygen_resident(tapes)
+    assert all(ctx.verify_resident_pk(B))
 # calibration: k_rows_copy moves n*407 u16 in and n*1454 u16 out (2-byte-per-lane coalesced accesses, like the hash kernel's loads)
 n = 8192
 y = torch.randint(0, 3329, (n, 407), dtype=torch.int16, device="cuda")
