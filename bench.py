@@ -129,7 +129,26 @@ def kernel_microbench(ctx, torch, k, lanes=65536, reps=20):
         ctx.ntt256_batch(polys.data_ptr(), outp.data_ptr(), lanes)
     ms = ctx.timer_stop_ms() / reps
     out["ntt256"] = {"polys": lanes, "us": ms * 1e3, "GBps": lanes * 1024 / ms / 1e6,
-                     "frac_hbm_peak": lanes * 1024 / ms / 1e6 / HBM_PEAK_GBS}
+                     "frac_hbm_peak": lanes * 1024 / ms / 1e6 / HBM_PEAK_GBS, "arithmetic": "integer Montgomery (default)"}
+    # the opt-in packed-fp32 butterflies (KOSK_NTT_FP32=1; operands pinned to VGPRs, see k_ntt256_fp32's HAZARD note)
+    from mpcith_kyber_kosk_amd import api
+    old = os.environ.get("KOSK_NTT_FP32")
+    os.environ["KOSK_NTT_FP32"] = "1"
+    cf = api.Kosk(kyber_k=k, max_batch=1)
+    if old is None:
+        del os.environ["KOSK_NTT_FP32"]
+    else:
+        os.environ["KOSK_NTT_FP32"] = old
+    for _ in range(3):
+        cf.ntt256_batch(polys.data_ptr(), outp.data_ptr(), lanes)
+    cf.synchronize()
+    cf.timer_start()
+    for _ in range(reps):
+        cf.ntt256_batch(polys.data_ptr(), outp.data_ptr(), lanes)
+    ms = cf.timer_stop_ms() / reps
+    cf.close()
+    out["ntt256_packed_fp32"] = {"polys": lanes, "us": ms * 1e3, "GBps": lanes * 1024 / ms / 1e6,
+                                 "frac_hbm_peak": lanes * 1024 / ms / 1e6 / HBM_PEAK_GBS, "arithmetic": "packed fp32, opt-in (KOSK_NTT_FP32=1)"}
     return out
 
 

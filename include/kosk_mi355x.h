@@ -160,9 +160,10 @@ int kosk_resident_proofs(kosk_ctx *ctx, void **d_proofs, size_t *stride);
  * (:397-444, input of :445-449); `stride` = bytes per proof (1454 * 32).  This is what a multi-GPU job all-gathers
  * (RCCL) after each commitment round (BASELINE.json configs[3]).  Needs KOSK_STREAMS=1. */
 int kosk_resident_digests(kosk_ctx *ctx, int round, void **d_digests, size_t *stride);
-/* Called on the calling thread as soon as a round's table is complete in HBM and the context's stream is idle
- * (role 0 prover / 1 verifier; round as above; bytes = n * 1454 * 32): the place to start that all-gather so that it
- * overlaps the host's Fiat-Shamir hashing.  fn == NULL removes the hook. */
+/* Called on the calling thread as soon as a round's table is complete in HBM (role 0 prover / 1 verifier; round as
+ * above; bytes = n * 1454 * 32); the context's stream may already be running the kernels of the next segment, none of
+ * which writes the tables.  The place to start that all-gather so that it overlaps the host's Fiat-Shamir hashing.
+ * fn == NULL removes the hook. */
 typedef void (*kosk_round_fn)(void *user, int role, int round, const void *d_digests, size_t bytes);
 int kosk_set_round_hook(kosk_ctx *ctx, kosk_round_fn fn, void *user);
 

@@ -19,6 +19,7 @@ struct kosk_ctx {
     Ctx *c; // sub[0]: kernel-level entry points, error text, sizes
     int max_batch;
     std::string err;
+    std::vector<uint32_t> masks; // fail masks of the last verify call, in the caller's proof order
 
     // [first, count) of sub-batch i of an n-proof call
     void split(int n, int i, int &first, int &count) const
@@ -55,6 +56,31 @@ struct kosk_ctx {
         return 0;
     }
 };
+
+// Batches larger than a sub-context: the chunks (of a sub-context's capacity each) are dealt round-robin to the S
+// sub-contexts, which work through theirs concurrently on S host threads.  With KOSK_STREAMS >= 2 one chunk's PCIe
+// transfers (tapes in, 0.68 MB of proof image out per proof; proofs and keys in for the verifier) and host hashing run
+// under another chunk's kernels: the streaming write-back of SURVEY.md 8 f4 for a single caller thread.
+template <typename F>
+static int run_chunks(kosk_ctx *h, int n, F &&fn)
+{
+    h->clear_err();
+    const int S = (int)h->sub.size(), per = h->sub[0]->max_batch, nchunks = (n + per - 1) / per;
+    std::vector<int> rc(S, 0);
+    auto lane = [&](int i) {
+        for (int j = i; j < nchunks && !rc[i]; j += S) {
+            const int first = j * per, count = (n - first) < per ? (n - first) : per;
+            rc[i] = fn(*h->sub[i], first, count);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < S && i < nchunks; i++) th.emplace_back(lane, i);
+    lane(0);
+    for (auto &t : th) t.join();
+    for (int i = 0; i < S; i++)
+        if (rc[i]) { h->err = h->sub[i]->err; h->c->err = h->err; return -1; }
+    return 0;
+}
 
 static thread_local std::string g_create_err; // error text of the last failed kosk_create on this thread
 
@@ -178,7 +204,12 @@ int kosk_stage_verifier_inputs(kosk_ctx *ctx, int n, const uint8_t *pi, const ui
 int kosk_verify_resident(kosk_ctx *ctx, int n, uint8_t *ok)
 {
     if (!ctx || n < 1 || n > ctx->max_batch) return -1;
-    return ctx->run(n, [&](Ctx &c, int first, int count) { return verify_resident(c, count, ok + first); });
+    ctx->masks.assign((size_t)n, 0);
+    return ctx->run(n, [&](Ctx &c, int first, int count) {
+        if (verify_resident(c, count, ok + first)) return -1;
+        memcpy(ctx->masks.data() + first, c.h_fail, sizeof(uint32_t) * (size_t)count);
+        return 0;
+    });
 }
 
 int kosk_verifiable_keygen_resident(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk)
@@ -211,8 +242,11 @@ int kosk_verify_resident_pk(kosk_ctx *ctx, int n, const uint8_t *pk, uint8_t *ok
 {
     if (!ctx || n < 1 || n > ctx->max_batch || !ok) return -1;
     const Params &P = ctx->c->P;
+    ctx->masks.assign((size_t)n, 0);
     return ctx->run(n, [&](Ctx &c, int first, int count) {
-        return verify_resident(c, count, ok + first, pk ? 1 : 2, pk ? pk + (size_t)first * P.pk_bytes : nullptr);
+        if (verify_resident(c, count, ok + first, pk ? 1 : 2, pk ? pk + (size_t)first * P.pk_bytes : nullptr)) return -1;
+        memcpy(ctx->masks.data() + first, c.h_fail, sizeof(uint32_t) * (size_t)count);
+        return 0;
     });
 }
 int kosk_set_round_hook(kosk_ctx *ctx, kosk_round_fn fn, void *user)
@@ -234,30 +268,44 @@ int kosk_resident_digests(kosk_ctx *ctx, int round, void **d_digests, size_t *st
 int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride,
                                  uint8_t *pk, uint8_t *sk, uint8_t *pi)
 {
-    if (!ctx || n < 0) return -1;
+    if (!ctx || n < 0 || !pk || !sk || !pi) return -1;
+    if (n == 0) return 0;
     const Params &P = ctx->c->P;
-    for (int done = 0; done < n;) {
-        const int m = (n - done) < ctx->max_batch ? (n - done) : ctx->max_batch;
-        const uint8_t *tp = tapes ? tapes + (size_t)done * tape_stride : nullptr;
-        if (kosk_stage_prover_inputs(ctx, m, tp, tape_stride, pk + (size_t)done * P.pk_bytes, sk + (size_t)done * P.sk_bytes)) return -1;
-        if (kosk_prove_resident(ctx, m)) return -1;
-        if (kosk_fetch_proofs(ctx, m, pi + (size_t)done * P.proof_bytes)) return -1;
-        done += m;
+    std::vector<uint8_t> drawn;
+    if (!tapes) {
+        // the randombytes callback is stateful: draw every tape sequentially, in proof order (reference call order:
+        // kosk.cpp:12, mlwe_prover.cpp:9, ss.cpp:5), then work through the chunks in parallel
+        drawn.resize((size_t)n * P.tape_bytes);
+        Ctx &c0 = *ctx->c;
+        uint8_t *tp = drawn.data();
+        auto draw = [&](size_t len) { if (c0.rb) c0.rb(c0.rb_user, tp, len); else os_randombytes(tp, len); tp += len; };
+        for (int b = 0; b < n; b++) {
+            draw(64);
+            for (int i = 0; i < P.M; i++) draw(32);
+            for (int i = 0; i < P.nfresh; i++) draw(302);
+        }
+        tapes = drawn.data();
+        tape_stride = P.tape_bytes;
     }
-    return 0;
+    return run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
+        const KeygenIn kg{tapes + (size_t)first * tape_stride, tape_stride, pk + (size_t)first * P.pk_bytes, sk + (size_t)first * P.sk_bytes};
+        if (prove_resident(c, count, false, &kg)) return -1;
+        return fetch_proofs(c, count, pi + (size_t)first * P.proof_bytes);
+    });
 }
 
 int kosk_verify_batch(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk, uint8_t *ok)
 {
-    if (!ctx || n < 0) return -1;
+    if (!ctx || n < 0 || !pi || !pk || !ok) return -1;
+    if (n == 0) return 0;
     const Params &P = ctx->c->P;
-    for (int done = 0; done < n;) {
-        const int m = (n - done) < ctx->max_batch ? (n - done) : ctx->max_batch;
-        if (kosk_stage_verifier_inputs(ctx, m, pi + (size_t)done * P.proof_bytes, pk + (size_t)done * P.pk_bytes)) return -1;
-        if (kosk_verify_resident(ctx, m, ok + done)) return -1;
-        done += m;
-    }
-    return 0;
+    ctx->masks.assign((size_t)n, 0);
+    return run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
+        if (stage_verifier_inputs(c, count, pi + (size_t)first * P.proof_bytes, pk + (size_t)first * P.pk_bytes)) return -1;
+        if (verify_resident(c, count, ok + first)) return -1;
+        memcpy(ctx->masks.data() + first, c.h_fail, sizeof(uint32_t) * (size_t)count);
+        return 0;
+    });
 }
 
 // ---- second-level entry points (kosk_split.cpp) -----------------------------------------------------------
@@ -315,6 +363,8 @@ int kosk_verify_inst(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *ins
         const int m = (n - done) < c.max_batch ? (n - done) : c.max_batch;
         if (stage_verifier_inst(c, m, pi + (size_t)done * c.P.proof_bytes, inst + (size_t)done * mlwe_inst_bytes(c.P))) return -1;
         if (verify_resident(c, m, ok + done)) return -1;
+        if (ctx->masks.size() < (size_t)n) ctx->masks.resize((size_t)n, 0);
+        memcpy(ctx->masks.data() + done, c.h_fail, sizeof(uint32_t) * (size_t)m);
         done += m;
     }
     return 0;
@@ -353,12 +403,8 @@ int kosk_stage_verifier_inputs_compact(kosk_ctx *ctx, int n, const uint8_t *in, 
 
 int kosk_verify_fail_masks(const kosk_ctx *ctx, uint32_t *masks, int n)
 {
-    if (!ctx || !masks || n < 0 || n > ctx->max_batch) return -1;
-    for (int i = 0; i < (int)ctx->sub.size(); i++) {
-        int first, count;
-        ctx->split(n, i, first, count);
-        if (count > 0) memcpy(masks + first, ctx->sub[i]->h_fail, sizeof(uint32_t) * (size_t)count);
-    }
+    if (!ctx || !masks || n < 0 || (size_t)n > ctx->masks.size()) return -1;
+    memcpy(masks, ctx->masks.data(), sizeof(uint32_t) * (size_t)n);
     return 0;
 }
 
@@ -489,7 +535,7 @@ int kosk_ntt256_batch(kosk_ctx *ctx, const int16_t *d_in, int16_t *d_out, int n)
     na.out = d_out;
     na.npg = n;
     na.npoly = n;
-    na.out_canonical = 0;
+    na.out_canonical = 0; na.fp32 = c.ntt_fp32;
     HIPCHK_C(launch_ntt(na, c.stream));
     return 0;
 }

@@ -64,12 +64,12 @@ Ctx::~Ctx()
         for (auto e : pe)
             if (e) (void)hipEventDestroy(e);
     void *dev[] = {t_expand.d, t_recon_d.d, t_recon_2d.d, t_expand.dfrag, t_recon_d.dfrag, t_recon_2d.dfrag, d_fresh_rows, d_gemm1_rows, d_gemm2_rows, d_off, d_fields,
-                   d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_seeds, d_pk, d_sb, d_sehat, d_t, d_alpha, d_I, d_pwT, d_limbs, d_linA, d_coef, d_lin_rows,
-                   d_gather, d_gather2, d_W, d_W2, d_w, d_ell, d_sec, d_sec_u1, d_sec_u2, d_fail, d_inv, d_vfields,
+                   d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_kg, d_sehat, d_t, d_alpha, d_I, d_pwT, d_limbs, d_linA, d_coef, d_lin_rows,
+                   d_gather, d_gather2, d_O, d_W, d_W2, d_w, d_ell, d_sec, d_sec_u1, d_sec_u2, d_fail, d_inv, d_vfields,
                    d_vrowtab, d_rows_bg, d_rows_isrc, d_rows_idst, d_rows_u, d_fact, d_invfact, d_node_of, d_isort, d_hrange};
     for (void *p : dev)
         if (p) (void)hipFree(p);
-    void *host[] = {h_tape, h_dig, h_proof, h_alpha, h_I, h_fail, h_Iimg, h_seeds, h_pk, h_sb};
+    void *host[] = {h_tape, h_dig, h_proof, h_alpha, h_I, h_fail, h_Iimg, h_kg};
     for (void *p : host)
         if (p) (void)hipHostFree(p);
     if (d_compact) (void)hipFree(d_compact);
@@ -282,6 +282,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     if (const char *e = getenv("KOSK_HOST_THREADS")) c.nthreads = atoi(e) > 0 ? atoi(e) : c.nthreads;
     if (const char *e = getenv("KOSK_GRAPHS")) c.use_graphs = atoi(e) != 0;
     if (const char *e = getenv("KOSK_LINCOMB_FUSED")) c.lincomb_fused = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_NTT_FP32")) c.ntt_fp32 = atoi(e) != 0;
 
     auto body = [&]() -> int {
         HIPCHK(hipSetDevice(device));
@@ -307,15 +308,15 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
         HIPCHK(dalloc(&c.d_A, B * c.key_stride));
         HIPCHK(dalloc(&c.d_se, B * c.se_stride));
         HIPCHK(dalloc(&c.d_t, B * P.K * 256));
-        c.pk_stride = (P.pk_bytes + 15) / 16 * 16;
-        c.sb_stride = (size_t)384 * P.K;
-        HIPCHK(dalloc(&c.d_seeds, B * 64));
-        HIPCHK(dalloc(&c.d_pk, B * c.pk_stride));
-        HIPCHK(dalloc(&c.d_sb, B * c.sb_stride));
+        const size_t pkpad = (P.pk_bytes + 15) / 16 * 16;
+        c.sb_bytes = (size_t)384 * P.K;
+        c.kg_rec = pkpad + c.sb_bytes + 64;
+        c.pk_stride = c.sb_stride = c.kg_rec;
+        HIPCHK(dalloc(&c.d_kg, B * c.kg_rec));
+        HIPCHK(halloc(&c.h_kg, B * c.kg_rec));
+        c.d_pk = c.d_kg; c.d_sb = c.d_kg + pkpad; c.d_seeds = c.d_kg + pkpad + c.sb_bytes;
+        c.h_pk = c.h_kg; c.h_sb = c.h_kg + pkpad; c.h_seeds = c.h_kg + pkpad + c.sb_bytes;
         HIPCHK(dalloc(&c.d_sehat, B * c.se_stride));
-        HIPCHK(halloc(&c.h_seeds, B * 64));
-        HIPCHK(halloc(&c.h_pk, B * c.pk_stride));
-        HIPCHK(halloc(&c.h_sb, B * c.sb_stride));
         HIPCHK(dalloc(&c.d_alpha, B * 80));
         HIPCHK(dalloc(&c.d_I, 2 * B * c.sel_stride)); // I rows then complement rows: one upload
         c.d_rest = c.d_I + B * c.sel_stride;
@@ -397,17 +398,15 @@ int issue_keygen(Ctx &c, int n, bool sampled)
     const Params &P = c.P;
     const int K = P.K;
     // `sampled`: seeds, A, s, e were already produced as roles of the prover's first launch (issue_sharing_front)
-    if (!sampled) HIPCHK(launch_keygen(c.tape_cur, c.tape_cur_stride, c.d_seeds, c.d_A, c.key_stride, c.d_se, c.se_stride, K, P.eta1, n, c.stream));
+    if (!sampled) HIPCHK(launch_keygen(c.tape_cur, c.tape_cur_stride, c.d_seeds, c.kg_rec, c.d_A, c.key_stride, c.d_se, c.se_stride, K, P.eta1, n, c.stream));
     NttArgs na{};
     na.in = c.d_se; na.in_gstride = c.se_stride; na.src_off = nullptr;
     na.out = c.d_sehat; na.out_gstride = c.se_stride; na.dst_off = nullptr;
-    na.npg = 2 * K; na.npoly = 2 * K * n; na.out_canonical = 0;
+    na.npg = 2 * K; na.npoly = 2 * K * n; na.out_canonical = 0; na.fp32 = c.ntt_fp32;
     HIPCHK(launch_ntt(na, c.stream)); // polyvec_ntt(s), polyvec_ntt(e)   kosk.cpp:39-40
-    HIPCHK(launch_keygen_pack(c.d_A, c.key_stride, c.d_sehat, c.se_stride, c.d_seeds, c.d_t, c.d_pk, c.pk_stride, c.d_sb,
+    HIPCHK(launch_keygen_pack(c.d_A, c.key_stride, c.d_sehat, c.se_stride, c.d_seeds, c.kg_rec, c.d_t, c.d_pk, c.pk_stride, c.d_sb,
                               c.sb_stride, K, n, c.stream));
-    HIPCHK(hipMemcpyAsync(c.h_pk, c.d_pk, (size_t)n * c.pk_stride, hipMemcpyDeviceToHost, c.stream));
-    HIPCHK(hipMemcpyAsync(c.h_sb, c.d_sb, (size_t)n * c.sb_stride, hipMemcpyDeviceToHost, c.stream));
-    HIPCHK(hipMemcpyAsync(c.h_seeds, c.d_seeds, (size_t)n * 64, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipMemcpyAsync(c.h_kg, c.d_kg, (size_t)n * c.kg_rec, hipMemcpyDeviceToHost, c.stream)); // pk, NTT(s) bytes, seeds: one copy
     return 0;
 }
 
@@ -417,10 +416,10 @@ void finish_keygen_host(Ctx &c, int n, uint8_t *pk, uint8_t *sk)
     parallel_for(c.pool, n, c.nthreads, [&](int b) { // sk = NTT(s) bytes || pk || H(pk) || z, z = noise seed   kosk.cpp:62-69
         uint8_t *pkb = pk + (size_t)b * P.pk_bytes, *skb = sk + (size_t)b * P.sk_bytes;
         memcpy(pkb, c.h_pk + (size_t)b * c.pk_stride, P.pk_bytes);
-        memcpy(skb, c.h_sb + (size_t)b * c.sb_stride, c.sb_stride);
-        memcpy(skb + c.sb_stride, pkb, P.pk_bytes);
+        memcpy(skb, c.h_sb + (size_t)b * c.sb_stride, c.sb_bytes);
+        memcpy(skb + c.sb_bytes, pkb, P.pk_bytes);
         sha3_256(skb + P.sk_bytes - 64, pkb, P.pk_bytes);
-        memcpy(skb + P.sk_bytes - 32, c.h_seeds + (size_t)b * 64 + 32, 32);
+        memcpy(skb + P.sk_bytes - 32, c.h_seeds + (size_t)b * c.kg_rec + 32, 32);
     });
 }
 
@@ -452,7 +451,7 @@ int issue_sharing_front(Ctx &c, int n, FrontPart part, bool with_keygen)
     if (part == FRONT_RANDOMNESS) { s1 = noff_f; witness = 0; ntt_count = P.M; matvec = false; }
     else if (part == FRONT_RANGE) { s0 = noff_f; s1 = noff; witness = 2; ntt_count = 0; expand = false; matvec = false; }
     else if (part == FRONT_ONLINE) { s0 = noff; expand = false; ntt_first = P.M; ntt_count = K; }
-    const KeygenFront kgf{c.d_seeds, c.d_A, c.key_stride, c.d_se, c.se_stride};
+    const KeygenFront kgf{c.d_seeds, c.kg_rec, c.d_A, c.key_stride, c.d_se, c.se_stride};
     HIPCHK(launch_prover_pre(c.tape_cur, c.tape_cur_stride, c.d_P, c.proof_stride, rm.f, P.M, 64 + 32 * P.M, c.d_fresh_rows, s0, s1, expand,
                              witness, c.d_se, c.se_stride, rm, P.eta1, n, st, with_keygen ? &kgf : nullptr));
     if (with_keygen && issue_keygen(c, n, true)) return -1; // NTT(s), NTT(e), t = A o s + e, pk / sk bytes and their D2H
@@ -466,7 +465,7 @@ int issue_sharing_front(Ctx &c, int n, FrontPart part, bool with_keygen)
         na.dst_off = c.d_off + c.off_ntt1_dst + ntt_first;
         na.npg = ntt_count;
         na.npoly = ntt_count * n;
-        na.out_canonical = 1;
+        na.out_canonical = 1; na.fp32 = c.ntt_fp32;
         c.prof_begin(PR_NTT_F);
         HIPCHK(launch_ntt(na, st));
         c.prof_end(PR_NTT_F);
@@ -516,18 +515,20 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig1, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
         return 0;
     })) return -1;
+    HIPCHK(hipEventRecord(c.ev, st)); // the Tcomm digests are on the host once this event has passed
     c.phase_sec[PH_P1_ISSUE] = now_sec() - t0;
-    HIPCHK(hipStreamSynchronize(st));
-    t1 = now_sec(); c.phase_sec[PH_GPU_COMMIT] = t1 - t0; t0 = t1;
-    if (c.round_hook) c.round_hook(c.round_user, 0, 0, c.d_dig1, (size_t)n * NPARTY * 32);
 
-    // ---- P1B: what neither Tcomm nor alpha needs is issued now and runs while the host hashes: the multiplication
-    // gates on the expanded shares (:338-381) and the transposed limb form of the f rows for the beta/gamma product
+    // ---- P1B: what neither Tcomm nor alpha needs is queued behind the digest copy BEFORE the host waits for it, and runs
+    // while the host hashes: the multiplication gates on the expanded shares (:338-381) and the transposed limb form of
+    // the f rows for the beta/gamma product
     if (run_segment(c, Ctx::SEG_P1B, n, [&]() -> int {
         HIPCHK(launch_post_gates(c.d_P, c.proof_stride, rm, n, st));
         if (!c.lincomb_fused) HIPCHK(launch_cols_to_limbs(c.d_P, c.proof_stride, rm.f, rm.tf, P.M, c.d_linA, a_gstride, n, st));
         return 0;
     })) return -1;
+    HIPCHK(hipEventSynchronize(c.ev));
+    t1 = now_sec(); c.phase_sec[PH_GPU_COMMIT] = t1 - t0; t0 = t1;
+    if (c.round_hook) c.round_hook(c.round_user, 0, 0, c.d_dig1, (size_t)n * NPARTY * 32);
 
     // ---- Fiat-Shamir round 1 on the host (and the host half of the key generation)
     if (keygen) finish_keygen_host(c, n, keygen->pk, keygen->sk);
@@ -561,12 +562,11 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     HIPCHK(launch_commit_hash(ha, n, K, true, st));
     c.prof_end(PR_HASH_VIEW);
     HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig2, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(c.ev, st));
     c.phase_sec[PH_P2_ISSUE] = now_sec() - t0;
-    HIPCHK(hipStreamSynchronize(st));
-    t1 = now_sec(); c.phase_sec[PH_GPU_RELATION] = t1 - t0; t0 = t1;
-    if (c.round_hook) c.round_hook(c.round_user, 0, 1, c.d_dig2, (size_t)n * NPARTY * 32);
 
-    // ---- P2B: the NTT-domain half of the relation is not hashed, only opened; it runs while the host derives I
+    // ---- P2B: the NTT-domain half of the relation is not hashed, only opened; queued behind the digest copy before the
+    // host waits for it, it runs while the host derives I
     if (run_segment(c, Ctx::SEG_P2B, n, [&]() -> int {
         NttArgs na{};
         na.in = reinterpret_cast<const int16_t *>(c.d_P);
@@ -577,7 +577,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         na.out = reinterpret_cast<int16_t *>(c.d_P);
         na.out_gstride = c.proof_stride;
         na.dst_off = c.d_off + c.off_nttsr_er;
-        na.out_canonical = 1;
+        na.out_canonical = 1; na.fp32 = c.ntt_fp32;
         HIPCHK(launch_relation_ntt(na, c.d_A, c.key_stride, c.d_P, c.proof_stride, rm, n, st)); // NTT, A o NTT(s+r) (:287-288), tails
         const GemmSrc x2src{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, 0, XLEN};
         const GemmDst x2dst{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, EXP_OFF};
@@ -587,6 +587,10 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         HIPCHK(launch_post_relation(c.d_P, c.proof_stride, rm, n, st));
         return 0;
     })) return -1;
+
+    HIPCHK(hipEventSynchronize(c.ev));
+    t1 = now_sec(); c.phase_sec[PH_GPU_RELATION] = t1 - t0; t0 = t1;
+    if (c.round_hook) c.round_hook(c.round_user, 0, 1, c.d_dig2, (size_t)n * NPARTY * 32);
 
     // ---- Fiat-Shamir round 2 on the host
     fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, c.h_I, c.h_rest, c.sel_stride, c.nthreads, c.pool);

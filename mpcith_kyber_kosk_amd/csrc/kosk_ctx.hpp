@@ -13,7 +13,8 @@
 namespace kosk {
 
 typedef void (*randombytes_fn)(void *user, uint8_t *out, size_t len);
-// called on the calling thread when a commitment round's digest table [n][1454][32] is complete in HBM (stream idle):
+// called on the calling thread when a commitment round's digest table [n][1454][32] is complete in HBM (the stream may already run
+// the next segment, which never writes the tables):
 // role 0 prover / 1 verifier, round 0 Tcomm / 1 view commitments
 typedef void (*round_fn)(void *user, int role, int round, const void *d_digests, size_t bytes);
 
@@ -105,6 +106,10 @@ struct Ctx {
     size_t tape_cur_stride = 0;
     int16_t *d_A = nullptr, *d_se = nullptr;
     // key generation on the device (kosk_keygen_kernels.hip)
+    // one record per proof [pk | NTT(s) bytes | sha3_512 output], kg_rec bytes apart, so that the key generation's
+    // outputs cross PCIe in ONE copy; d_pk / d_sb / d_seeds (and the h_ mirrors) point into it, all with stride kg_rec
+    uint8_t *d_kg = nullptr, *h_kg = nullptr;
+    size_t kg_rec = 0, sb_bytes = 0;
     uint8_t *d_seeds = nullptr, *d_pk = nullptr, *d_sb = nullptr; // sha3_512 output, packed pk, packed NTT(s)
     int16_t *d_sehat = nullptr;
     size_t pk_stride = 0, sb_stride = 0;
@@ -118,6 +123,8 @@ struct Ctx {
     size_t limb_cap = 0;
     // verifier workspace (allocated on first use, kosk_verify.cpp)
     bool verify_ready = false;
+    uint16_t *d_O = nullptr;         // opened matrix [proof][nrows][OS] (kosk_params.hpp)
+    size_t o_stride = 0;
     uint16_t *d_inv = nullptr;       // [Q] field inverses
     FieldDesc *d_vfields = nullptr;  // proof image -> rows (verifier row assignment)
     int16_t *d_vrowtab = nullptr;
@@ -160,6 +167,7 @@ struct Ctx {
     SegGraph seg[SEG_COUNT];
     bool use_graphs = false; // KOSK_GRAPHS=1 turns them on (measured on ROCm 7.2: no gain over plain launches)
     bool capturing = false;
+    int ntt_fp32 = 0; // KOSK_NTT_FP32=1: packed-fp32 NTT kernel (see its HAZARD note in kosk_kernels.hip); default integer
     bool lincomb_fused = true; // KOSK_LINCOMB_FUSED=0: separate transposition pass + generic GEMM
 
     double phase_sec[PH_COUNT] = {0};

@@ -34,6 +34,7 @@ struct NttArgs {
     // output position and bit cmp_bit of cmp_fail[group] is set on a mismatch (NTT(beta_j) == gamma_j, mlwe_verifier.cpp:110-124)
     uint32_t *cmp_fail;
     int cmp_delta, cmp_bit;
+    int fp32; // 1: the packed-fp32 butterflies (k_ntt256_fp32; KOSK_NTT_FP32=1 at kosk_create), 0: integer Montgomery
 };
 
 // ---- "limb matrix": the MFMA operand format of the mod-q GEMM -------------------------------
@@ -95,6 +96,8 @@ struct GemmArgs {
 struct LincombArgs {
     uint16_t *P;
     size_t proof_stride;
+    uint16_t *O;      // opened matrix (verifier): inputs and outputs live there; beta / gamma of parties < 407 also go to P
+    size_t o_stride;
     RowMap rm;
     int J;
     const int32_t *pwT; // [proof][MAXM][80]
@@ -153,6 +156,8 @@ struct GateOffsets {
 struct VerifyArgs {
     uint16_t *P;
     size_t proof_stride;
+    uint16_t *O;      // opened matrix [proof][row][OS]
+    size_t o_stride;
     RowMap rm;
     int eta1;
     const uint16_t *opened, *rest; // [proof][sel_stride]
@@ -194,6 +199,8 @@ struct OpenedHashArgs {
     uint32_t off_s, off_e, off_f, off_nttf, off_zs, off_ze;
     const uint16_t *P;
     size_t proof_stride;
+    const uint16_t *O; // opened matrix: beta, gamma, u of the opened parties
+    size_t o_stride;
     RowMap rm;
     const uint16_t *opened;
     int sel_stride;
@@ -214,10 +221,10 @@ hipError_t launch_interp_fixup(uint16_t *P, size_t proof_stride, const int16_t *
 hipError_t launch_check_opened(const VerifyArgs &v, int nproofs, hipStream_t st);
 
 // ---- key generation (kosk_keygen_kernels.hip) ----
-hipError_t launch_keygen(const uint8_t *tape, size_t tape_stride, uint8_t *seeds, int16_t *A, size_t A_stride, int16_t *se,
-                         size_t se_stride, int K, int eta1, int n, hipStream_t st);
+hipError_t launch_keygen(const uint8_t *tape, size_t tape_stride, uint8_t *seeds, size_t seed_stride, int16_t *A, size_t A_stride,
+                         int16_t *se, size_t se_stride, int K, int eta1, int n, hipStream_t st);
 hipError_t launch_keygen_pack(const int16_t *A, size_t A_stride, const int16_t *sehat, size_t sehat_stride, const uint8_t *seeds,
-                              uint16_t *t_out, uint8_t *pk, size_t pk_stride, uint8_t *shat_bytes, size_t sb_stride, int K, int n,
+                              size_t seed_stride, uint16_t *t_out, uint8_t *pk, size_t pk_stride, uint8_t *shat_bytes, size_t sb_stride, int K, int n,
                               hipStream_t st);
 hipError_t launch_decode_pk(const uint8_t *pk, size_t pk_stride, uint16_t *t_out, int16_t *A, size_t A_stride, int K, int n, hipStream_t st);
 
@@ -230,6 +237,7 @@ hipError_t launch_rows_copy(const uint16_t *src, size_t src_stride, uint16_t *ds
 // key generation outputs when it runs as roles of the prover's first launch
 struct KeygenFront {
     uint8_t *seeds;
+    size_t seed_stride;
     int16_t *A;
     size_t A_stride;
     int16_t *se;

@@ -308,7 +308,8 @@ struct PreArgs {
     // key generation as two more roles of the same launch (kosk.cpp:12-20): G one thread per matrix entry A[i][j], N one per
     // noise polynomial; each hashes d || K itself (one extra permutation) so that no role waits for another
     int nbG, nbN, K;
-    uint8_t *kg_seeds;   // [proof][64] public seed || noise seed (written by the nonce-0 thread of role N)
+    uint8_t *kg_seeds;   // public seed || noise seed of proof b at kg_seeds + b * kg_seed_stride (written by the nonce-0 thread of role N)
+    size_t kg_seed_stride;
     int16_t *kg_A;       // [proof][K][K][256]
     size_t kg_A_stride;
     int16_t *kg_se;      // [proof][2K][256] s then e
@@ -411,7 +412,7 @@ __device__ __forceinline__ void pre_noise(const PreArgs &a, int t)
     uint32_t pub[8], noise[8];
     kg_seed_hash(a.tape + (size_t)b * a.tape_stride, a.K, pub, noise);
     if (nonce == 0) {
-        uint32_t *o = reinterpret_cast<uint32_t *>(a.kg_seeds + (size_t)b * 64);
+        uint32_t *o = reinterpret_cast<uint32_t *>(a.kg_seeds + (size_t)b * a.kg_seed_stride);
 #pragma unroll
         for (int q = 0; q < 8; q++) { o[q] = pub[q]; o[8 + q] = noise[q]; }
     }
@@ -547,6 +548,147 @@ __global__ __launch_bounds__(256) void k_ntt256(NttArgs a)
 {
     __shared__ __attribute__((aligned(16))) int16_t lds[NTT_PPB * NTT_LSTRIDE];
     ntt256_tile(a, blockIdx.x * NTT_PPB, lds);
+}
+
+// ---- K5, packed-fp32 variant (opt-in: KOSK_NTT_FP32=1) ---------------------------------------------------------
+// The integer butterfly costs ~44 SIMD cycles (24/32-bit multiplies are half rate: profiles/r02_probe_keccak.txt); in
+// packed fp32 a PAIR of butterflies is six full-rate instructions.  Exact: every value is an integer below 2^24, products
+// and sums are exact, and  t = p - rint(p / q) q  (rint by the 1.5 * 2^23 trick) is the residue within +-(q/2 + 2).
+// Zetas are the plain roots, so the residues are those of ntt.c:80-95 + poly_reduce (poly.c:261-265).
+// HAZARD (root-caused in round 2, tools/ntt_lab.hip, profiles/r02_ntt_lab.txt): with the constants and uniform zetas as
+// SGPR / literal source operands -- what hipcc emits for the natural code -- this kernel returned wrong polynomials in
+// 85 % of its launches while an int8-MFMA kernel ran on another stream (one butterfly's product came out 0 for one
+// 16-lane group), and in none with VALU, packed-fp32 or HBM load generators; with every operand of the packed
+// instructions in VGPRs it is clean (0 of 6 322 launches under the same MFMA load), as are mul/add kept apart, the integer
+// kernel, and isolated FMA instructions with SGPR operands (tools/fma_probe.hip).  The pipeline runs MFMA GEMMs beside
+// everything, so the operands below are pinned to VGPRs (asm "+v") and the integer kernel stays the default.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__constant__ static const ZetaTableF kZetasF = ZetaTableF();
+constexpr int NTT_FSTRIDE = 16 * 20 + 16; // floats per polynomial in the fp32 transposition buffer (rows of 16 padded to 20)
+
+struct NttFConst {
+    v2f qinv, magic, q;
+};
+__device__ __forceinline__ v2f nttf_red(v2f p, const NttFConst &k) // |p| < 2^24 -> residue in [-q/2 - 2, q/2 + 2]
+{
+    const v2f r = (p * k.qinv + k.magic) - k.magic;
+    return p - r * k.q;
+}
+__device__ __forceinline__ void nttf_bfly(v2f &lo, v2f &hi, v2f z, const NttFConst &k)
+{
+    asm volatile("" : "+v"(z)); // VGPR operand, never an SGPR pair (see HAZARD above)
+    const v2f t = nttf_red(hi * z, k);
+    hi = lo - t;
+    lo = lo + t;
+}
+
+__global__ __launch_bounds__(256) void k_ntt256_fp32(NttArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float ldsf[NTT_PPB * NTT_FSTRIDE];
+    int16_t *lds16 = reinterpret_cast<int16_t *>(ldsf); // the int16 staging image lives in the same memory
+    const int tid = threadIdx.x, p0 = blockIdx.x * NTT_PPB;
+    NttFConst kc;
+    kc.qinv = (v2f){1.0f / (float)Q, 1.0f / (float)Q};
+    kc.magic = (v2f){12582912.0f, 12582912.0f};
+    kc.q = (v2f){(float)Q, (float)Q};
+    asm volatile("" : "+v"(kc.qinv), "+v"(kc.magic), "+v"(kc.q));
+
+    for (int c = tid; c < NTT_PPB * 32; c += 256) {
+        const int pl = c >> 5, ch = c & 31, p = p0 + pl;
+        if (p < a.npoly) {
+            const int g = p / a.npg, i = p - g * a.npg;
+            const size_t off = (size_t)g * a.in_gstride + (a.src_off ? (size_t)a.src_off[i] : (size_t)i * 256);
+            *reinterpret_cast<uint4 *>(lds16 + pl * 2 * NTT_FSTRIDE + ch * 8) = *reinterpret_cast<const uint4 *>(a.in + off + ch * 8);
+        }
+    }
+    __syncthreads();
+    const int pl = tid >> 4, l = tid & 15;
+    const int16_t *mine16 = lds16 + pl * 2 * NTT_FSTRIDE;
+    float *minef = ldsf + pl * NTT_FSTRIDE;
+    // P[q] = (r[2q], r[2q+1]); coefficient index of r[i] is l + 16 i
+    v2f P[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) P[q] = (v2f){(float)mine16[l + 32 * q], (float)mine16[l + 32 * q + 16]};
+    __syncthreads(); // the fp32 image overwrites the staging bytes
+    {
+        const v2f z = {kZetasF.z[1], kZetasF.z[1]};
+#pragma unroll
+        for (int q = 0; q < 4; q++) nttf_bfly(P[q], P[q + 4], z, kc);
+    }
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const v2f z = {kZetasF.z[2 + b], kZetasF.z[2 + b]};
+#pragma unroll
+        for (int q = 0; q < 2; q++) nttf_bfly(P[4 * b + q], P[4 * b + q + 2], z, kc);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const v2f z = {kZetasF.z[4 + b], kZetasF.z[4 + b]};
+        nttf_bfly(P[2 * b], P[2 * b + 1], z, kc);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) { // len = 16: the two halves of one pair, regrouped with their own zetas
+        v2f lo = {P[2 * m].x, P[2 * m + 1].x}, hi = {P[2 * m].y, P[2 * m + 1].y};
+        const v2f z = {kZetasF.z[8 + 2 * m], kZetasF.z[8 + 2 * m + 1]};
+        nttf_bfly(lo, hi, z, kc);
+        lo = nttf_red(lo, kc); // the one mid-way reduction: keeps every later product below 2^24
+        hi = nttf_red(hi, kc);
+        minef[l + 20 * (4 * m)] = lo.x;
+        minef[l + 20 * (4 * m + 1)] = hi.x;
+        minef[l + 20 * (4 * m + 2)] = lo.y;
+        minef[l + 20 * (4 * m + 3)] = hi.y;
+    }
+    __syncthreads();
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(minef + 20 * l);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 v = src[q];
+            P[2 * q] = (v2f){v.x, v.y};
+            P[2 * q + 1] = (v2f){v.z, v.w};
+        }
+    }
+    { // coefficient index 16 l + c with P[q] = (c = 2q, 2q + 1): zeta index = 128/len + j/(2 len)
+        const v2f z8 = {kZetasF.z[16 + l], kZetasF.z[16 + l]};
+#pragma unroll
+        for (int q = 0; q < 4; q++) nttf_bfly(P[q], P[q + 4], z8, kc);
+        const v2f z4a = {kZetasF.z[32 + 2 * l], kZetasF.z[32 + 2 * l]}, z4b = {kZetasF.z[33 + 2 * l], kZetasF.z[33 + 2 * l]};
+#pragma unroll
+        for (int q = 0; q < 2; q++) { nttf_bfly(P[q], P[q + 2], z4a, kc); nttf_bfly(P[4 + q], P[6 + q], z4b, kc); }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const v2f z2 = {kZetasF.z[64 + 4 * l + q], kZetasF.z[64 + 4 * l + q]};
+            nttf_bfly(P[2 * q], P[2 * q + 1], z2, kc);
+        }
+    }
+    const int p = p0 + pl;
+    if (p < a.npoly) {
+        uint32_t w[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const v2f rr = nttf_red(P[q], kc);
+            int32_t x0 = (int32_t)rr.x, x1 = (int32_t)rr.y; // integers in [-q/2 - 2, q/2 + 2]
+            if (a.out_canonical) {
+                x0 += x0 < 0 ? Q : 0;
+                x1 += x1 < 0 ? Q : 0;
+            } else { // the centred representative of poly_reduce: [-(q-1)/2, (q-1)/2]
+                x0 += x0 < -(Q / 2) ? Q : (x0 > Q / 2 ? -Q : 0);
+                x1 += x1 < -(Q / 2) ? Q : (x1 > Q / 2 ? -Q : 0);
+            }
+            w[q] = ((uint32_t)x0 & 0xFFFFu) | ((uint32_t)x1 << 16);
+        }
+        const int g = p / a.npg, i = p - g * a.npg;
+        const size_t off = (size_t)g * a.out_gstride + (a.dst_off ? (size_t)a.dst_off[i] : (size_t)i * 256);
+        uint4 *o = reinterpret_cast<uint4 *>(a.out + off + 16 * l);
+        if (a.cmp_fail) {
+            const uint4 c0 = o[a.cmp_delta / 8], c1 = o[a.cmp_delta / 8 + 1];
+            if (c0.x != w[0] || c0.y != w[1] || c0.z != w[2] || c0.w != w[3] || c1.x != w[4] || c1.y != w[5] || c1.z != w[6] || c1.w != w[7])
+                atomicOr(&a.cmp_fail[g], 1u << a.cmp_bit);
+        } else {
+            o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+    }
 }
 
 // K6  r_i = tomont(Barrett(sum_l basemul(A[i][l], v[l])))      polyvec.c:202-214, poly.c:307-313
@@ -841,12 +983,13 @@ __global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
 // table) and points >= 407 meet zero table columns, so any value read there is harmless.
 constexpr int TG_NB = 48, TG_WAVES = 8;
 
-__device__ __forceinline__ uint32_t gf_reduce_pos(uint32_t x) // x < 2^31
+__device__ __forceinline__ uint32_t gf_reduce_pos(uint32_t x) // x < 2^32 - q
 {
-    const uint32_t t = __umulhi(x, 1290167u); // floor(2^32 / q): t in {floor(x/q) - 1, floor(x/q)}
-    uint32_t r = x - t * (uint32_t)Q;
-    r = r >= (uint32_t)Q ? r - Q : r;
-    return r >= (uint32_t)Q ? r - Q : r;
+    // t = floor(x * floor(2^32 / q) / 2^32) is floor(x / q) or one less, so x - t q < 2 q: one conditional subtraction,
+    // done as an unsigned minimum (r - q wraps above r when r < q)
+    const uint32_t t = __umulhi(x, 1290167u);
+    const uint32_t r = x - t * (uint32_t)Q;
+    return min(r, r - (uint32_t)Q);
 }
 
 // TG_RT = table row tiles (of 16) per chunk
@@ -925,47 +1068,56 @@ __global__ __launch_bounds__(512, 2) void k_table_gemm(GemmArgs a, int nchunks, 
     }
 
     v4i s0[TG_RT][3], s1[TG_RT][3], s2[TG_RT][3];
-#pragma unroll
-    for (int i = 0; i < TG_RT; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) { s0[i][j] = (v4i){0, 0, 0, 0}; s1[i][j] = s0[i][j]; s2[i][j] = s0[i][j]; }
+    const v4i zero4 = {0, 0, 0, 0};
 
+    // the data fragments of the next k-step are read from LDS while the current k-step multiplies; the rows are the same
+    // for every chunk, so the last k-step prefetches k-step 0 again (into a buffer of its own: KS is odd)
+    v4i fb[2][6], fb0[6];
+    auto load_b = [&](int ks, v4i (&dst)[6]) {
+        const uint8_t *lb = ldsB + ks * 3 * 2048 + frag;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            dst[2 * j] = *reinterpret_cast<const v4i *>(lb + j * 2048);
+            dst[2 * j + 1] = *reinterpret_cast<const v4i *>(lb + j * 2048 + 1024);
+        }
+    };
+    load_b(0, fb0);
     for (int ci = 0; ci < nmy; ci++) {
         const int c = c_first + ci * TG_WAVES;
         const int cn = ci + 1 < nmy ? c + TG_WAVES : c; // the chunk to prefetch (the last one re-loads itself: harmless)
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
-            const uint8_t *lb = ldsB + ks * 3 * 2048 + frag;
-            v4i b0[3], b1[3];
+            v4i(&bc)[6] = ks == 0 ? fb0 : fb[ks & 1];
+            v4i(&bn)[6] = ks + 1 == KS ? fb0 : fb[(ks & 1) ^ 1];
+            load_b(ks + 1 < KS ? ks + 1 : 0, bn);
+            __builtin_amdgcn_sched_barrier(0); // the reads for the NEXT k-step go out before this k-step's MFMAs, not after them
+            // four limb products per 16 x 16 x 64 block, ordered so that no accumulator is used twice in a row; the first
+            // k-step starts from a zero operand instead of zeroed registers
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                b0[j] = *reinterpret_cast<const v4i *>(lb + j * 2048);
-                b1[j] = *reinterpret_cast<const v4i *>(lb + j * 2048 + 1024);
+            for (int i = 0; i < TG_RT; i++) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) s0[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i], bc[2 * j], ks == 0 ? zero4 : s0[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 3; j++) s1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i], bc[2 * j + 1], ks == 0 ? zero4 : s1[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 3; j++) s1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i + 1], bc[2 * j], s1[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 3; j++) s2[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i + 1], bc[2 * j + 1], ks == 0 ? zero4 : s2[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < TG_RT; i++)
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    s0[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i], b0[j], s0[i][j], 0, 0, 0);
-                    s1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i], b1[j], s1[i][j], 0, 0, 0);
-                    s1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i + 1], b0[j], s1[i][j], 0, 0, 0);
-                    s2[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i + 1], b1[j], s2[i][j], 0, 0, 0);
-                }
             load_chunk_ks(cn, ks, fa[ks]); // in flight for a whole chunk of arithmetic before it is used
             __builtin_amdgcn_sched_barrier(0); // keep the k-steps apart: hoisting every LDS read of the chunk costs 150 VGPRs
         }
         // epilogue of the chunk: D[row = m: 4 (lane >> 4) + r][col = n: lane & 15] -> four consecutive m per lane, one 8-byte
         // store per block.  |S0 + 64 S1 + 767 S2| < 2^29 for k <= 448, so adding 90 000 q makes it a positive u32.
+        // (Few VALU instructions on purpose: an MFMA leaves the SIMD's vector issue free only half of the time.)
 #pragma unroll
         for (int j = 0; j < 3; j++)
 #pragma unroll
             for (int i = 0; i < TG_RT; i++) {
                 uint32_t v[4];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
+                for (int r = 0; r < 4; r++)
                     v[r] = gf_reduce_pos((uint32_t)(s0[i][j][r] + 64 * s1[i][j][r] + 767 * s2[i][j][r] + 90000 * Q));
-                    s0[i][j][r] = 0; s1[i][j][r] = 0; s2[i][j][r] = 0;
-                }
                 if (crow[j]) *reinterpret_cast<uint2 *>(crow[j] + c * TG_CHUNK + i * 16) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
             }
     }
@@ -1192,22 +1344,26 @@ __global__ __launch_bounds__(256) void k_lincomb(LincombArgs a)
     const int jc = blockIdx.y;
     const int b = blockIdx.z >> 1, which = blockIdx.z & 1;
     if (xi >= a.ncols) return;
+    // verifier (a.O): entry xi of the opened matrix's rows -- consecutive threads, consecutive addresses; otherwise column
+    // `col` of the row matrix
     const int col = a.col_map ? NSEC + (int)a.col_map[(size_t)b * a.col_map_stride + xi] : xi;
     uint16_t *__restrict__ Pb = a.P + (size_t)b * a.proof_stride;
-    const uint16_t *__restrict__ in0 = Pb + (size_t)(which ? a.rm.tf : a.rm.f) * RS + col;
+    uint16_t *__restrict__ Ob = a.O ? a.O + (size_t)b * a.o_stride + xi : nullptr;
+    const size_t istride = a.O ? (size_t)OS : (size_t)RS;
+    const uint16_t *__restrict__ in0 = (a.O ? Ob : Pb + col) + (size_t)(which ? a.rm.tf : a.rm.f) * istride;
     const int32_t *__restrict__ pw = a.pwT + (size_t)b * MAXM * LC_JPAD + jc * LC_JC;
 
     int32_t acc[LC_JC];
 #pragma unroll
     for (int j = 0; j < LC_JC; j++) acc[j] = 0;
 #pragma unroll 8
-    for (int k = 1; k < a.rm.M; k++) { // independent gathers: unrolled so that eight are in flight
-        const int32_t v = gf_center(in0[(size_t)k * RS]);
+    for (int k = 1; k < a.rm.M; k++) { // independent loads: unrolled so that eight are in flight
+        const int32_t v = gf_center(in0[(size_t)k * istride]);
         const int32_t *pk = pw + (size_t)k * LC_JPAD;
 #pragma unroll
         for (int j = 0; j < LC_JC; j++) acc[j] += pk[j] * v;
     }
-    const int32_t base_chk = in0[0], base_r = in0[(size_t)(NCHK + 1) * RS];
+    const int32_t base_chk = in0[0], base_r = in0[(size_t)(NCHK + 1) * istride];
 #pragma unroll
     for (int jj = 0; jj < LC_JC; jj++) {
         const int j = jc * LC_JC + jj;
@@ -1216,7 +1372,14 @@ __global__ __launch_bounds__(256) void k_lincomb(LincombArgs a)
         if (j < NCHK) row = which ? a.rm.gamma(j) : a.rm.beta(j);
         else row = (which ? a.rm.nttr : a.rm.r) + (j - NCHK);
         const int32_t base = j < NCHK ? base_chk : base_r;
-        Pb[(size_t)row * RS + col] = (uint16_t)gf_from_i32(acc[jj] + base);
+        const uint16_t out = (uint16_t)gf_from_i32(acc[jj] + base);
+        if (Ob) {
+            Ob[(size_t)row * OS] = out;
+            // recon_secrets_ddeg (mlwe_verifier.cpp:106-107) reads the beta / gamma shares of parties 0..406 from the merged row
+            if (j < NCHK && col < NSEC + XLEN) Pb[(size_t)row * RS + col] = out;
+        } else {
+            Pb[(size_t)row * RS + col] = out;
+        }
     }
 }
 
@@ -1468,7 +1631,7 @@ hipError_t launch_prover_pre(const uint8_t *tape, size_t tape_stride, uint16_t *
     const int nbC = witness_mode ? 4 * nproofs : 0;
     if (kg) {
         // the witness secrets (role C) read s and e, which role N of this launch produces: they follow in a launch of their own
-        a.kg_seeds = kg->seeds; a.kg_A = kg->A; a.kg_A_stride = kg->A_stride; a.kg_se = kg->se; a.kg_se_stride = kg->se_stride;
+        a.kg_seeds = kg->seeds; a.kg_seed_stride = kg->seed_stride; a.kg_A = kg->A; a.kg_A_stride = kg->A_stride; a.kg_se = kg->se; a.kg_se_stride = kg->se_stride;
         a.nbG = (nproofs * rm.K * rm.K + 63) / 64;
         a.nbN = (nproofs * 2 * rm.K + 63) / 64;
         hipLaunchKernelGGL(k_prover_pre, dim3(a.nbA + a.nbB + a.nbG + a.nbN), dim3(64), 0, st, a);
@@ -1485,12 +1648,12 @@ hipError_t launch_prover_pre(const uint8_t *tape, size_t tape_stride, uint16_t *
 }
 
 // key generation alone (kosk_stage_prover_inputs): roles G and N of the same kernel
-hipError_t launch_keygen(const uint8_t *tape, size_t tape_stride, uint8_t *seeds, int16_t *A, size_t A_stride, int16_t *se,
-                         size_t se_stride, int K, int eta1, int n, hipStream_t st)
+hipError_t launch_keygen(const uint8_t *tape, size_t tape_stride, uint8_t *seeds, size_t seed_stride, int16_t *A, size_t A_stride,
+                         int16_t *se, size_t se_stride, int K, int eta1, int n, hipStream_t st)
 {
     PreArgs a{};
     a.tape = tape; a.tape_stride = tape_stride; a.nproofs = n; a.eta1 = eta1; a.K = K;
-    a.kg_seeds = seeds; a.kg_A = A; a.kg_A_stride = A_stride; a.kg_se = se; a.kg_se_stride = se_stride;
+    a.kg_seeds = seeds; a.kg_seed_stride = seed_stride; a.kg_A = A; a.kg_A_stride = A_stride; a.kg_se = se; a.kg_se_stride = se_stride;
     a.nbG = (n * K * K + 63) / 64;
     a.nbN = (n * 2 * K + 63) / 64;
     hipLaunchKernelGGL(k_prover_pre, dim3(a.nbG + a.nbN), dim3(64), 0, st, a);
@@ -1500,7 +1663,8 @@ hipError_t launch_keygen(const uint8_t *tape, size_t tape_stride, uint8_t *seeds
 hipError_t launch_ntt(const NttArgs &a, hipStream_t st)
 {
     if (a.npoly <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_ntt256, dim3((a.npoly + NTT_PPB - 1) / NTT_PPB), dim3(256), 0, st, a);
+    if (a.fp32) hipLaunchKernelGGL(k_ntt256_fp32, dim3((a.npoly + NTT_PPB - 1) / NTT_PPB), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_ntt256, dim3((a.npoly + NTT_PPB - 1) / NTT_PPB), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
@@ -1557,16 +1721,14 @@ hipError_t launch_table_gemm(const GemmArgs &a, uint16_t *sink, hipStream_t st)
 {
     const int ntot = a.npg * a.ngroups;
     if (ntot <= 0) return hipSuccess;
-    static const int rt = getenv("KOSK_TG_RT") ? atoi(getenv("KOSK_TG_RT")) : 1;
-    const int nchunks = a.M / (rt == 2 ? 32 : 16), nblk = (ntot + TG_NB - 1) / TG_NB;
+    const int nchunks = a.M / 16, nblk = (ntot + TG_NB - 1) / TG_NB;
     // few data rows: split the table over several workgroups per row block so that the launch still covers the chip
     int msplit = nblk >= 160 ? 1 : (256 + nblk - 1) / nblk;
     if (msplit > nchunks) msplit = nchunks;
     const int cpb = (nchunks + msplit - 1) / msplit;
     msplit = (nchunks + cpb - 1) / cpb;
     (void)sink;
-    if (rt == 2) hipLaunchKernelGGL((k_table_gemm<7, 2>), dim3(nblk, msplit), dim3(512), 0, st, a, nchunks, cpb);
-    else hipLaunchKernelGGL((k_table_gemm<7, 1>), dim3(nblk, msplit), dim3(512), 0, st, a, nchunks, cpb);
+    hipLaunchKernelGGL((k_table_gemm<7, 1>), dim3(nblk, msplit), dim3(512), 0, st, a, nchunks, cpb);
     return hipGetLastError();
 }
 

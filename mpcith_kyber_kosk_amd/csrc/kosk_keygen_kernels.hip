@@ -43,7 +43,8 @@ __device__ __forceinline__ void tobytes3(uint8_t *r, int32_t c0, int32_t c1)
 
 // blockIdx.x = polynomial i, thread = degree-1 factor.  sehat = NTT(s) then NTT(e), centred int16.
 __global__ __launch_bounds__(128) void k_keygen_pack(const int16_t *__restrict__ A, size_t A_stride, const int16_t *__restrict__ sehat,
-                                                     size_t sehat_stride, const uint8_t *__restrict__ seeds, uint16_t *__restrict__ t_out,
+                                                     size_t sehat_stride, const uint8_t *__restrict__ seeds, size_t seed_stride,
+                                                     uint16_t *__restrict__ t_out,
                                                      uint8_t *__restrict__ pk, size_t pk_stride, uint8_t *__restrict__ shat_bytes,
                                                      size_t sb_stride, int K)
 {
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(128) void k_keygen_pack(const int16_t *__restrict__
     t_out[((size_t)b * K + i) * 256 + 2 * p + 1] = (uint16_t)gf_encode(r1);
     tobytes3(pk + (size_t)b * pk_stride + 384 * i + 3 * p, r0, r1);
     tobytes3(shat_bytes + (size_t)b * sb_stride + 384 * i + 3 * p, sh[i * 256 + 2 * p], sh[i * 256 + 2 * p + 1]);
-    if (i == 0 && p < 32) pk[(size_t)b * pk_stride + 384 * K + p] = seeds[(size_t)b * 64 + p];
+    if (i == 0 && p < 32) pk[(size_t)b * pk_stride + 384 * K + p] = seeds[(size_t)b * seed_stride + p];
 }
 
 // verifier: t (12-bit values as stored) from the pk bytes
@@ -79,10 +80,10 @@ __global__ __launch_bounds__(128) void k_decode_pk(const uint8_t *__restrict__ p
 }
 
 hipError_t launch_keygen_pack(const int16_t *A, size_t A_stride, const int16_t *sehat, size_t sehat_stride, const uint8_t *seeds,
-                              uint16_t *t_out, uint8_t *pk, size_t pk_stride, uint8_t *shat_bytes, size_t sb_stride, int K, int n,
+                              size_t seed_stride, uint16_t *t_out, uint8_t *pk, size_t pk_stride, uint8_t *shat_bytes, size_t sb_stride, int K, int n,
                               hipStream_t st)
 {
-    hipLaunchKernelGGL(k_keygen_pack, dim3(K, n), dim3(128), 0, st, A, A_stride, sehat, sehat_stride, seeds, t_out, pk, pk_stride,
+    hipLaunchKernelGGL(k_keygen_pack, dim3(K, n), dim3(128), 0, st, A, A_stride, sehat, sehat_stride, seeds, seed_stride, t_out, pk, pk_stride,
                        shat_bytes, sb_stride, K);
     return hipGetLastError();
 }

@@ -56,6 +56,24 @@ struct ZetaTable {
 };
 static constexpr ZetaTable kZetas{};
 
+// plain (non-Montgomery) roots 17^bitrev7(k) mod q, centred, as floats: the packed-fp32 NTT variant
+struct ZetaTableF {
+    float z[128];
+    constexpr ZetaTableF() : z()
+    {
+        int32_t pw[128] = {};
+        pw[0] = 1;
+        for (int i = 1; i < 128; i++) pw[i] = pw[i - 1] * 17 % Q;
+        for (int i = 0; i < 128; i++) {
+            int br = 0;
+            for (int b = 0; b < 7; b++) br |= ((i >> b) & 1) << (6 - b);
+            int32_t v = pw[br];
+            if (v > Q / 2) v -= Q;
+            z[i] = (float)v;
+        }
+    }
+};
+
 // ------------------------------------------------------------------ Keccak --
 struct KeccakConsts {
     uint64_t rc[24];

@@ -37,6 +37,10 @@ constexpr int XLEN = DEG + 1;         // 407 expansion inputs
 constexpr int EXP_OFF = 384;          // first point written by the expand GEMM (party 128)
 constexpr int EXP_M = RS - EXP_OFF;   // 1344 = 21 x 64 outputs per row
 constexpr int NFIELDS = 24;
+// verifier: the values of the 150 OPENED parties of every row, in the order of the proof's list I, live in a compact
+// second matrix O[proof][row][OS] (same row ids as the row matrix): what the proof image holds party-major lands there
+// with coalesced writes, and the opened-party steps (lincomb, view hash, relation checks) read it without column gathers
+constexpr int OS = 160;
 // an opened-list row [proof][sel_stride] holds I in [0,150) and, from SEL_WIN on, for each aligned window of 64
 // parties w = 0..23 the number of unopened parties below 64w (so window w owns complement entries [win[w], win[w+1]))
 constexpr int SEL_WIN = 160, NWIN = (NPARTY + 63) / 64;

@@ -123,6 +123,9 @@ int ensure_verify_workspace(Ctx &c)
     c.w2_Mpad = 256; c.w2_KS = 13;  // 256 evaluation points x 813 nodes (pad 832)
     c.w_stride = (size_t)c.w_KS * (c.w_Mpad / 16) * 2048;
     c.w2_stride = (size_t)c.w2_KS * (c.w2_Mpad / 16) * 2048;
+    c.o_stride = (size_t)rm.nrows * OS;
+    HIPCHK(dalloc(&c.d_O, B * c.o_stride));
+    HIPCHK(hipMemset(c.d_O, 0, B * c.o_stride * sizeof(uint16_t)));
     HIPCHK(dalloc(&c.d_W, B * c.w_stride));
     HIPCHK(dalloc(&c.d_W2, B * c.w2_stride));
     HIPCHK(dalloc(&c.d_w, B * 2 * 832));
@@ -197,6 +200,8 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     OpenedHashArgs oh{};
     va.P = c.d_P;
     va.proof_stride = c.proof_stride;
+    va.O = c.d_O;
+    va.o_stride = c.o_stride;
     va.rm = rm;
     va.eta1 = P.eta1;
     va.opened = c.d_I;
@@ -209,6 +214,8 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     oh.off_nttf = (uint32_t)P.off[F_NTTF]; oh.off_zs = (uint32_t)P.off[F_ZS]; oh.off_ze = (uint32_t)P.off[F_ZE];
     oh.P = c.d_P;
     oh.proof_stride = c.proof_stride;
+    oh.O = c.d_O;
+    oh.o_stride = c.o_stride;
     oh.rm = rm;
     oh.opened = c.d_I;
     oh.sel_stride = c.sel_stride;
@@ -231,10 +238,8 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig1, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
     return 0;
     })) return -1;
+    HIPCHK(hipEventRecord(c.ev, st)); // the opened parties' Tcomm digests are on the host once this event has passed
     t1 = now_sec(); c.phase_sec[PH_V1_ISSUE] = t1 - t0; t0 = t1;
-    HIPCHK(hipStreamSynchronize(st)); // the opened parties' Tcomm digests are on the host
-    t1 = now_sec(); c.phase_sec[PH_V1_WAIT] = t1 - t0; t0 = t1;
-    if (c.round_hook) c.round_hook(c.round_user, 1, 0, c.d_dig1, (size_t)n * NPARTY * 32);
 
     // ---- alpha-independent GPU work, issued before the host hashes so that it runs meanwhile: interpolation of
     // the unopened shares
@@ -295,7 +300,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     na.out = reinterpret_cast<int16_t *>(c.d_P);
     na.out_gstride = c.proof_stride;
     na.dst_off = c.d_off + c.off_nttsr_er;
-    na.out_canonical = 1;
+    na.out_canonical = 1; na.fp32 = c.ntt_fp32;
     HIPCHK(launch_relation_ntt(na, c.d_A, c.key_stride, c.d_P, c.proof_stride, rm, n, st));
     {
         const GemmSrc xs{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, 0, XLEN};
@@ -304,6 +309,10 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     }
     return 0;
     })) return -1;
+
+    HIPCHK(hipEventSynchronize(c.ev));
+    t1 = now_sec(); c.phase_sec[PH_V1_WAIT] = t1 - t0; t0 = t1;
+    if (c.round_hook) c.round_hook(c.round_user, 1, 0, c.d_dig1, (size_t)n * NPARTY * 32);
 
     // ---- host: alpha while the GPU works
     fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool);
@@ -317,6 +326,8 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     LincombArgs la{};
     la.P = c.d_P;
     la.proof_stride = c.proof_stride;
+    la.O = c.d_O;
+    la.o_stride = c.o_stride;
     la.rm = rm;
     la.J = P.J;
     la.pwT = c.d_pwT;
@@ -336,10 +347,8 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     HIPCHK(launch_opened_hash(oh, K, true, n, st));
     c.prof_end(PR_V_HASH_VIEW);
     HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig2, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(c.ev, st));
     t1 = now_sec(); c.phase_sec[PH_V2_ISSUE] = t1 - t0; t0 = t1;
-    HIPCHK(hipStreamSynchronize(st));
-    t1 = now_sec(); c.phase_sec[PH_V2_WAIT] = t1 - t0; t0 = t1;
-    if (c.round_hook) c.round_hook(c.round_user, 1, 1, c.d_dig2, (size_t)n * NPARTY * 32);
 
     // ---- V2B: the checks that feed no hash run while the host derives the opened set: reconstruction of the 140
     // beta/gamma secrets with the NTT comparison (:106-131) and the relation checks on the opened columns
@@ -361,7 +370,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     na.dst_off = nullptr;
     na.npg = NCHK;
     na.npoly = NCHK * n;
-    na.out_canonical = 1;
+    na.out_canonical = 1; na.fp32 = c.ntt_fp32;
     na.cmp_fail = c.d_fail; // NTT(beta_j) is compared with gamma_j (70 polynomials further) as it is produced
     na.cmp_delta = NCHK * 256;
     na.cmp_bit = FB_BETA_GAMMA;
@@ -371,6 +380,9 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     return 0;
     })) return -1;
 
+    HIPCHK(hipEventSynchronize(c.ev)); // the view digests are on the host; V2B keeps running
+    t1 = now_sec(); c.phase_sec[PH_V2_WAIT] = t1 - t0; t0 = t1;
+    if (c.round_hook) c.round_hook(c.round_user, 1, 1, c.d_dig2, (size_t)n * NPARTY * 32);
     std::vector<uint16_t> I2((size_t)n * c.sel_stride), rest2((size_t)n * c.sel_stride);
     fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, I2.data(), rest2.data(), c.sel_stride, c.nthreads, c.pool);
     HIPCHK(hipStreamSynchronize(st)); // fail masks of V2B

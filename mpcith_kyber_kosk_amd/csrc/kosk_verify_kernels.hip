@@ -34,6 +34,7 @@ __global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const F
             const RowMap &rm = v.rm;
             const uint8_t *img = proof + (size_t)b * image_stride;
             uint16_t *Pc = v.P + (size_t)b * v.proof_stride + NSEC + v.opened[(size_t)b * v.sel_stride + t];
+            uint16_t *Oc = v.O + (size_t)b * v.o_stride + t; // the same values for the view hash (coalesced over t)
             bool bad = false;
             auto rd = [&](uint32_t off, int idx) { uint32_t x_ = reinterpret_cast<const uint16_t *>(img + off)[idx]; if (x_ >= (uint32_t)Q) { bad = true; x_ %= Q; } return x_; };
             for (int who = 0; who < 2; who++)
@@ -43,7 +44,9 @@ __global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const F
                     for (int j = 0; j < rm.Z; j++) {
                         const uint32_t z2 = gf_mul(prev, rd(osub, (t * rm.K + i) * rm.E + j + 1));
                         const uint32_t zd = rd(oz, (t * rm.K + i) * rm.Z + j);
-                        Pc[(size_t)(who ? rm.ue(i, j) : rm.us(i, j)) * RS] = (uint16_t)gf_sub(z2, zd);
+                        const uint16_t uv = (uint16_t)gf_sub(z2, zd);
+                        Pc[(size_t)(who ? rm.ue(i, j) : rm.us(i, j)) * RS] = uv; // recon_secrets_2ddeg reads the merged row
+                        Oc[(size_t)(who ? rm.ue(i, j) : rm.us(i, j)) * OS] = uv;
                         prev = zd;
                     }
                 }
@@ -111,11 +114,18 @@ __global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const F
     __builtin_amdgcn_wave_barrier();
     const uint16_t *sel = kind ? v.rest + (size_t)b * v.sel_stride : orow;
     if (lane < cnt) {
-        uint16_t *dst = v.P + (size_t)b * v.proof_stride + NSEC + sel[i0 + lane];
         const int16_t *rt = rowtab + fd.rowtab_off;
         const uint16_t *t = tile + lane * fd.width;
+        if (kind) {
+            uint16_t *dst = v.P + (size_t)b * v.proof_stride + NSEC + sel[i0 + lane];
 #pragma unroll 8
-        for (int e = 0; e < fd.width; e++) dst[(size_t)rt[e] * RS] = t[e];
+            for (int e = 0; e < fd.width; e++) dst[(size_t)rt[e] * RS] = t[e];
+        } else {
+            // records of the opened parties: into the opened matrix, consecutive lanes = consecutive entries of a row
+            uint16_t *dst = v.O + (size_t)b * v.o_stride + i0 + lane;
+#pragma unroll 8
+            for (int e = 0; e < fd.width; e++) dst[(size_t)rt[e] * OS] = t[e];
+        }
     }
     if (bad) atomicOr(&v.fail[b], 1u << FB_MALFORMED);
 }
@@ -129,30 +139,30 @@ struct OpenedMsg {
     static constexpr int BASE = 2 * K + 2 * M;                      // s, e, f, NTT f
     static constexpr int WORDS = VIEW ? BASE + 4 * K + 4 * Z * K : BASE; // + beta, gamma, s+r, e+r, gates
     template <int W>
-    static __device__ __forceinline__ uint32_t word(const OpenedHashArgs &a, const uint8_t *img, const uint16_t *col, int i)
+    static __device__ __forceinline__ uint32_t word(const OpenedHashArgs &a, const uint8_t *img, const uint16_t *col, const uint16_t *ocol, int i)
     {
         auto im = [&](uint32_t off, int idx) { return (uint32_t)reinterpret_cast<const uint16_t *>(img + off)[idx]; };
         if constexpr (W < K) return im(a.off_s, i * K + W);
         else if constexpr (W < 2 * K) return im(a.off_e, i * K + (W - K));
         else if constexpr (W < 2 * K + M) return im(a.off_f, i * M + (W - 2 * K));
         else if constexpr (W < BASE) return im(a.off_nttf, i * M + (W - 2 * K - M));
-        else if constexpr (W < BASE + K) return col[(size_t)(a.rm.beta0 + (W - BASE)) * RS];
-        else if constexpr (W < BASE + 2 * K) return col[(size_t)(a.rm.gamma0 + (W - BASE - K)) * RS];
+        else if constexpr (W < BASE + K) return ocol[(size_t)(a.rm.beta0 + (W - BASE)) * OS];
+        else if constexpr (W < BASE + 2 * K) return ocol[(size_t)(a.rm.gamma0 + (W - BASE - K)) * OS];
         else if constexpr (W < BASE + 3 * K) return col[(size_t)(a.rm.sr + (W - BASE - 2 * K)) * RS];
         else if constexpr (W < BASE + 4 * K) return col[(size_t)(a.rm.er + (W - BASE - 3 * K)) * RS];
         else {
             constexpr int g = W - (BASE + 4 * K), j = g / (4 * Z), q = g % (4 * Z), part = q / Z, z = q % Z;
             if constexpr (part == 0) return im(a.off_zs, (i * K + j) * Z + z);
             else if constexpr (part == 1) return im(a.off_ze, (i * K + j) * Z + z);
-            else if constexpr (part == 2) return col[(size_t)(a.rm.gate + j * 4 * Z + 2 * Z + z) * RS];
-            else return col[(size_t)(a.rm.gate + j * 4 * Z + 3 * Z + z) * RS];
+            else if constexpr (part == 2) return ocol[(size_t)(a.rm.gate + j * 4 * Z + 2 * Z + z) * OS];
+            else return ocol[(size_t)(a.rm.gate + j * 4 * Z + 3 * Z + z) * OS];
         }
     }
 };
 
 template <int K, bool VIEW, int W0, int N>
-__device__ __forceinline__ void opened_absorb_block(KState &s, const OpenedHashArgs &a, const uint8_t *img, const uint16_t *col, int i,
-                                                    const uint8_t *prefix)
+__device__ __forceinline__ void opened_absorb_block(KState &s, const OpenedHashArgs &a, const uint8_t *img, const uint16_t *col,
+                                                    const uint16_t *ocol, int i, const uint8_t *prefix)
 {
     // message words W0 .. W0+N-1 (N <= 68) into lanes 0..16; with VIEW the first 16 words are the 32-byte prefix
     using Msg = OpenedMsg<K, VIEW>;
@@ -164,8 +174,8 @@ __device__ __forceinline__ void opened_absorb_block(KState &s, const OpenedHashA
             uint32_t v;
             if constexpr (gw + 1 < PW + 1 && gw < PW) v = *reinterpret_cast<const uint32_t *>(prefix + 2 * gw);
             else {
-                v = Msg::template word<gw - PW>(a, img, col, i);
-                if constexpr (gw + 1 < TOTAL) v |= Msg::template word<gw + 1 - PW>(a, img, col, i) << 16;
+                v = Msg::template word<gw - PW>(a, img, col, ocol, i);
+                if constexpr (gw + 1 < TOTAL) v |= Msg::template word<gw + 1 - PW>(a, img, col, ocol, i) << 16;
             }
             if constexpr ((w & 2) == 0) s.lo[w / 4] ^= v;
             else s.hi[w / 4] ^= v;
@@ -184,14 +194,15 @@ __global__ __launch_bounds__(64) void k_opened_hash(OpenedHashArgs a)
     constexpr int PW = VIEW ? 16 : 0, TOTAL = PW + Msg::WORDS, NBLK = TOTAL / 68 + 1;
     const int party = a.opened[(size_t)b * a.sel_stride + i];
     const uint8_t *img = a.proof + (size_t)b * a.image_stride;
-    const uint16_t *col = a.P + (size_t)b * a.proof_stride + NSEC + party;
+    const uint16_t *col = a.P + (size_t)b * a.proof_stride + NSEC + party; // s + r, e + r: recomputed shares of every party
+    const uint16_t *ocol = a.O + (size_t)b * a.o_stride + i;               // beta, gamma, u of the opened parties
     const size_t dig = ((size_t)b * NPARTY + party) * 32;
     const uint8_t *prefix = VIEW ? a.prefix + dig : nullptr;
     KState s;
     kstate_zero(s);
     [&]<int... Bs>(std::integer_sequence<int, Bs...>) {
         (([&] {
-             opened_absorb_block<K, VIEW, Bs * 68, 68>(s, a, img, col, i, prefix);
+             opened_absorb_block<K, VIEW, Bs * 68, 68>(s, a, img, col, ocol, i, prefix);
              if constexpr (Bs == NBLK - 1) {
                  constexpr int padbyte = 2 * TOTAL - (NBLK - 1) * 136;
                  constexpr uint32_t padv = 0x06u << (8 * (padbyte % 4));
@@ -362,17 +373,21 @@ __global__ __launch_bounds__(192) void k_check_opened(VerifyArgs v)
     const int t = threadIdx.x, b = blockIdx.x;
     if (t >= NOPEN) return;
     const RowMap &rm = v.rm;
+    // recomputed sharings (every party) come from the row matrix, what the proof holds for the opened parties and what the
+    // lincomb made of it from the opened matrix
     const uint16_t *Pb = v.P + (size_t)b * v.proof_stride + NSEC + v.opened[(size_t)b * v.sel_stride + t];
+    const uint16_t *Ob = v.O + (size_t)b * v.o_stride + t;
     auto at = [&](int row) { return (uint32_t)Pb[(size_t)row * RS]; };
+    auto op = [&](int row) { return (uint32_t)Ob[(size_t)row * OS]; };
     uint32_t bits = 0;
     for (int i = 0; i < rm.K; i++) {
-        if (at(rm.ntts + i) != gf_sub(at(rm.nttsr + i), at(rm.nttr + i))) bits |= 1u << FB_NTT_S_E;
-        if (at(rm.ntte + i) != gf_sub(at(rm.ntter + i), at(rm.nttr + rm.K + i))) bits |= 1u << FB_NTT_S_E;
-        if (at(rm.nttasr + i) != gf_add(at(rm.nttas + i), at(rm.nttar + i))) bits |= 1u << FB_A_SR;
-        if (at(rm.t + i) != gf_add(at(rm.nttas + i), at(rm.ntte + i))) bits |= 1u << FB_T_RELATION;
+        if (op(rm.ntts + i) != gf_sub(at(rm.nttsr + i), op(rm.nttr + i))) bits |= 1u << FB_NTT_S_E;
+        if (op(rm.ntte + i) != gf_sub(at(rm.ntter + i), op(rm.nttr + rm.K + i))) bits |= 1u << FB_NTT_S_E;
+        if (at(rm.nttasr + i) != gf_add(op(rm.nttas + i), op(rm.nttar + i))) bits |= 1u << FB_A_SR;
+        if (at(rm.t + i) != gf_add(op(rm.nttas + i), op(rm.ntte + i))) bits |= 1u << FB_T_RELATION;
         for (int m = 0; m < rm.E; m++) {
-            if (at(rm.ssub + i * rm.E + m) != gf_sub(at(rm.s + i), at(rm.seta + i * rm.E + m))) bits |= 1u << FB_SUB_ETA;
-            if (at(rm.esub + i * rm.E + m) != gf_sub(at(rm.e + i), at(rm.eeta + i * rm.E + m))) bits |= 1u << FB_SUB_ETA;
+            if (op(rm.ssub + i * rm.E + m) != gf_sub(op(rm.s + i), at(rm.seta + i * rm.E + m))) bits |= 1u << FB_SUB_ETA;
+            if (op(rm.esub + i * rm.E + m) != gf_sub(op(rm.e + i), at(rm.eeta + i * rm.E + m))) bits |= 1u << FB_SUB_ETA;
         }
     }
     if (bits) atomicOr(&v.fail[b], bits);
