@@ -82,6 +82,12 @@ static int run_chunks(kosk_ctx *h, int n, F &&fn)
     return 0;
 }
 
+static bool register_enabled()
+{
+    static const bool on = !(getenv("KOSK_REGISTER") && atoi(getenv("KOSK_REGISTER")) == 0);
+    return on;
+}
+
 static thread_local std::string g_create_err; // error text of the last failed kosk_create on this thread
 
 #define HIPCHK_C(x)                                                        \
@@ -287,11 +293,18 @@ int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, siz
         tapes = drawn.data();
         tape_stride = P.tape_bytes;
     }
-    return run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
+    // several chunks: page-lock the caller's proof buffer for the call so that the images are copied straight into it
+    // (KOSK_REGISTER=0 keeps the pinned staging buffer + host memcpy)
+    const bool reg = n > ctx->sub[0]->max_batch && register_enabled() &&
+                     hipHostRegister(pi, (size_t)n * P.proof_bytes, hipHostRegisterDefault) == hipSuccess;
+    const int rc = run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
         const KeygenIn kg{tapes + (size_t)first * tape_stride, tape_stride, pk + (size_t)first * P.pk_bytes, sk + (size_t)first * P.sk_bytes};
         if (prove_resident(c, count, false, &kg)) return -1;
-        return fetch_proofs(c, count, pi + (size_t)first * P.proof_bytes);
+        return fetch_proofs(c, count, pi + (size_t)first * P.proof_bytes, reg);
     });
+    if (reg) (void)hipHostUnregister(pi);
+    else (void)hipGetLastError();
+    return rc;
 }
 
 int kosk_verify_batch(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk, uint8_t *ok)
@@ -300,12 +313,17 @@ int kosk_verify_batch(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk
     if (n == 0) return 0;
     const Params &P = ctx->c->P;
     ctx->masks.assign((size_t)n, 0);
-    return run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
-        if (stage_verifier_inputs(c, count, pi + (size_t)first * P.proof_bytes, pk + (size_t)first * P.pk_bytes)) return -1;
+    const bool reg = n > ctx->sub[0]->max_batch && register_enabled() &&
+                     hipHostRegister(const_cast<uint8_t *>(pi), (size_t)n * P.proof_bytes, hipHostRegisterDefault) == hipSuccess;
+    const int rc = run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
+        if (stage_verifier_inputs(c, count, pi + (size_t)first * P.proof_bytes, pk + (size_t)first * P.pk_bytes, reg)) return -1;
         if (verify_resident(c, count, ok + first)) return -1;
         memcpy(ctx->masks.data() + first, c.h_fail, sizeof(uint32_t) * (size_t)count);
         return 0;
     });
+    if (reg) (void)hipHostUnregister(const_cast<uint8_t *>(pi));
+    else (void)hipGetLastError();
+    return rc;
 }
 
 // ---- second-level entry points (kosk_split.cpp) -----------------------------------------------------------

@@ -632,14 +632,20 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     return 0;
 }
 
-int fetch_proofs(Ctx &c, int n, uint8_t *pi)
+int fetch_proofs(Ctx &c, int n, uint8_t *pi, bool registered)
 {
     if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
     HIPCHK(hipSetDevice(c.device));
     const double t0 = now_sec();
-    HIPCHK(hipMemcpyAsync(c.h_proof, c.d_proof, (size_t)n * c.image_stride, hipMemcpyDeviceToHost, c.stream));
-    HIPCHK(hipStreamSynchronize(c.stream));
-    parallel_for(c.pool, n, c.nthreads, [&](int b) { memcpy(pi + (size_t)b * c.P.proof_bytes, c.h_proof + (size_t)b * c.image_stride, c.P.proof_bytes); });
+    if (registered) {
+        // the caller's buffer is page-locked for the duration of the call (kosk_capi.cpp): the images go straight there
+        HIPCHK(hipMemcpy2DAsync(pi, c.P.proof_bytes, c.d_proof, c.image_stride, c.P.proof_bytes, n, hipMemcpyDeviceToHost, c.stream));
+        HIPCHK(hipStreamSynchronize(c.stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(c.h_proof, c.d_proof, (size_t)n * c.image_stride, hipMemcpyDeviceToHost, c.stream));
+        HIPCHK(hipStreamSynchronize(c.stream));
+        parallel_for(c.pool, n, c.nthreads, [&](int b) { memcpy(pi + (size_t)b * c.P.proof_bytes, c.h_proof + (size_t)b * c.image_stride, c.P.proof_bytes); });
+    }
     c.phase_sec[PH_D2H] = now_sec() - t0;
     return 0;
 }

@@ -256,9 +256,10 @@ int stage_verifier_inst(Ctx &c, int n, const uint8_t *pi, const uint8_t *inst);
 int ensure_verify_workspace(Ctx &c);
 int fetch_proofs_compact(Ctx &c, int n, uint8_t *out);
 int stage_verifier_inputs_compact(Ctx &c, int n, const uint8_t *in, const uint8_t *pk);
-int fetch_proofs(Ctx &c, int n, uint8_t *pi);
+// registered: `pi` is page-locked host memory (hipHostRegister): copied to directly, no staging
+int fetch_proofs(Ctx &c, int n, uint8_t *pi, bool registered = false);
 
-int stage_verifier_inputs(Ctx &c, int n, const uint8_t *pi, const uint8_t *pk);
+int stage_verifier_inputs(Ctx &c, int n, const uint8_t *pi, const uint8_t *pk, bool registered = false);
 // pk_mode 0: A and t are already resident (stage_verifier_inputs / stage_verifier_inst); 1: decode `pk` (host or
 // device memory, n records of pk_bytes) at the head of the first segment (kosk.cpp:94-99: polyvec_frombytes + gen_matrix);
 // 2: decode the pk bytes the key generation left resident in HBM

@@ -143,17 +143,20 @@ int ensure_verify_workspace(Ctx &c)
     return 0;
 }
 
-int stage_verifier_inputs(Ctx &c, int n, const uint8_t *pi, const uint8_t *pk)
+int stage_verifier_inputs(Ctx &c, int n, const uint8_t *pi, const uint8_t *pk, bool registered)
 {
     if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
     HIPCHK(hipSetDevice(c.device));
     const Params &P = c.P;
     parallel_for(c.pool, n, c.nthreads, [&](int b) {
         memcpy(c.h_pk + (size_t)b * c.pk_stride, pk + (size_t)b * P.pk_bytes, P.pk_bytes);
-        memcpy(c.h_proof + (size_t)b * c.image_stride, pi + (size_t)b * P.proof_bytes, P.proof_bytes);
+        if (!registered) memcpy(c.h_proof + (size_t)b * c.image_stride, pi + (size_t)b * P.proof_bytes, P.proof_bytes);
     });
     HIPCHK(hipMemcpyAsync(c.d_pk, c.h_pk, (size_t)n * c.pk_stride, hipMemcpyHostToDevice, c.stream));
-    HIPCHK(hipMemcpyAsync(c.d_proof, c.h_proof, (size_t)n * c.image_stride, hipMemcpyHostToDevice, c.stream));
+    if (registered) // page-locked caller memory (kosk_capi.cpp): no staging copy
+        HIPCHK(hipMemcpy2DAsync(c.d_proof, c.image_stride, pi, P.proof_bytes, P.proof_bytes, n, hipMemcpyHostToDevice, c.stream));
+    else
+        HIPCHK(hipMemcpyAsync(c.d_proof, c.h_proof, (size_t)n * c.image_stride, hipMemcpyHostToDevice, c.stream));
     // polyvec_frombytes(t) and gen_matrix(A, seed) on the device   kosk.cpp:94-99
     HIPCHK(launch_decode_pk(c.d_pk, c.pk_stride, c.d_t, c.d_A, c.key_stride, P.K, n, c.stream));
     HIPCHK(hipStreamSynchronize(c.stream));
