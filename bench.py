@@ -507,7 +507,7 @@ def main():
             "host_cpu_cores_busy": round(host_cpu_s / max(dt_drained, 1e-9), 2),
             "host_cpus_usable": len(os.sched_getaffinity(0)),
             "kernels_in_pipeline": kern,
-            "profiled_kernel_ms_per_step": round(sum(v["total_ms"] for v in kern.values()) / max(1, sum(sl.steps_done for sl in slots) - S), 4),
+            "profiled_kernel_ms_per_step": round(sum(v["total_ms"] for v in kern.values()) / max(1, (hv or {}).get("launches", 0)), 4),
             "prove_phase_ms": dict(zip(["host_pre", "gpu_commit", "fs_alpha_host", "gpu_relation", "fs_open_host", "gpu_assemble", "d2h"],
                                        [round(x * 1e3, 3) for x in phases])),
         }

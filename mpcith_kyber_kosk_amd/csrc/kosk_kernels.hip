@@ -146,6 +146,9 @@ __global__ __launch_bounds__(64) void k_commit_hash_dma(HashArgs a)
     constexpr int STAGE_ROWS = 72;          // 9 DMA pieces of 8 rows
     __shared__ __attribute__((aligned(16))) uint16_t stage[NBUF][STAGE_ROWS * 64];
 
+    // the commitments gate the host's Fiat-Shamir round: when kernels of other pipeline slots share the SIMD, these waves
+    // issue first
+    __builtin_amdgcn_s_setprio(3);
     const int tl = threadIdx.x;
     const int lane = blockIdx.x * 64 + tl;
     const int g = blockIdx.y;
