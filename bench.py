@@ -288,6 +288,11 @@ def main():
     k, B = cfg["k"], cfg["batch"]
     S = args.slots if args.slots > 0 else cfg["slots"]
     os.environ.setdefault("KOSK_HOST_THREADS", str(cfg["threads"]))
+    # stdout carries exactly ONE line (the JSON): whatever libraries print there (RCCL's version banner on the first
+    # communicator, for one) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     if not torch.cuda.is_available():
@@ -532,7 +537,7 @@ def main():
             line["extras"] = pcie_inclusive(api, k, B, tapes)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(k, tapes, min(args.cpu_proofs, B))
-        print(json.dumps(line), flush=True)  # flushed here: the RCCL teardown below can end the process without Python's exit flush
+        os.write(json_fd, (json.dumps(line) + "\n").encode())  # written here: the RCCL teardown below can end the process without Python's exit flush
     state["limit"] = -1
     for g_ in gos:
         g_.set()
