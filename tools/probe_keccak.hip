@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <utility>
 #include <vector>
 
 #include "kosk_keccak_dev.hpp"
@@ -89,6 +90,31 @@ __global__ __launch_bounds__(64) void k_keccak_split(uint32_t *out, Stamp *st, i
     for (int i = 0; i < 25; i++) acc ^= s.w[i];
     out[blockIdx.x * 64 + threadIdx.x] = acc;
     if (threadIdx.x == 0) st[blockIdx.x] = Stamp{c1 - c0, r1 - r0};
+}
+
+// hybrid launch: blocks [0, nmain) hold 64 states in the one-lane form, blocks from nmain on 32 states in the lane-pair form
+__global__ __launch_bounds__(64) void k_keccak_hybrid(uint32_t *out, int nmain, int nperm)
+{
+    uint32_t acc = 0;
+    if ((int)blockIdx.x < nmain) {
+        kosk::KState s;
+#pragma unroll
+        for (int i = 0; i < 25; i++) { s.lo[i] = threadIdx.x * 2654435761u + i; s.hi[i] = blockIdx.x * 40503u + i * 7; }
+#pragma unroll 1
+        for (int p = 0; p < nperm; p++) kosk::keccak_f1600_dev(s);
+#pragma unroll
+        for (int i = 0; i < 25; i++) acc ^= s.lo[i] ^ s.hi[i];
+    } else {
+        kosk::KHalf s;
+        const bool hi = threadIdx.x & 1;
+#pragma unroll
+        for (int i = 0; i < 25; i++) s.w[i] = (threadIdx.x * 2654435761u + i) ^ (blockIdx.x * 40503u + i * 7);
+#pragma unroll 1
+        for (int p = 0; p < nperm; p++) kosk::keccak_f1600_split(s, hi);
+#pragma unroll
+        for (int i = 0; i < 25; i++) acc ^= s.w[i];
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = acc;
 }
 
 // both layouts on the same 32 states per wave: out[state][50] one-lane form, out2[state][50] pair form
@@ -216,6 +242,24 @@ int main()
             timed([&] { hipLaunchKernelGGL(k_keccak_split, dim3(blocks), dim3(64), 0, 0, (uint32_t *)out, st, 4); }, blocks, st, ms, cyc, ghz);
             printf("# 4 permutations per state, %6d states as %5d pair-waves: %.1f us\n", states, blocks, ms * 1e3);
         }
+    }
+    printf("# (4) hybrid launch, 4 permutations per state: <main> one-lane waves of 64 states first, then <tail> lane-pair waves of 32 states\n");
+    for (auto mt : {std::pair<int, int>{1024, 0}, {1024, 43}, {1012, 92}, {1012, 0}, {960, 171}, {1024, 128}, {1024, 512}, {512, 1024}, {0, 1024}}) {
+        const int blocks = mt.first + mt.second;
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        float best = 1e9f;
+        for (int rep = 0; rep < 5; rep++) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k_keccak_hybrid, dim3(blocks), dim3(64), 0, 0, (uint32_t *)out, mt.first, 4);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float f;
+            hipEventElapsedTime(&f, e0, e1);
+            best = std::min(best, f);
+        }
+        printf("# main %5d + tail %5d waves = %6d states: %.1f us\n", mt.first, mt.second, mt.first * 64 + mt.second * 32, best * 1e3);
     }
     return 0;
 }
