@@ -65,7 +65,7 @@ Ctx::~Ctx()
             if (e) (void)hipEventDestroy(e);
     void *dev[] = {t_expand.d, t_recon_d.d, t_recon_2d.d, t_expand.dfrag, t_recon_d.dfrag, t_recon_2d.dfrag, d_fresh_rows, d_gemm1_rows, d_gemm2_rows, d_off, d_fields,
                    d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_kg, d_sehat, d_t, d_alpha, d_I, d_pwT, d_limbs, d_linA, d_coef, d_lin_rows,
-                   d_gather, d_gather2, d_O, d_W, d_W2, d_w, d_ell, d_sec, d_sec_u1, d_sec_u2, d_fail, d_inv, d_vfields,
+                   d_gather, d_gather2, d_O, d_w, d_ell, d_sec, d_sec_u1, d_sec_u2, d_fail, d_inv, d_invlimb, d_vfields,
                    d_vrowtab, d_rows_bg, d_rows_isrc, d_rows_idst, d_rows_u, d_fact, d_invfact, d_node_of, d_isort, d_hrange};
     for (void *p : dev)
         if (p) (void)hipFree(p);

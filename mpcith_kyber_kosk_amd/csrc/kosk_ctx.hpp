@@ -137,10 +137,8 @@ struct Ctx {
     uint16_t *d_w = nullptr, *d_ell = nullptr, *d_fact = nullptr, *d_invfact = nullptr;
     int16_t *d_node_of = nullptr;
     uint16_t *d_isort = nullptr, *d_hrange = nullptr;
-    uint8_t *d_W = nullptr, *d_W2 = nullptr; // per-proof interpolation operators as limb matrices
-    size_t w_stride = 0, w2_stride = 0;
-    int w_Mpad = 0, w_KS = 0, w2_Mpad = 0, w2_KS = 0;
-    uint16_t *d_gather = nullptr, *d_gather2 = nullptr;
+    uint8_t *d_gather = nullptr, *d_gather2 = nullptr; // weighted shares as MFMA fragment tiles (k_gather_frags)
+    uint16_t *d_invlimb = nullptr;
     uint16_t *d_sec = nullptr, *d_sec_u1 = nullptr, *d_sec_u2 = nullptr;
     uint32_t *d_fail = nullptr;      // [proof] bit mask of failed checks (FailBit)
     uint16_t *h_Iimg = nullptr;      // I fields as read from the proof images

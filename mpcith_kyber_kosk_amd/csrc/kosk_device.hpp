@@ -177,12 +177,10 @@ struct InterpArgs {
     const uint16_t *hrange;  // [proof][4]: hole index range [h0,h1) into isort for set 0, then set 1
     int sel_stride;
     const uint16_t *inv, *fact, *invfact; // field inverses, k!, 1/k!  (k < 3329)
+    const uint16_t *invlimb;  // (low limb | high limb << 8) of 1/d at index d + interp_table_off(), see k_interp_apply
     uint16_t *w;             // [proof][2][832] barycentric weights
     uint16_t *ell;           // [proof][416]   l(k) of set 0 (0 where k is a node)
     int16_t *node_of;        // [proof][416]   j if evaluation point k is node x_j, else -1
-    uint8_t *W, *W2;         // per-proof Cauchy operators as limb matrices (rows = evaluation point, k = node)
-    size_t w_stride, w2_stride; // bytes
-    int Mpad1, KS1, Mpad2, KS2;
 };
 
 // opened list from the image -> I, complement, sorted I, hole ranges, MALFORMED bit (overwrites fail[])
@@ -210,14 +208,19 @@ struct OpenedHashArgs {
 hipError_t launch_opened_hash(const OpenedHashArgs &a, int K, bool view, int nproofs, hipStream_t st);
 hipError_t launch_check_batch(const VerifyArgs &v, const uint16_t *t_pk, const uint16_t *u1, const uint16_t *u2, int nu, int nproofs,
                               hipStream_t st);
-hipError_t launch_gather_cols2(const uint16_t *P, size_t proof_stride, const int16_t *rows1, int nrows1, uint16_t *out1,
-                               const int16_t *rows2, int nrows2, uint16_t *out2, const uint16_t *rest, int sel_stride,
+// weighted shares of both interpolations as MFMA fragment tiles: interp_y_bytes(set) bytes per proof
+size_t interp_y_bytes(int set);
+int interp_table_len(); // entries of InterpArgs::invlimb
+int interp_table_off(); // entry d + off = limbs of 1/d
+hipError_t launch_gather_frags(const uint16_t *P, size_t proof_stride, const int16_t *rows1, int nrows1, uint8_t *out1,
+                               const int16_t *rows2, int nrows2, uint8_t *out2, const uint16_t *rest, int sel_stride,
                                const uint16_t *w, int nproofs, hipStream_t st);
-hipError_t launch_interp_build(const InterpArgs &a, int nproofs, hipStream_t st);
-// out[b][r][j] = w[b][set][j] * P[b][rows[r]][256 + rest[b][j]]
-// P[b][dst_rows[r]][k] = node(k) ? P[b][src_rows[r]][256 + rest[node]] : ell[k] * P[b][dst_rows[r]][k],  k < 407
-hipError_t launch_interp_fixup(uint16_t *P, size_t proof_stride, const int16_t *src_rows, const int16_t *dst_rows, int nrows,
-                               const InterpArgs &a, int nproofs, hipStream_t st);
+// weights, l(k), node map (k_interp_setup), then the interpolation itself with the Cauchy operator built in registers
+// (k_interp_apply): degree d: P[b][dst_rows[r]][k] = node(k) ? P[b][src_rows[r]][256 + rest[node]] : l(k) sum_j y1[b][r][j] / (k - x_j),
+// k < 407; degree 2d: out2[b][r][k] = sum_j y2[b][r][j] / (k - x_j), k < 256
+hipError_t launch_interp_setup(const InterpArgs &a, int nproofs, hipStream_t st);
+hipError_t launch_interp_apply(const InterpArgs &a, uint16_t *P, size_t proof_stride, const int16_t *src_rows, const int16_t *dst_rows,
+                               int n1, const uint8_t *y1, int n2, const uint8_t *y2, uint16_t *out2, int nproofs, hipStream_t st);
 hipError_t launch_check_opened(const VerifyArgs &v, int nproofs, hipStream_t st);
 
 // ---- key generation (kosk_keygen_kernels.hip) ----

@@ -21,6 +21,7 @@
 #include "kosk_keccak_dev.hpp"
 #include "kosk_keygen_dev.hpp"
 #include "kosk_math.hpp"
+#include "kosk_limb_dev.hpp"
 
 namespace kosk {
 
@@ -764,7 +765,6 @@ __global__ __launch_bounds__(256) void k_relation_ntt(NttArgs na, const int16_t 
 // Both operands arrive pre-tiled as limb matrices (kosk_device.hpp); a workgroup computes 128 m x 64 n,
 // a wave 64 x 32 (4 x 2 MFMA blocks), double-buffered through LDS with plain 16-byte copies.
 // =========================================================================
-typedef int v4i __attribute__((ext_vector_type(4)));
 
 // canonical u16 rows -> limb matrix; one thread per (row, 16-k chunk)
 __global__ __launch_bounds__(256) void k_rows_to_limbs(LimbArgs a)
@@ -806,24 +806,6 @@ __global__ __launch_bounds__(256) void k_rows_to_limbs(LimbArgs a)
 constexpr int GM_TM = 128, GM_TN = 64;            // workgroup tile
 constexpr int GM_A_BYTES = (GM_TM / 16) * 2048;    // 16 KiB per k-step
 constexpr int GM_B_BYTES = (GM_TN / 16) * 2048;    //  8 KiB per k-step
-
-// 16 canonical u16 (two uint4) -> 16 low-limb bytes + 16 high-limb bytes of the centred representatives
-__device__ __forceinline__ void gm_split16(const uint4 &x0, const uint4 &x1, uint4 &lo, uint4 &hi)
-{
-    const uint32_t w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-    uint32_t l[4] = {0, 0, 0, 0}, h[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-        uint32_t v = (q & 1) ? (w[q >> 1] >> 16) : (w[q >> 1] & 0xFFFFu);
-        if (v >= (uint32_t)Q) v %= Q; // never for honest data; keeps arbitrary input bounded
-        int c0, c1;
-        limb_split(gf_center(v), c0, c1);
-        l[q >> 2] |= ((uint32_t)c0 & 0xFFu) << (8 * (q & 3));
-        h[q >> 2] |= ((uint32_t)c1 & 0xFFu) << (8 * (q & 3));
-    }
-    lo = make_uint4(l[0], l[1], l[2], l[3]);
-    hi = make_uint4(h[0], h[1], h[2], h[3]);
-}
 
 // BLIMB: the data operand is already a limb matrix (lincomb coefficients); otherwise it is converted from
 // canonical u16 rows while it is staged (16 values per thread and k-step), which saves a conversion launch.
@@ -985,15 +967,6 @@ __global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
 // writing points 384..447 of the same rows -- points < 407 are rewritten with their own values (identity rows of the
 // table) and points >= 407 meet zero table columns, so any value read there is harmless.
 constexpr int TG_NB = 48, TG_WAVES = 8;
-
-__device__ __forceinline__ uint32_t gf_reduce_pos(uint32_t x) // x < 2^32 - q
-{
-    // t = floor(x * floor(2^32 / q) / 2^32) is floor(x / q) or one less, so x - t q < 2 q: one conditional subtraction,
-    // done as an unsigned minimum (r - q wraps above r when r < q)
-    const uint32_t t = __umulhi(x, 1290167u);
-    const uint32_t r = x - t * (uint32_t)Q;
-    return min(r, r - (uint32_t)Q);
-}
 
 // TG_RT = table row tiles (of 16) per chunk
 template <int KS, int TG_RT>

@@ -55,9 +55,20 @@ int ensure_verify_workspace(Ctx &c)
     const int K = P.K, M = P.M, E = P.E, Z = P.Z;
     const size_t B = (size_t)c.max_batch;
 
-    std::vector<uint16_t> inv(Q);
+    std::vector<uint16_t> inv(Q + 1, 0); // one u16 of padding: k_interp_build copies the table to LDS as dwords
     for (int a = 0; a < Q; a++) inv[a] = gf_inv_host((uint16_t)a);
     if (upload_vec(c, &c.d_inv, inv)) return -1;
+    { // limb pairs of 1/d for every difference d = k - x_j the interpolation meets (k_interp_apply)
+        const int len = interp_table_len(), off = interp_table_off();
+        std::vector<uint16_t> il(len, 0);
+        for (int i = 0; i + 2 < len; i++) {
+            const int d = ((i - off) % Q + Q) % Q;
+            int c0, c1;
+            limb_split(gf_center(inv[d]), c0, c1);
+            il[i] = (uint16_t)((c0 & 0xFF) | ((c1 & 0xFF) << 8));
+        }
+        if (upload_vec(c, &c.d_invlimb, il)) return -1;
+    }
     std::vector<uint16_t> fact(Q), invfact(Q);
     fact[0] = 1;
     for (int a = 1; a < Q; a++) fact[a] = (uint16_t)((uint32_t)fact[a - 1] * a % Q);
@@ -119,22 +130,16 @@ int ensure_verify_workspace(Ctx &c)
         upload_vec(c, &c.d_rows_u, urows))
         return -1;
 
-    c.w_Mpad = 512;  c.w_KS = 7;    // 407 evaluation points (pad 512) x 407 nodes (pad 448)
-    c.w2_Mpad = 256; c.w2_KS = 13;  // 256 evaluation points x 813 nodes (pad 832)
-    c.w_stride = (size_t)c.w_KS * (c.w_Mpad / 16) * 2048;
-    c.w2_stride = (size_t)c.w2_KS * (c.w2_Mpad / 16) * 2048;
     c.o_stride = (size_t)rm.nrows * OS;
     HIPCHK(dalloc(&c.d_O, B * c.o_stride));
     HIPCHK(hipMemset(c.d_O, 0, B * c.o_stride * sizeof(uint16_t)));
-    HIPCHK(dalloc(&c.d_W, B * c.w_stride));
-    HIPCHK(dalloc(&c.d_W2, B * c.w2_stride));
     HIPCHK(dalloc(&c.d_w, B * 2 * 832));
     HIPCHK(dalloc(&c.d_ell, B * 416));
     HIPCHK(dalloc(&c.d_node_of, B * 416));
     HIPCHK(dalloc(&c.d_isort, B * c.sel_stride));
     HIPCHK(dalloc(&c.d_hrange, B * 4));
-    HIPCHK(dalloc(&c.d_gather, B * c.n_interp_d * 416 + 64));
-    HIPCHK(dalloc(&c.d_gather2, B * c.n_interp_2d * 832));
+    HIPCHK(dalloc(&c.d_gather, B * interp_y_bytes(0)));
+    HIPCHK(dalloc(&c.d_gather2, B * interp_y_bytes(1)));
     HIPCHK(dalloc(&c.d_sec, B * 2 * NCHK * 256));
     HIPCHK(dalloc(&c.d_sec_u1, B * c.n_interp_2d * 256));
     HIPCHK(dalloc(&c.d_sec_u2, B * c.n_interp_2d * 256));
@@ -254,38 +259,29 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     ia.hrange = c.d_hrange;
     ia.sel_stride = c.sel_stride;
     ia.inv = c.d_inv;
+    ia.invlimb = c.d_invlimb;
     ia.fact = c.d_fact;
     ia.invfact = c.d_invfact;
     ia.w = c.d_w;
     ia.ell = c.d_ell;
     ia.node_of = c.d_node_of;
-    ia.W = c.d_W;
-    ia.W2 = c.d_W2;
-    ia.w_stride = c.w_stride;
-    ia.w2_stride = c.w2_stride;
-    ia.Mpad1 = c.w_Mpad; ia.KS1 = c.w_KS; ia.Mpad2 = c.w2_Mpad; ia.KS2 = c.w2_KS;
     c.prof_begin(PR_V_INTERP_BUILD);
-    HIPCHK(launch_interp_build(ia, n, st));
+    HIPCHK(launch_interp_setup(ia, n, st));
     c.prof_end(PR_V_INTERP_BUILD);
-    HIPCHK(launch_gather_cols2(c.d_P, c.proof_stride, c.d_rows_isrc, c.n_interp_d, c.d_gather, c.d_rows_u, c.n_interp_2d, c.d_gather2,
+    HIPCHK(launch_gather_frags(c.d_P, c.proof_stride, c.d_rows_isrc, c.n_interp_d, c.d_gather, c.d_rows_u, c.n_interp_2d, c.d_gather2,
                                c.d_rest, c.sel_stride, c.d_w, n, st));
-    { // three independent products in one launch: values at points 0..406 of every interpolated sharing (:201-219 etc.),
-      // the 813-node Cauchy sums of the u shares at the packed positions (:523-543), and recon_secrets_2ddeg of the
-      // merged u rows (:555-556)
-        const GemmSrc gs{c.d_gather, (size_t)c.n_interp_d * 416, nullptr, 416, 0, DEG + 1};
-        const GemmDst gd{c.d_P, c.proof_stride, c.d_rows_idst, RS, 0};
-        const GemmSrc gs2{c.d_gather2, (size_t)c.n_interp_2d * 832, nullptr, 832, 0, DEG2 + 1};
-        const GemmDst gd2{c.d_sec_u1, (size_t)c.n_interp_2d * 256, nullptr, 256, 0};
+    { // values at points 0..406 of every interpolated sharing (:201-219 etc.) and the 813-node Cauchy sums of the u shares
+      // at the packed positions (:523-543) with the per-proof operators built on the fly; recon_secrets_2ddeg of the merged
+      // u rows (:555-556) is a product with a fixed table
+        c.prof_begin(PR_V_GEMM_INTERP);
+        HIPCHK(launch_interp_apply(ia, c.d_P, c.proof_stride, c.d_rows_isrc, c.d_rows_idst, c.n_interp_d, c.d_gather, c.n_interp_2d,
+                                   c.d_gather2, c.d_sec_u1, n, st));
+        c.prof_end(PR_V_GEMM_INTERP);
         const GemmSrc gs3{c.d_P, c.proof_stride, c.d_rows_u, RS, NSEC, DEG2 + 1};
         const GemmDst gd3{c.d_sec_u2, (size_t)c.n_interp_2d * 256, nullptr, 256, 0};
-        const GemmArgs list[3] = {
-            gemm_args_small(c.d_W, c.w_stride, c.w_Mpad, DEG + 1, c.w_KS, gs, gd, c.n_interp_d, n, true),
-            gemm_args_small(c.d_W2, c.w2_stride, c.w2_Mpad, NSEC, c.w2_KS, gs2, gd2, c.n_interp_2d, n, true),
+        const GemmArgs list[1] = {
             gemm_args_small(c.t_recon_2d.d, 0, c.t_recon_2d.Mpad, c.t_recon_2d.M, c.t_recon_2d.KS, gs3, gd3, c.n_interp_2d, n, false)};
-        c.prof_begin(PR_V_GEMM_INTERP);
-        HIPCHK(launch_gemm_batch(list, 3, st));
-        c.prof_end(PR_V_GEMM_INTERP);
-        HIPCHK(launch_interp_fixup(c.d_P, c.proof_stride, c.d_rows_isrc, c.d_rows_idst, c.n_interp_d, ia, n, st));
+        HIPCHK(launch_gemm_batch(list, 1, st));
         const GemmSrc xs{c.d_P, c.proof_stride, c.d_rows_idst, RS, 0, XLEN};
         const GemmDst xd{c.d_P, c.proof_stride, c.d_rows_idst, RS, EXP_OFF};
         c.prof_begin(PR_V_GEMM_EXPAND);

@@ -11,6 +11,7 @@
 #include "kosk_device.hpp"
 #include "kosk_keccak_dev.hpp"
 #include "kosk_math.hpp"
+#include "kosk_limb_dev.hpp"
 
 namespace kosk {
 
@@ -239,12 +240,15 @@ hipError_t launch_opened_hash(const OpenedHashArgs &a, int K, bool view, int npr
 __device__ __forceinline__ uint32_t gf_neg_if(uint32_t v, int odd) { return (odd & 1) && v ? (uint32_t)Q - v : v; }
 
 // weights of both sets, l(k) and the node map of set 0
-__device__ __forceinline__ void interp_setup_block(const InterpArgs &a, const int bx, const int b, const int set)
+__device__ __forceinline__ void interp_setup_block(const InterpArgs &a, const int bx, const int b, const int set, uint16_t *is)
 {
     const int t = bx * 256 + threadIdx.x;
     const int n = set ? DEG2 + 1 : DEG + 1;
     const uint16_t *rest = a.rest + (size_t)b * a.sel_stride;
-    const uint16_t *is = a.isort + (size_t)b * a.sel_stride;
+    // the sorted opened list in LDS: both loops below walk it once per thread (from global memory every trip waited for
+    // its own load: 40 us for the whole set-up)
+    if (threadIdx.x < NOPEN) is[threadIdx.x] = a.isort[(size_t)b * a.sel_stride + threadIdx.x];
+    __syncthreads();
     const int h0 = a.hrange[b * 4 + 2 * set], h1 = a.hrange[b * 4 + 2 * set + 1];
     const int lo = rest[0], hi = rest[n - 1]; // parties; the nodes are [lo, hi] minus the holes is[h0..h1)
     if (t < 832) { // w_j = prod_holes (x_j - h) / ((x_j - lo)! (hi - x_j)! (-1)^(hi - x_j))
@@ -289,79 +293,199 @@ __device__ __forceinline__ void interp_setup_block(const InterpArgs &a, const in
     }
 }
 
-// Cauchy operators in limb-matrix form (kosk_device.hpp): row = evaluation point k, column = node j,
-// entry 1/(k - x_j) (0 when k == x_j).  One thread per (k, 16-node chunk).
-__device__ __forceinline__ void interp_cauchy_block(const InterpArgs &a, const int bx, const int by, const int bz)
+// weights of both node sets, l(k) and the node map of set 0: 8 blocks per proof
+__global__ __launch_bounds__(256) void k_interp_setup(InterpArgs a, int nproofs)
 {
-    const int k = bx * 64 + (threadIdx.x & 63);
-    const int ch = by * 4 + (threadIdx.x >> 6); // 16-node chunk
-    const int b = bz >> 1, set = bz & 1;
-    const int n = set ? DEG2 + 1 : DEG + 1, neval = set ? NSEC : DEG + 1;
-    const int Mpad = set ? a.Mpad2 : a.Mpad1, KS = set ? a.KS2 : a.KS1;
-    if (k >= Mpad || ch >= KS * 4) return;
-    uint8_t *W = set ? a.W2 + (size_t)b * a.w2_stride : a.W + (size_t)b * a.w_stride;
-    uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
-    if (k < neval && ch * 16 < n) {
-        const uint16_t *rest = a.rest + (size_t)b * a.sel_stride + ch * 16;
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            uint32_t e = 0;
-            if (ch * 16 + q < n) e = a.inv[gf_from_i32(k - NSEC - (int)rest[q])];
-            int c0, c1;
-            limb_split(gf_center(e), c0, c1);
-            lo[q >> 2] |= ((uint32_t)c0 & 0xFFu) << (8 * (q & 3));
-            hi[q >> 2] |= ((uint32_t)c1 & 0xFFu) << (8 * (q & 3));
-        }
-    }
-    uint8_t *d = W + limb_offset(k, ch * 16, 0, Mpad / 16);
-    *reinterpret_cast<uint4 *>(d) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-    *reinterpret_cast<uint4 *>(d + 1024) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    __shared__ uint16_t is_s[256];
+    const int id = blockIdx.x;
+    interp_setup_block(a, id & 3, (id >> 2) % nproofs, (id >> 2) / nproofs, is_s);
 }
 
+// The weighted shares y[r][j] = w[b][set][j] * P[b][rows[r]][256 + rest[b][j]] of both interpolations (degree-d rows, then
+// the u rows of degree 2d), written as the MFMA operand of k_interp_apply: int8 limb tiles [k-step][column tile][limb] of
+// 1 KiB in fragment order (lane 16 (j / 16 % 4) + r % 16 holds its 16 consecutive nodes at byte 16 lane), zero where
+// j >= the node count or r >= the row count.  One thread per (column, 16 nodes).
+constexpr int IA_NT1 = 4, IA_NT2 = 2, IA_KS1 = 7, IA_KS2 = 13; // 64 columns x 448 nodes, 32 columns x 832 nodes (K = 4: 52 and 32)
+constexpr int IA_Y1_BYTES = IA_KS1 * IA_NT1 * 2048, IA_Y2_BYTES = IA_KS2 * IA_NT2 * 2048;
 
-// weights / l(k) (setup) and the two Cauchy operators are independent of each other: one launch, role by block range,
-// so that the 20 us of the set-up run under the 33 us of the operator build instead of in front of them
-__global__ __launch_bounds__(256) void k_interp_build(InterpArgs a, int nproofs, int cx, int cy)
-{
-    const int nsetup = 8 * nproofs;
-    int id = blockIdx.x;
-    if (id < nsetup) {
-        interp_setup_block(a, id & 3, (id >> 2) % nproofs, (id >> 2) / nproofs);
-        return;
-    }
-    id -= nsetup;
-    interp_cauchy_block(a, id % cx, (id / cx) % cy, id / (cx * cy));
-}
-
-// out[b][r][j] = w[b][set][j] * P[b][rows[r]][256 + rest[b][j]] for j < ncols, zero padded to out_cols;
-// both gathers of the verifier (degree-d rows, then the u rows of degree 2d) in one launch: blockIdx.y < nrows1 -> set 0
-__global__ __launch_bounds__(256) void k_gather_cols2(const uint16_t *__restrict__ P, size_t proof_stride,
-                                                      const int16_t *__restrict__ rows1, int nrows1, uint16_t *__restrict__ out1,
-                                                      const int16_t *__restrict__ rows2, int nrows2, uint16_t *__restrict__ out2,
+__global__ __launch_bounds__(256) void k_gather_frags(const uint16_t *__restrict__ P, size_t proof_stride,
+                                                      const int16_t *__restrict__ rows1, int nrows1, uint8_t *__restrict__ out1,
+                                                      const int16_t *__restrict__ rows2, int nrows2, uint8_t *__restrict__ out2,
                                                       const uint16_t *__restrict__ rest, int sel_stride, const uint16_t *__restrict__ w)
 {
-    const int set = (int)blockIdx.y >= nrows1, b = blockIdx.z;
-    const int r = set ? blockIdx.y - nrows1 : blockIdx.y;
-    const int ncols = set ? DEG2 + 1 : DEG + 1, out_cols = set ? 832 : 416, nrows = set ? nrows2 : nrows1;
-    const uint16_t *src = P + (size_t)b * proof_stride + (size_t)(set ? rows2 : rows1)[r] * RS + NSEC;
-    const uint16_t *wb = w + ((size_t)b * 2 + set) * 832;
-    const uint16_t *rb = rest + (size_t)b * sel_stride;
-    uint16_t *dst = (set ? out2 : out1) + ((size_t)b * nrows + r) * out_cols;
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < out_cols; j += gridDim.x * 256)
-        dst[j] = j < ncols ? (uint16_t)gf_mul(wb[j], src[rb[j]]) : (uint16_t)0;
+    constexpr int T1 = IA_NT1 * 16 * IA_KS1 * 4;
+    int t = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    const int set = t >= T1;
+    if (set) t -= T1;
+    const int KS = set ? IA_KS2 : IA_KS1, NT = set ? IA_NT2 : IA_NT1;
+    if (t >= NT * 16 * KS * 4) return;
+    const int r = t % (NT * 16), kc16 = t / (NT * 16); // consecutive threads: consecutive columns of one chunk -> one tile
+    const int ncols = set ? DEG2 + 1 : DEG + 1, nrows = set ? nrows2 : nrows1;
+    uint4 x0 = make_uint4(0, 0, 0, 0), x1 = x0;
+    if (r < nrows && kc16 * 16 < ncols) {
+        const uint16_t *src = P + (size_t)b * proof_stride + (size_t)(set ? rows2 : rows1)[r] * RS + NSEC;
+        const uint16_t *wb = w + ((size_t)b * 2 + set) * 832 + kc16 * 16;   // zero behind the nodes (k_interp_setup)
+        const uint16_t *rb = rest + (size_t)b * sel_stride + kc16 * 16;
+        const uint4 w0 = *reinterpret_cast<const uint4 *>(wb), w1 = *reinterpret_cast<const uint4 *>(wb + 8);
+        const uint4 r0 = *reinterpret_cast<const uint4 *>(rb), r1 = *reinterpret_cast<const uint4 *>(rb + 8);
+        const uint32_t ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w}, rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        uint32_t v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = src[(rw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu];
+        uint32_t o[8];
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+            const uint32_t lo = gf_mul(ww[q >> 1] & 0xFFFFu, v[q]), hi = gf_mul(ww[q >> 1] >> 16, v[q + 1]);
+            o[q >> 1] = lo | (hi << 16);
+        }
+        x0 = make_uint4(o[0], o[1], o[2], o[3]);
+        x1 = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+    uint4 lo, hi;
+    gm_split16(x0, x1, lo, hi);
+    uint8_t *d = (set ? out2 + (size_t)b * IA_Y2_BYTES : out1 + (size_t)b * IA_Y1_BYTES) +
+                 (size_t)(((kc16 >> 2) * NT + (r >> 4)) * 2) * 1024 + ((kc16 & 3) * 16 + (r & 15)) * 16;
+    *reinterpret_cast<uint4 *>(d) = lo;
+    *reinterpret_cast<uint4 *>(d + 1024) = hi;
 }
 
-__global__ __launch_bounds__(448) void k_interp_fixup(uint16_t *__restrict__ P, size_t proof_stride,
-                                                      const int16_t *__restrict__ src_rows, const int16_t *__restrict__ dst_rows,
-                                                      InterpArgs a)
+// ---- interpolation of the unopened shares, applied without ever storing the operator -------------------------------
+// NTL interpolate + eval of mlwe_verifier.cpp:201-219, :337-350, :410-440 (degree d: the values at points 0..406 of
+// every interpolated sharing) and :523-543 (degree 2d: the Cauchy sums of the u shares at the 256 packed positions).
+// In barycentric form the operator of one proof is the Cauchy matrix C[k][j] = 1/(k - x_j) over its nodes
+// x_j = 256 + rest[j] (407 or 813 of them); it differs from proof to proof and multiplies only 34-52 (24-32) vectors, so
+// materialising it (40 MB written and read back per 46 proofs, 17 M table look-ups behind per-element stores) cost more
+// than the product.  Here every lane builds its own MFMA operand fragment -- row = evaluation point lane & 15, sixteen
+// consecutive nodes lane >> 4 -- from the inverse table in LDS, limb-splits it in registers and multiplies right away;
+// the weighted shares (k_gather_cols2) sit in LDS as the other operand.  A wave owns 16 evaluation points, a workgroup
+// 64.  Epilogue: reduce mod q; degree d: times l(k), or the share itself where k is a node (what k_interp_fixup did),
+// into the row matrix; degree 2d: the raw sums for k_check_batch.
+// IA_OFF: the table of limb pairs is indexed by k - x_j + IA_OFF with k - 256 in [-256, 150] and x_j in [0, 1453]
+constexpr int IA_OFF = NPARTY - 1 + NSEC, IA_TAB = IA_OFF + (DEG - NSEC) + 1; // 1709, 1860 entries (+ one of padding)
+
+struct InterpApplyArgs {
+    InterpArgs ia;
+    uint16_t *P;
+    size_t proof_stride;
+    const int16_t *src_rows, *dst_rows; // degree d: shares read from / values written to these rows of the row matrix
+    int n1;                             // sharings of degree d per proof (<= 64)
+    const uint8_t *y1;                  // [proof][IA_Y1_BYTES] weighted shares as fragment tiles (k_gather_frags)
+    int n2;                             // sharings of degree 2d per proof (<= 32)
+    const uint8_t *y2;                  // [proof][IA_Y2_BYTES]
+    uint16_t *out2;                     // [proof][n2][256]
+};
+
+template <int SET>
+__device__ __forceinline__ void interp_apply_block(const InterpApplyArgs &g, const int b, const int mblk, uint16_t *tab_s, uint16_t *rest_s)
 {
-    const int k = threadIdx.x, r = blockIdx.x, b = blockIdx.y;
-    if (k > DEG) return;
-    uint16_t *Pb = P + (size_t)b * proof_stride;
-    uint16_t *d = Pb + (size_t)dst_rows[r] * RS + k;
-    const int node = a.node_of[(size_t)b * 416 + k];
-    if (node >= 0) *d = Pb[(size_t)src_rows[r] * RS + NSEC + a.rest[(size_t)b * a.sel_stride + node]];
-    else *d = (uint16_t)gf_mul(a.ell[(size_t)b * 416 + k], *d);
+    constexpr int KS = SET ? IA_KS2 : IA_KS1, NT = SET ? IA_NT2 : IA_NT1;
+    constexpr int NEVAL = SET ? NSEC : DEG + 1;
+    const InterpArgs &a = g.ia;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ncol = SET ? g.n2 : g.n1;
+    { // limb-pair table of the inverses: all of a thread's loads in flight at once
+        constexpr int ND = (IA_TAB + 2) / 2, TRIPS = (ND + 255) / 256;
+        uint32_t tmp[TRIPS];
+#pragma unroll
+        for (int i = 0; i < TRIPS; i++) {
+            const int idx = tid + i * 256;
+            tmp[i] = reinterpret_cast<const uint32_t *>(a.invlimb)[idx < ND ? idx : ND - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < TRIPS; i++) {
+            const int idx = tid + i * 256;
+            if (idx < ND) reinterpret_cast<uint32_t *>(tab_s)[idx] = tmp[i];
+        }
+    }
+    // nodes (sel_stride leaves readable entries behind them: further unopened parties, which meet zero shares)
+    for (int j = tid; j < KS * 64; j += 256) rest_s[j] = a.rest[(size_t)b * a.sel_stride + j];
+    __syncthreads();
+
+    const int m0 = (mblk * 4 + wv) * 16;
+    if (m0 >= NEVAL) return;
+    const int kq = m0 + (lane & 15) - NSEC + IA_OFF; // this lane's evaluation point, offset for the table
+    const uint8_t *yt = (SET ? g.y2 + (size_t)b * IA_Y2_BYTES : g.y1 + (size_t)b * IA_Y1_BYTES) + lane * 16;
+    v4i s0[NT], s1[NT], s2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) { s0[j] = (v4i){0, 0, 0, 0}; s1[j] = s0[j]; s2[j] = s0[j]; }
+    v4i fb[2][2 * NT]; // the other operand's fragments, one k-step ahead
+    auto load_b = [&](int ks, v4i (&dst)[2 * NT]) {
+#pragma unroll
+        for (int q = 0; q < 2 * NT; q++) dst[q] = *reinterpret_cast<const v4i *>(yt + (size_t)(ks * NT * 2 + q) * 1024);
+    };
+    load_b(0, fb[0]);
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        if (ks + 1 < KS) load_b(ks + 1, fb[(ks + 1) & 1]);
+        // operand fragment: 1/(k - x_j) for the 16 nodes j = 64 ks + 16 (lane >> 4) + q, as (low limb | high limb << 8)
+        const uint16_t *rn = rest_s + ks * 64 + (lane >> 4) * 16;
+        const uint4 r0 = *reinterpret_cast<const uint4 *>(rn), r1 = *reinterpret_cast<const uint4 *>(rn + 8);
+        const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        uint32_t e[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int xj = (int)((rw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu);
+            e[q] = tab_s[min((uint32_t)(kq - xj), (uint32_t)IA_TAB)]; // the clamp only matters for a malformed list (entry IA_TAB is 0)
+        }
+        uint32_t lo[4], hi[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t t01 = e[4 * q] | (e[4 * q + 1] << 16), t23 = e[4 * q + 2] | (e[4 * q + 3] << 16);
+            lo[q] = __builtin_amdgcn_perm(t23, t01, 0x06040200u);
+            hi[q] = __builtin_amdgcn_perm(t23, t01, 0x07050301u);
+        }
+        const v4i a0 = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3]}, a1 = {(int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        v4i(&bc)[2 * NT] = fb[ks & 1];
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            s0[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bc[2 * j], s0[j], 0, 0, 0);
+            s1[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bc[2 * j + 1], s1[j], 0, 0, 0);
+            s2[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bc[2 * j + 1], s2[j], 0, 0, 0);
+            s1[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bc[2 * j], s1[j], 0, 0, 0);
+        }
+    }
+    // D[row = evaluation point m0 + 4 (lane >> 4) + r][col = sharing 16 j + (lane & 15)];
+    // |S0 + 64 S1 + 767 S2| < 2^29 for k <= 832, so adding 90 000 q makes it a positive u32
+    const int kb = m0 + (lane >> 4) * 4;
+    int node[4] = {-1, -1, -1, -1};
+    uint32_t ell[4] = {0, 0, 0, 0}, xn[4] = {0, 0, 0, 0};
+    if constexpr (!SET) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (kb + r <= DEG) { node[r] = a.node_of[(size_t)b * 416 + kb + r]; ell[r] = a.ell[(size_t)b * 416 + kb + r]; }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (node[r] >= 0) xn[r] = rest_s[node[r]]; // node indices are < 407
+    }
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        const int col = j * 16 + (lane & 15);
+        if (col >= ncol) continue;
+        uint32_t v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = gf_reduce_pos((uint32_t)(s0[j][r] + 64 * s1[j][r] + 767 * s2[j][r] + 90000 * Q));
+        if constexpr (SET) {
+            *reinterpret_cast<uint2 *>(g.out2 + ((size_t)b * ncol + col) * NSEC + kb) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+        } else {
+            uint16_t *Pb = g.P + (size_t)b * g.proof_stride;
+            const uint16_t *srow = Pb + (size_t)g.src_rows[col] * RS + NSEC;
+            uint16_t *drow = Pb + (size_t)g.dst_rows[col] * RS;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (kb + r <= DEG) drow[kb + r] = node[r] >= 0 ? srow[xn[r]] : (uint16_t)gf_mul(ell[r], v[r]);
+        }
+    }
+}
+
+// blocks per proof: 7 (degree d: 407 points in groups of 64) + 4 (degree 2d: 256 points)
+__global__ __launch_bounds__(256) void k_interp_apply(InterpApplyArgs g)
+{
+    __shared__ __attribute__((aligned(4))) uint16_t tab_s[IA_TAB + 2];
+    __shared__ __attribute__((aligned(16))) uint16_t rest_s[IA_KS2 * 64];
+    const int b = blockIdx.x / 11, m = blockIdx.x % 11;
+    if (m < 7) interp_apply_block<0>(g, b, m, tab_s, rest_s);
+    else interp_apply_block<1>(g, b, m - 7, tab_s, rest_s);
 }
 
 // ---- checks ---------------------------------------------------------------------
@@ -518,11 +642,16 @@ hipError_t launch_check_batch(const VerifyArgs &v, const uint16_t *t_pk, const u
     hipLaunchKernelGGL(k_check_batch, dim3((NREST + 255) / 256 + 1 + 2 * nu, nproofs), dim3(256), 0, st, v, t_pk, u1, u2, nu);
     return hipGetLastError();
 }
-hipError_t launch_gather_cols2(const uint16_t *P, size_t proof_stride, const int16_t *rows1, int nrows1, uint16_t *out1,
-                               const int16_t *rows2, int nrows2, uint16_t *out2, const uint16_t *rest, int sel_stride,
+size_t interp_y_bytes(int set) { return set ? IA_Y2_BYTES : IA_Y1_BYTES; }
+int interp_table_len() { return IA_TAB + 2; }
+int interp_table_off() { return IA_OFF; }
+hipError_t launch_gather_frags(const uint16_t *P, size_t proof_stride, const int16_t *rows1, int nrows1, uint8_t *out1,
+                               const int16_t *rows2, int nrows2, uint8_t *out2, const uint16_t *rest, int sel_stride,
                                const uint16_t *w, int nproofs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_gather_cols2, dim3(2, nrows1 + nrows2, nproofs), dim3(256), 0, st, P, proof_stride, rows1, nrows1, out1, rows2,
+    if (nrows1 > 16 * IA_NT1 || nrows2 > 16 * IA_NT2) return hipErrorInvalidValue;
+    const int threads = IA_NT1 * 16 * IA_KS1 * 4 + IA_NT2 * 16 * IA_KS2 * 4;
+    hipLaunchKernelGGL(k_gather_frags, dim3((threads + 255) / 256, nproofs), dim3(256), 0, st, P, proof_stride, rows1, nrows1, out1, rows2,
                        nrows2, out2, rest, sel_stride, w);
     return hipGetLastError();
 }
@@ -540,17 +669,27 @@ hipError_t launch_disassemble(const VerifyArgs &v, const FieldDesc *fields, cons
                        st, v, fields, plan, rowtab, proof, image_stride, (uint32_t)off_tcomm, (uint32_t)off_comm, dig1, dig2, go);
     return hipGetLastError();
 }
-hipError_t launch_interp_build(const InterpArgs &a, int nproofs, hipStream_t st)
+hipError_t launch_interp_setup(const InterpArgs &a, int nproofs, hipStream_t st)
 {
-    const int mp = a.Mpad1 > a.Mpad2 ? a.Mpad1 : a.Mpad2, ks = a.KS1 > a.KS2 ? a.KS1 : a.KS2;
-    const int cx = (mp + 63) / 64, cy = ks;
-    hipLaunchKernelGGL(k_interp_build, dim3(8 * nproofs + cx * cy * nproofs * 2), dim3(256), 0, st, a, nproofs, cx, cy);
+    hipLaunchKernelGGL(k_interp_setup, dim3(8 * nproofs), dim3(256), 0, st, a, nproofs);
     return hipGetLastError();
 }
-hipError_t launch_interp_fixup(uint16_t *P, size_t proof_stride, const int16_t *src_rows, const int16_t *dst_rows, int nrows,
-                               const InterpArgs &a, int nproofs, hipStream_t st)
+hipError_t launch_interp_apply(const InterpArgs &a, uint16_t *P, size_t proof_stride, const int16_t *src_rows, const int16_t *dst_rows,
+                               int n1, const uint8_t *y1, int n2, const uint8_t *y2, uint16_t *out2, int nproofs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_interp_fixup, dim3(nrows, nproofs), dim3(448), 0, st, P, proof_stride, src_rows, dst_rows, a);
+    if (n1 > 16 * IA_NT1 || n2 > 16 * IA_NT2 || n1 < 1 || n2 < 1) return hipErrorInvalidValue;
+    InterpApplyArgs g{};
+    g.ia = a;
+    g.P = P;
+    g.proof_stride = proof_stride;
+    g.src_rows = src_rows;
+    g.dst_rows = dst_rows;
+    g.n1 = n1;
+    g.y1 = y1;
+    g.n2 = n2;
+    g.y2 = y2;
+    g.out2 = out2;
+    hipLaunchKernelGGL(k_interp_apply, dim3(11 * nproofs), dim3(256), 0, st, g);
     return hipGetLastError();
 }
 hipError_t launch_check_opened(const VerifyArgs &v, int nproofs, hipStream_t st)
