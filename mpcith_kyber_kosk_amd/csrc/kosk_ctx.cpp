@@ -93,7 +93,7 @@ static int upload_table(Ctx &c, GemmTable &t, const std::vector<uint16_t> &A, in
     pack_limb_table(A, M, Kdim, t.Mpad, t.KS, pk);
     HIPCHK(dalloc(&t.d, pk.size()));
     HIPCHK(hipMemcpy(t.d, pk.data(), pk.size(), hipMemcpyHostToDevice));
-    if (t.KS == 7) {
+    if (t.KS == 7 || t.KS == 13) {
         pack_frag_table(A, M, Kdim, t.Mpad, t.KS, pk);
         HIPCHK(dalloc(&t.dfrag, pk.size()));
         HIPCHK(hipMemcpy(t.dfrag, pk.data(), pk.size(), hipMemcpyHostToDevice));

@@ -970,7 +970,7 @@ constexpr int TG_NB = 48, TG_WAVES = 8;
 
 // TG_RT = table row tiles (of 16) per chunk
 template <int KS, int TG_RT>
-__global__ __launch_bounds__(512, 2) void k_table_gemm(GemmArgs a, int nchunks, int chunks_per_block)
+__global__ __launch_bounds__(512, KS <= 7 ? 2 : 1) void k_table_gemm(GemmArgs a, int nchunks, int chunks_per_block)
 {
     constexpr int TG_CHUNK = 16 * TG_RT;
     __shared__ __attribute__((aligned(16))) uint8_t ldsB[KS * 3 * 2048]; // [k-step][row tile][limb][1 KiB]
@@ -1682,11 +1682,11 @@ hipError_t launch_gemm_batch(const GemmArgs *list, int count, hipStream_t st)
     return hipGetLastError();
 }
 
-// the table-product kernel: shared table, KS == 7 (407-wide inputs), aligned u16 rows
+// the table-product kernel: shared table, KS == 7 (407-wide inputs) or 13 (813-wide: recon_secrets_2ddeg), aligned u16 rows
 static bool table_gemm_ok(const GemmArgs &a)
 {
     static const bool on = !(getenv("KOSK_TABLE_GEMM") && atoi(getenv("KOSK_TABLE_GEMM")) == 0);
-    return on && a.Afrag && !a.grouped && !a.B && a.KS == 7 && a.M % 32 == 0 && a.c_gdiv <= 1 && a.src_koff % 8 == 0 && a.src_rstride % 8 == 0 &&
+    return on && a.Afrag && !a.grouped && !a.B && (a.KS == 7 || a.KS == 13) && a.M % 32 == 0 && a.c_gdiv <= 1 && a.src_koff % 8 == 0 && a.src_rstride % 8 == 0 &&
            a.src_gstride % 8 == 0 && (reinterpret_cast<uintptr_t>(a.src) & 15) == 0 && a.c_off % 4 == 0 && a.c_rstride % 4 == 0 &&
            a.c_gstride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C) & 7) == 0;
 }
@@ -1704,7 +1704,8 @@ hipError_t launch_table_gemm(const GemmArgs &a, uint16_t *sink, hipStream_t st)
     const int cpb = (nchunks + msplit - 1) / msplit;
     msplit = (nchunks + cpb - 1) / cpb;
     (void)sink;
-    hipLaunchKernelGGL((k_table_gemm<7, 1>), dim3(nblk, msplit), dim3(512), 0, st, a, nchunks, cpb);
+    if (a.KS == 7) hipLaunchKernelGGL((k_table_gemm<7, 1>), dim3(nblk, msplit), dim3(512), 0, st, a, nchunks, cpb);
+    else hipLaunchKernelGGL((k_table_gemm<13, 1>), dim3(nblk, msplit), dim3(512), 0, st, a, nchunks, cpb);
     return hipGetLastError();
 }
 

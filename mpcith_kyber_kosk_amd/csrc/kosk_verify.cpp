@@ -279,9 +279,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
         c.prof_end(PR_V_GEMM_INTERP);
         const GemmSrc gs3{c.d_P, c.proof_stride, c.d_rows_u, RS, NSEC, DEG2 + 1};
         const GemmDst gd3{c.d_sec_u2, (size_t)c.n_interp_2d * 256, nullptr, 256, 0};
-        const GemmArgs list[1] = {
-            gemm_args_small(c.t_recon_2d.d, 0, c.t_recon_2d.Mpad, c.t_recon_2d.M, c.t_recon_2d.KS, gs3, gd3, c.n_interp_2d, n, false)};
-        HIPCHK(launch_gemm_batch(list, 1, st));
+        if (gemm_modq(c, c.t_recon_2d, gs3, gd3, c.n_interp_2d, n)) return -1;
         const GemmSrc xs{c.d_P, c.proof_stride, c.d_rows_idst, RS, 0, XLEN};
         const GemmDst xd{c.d_P, c.proof_stride, c.d_rows_idst, RS, EXP_OFF};
         c.prof_begin(PR_V_GEMM_EXPAND);
