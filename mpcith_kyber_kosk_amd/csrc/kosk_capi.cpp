@@ -57,6 +57,18 @@ struct kosk_ctx {
     }
 };
 
+// argument validation failed: the call has done nothing; kosk_last_error(ctx) says which entry point refused
+static int bad_args(const kosk_ctx *, const char *) { return -1; } // read-only entry points leave the error string alone
+static int bad_args(kosk_ctx *ctx, const char *fn)
+{
+    if (ctx) {
+        ctx->clear_err();
+        ctx->err = std::string(fn) + ": invalid argument (null pointer, batch size out of range, or unsupported for this context)";
+        ctx->c->err = ctx->err;
+    }
+    return -1;
+}
+
 // Batches larger than a sub-context: the chunks (of a sub-context's capacity each) are dealt round-robin to the S
 // sub-contexts, which work through theirs concurrently on S host threads.  With KOSK_STREAMS >= 2 one chunk's PCIe
 // transfers (tapes in, 0.68 MB of proof image out per proof; proofs and keys in for the verifier) and host hashing run
@@ -165,7 +177,7 @@ int kosk_set_randombytes(kosk_ctx *ctx, kosk_randombytes_fn fn, void *user)
 
 int kosk_stage_prover_inputs(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk)
 {
-    if (!ctx || n < 1 || n > ctx->max_batch) return -1;
+    if (!ctx || n < 1 || n > ctx->max_batch) return bad_args(ctx, __func__);
     const Params &P = ctx->c->P;
     if (!tapes) {
         // the randombytes callback is stateful: draw every tape sequentially, in proof order, then stage in parallel
@@ -190,18 +202,18 @@ int kosk_stage_prover_inputs(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t 
 }
 int kosk_prove_resident(kosk_ctx *ctx, int n)
 {
-    if (!ctx || n < 1 || n > ctx->max_batch) return -1;
+    if (!ctx || n < 1 || n > ctx->max_batch) return bad_args(ctx, __func__);
     return ctx->run(n, [&](Ctx &c, int, int count) { return prove_resident(c, count); });
 }
 int kosk_fetch_proofs(kosk_ctx *ctx, int n, uint8_t *pi)
 {
-    if (!ctx || n < 1 || n > ctx->max_batch) return -1;
+    if (!ctx || n < 1 || n > ctx->max_batch) return bad_args(ctx, __func__);
     const Params &P = ctx->c->P;
     return ctx->run(n, [&](Ctx &c, int first, int count) { return fetch_proofs(c, count, pi + (size_t)first * P.proof_bytes); });
 }
 int kosk_stage_verifier_inputs(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk)
 {
-    if (!ctx || n < 1 || n > ctx->max_batch) return -1;
+    if (!ctx || n < 1 || n > ctx->max_batch) return bad_args(ctx, __func__);
     const Params &P = ctx->c->P;
     return ctx->run(n, [&](Ctx &c, int first, int count) {
         return stage_verifier_inputs(c, count, pi + (size_t)first * P.proof_bytes, pk + (size_t)first * P.pk_bytes);
@@ -209,7 +221,7 @@ int kosk_stage_verifier_inputs(kosk_ctx *ctx, int n, const uint8_t *pi, const ui
 }
 int kosk_verify_resident(kosk_ctx *ctx, int n, uint8_t *ok)
 {
-    if (!ctx || n < 1 || n > ctx->max_batch) return -1;
+    if (!ctx || n < 1 || n > ctx->max_batch) return bad_args(ctx, __func__);
     ctx->masks.assign((size_t)n, 0);
     return ctx->run(n, [&](Ctx &c, int first, int count) {
         if (verify_resident(c, count, ok + first)) return -1;
@@ -220,7 +232,7 @@ int kosk_verify_resident(kosk_ctx *ctx, int n, uint8_t *ok)
 
 int kosk_verifiable_keygen_resident(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk)
 {
-    if (!ctx || n < 1 || n > ctx->max_batch || !pk || !sk) return -1;
+    if (!ctx || n < 1 || n > ctx->max_batch || !pk || !sk) return bad_args(ctx, __func__);
     const Params &P = ctx->c->P;
     if (!tapes && ctx->sub.size() > 1) {
         // the randombytes callback is stateful: draw sequentially in proof order, then prove the sub-batches in parallel
@@ -246,7 +258,7 @@ int kosk_verifiable_keygen_resident(kosk_ctx *ctx, int n, const uint8_t *tapes, 
 }
 int kosk_verify_resident_pk(kosk_ctx *ctx, int n, const uint8_t *pk, uint8_t *ok)
 {
-    if (!ctx || n < 1 || n > ctx->max_batch || !ok) return -1;
+    if (!ctx || n < 1 || n > ctx->max_batch || !ok) return bad_args(ctx, __func__);
     const Params &P = ctx->c->P;
     ctx->masks.assign((size_t)n, 0);
     return ctx->run(n, [&](Ctx &c, int first, int count) {
@@ -264,7 +276,7 @@ int kosk_set_round_hook(kosk_ctx *ctx, kosk_round_fn fn, void *user)
 }
 int kosk_resident_digests(kosk_ctx *ctx, int round, void **d_digests, size_t *stride)
 {
-    if (!ctx || round < 0 || round > 1) return -1;
+    if (!ctx || round < 0 || round > 1) return bad_args(ctx, __func__);
     if (ctx->sub.size() > 1) { ctx->err = "kosk_resident_digests needs KOSK_STREAMS=1 (sub-batches keep separate tables)"; return -1; }
     if (d_digests) *d_digests = round ? ctx->c->d_dig2 : ctx->c->d_dig1;
     if (stride) *stride = (size_t)NPARTY * 32;
@@ -274,7 +286,7 @@ int kosk_resident_digests(kosk_ctx *ctx, int round, void **d_digests, size_t *st
 int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride,
                                  uint8_t *pk, uint8_t *sk, uint8_t *pi)
 {
-    if (!ctx || n < 0 || !pk || !sk || !pi) return -1;
+    if (!ctx || n < 0 || !pk || !sk || !pi) return bad_args(ctx, __func__);
     if (n == 0) return 0;
     const Params &P = ctx->c->P;
     std::vector<uint8_t> drawn;
@@ -309,7 +321,7 @@ int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, siz
 
 int kosk_verify_batch(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk, uint8_t *ok)
 {
-    if (!ctx || n < 0 || !pi || !pk || !ok) return -1;
+    if (!ctx || n < 0 || !pi || !pk || !ok) return bad_args(ctx, __func__);
     if (n == 0) return 0;
     const Params &P = ctx->c->P;
     ctx->masks.assign((size_t)n, 0);
@@ -333,7 +345,7 @@ size_t kosk_mlwe_inst_bytes(int k) { Params p; return make_params(k, p) ? mlwe_i
 
 int kosk_prepare_randomness(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *rand_out)
 {
-    if (!ctx || n < 0 || !rand_out) return -1;
+    if (!ctx || n < 0 || !rand_out) return bad_args(ctx, __func__);
     Ctx &c = *ctx->c;
     ctx->clear_err();
     for (int done = 0; done < n;) {
@@ -346,7 +358,7 @@ int kosk_prepare_randomness(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t t
 }
 int kosk_prepare_range_proof(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *range_out)
 {
-    if (!ctx || n < 0 || !range_out) return -1;
+    if (!ctx || n < 0 || !range_out) return bad_args(ctx, __func__);
     Ctx &c = *ctx->c;
     ctx->clear_err();
     for (int done = 0; done < n;) {
@@ -360,7 +372,7 @@ int kosk_prepare_range_proof(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t 
 int kosk_prove_prepared(kosk_ctx *ctx, int n, const uint8_t *inst, const uint8_t *rand_in, const uint8_t *range_in,
                         const uint8_t *tapes, size_t tape_stride, uint8_t *pi)
 {
-    if (!ctx || n < 0 || !inst || !rand_in || !range_in || !pi) return -1;
+    if (!ctx || n < 0 || !inst || !rand_in || !range_in || !pi) return bad_args(ctx, __func__);
     Ctx &c = *ctx->c;
     ctx->clear_err();
     for (int done = 0; done < n;) {
@@ -374,7 +386,7 @@ int kosk_prove_prepared(kosk_ctx *ctx, int n, const uint8_t *inst, const uint8_t
 }
 int kosk_verify_inst(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *inst, uint8_t *ok)
 {
-    if (!ctx || n < 0 || !pi || !inst || !ok) return -1;
+    if (!ctx || n < 0 || !pi || !inst || !ok) return bad_args(ctx, __func__);
     Ctx &c = *ctx->c;
     ctx->clear_err();
     for (int done = 0; done < n;) {
@@ -405,13 +417,13 @@ int kosk_proof_decompress(int k, const uint8_t *in, uint8_t *pi)
 }
 int kosk_fetch_proofs_compact(kosk_ctx *ctx, int n, uint8_t *out)
 {
-    if (!ctx || n < 0 || n > ctx->max_batch || !out) return -1;
+    if (!ctx || n < 0 || n > ctx->max_batch || !out) return bad_args(ctx, __func__);
     const size_t cb = make_compact_plan(ctx->c->P).bytes;
     return ctx->run(n, [&](Ctx &c, int first, int count) { return fetch_proofs_compact(c, count, out + (size_t)first * cb); });
 }
 int kosk_stage_verifier_inputs_compact(kosk_ctx *ctx, int n, const uint8_t *in, const uint8_t *pk)
 {
-    if (!ctx || n < 0 || n > ctx->max_batch || !in || !pk) return -1;
+    if (!ctx || n < 0 || n > ctx->max_batch || !in || !pk) return bad_args(ctx, __func__);
     const Params &P = ctx->c->P;
     const size_t cb = make_compact_plan(P).bytes;
     return ctx->run(n, [&](Ctx &c, int first, int count) {
@@ -421,7 +433,7 @@ int kosk_stage_verifier_inputs_compact(kosk_ctx *ctx, int n, const uint8_t *in, 
 
 int kosk_verify_fail_masks(const kosk_ctx *ctx, uint32_t *masks, int n)
 {
-    if (!ctx || !masks || n < 0 || (size_t)n > ctx->masks.size()) return -1;
+    if (!ctx || !masks || n < 0 || (size_t)n > ctx->masks.size()) return bad_args(ctx, __func__);
     memcpy(masks, ctx->masks.data(), sizeof(uint32_t) * (size_t)n);
     return 0;
 }
@@ -445,7 +457,7 @@ int kosk_profile_enable(kosk_ctx *ctx, int on)
 }
 int kosk_profile_read(const kosk_ctx *ctx, int id, double *total_ms, long *launches)
 {
-    if (!ctx || id < 0 || id >= PR_COUNT) return -1;
+    if (!ctx || id < 0 || id >= PR_COUNT) return bad_args(ctx, __func__);
     double ms = 0;
     long cnt = 0;
     for (const Ctx *c : ctx->sub) { ms += c->prof_ms[id]; cnt += c->prof_n[id]; }
@@ -466,7 +478,7 @@ int kosk_stream_timer_start(kosk_ctx *ctx)
 }
 int kosk_stream_timer_stop(kosk_ctx *ctx, double *ms)
 {
-    if (!ctx || !ctx->c->timer_ev[0]) return -1;
+    if (!ctx || !ctx->c->timer_ev[0]) return bad_args(ctx, __func__);
     Ctx &c = *ctx->c;
     ctx->clear_err();
     HIPCHK_C(hipSetDevice(c.device));
