@@ -20,10 +20,10 @@ echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_w -- python3 tools/pmc_workload.py > /dev/null 2>&1
 echo "write done"
 python3 - $out $tag <<'PY'
-import csv, sys, glob, collections, json
+import csv, sys, glob, collections, json, os
 out, tag = sys.argv[1], sys.argv[2]
 def load(d, name):
-    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    f = max(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
     acc = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != name: continue
@@ -31,11 +31,13 @@ def load(d, name):
         a = acc.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += float(r["Counter_Value"])
     return acc
 F, W = load(out + "/pmc_f", "FETCH_SIZE"), load(out + "/pmc_w", "WRITE_SIZE")
-with open("%s/%s_pmc_fetch_write.csv" % (out, tag), "w") as fo:
-    fo.write("kernel,grid_threads,dispatches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg\n")
+with open("%s/%s_pmc_fetch_write.csv" % (out, tag), "w", newline="") as fo:
+    wr = csv.writer(fo)  # kernel names carry commas (template arguments): quoted
+    wr.writerow(["kernel", "grid_threads", "dispatches", "FETCH_SIZE_KB_avg", "WRITE_SIZE_KB_avg", "HBM_MB_corrected_2F_plus_W"])
     for k, (n, v) in F.items():
         w = W.get(k, [1, 0.0])
-        fo.write("%s,%d,%d,%.0f,%.0f\n" % (k[0], k[1], n, v / n, w[1] / max(1, w[0])))
+        f_kb, w_kb = v / n, w[1] / max(1, w[0])
+        wr.writerow([k[0], k[1], n, "%.0f" % f_kb, "%.0f" % w_kb, "%.1f" % ((2 * f_kb + w_kb) / 1024)])
 # in-pipeline view hash: the k_commit_hash<16,220,...> dispatch with 46 proofs (grid 1472 x 46 threads)
 hv = [(k, v) for k, v in F.items() if "k_commit_hash" in k[0] and "<16, 220" in k[0] and k[1] == 1472 * 46]
 if hv:
