@@ -287,7 +287,18 @@ def main():
     custom = bool(args.kyber_k or args.batch)
     k, B = cfg["k"], cfg["batch"]
     S = args.slots if args.slots > 0 else cfg["slots"]
-    os.environ.setdefault("KOSK_HOST_THREADS", str(cfg["threads"]))
+    # host cores this rank can count on: when they are scarce (an 8-GPU node with few cores per GPU), the slots' waits sleep on
+    # events instead of spinning and the Fiat-Shamir pools shrink; with 32+ cores per rank nothing changes
+    try:
+        usable_cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable_cores = os.cpu_count() or 1
+    cores_per_rank = max(1, usable_cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))))
+    threads = cfg["threads"]
+    if cores_per_rank < S * (threads + 1):
+        os.environ.setdefault("KOSK_BLOCKING_SYNC", "1")
+        threads = max(1, min(threads, cores_per_rank // S))
+    os.environ.setdefault("KOSK_HOST_THREADS", str(threads))
     # stdout carries exactly ONE line (the JSON): whatever libraries print there (RCCL's version banner on the first
     # communicator, for one) goes to stderr instead
     sys.stdout.flush()
@@ -502,7 +513,7 @@ def main():
                                    "verifier), randomness tapes resident in HBM, a different tape set every step",
                        "baseline_config": "configs[%d]" % (args.config - 1), "kyber_k": k, "proofs_per_gpu": B, "party_lanes_per_gpu": B * 1454,
                        "sharding": "by proof", "pipeline_slots_per_gpu": S, "tape_sets_per_slot": args.tape_sets,
-                       "host_threads_per_slot": os.environ.get("KOSK_HOST_THREADS"),
+                       "host_threads_per_slot": os.environ.get("KOSK_HOST_THREADS"), "host_waits": "sleep" if os.environ.get("KOSK_BLOCKING_SYNC") == "1" else "spin",
                        "timing": "steady-state window: completion of step W to completion of step W+K, slots running continuously"},
             "drained_run": {"steps": total, "ms_per_step": dt_drained / total * 1e3, "value": world * total * B / dt_drained,
                             "note": "the same run from first issue to last completion, barrier + synchronize on both sides (fill and drain included)"},

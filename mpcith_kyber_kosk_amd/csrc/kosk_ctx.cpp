@@ -63,6 +63,7 @@ Ctx::~Ctx()
     for (auto &pe : prof_ev)
         for (auto e : pe)
             if (e) (void)hipEventDestroy(e);
+    if (ev_sync) (void)hipEventDestroy(ev_sync);
     void *dev[] = {t_expand.d, t_recon_d.d, t_recon_2d.d, t_expand.dfrag, t_recon_d.dfrag, t_recon_2d.dfrag, d_fresh_rows, d_gemm1_rows, d_gemm2_rows, d_off, d_fields,
                    d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_kg, d_sehat, d_t, d_alpha, d_I, d_pwT, d_limbs, d_linA, d_coef, d_lin_rows,
                    d_gather, d_gather2, d_O, d_w, d_ell, d_sec, d_sec_u1, d_sec_u2, d_fail, d_inv, d_invlimb, d_vfields,
@@ -111,6 +112,13 @@ GemmArgs gemm_args_small(const uint8_t *A, size_t a_gstride, int Mpad, int M, in
     ga.B = nullptr; ga.BRT = 0;
     ga.src = s.src; ga.src_gstride = s.gstride; ga.src_rows = s.rows; ga.src_rstride = s.rstride; ga.src_koff = s.koff;
     return ga;
+}
+
+hipError_t stream_sync(Ctx &c)
+{
+    if (!c.blocking_sync) return hipStreamSynchronize(c.stream);
+    const hipError_t e = hipEventRecord(c.ev_sync, c.stream);
+    return e != hipSuccess ? e : hipEventSynchronize(c.ev_sync);
 }
 
 int gemm_modq(Ctx &c, const uint8_t *A, size_t a_gstride, int Mpad, int M, int KS, const GemmSrc &s, const GemmDst &d,
@@ -283,11 +291,13 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     if (const char *e = getenv("KOSK_GRAPHS")) c.use_graphs = atoi(e) != 0;
     if (const char *e = getenv("KOSK_LINCOMB_FUSED")) c.lincomb_fused = atoi(e) != 0;
     if (const char *e = getenv("KOSK_NTT_FP32")) c.ntt_fp32 = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_BLOCKING_SYNC")) c.blocking_sync = atoi(e) != 0;
 
     auto body = [&]() -> int {
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
+        if (c.blocking_sync) HIPCHK(hipEventCreateWithFlags(&c.ev_sync, hipEventDisableTiming | hipEventBlockingSync));
         for (auto &pe : c.prof_ev)
             for (auto &e : pe) HIPCHK(hipEventCreate(&e));
         if (build_tables(c)) return -1;
@@ -335,7 +345,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
         c.h_rest = c.h_I + B * c.sel_stride;
         HIPCHK(halloc(&c.h_fail, B));
         memset(c.h_alpha, 0, B * 80 * sizeof(uint16_t));
-        HIPCHK(hipStreamSynchronize(c.stream));
+        HIPCHK(stream_sync(c));
         return 0;
     };
     if (body()) return fail();
@@ -431,7 +441,7 @@ int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride,
     const double t0 = now_sec();
     if (upload_tapes(c, n, tapes, tape_stride)) return -1;
     if (issue_keygen(c, n)) return -1;
-    HIPCHK(hipStreamSynchronize(c.stream));
+    HIPCHK(stream_sync(c));
     finish_keygen_host(c, n, pk, sk);
     c.phase_sec[PH_HOST_PRE] = now_sec() - t0;
     return 0;
@@ -626,7 +636,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         return 0;
     })) return -1;
     c.phase_sec[PH_P3_ISSUE] = now_sec() - t0;
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(stream_sync(c));
     t1 = now_sec(); c.phase_sec[PH_GPU_ASSEMBLE] = t1 - t0;
     c.prof_collect();
     return 0;
@@ -640,10 +650,10 @@ int fetch_proofs(Ctx &c, int n, uint8_t *pi, bool registered)
     if (registered) {
         // the caller's buffer is page-locked for the duration of the call (kosk_capi.cpp): the images go straight there
         HIPCHK(hipMemcpy2DAsync(pi, c.P.proof_bytes, c.d_proof, c.image_stride, c.P.proof_bytes, n, hipMemcpyDeviceToHost, c.stream));
-        HIPCHK(hipStreamSynchronize(c.stream));
+        HIPCHK(stream_sync(c));
     } else {
         HIPCHK(hipMemcpyAsync(c.h_proof, c.d_proof, (size_t)n * c.image_stride, hipMemcpyDeviceToHost, c.stream));
-        HIPCHK(hipStreamSynchronize(c.stream));
+        HIPCHK(stream_sync(c));
         parallel_for(c.pool, n, c.nthreads, [&](int b) { memcpy(pi + (size_t)b * c.P.proof_bytes, c.h_proof + (size_t)b * c.image_stride, c.P.proof_bytes); });
     }
     c.phase_sec[PH_D2H] = now_sec() - t0;

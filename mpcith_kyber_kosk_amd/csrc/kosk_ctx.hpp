@@ -143,6 +143,8 @@ struct Ctx {
     uint32_t *d_fail = nullptr;      // [proof] bit mask of failed checks (FailBit)
     uint16_t *h_Iimg = nullptr;      // I fields as read from the proof images
     hipEvent_t ev = nullptr;
+    hipEvent_t ev_sync = nullptr; // KOSK_BLOCKING_SYNC=1: every host wait sleeps on an event instead of spinning (few host cores per GPU)
+    bool blocking_sync = false;
     hipEvent_t timer_ev[2] = {nullptr, nullptr}; // kosk_stream_timer_start / _stop
     // compact wire format staging (allocated on first use)
     CompactPlan cplan{};
@@ -218,6 +220,8 @@ int run_segment(Ctx &c, int seg, int n, F &&body)
 int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &err);
 
 // C[g][rows_d[i]][off + m] = sum_k A[m][k] * src[g][rows_s[i]][koff + k] mod q  (conversion to limbs + MFMA GEMM)
+// host wait for everything queued on the context's stream (spinning, or sleeping with KOSK_BLOCKING_SYNC=1)
+hipError_t stream_sync(Ctx &c);
 int gemm_modq(Ctx &c, const uint8_t *A, size_t a_gstride, int Mpad, int M, int KS, const GemmSrc &s, const GemmDst &d,
               int npg, int ngroups, bool grouped, const uint8_t *Afrag = nullptr);
 // argument block of a small product (data operand converted inside the kernel), for launch_gemm_batch

@@ -81,7 +81,7 @@ int prepare_randomness(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride, 
     const int M = P.M;
     if (fill_tape_part(c, n, true, 0, 2 * M, tapes, tape_stride)) return -1;
     if (issue_sharing_front(c, n, FRONT_RANDOMNESS)) return -1;
-    HIPCHK(hipStreamSynchronize(c.stream));
+    HIPCHK(stream_sync(c));
     if (rm.tf != rm.f + M) { c.err = "internal: f / NTT f rows not adjacent"; return -1; }
     std::vector<uint16_t> rows((size_t)2 * M * RS);
     for (int b = 0; b < n; b++) {
@@ -107,7 +107,7 @@ int prepare_range_proof(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride,
     const int KE = P.K * P.E;
     if (fill_tape_part(c, n, false, 2 * P.M, 2 * P.M + 2 * KE, tapes, tape_stride)) return -1;
     if (issue_sharing_front(c, n, FRONT_RANGE)) return -1;
-    HIPCHK(hipStreamSynchronize(c.stream));
+    HIPCHK(stream_sync(c));
     if (rm.eeta != rm.seta + KE) { c.err = "internal: eta rows not adjacent"; return -1; }
     std::vector<uint16_t> rows((size_t)2 * KE * RS);
     for (int b = 0; b < n; b++) {
@@ -193,7 +193,7 @@ int stage_verifier_inst(Ctx &c, int n, const uint8_t *pi, const uint8_t *inst)
     const Params &P = c.P;
     parallel_for(c.pool, n, c.nthreads, [&](int b) { memcpy(c.h_proof + (size_t)b * c.image_stride, pi + (size_t)b * P.proof_bytes, P.proof_bytes); });
     HIPCHK(hipMemcpyAsync(c.d_proof, c.h_proof, (size_t)n * c.image_stride, hipMemcpyHostToDevice, c.stream));
-    HIPCHK(hipStreamSynchronize(c.stream));
+    HIPCHK(stream_sync(c));
     return upload_inst(c, n, inst, false, true);
 }
 

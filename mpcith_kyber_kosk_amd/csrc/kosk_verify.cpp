@@ -164,7 +164,7 @@ int stage_verifier_inputs(Ctx &c, int n, const uint8_t *pi, const uint8_t *pk, b
         HIPCHK(hipMemcpyAsync(c.d_proof, c.h_proof, (size_t)n * c.image_stride, hipMemcpyHostToDevice, c.stream));
     // polyvec_frombytes(t) and gen_matrix(A, seed) on the device   kosk.cpp:94-99
     HIPCHK(launch_decode_pk(c.d_pk, c.pk_stride, c.d_t, c.d_A, c.key_stride, P.K, n, c.stream));
-    HIPCHK(hipStreamSynchronize(c.stream));
+    HIPCHK(stream_sync(c));
     return 0;
 }
 
@@ -382,7 +382,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     if (c.round_hook) c.round_hook(c.round_user, 1, 1, c.d_dig2, (size_t)n * NPARTY * 32);
     std::vector<uint16_t> I2((size_t)n * c.sel_stride), rest2((size_t)n * c.sel_stride);
     fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, I2.data(), rest2.data(), c.sel_stride, c.nthreads, c.pool);
-    HIPCHK(hipStreamSynchronize(st)); // fail masks of V2B
+    HIPCHK(stream_sync(c)); // fail masks of V2B
     c.prof_collect();
     for (int b = 0; b < n; b++) {
         uint32_t f = c.h_fail[b];
