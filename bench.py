@@ -480,23 +480,38 @@ def main():
         hv = kern.get("hash_view")
         roof = None
         if hv:
-            lanes_per_launch = B * 1454
+            # a commitment round of B proofs is one launch, or two when B x 23 waves would spill a few waves into another
+            # round of the SIMDs (46 proofs on 1 024 SIMDs: 44 proofs = 1 012 waves, then 2 proofs = 46 waves):
+            # `roofline` is the first launch, the second one is reported beside it
+            b_main = ctx.commit_launch_groups(B)
+            lanes_per_launch = b_main * 1454
             nbytes = lanes_per_launch * (VIEW_MSG[k] + 32)
             ach = nbytes / (hv["avg_us"] * 1e-6) / 1e9
             traffic, tsrc = None, None
             tfile = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tfile) and k == 3 and B == 46:
                 tj = json.load(open(tfile))
-                traffic, tsrc = tj.get("hash_view_hbm_bytes_per_launch"), tj.get("source")
-            roof = {"kernel": "k_commit_hash (SHA3-256 view commitment, prover, %d party lanes per launch)" % lanes_per_launch,
+                if tj.get("hash_view_lanes_per_launch", 46 * 1454) == lanes_per_launch:
+                    traffic, tsrc = tj.get("hash_view_hbm_bytes_per_launch"), tj.get("source")
+            roof = {"kernel": "k_commit_hash_dma (SHA3-256 view commitment, prover, %d party lanes per launch)" % lanes_per_launch,
                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": hv["avg_us"],
                     "lanes_per_launch": lanes_per_launch,
                     "note": "HIP events on the slot's stream inside the run; %d slots share the GPU, so a launch's duration includes "
                             "co-running kernels of other slots" % S}
+            hvt = kern.get("hash_view_tail")
+            if hvt and b_main < B:
+                tl = (B - b_main) * 1454
+                roof["second_launch"] = {"lanes_per_launch": tl, "avg_launch_us": hvt["avg_us"],
+                                         "achieved": tl * (VIEW_MSG[k] + 32) / (hvt["avg_us"] * 1e-6) / 1e9,
+                                         "note": "the batch's last %d proofs, %d waves: latency-bound, runs behind the first launch while "
+                                                 "other slots' kernels use the GPU" % (B - b_main, (B - b_main) * 23)}
+                roof["whole_round"] = {"lanes": B * 1454, "us": hv["avg_us"] + hvt["avg_us"],
+                                       "achieved": B * 1454 * (VIEW_MSG[k] + 32) / ((hv["avg_us"] + hvt["avg_us"]) * 1e-6) / 1e9,
+                                       "note": "both launches back to back (stream time of the round; the GPU is shared meanwhile)"}
             ht = kern.get("hash_tcomm")
             if ht:
-                ht["GBps"] = B * 1454 * (TCOMM_MSG[k] + 32) / (ht["avg_us"] * 1e-6) / 1e9
+                ht["GBps"] = b_main * 1454 * (TCOMM_MSG[k] + 32) / (ht["avg_us"] * 1e-6) / 1e9
             hv["GBps"] = ach
         g1 = kern.get("gemm_expand1")
         if g1:

@@ -150,6 +150,11 @@ int kosk_lagrange_expand(kosk_ctx *ctx, const uint16_t *d_y407, uint16_t *d_shar
 /* recon_secrets_ddeg / recon_secrets_2ddeg (ss.cpp:37-73): in n x 1454 u16, out n x 256 u16 */
 int kosk_recon_secrets(kosk_ctx *ctx, const uint16_t *d_shares, uint16_t *d_secrets, int n, int two_d);
 int kosk_device_synchronize(kosk_ctx *ctx);
+/* Proofs of an n-proof batch hashed by the first launch of a commitment round (mlwe_prover.cpp:116-127, :397-444): n unless
+ * the handle was created with KOSK_HASH_SPLIT=1, which cuts a round whose waves would spill a few waves into another round
+ * of the SIMDs (n = 46 on a 256-CU device: 44, the other 2 proofs follow in a second, small launch).
+ * For callers that time the launches (kosk_profile_read ids 0/1 = first launch, 14/15 = second). */
+int kosk_commit_launch_groups(const kosk_ctx *ctx, int n, int *main_groups);
 /* number of sub-batches a handle keeps in flight on separate HIP streams (env KOSK_STREAMS, default 1) */
 int kosk_streams(const kosk_ctx *ctx);
 /* device pointer / stride of the resident proof images of sub-batch 0, for callers chaining work in HBM

@@ -67,6 +67,7 @@ def _load():
         "kosk_stream_timer_stop": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "kosk_device_synchronize": (C.c_int, [vp]),
         "kosk_streams": (C.c_int, [vp]),
+        "kosk_commit_launch_groups": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
         "kosk_resident_proofs": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
         "kosk_keygen": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp]),
         "kosk_fs_alpha": (C.c_int, [C.c_int, vp, vp]),
@@ -92,7 +93,7 @@ EXPORTS = ["kosk_pk_bytes", "kosk_sk_bytes", "kosk_proof_bytes", "kosk_tape_byte
            "kosk_stage_verifier_inputs", "kosk_verify_resident", "kosk_verifiable_keygen_resident", "kosk_verify_resident_pk",
            "kosk_resident_digests", "kosk_set_round_hook", "kosk_phase_seconds", "kosk_sha3_256_batch",
            "kosk_shake256_batch", "kosk_commit_hash_lanes", "kosk_ntt256_batch", "kosk_lagrange_expand",
-           "kosk_recon_secrets", "kosk_profile_enable", "kosk_profile_read", "kosk_stream_timer_start", "kosk_stream_timer_stop", "kosk_device_synchronize", "kosk_streams", "kosk_resident_proofs", "kosk_keygen", "kosk_fs_alpha",
+           "kosk_recon_secrets", "kosk_profile_enable", "kosk_profile_read", "kosk_stream_timer_start", "kosk_stream_timer_stop", "kosk_device_synchronize", "kosk_streams", "kosk_commit_launch_groups", "kosk_resident_proofs", "kosk_keygen", "kosk_fs_alpha",
            "kosk_fs_opened", "kosk_host_sha3_256", "kosk_host_shake256", "kosk_host_sha3_256_multi", "kosk_lagrange_table"]
 
 
@@ -344,7 +345,7 @@ class Kosk:
         return list(out)
 
     PROFILE_IDS = ["hash_tcomm", "hash_view", "gemm_expand1", "gemm_expand2", "lincomb", "ntt_f", "assemble",
-                   "v_hash_tcomm", "v_hash_view", "v_interp_build", "v_gemm_interp", "v_gemm_expand", "v_gemm_recon", "v_lincomb"]
+                   "v_hash_tcomm", "v_hash_view", "v_interp_build", "v_gemm_interp", "v_gemm_expand", "v_gemm_recon", "v_lincomb", "hash_tcomm_tail", "hash_view_tail"]
 
     def profile_enable(self, on=True):
         self._chk(lib.kosk_profile_enable(self._h, int(on)), "profile_enable")
@@ -365,6 +366,12 @@ class Kosk:
         ms = C.c_double()
         self._chk(lib.kosk_stream_timer_stop(self._h, C.byref(ms)), "timer_stop")
         return ms.value
+
+    def commit_launch_groups(self, n):
+        """proofs hashed by the first of the (one or two) launches of a commitment round of an n-proof batch"""
+        m = C.c_int()
+        self._chk(lib.kosk_commit_launch_groups(self._h, n, C.byref(m)), "commit_launch_groups")
+        return m.value
 
     @property
     def streams(self):

@@ -501,6 +501,12 @@ int kosk_device_synchronize(kosk_ctx *ctx)
     }
     return 0;
 }
+int kosk_commit_launch_groups(const kosk_ctx *ctx, int n, int *main_groups)
+{
+    if (!ctx || n < 1 || !main_groups) return bad_args(ctx, __func__);
+    *main_groups = commit_hash_groups(*ctx->c, n);
+    return 0;
+}
 int kosk_streams(const kosk_ctx *ctx) { return ctx ? (int)ctx->sub.size() : -1; }
 
 int kosk_resident_proofs(kosk_ctx *ctx, void **d_proofs, size_t *stride)

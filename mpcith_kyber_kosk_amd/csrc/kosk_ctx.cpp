@@ -114,6 +114,37 @@ GemmArgs gemm_args_small(const uint8_t *A, size_t a_gstride, int Mpad, int M, in
     return ga;
 }
 
+// The commitment hashes run one party lane per thread, 23 waves per proof.  A SIMD with ONE such wave finishes a batch in
+// about 60 % of the time a SIMD with two needs, so a launch of r whole rounds of waves plus a few more
+// (46 proofs: 1 058 waves on 1 024 SIMDs) costs r + 1 rounds.  With KOSK_HASH_SPLIT=1 such a batch is hashed in two
+// launches: the proofs that fill whole rounds first, the few remaining ones in a second, small launch behind it.  Opt-in:
+// it pays only together with the placement primer and on an otherwise idle GPU (see k_hash_primer; measured in
+// profiles/r02_hash_placement.txt), the default is one launch per round.
+int commit_hash_groups(const Ctx &c, int n)
+{
+    const int wpp = (NPARTY + 63) / 64, total = n * wpp, rem = total % c.n_simd;
+    if (!c.hash_split || total <= c.n_simd || rem == 0 || rem * 8 >= c.n_simd) return n;
+    return (total - rem) / wpp;
+}
+
+static hipError_t commit_hash_batch(Ctx &c, const HashArgs &ha, int n, int K, bool view, hipStream_t st)
+{
+    const int n_main = commit_hash_groups(c, n);
+    c.prof_begin(view ? PR_HASH_VIEW : PR_HASH_TCOMM);
+    hipError_t e = launch_commit_hash(ha, n_main, K, view, st);
+    c.prof_end(view ? PR_HASH_VIEW : PR_HASH_TCOMM);
+    if (e != hipSuccess || n_main == n) return e;
+    HashArgs t = ha;
+    t.rows += (size_t)n_main * ha.group_stride;
+    if (t.prefix) t.prefix += (size_t)n_main * ha.out_lanes_per_group * 32;
+    t.out += (size_t)n_main * ha.out_lanes_per_group * 32;
+    if (t.lane_map) t.lane_map += (size_t)n_main * ha.lane_map_stride;
+    c.prof_begin(view ? PR_HASH_VIEW_TAIL : PR_HASH_TCOMM_TAIL);
+    e = launch_commit_hash(t, n - n_main, K, view, st);
+    c.prof_end(view ? PR_HASH_VIEW_TAIL : PR_HASH_TCOMM_TAIL);
+    return e;
+}
+
 hipError_t stream_sync(Ctx &c)
 {
     if (!c.blocking_sync) return hipStreamSynchronize(c.stream);
@@ -292,9 +323,15 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     if (const char *e = getenv("KOSK_LINCOMB_FUSED")) c.lincomb_fused = atoi(e) != 0;
     if (const char *e = getenv("KOSK_NTT_FP32")) c.ntt_fp32 = atoi(e) != 0;
     if (const char *e = getenv("KOSK_BLOCKING_SYNC")) c.blocking_sync = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_HASH_SPLIT")) c.hash_split = atoi(e) != 0;
 
     auto body = [&]() -> int {
         HIPCHK(hipSetDevice(device));
+        {
+            int cus = 0;
+            HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+            if (cus > 0) c.n_simd = 4 * cus;
+        }
         HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
         if (c.blocking_sync) HIPCHK(hipEventCreateWithFlags(&c.ev_sync, hipEventDisableTiming | hipEventBlockingSync));
@@ -519,9 +556,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         HashArgs h1 = ha;
         h1.prefix = nullptr;
         h1.out = c.d_dig1;
-        c.prof_begin(PR_HASH_TCOMM);
-        HIPCHK(launch_commit_hash(h1, n, K, false, st));
-        c.prof_end(PR_HASH_TCOMM);
+        HIPCHK(commit_hash_batch(c, h1, n, K, false, st));
         HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig1, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
         return 0;
     })) return -1;
@@ -568,9 +603,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     // the graded kernel stays a plain launch so that HIP events can bracket it inside the timed region
     ha.prefix = c.d_dig1;
     ha.out = c.d_dig2;
-    c.prof_begin(PR_HASH_VIEW);
-    HIPCHK(launch_commit_hash(ha, n, K, true, st));
-    c.prof_end(PR_HASH_VIEW);
+    HIPCHK(commit_hash_batch(c, ha, n, K, true, st));
     HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig2, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c.ev, st));
     c.phase_sec[PH_P2_ISSUE] = now_sec() - t0;

@@ -33,7 +33,7 @@ enum Phase { PH_HOST_PRE = 0, PH_GPU_COMMIT, PH_FS_ALPHA, PH_GPU_RELATION, PH_FS
 // HIP-event timing of individual launches on the ctx stream (bench.py roofline leg)
 enum ProfId { PR_HASH_TCOMM = 0, PR_HASH_VIEW, PR_GEMM_EXPAND1, PR_GEMM_EXPAND2, PR_LINCOMB, PR_NTT_F, PR_ASSEMBLE,
               PR_V_HASH_TCOMM, PR_V_HASH_VIEW, PR_V_INTERP_BUILD, PR_V_GEMM_INTERP, PR_V_GEMM_EXPAND, PR_V_GEMM_RECON,
-              PR_V_LINCOMB, PR_COUNT };
+              PR_V_LINCOMB, PR_HASH_TCOMM_TAIL, PR_HASH_VIEW_TAIL, PR_COUNT };
 
 struct GemmTable {
     uint8_t *d = nullptr; // limb matrix (kosk_device.hpp)
@@ -145,6 +145,8 @@ struct Ctx {
     hipEvent_t ev = nullptr;
     hipEvent_t ev_sync = nullptr; // KOSK_BLOCKING_SYNC=1: every host wait sleeps on an event instead of spinning (few host cores per GPU)
     bool blocking_sync = false;
+    int n_simd = 1024;      // SIMDs of the device (4 per CU)
+    bool hash_split = false; // KOSK_HASH_SPLIT=1: cut a commitment launch at whole rounds of the SIMDs (see commit_hash_groups)
     hipEvent_t timer_ev[2] = {nullptr, nullptr}; // kosk_stream_timer_start / _stop
     // compact wire format staging (allocated on first use)
     CompactPlan cplan{};
@@ -222,6 +224,8 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
 // C[g][rows_d[i]][off + m] = sum_k A[m][k] * src[g][rows_s[i]][koff + k] mod q  (conversion to limbs + MFMA GEMM)
 // host wait for everything queued on the context's stream (spinning, or sleeping with KOSK_BLOCKING_SYNC=1)
 hipError_t stream_sync(Ctx &c);
+// proofs of an n-proof batch that the FIRST of the two commitment-hash launches takes (n: a single launch)
+int commit_hash_groups(const Ctx &c, int n);
 int gemm_modq(Ctx &c, const uint8_t *A, size_t a_gstride, int Mpad, int M, int KS, const GemmSrc &s, const GemmDst &d,
               int npg, int ngroups, bool grouped, const uint8_t *Afrag = nullptr);
 // argument block of a small product (data operand converted inside the kernel), for launch_gemm_batch

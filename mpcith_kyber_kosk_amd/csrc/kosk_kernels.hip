@@ -151,9 +151,11 @@ __global__ __launch_bounds__(64) void k_commit_hash_dma(HashArgs a)
     // issue first
     __builtin_amdgcn_s_setprio(3);
     const int tl = threadIdx.x;
-    const int lane = blockIdx.x * 64 + tl;
-    const int g = blockIdx.y;
-    const uint16_t *__restrict__ rowbase = a.rows + (size_t)g * a.group_stride + a.col_off + blockIdx.x * 64; // wave-uniform
+    // one-dimensional grid, group-major (the dispatcher deals consecutive workgroups evenly over XCDs and SIMDs)
+    const int wpg = (a.lanes_per_group + 63) >> 6;
+    const int g = (int)blockIdx.x / wpg, bx = (int)blockIdx.x - g * wpg;
+    const int lane = bx * 64 + tl;
+    const uint16_t *__restrict__ rowbase = a.rows + (size_t)g * a.group_stride + a.col_off + bx * 64; // wave-uniform
     const size_t dig = ((size_t)g * a.out_lanes_per_group + lane) * 32;
     const bool live = lane < a.lanes_per_group;
 
@@ -236,6 +238,24 @@ __global__ __launch_bounds__(64) void k_commit_hash_dma(HashArgs a)
         o[0] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
         o[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
     }
+}
+
+// Placement primer for the commitment hashes.  A launch of ~1 000 one-wave workgroups lands one wave per SIMD only when
+// the launch before it on the GPU had the same shape: directly behind any other large kernel (the table product, the fused
+// lincomb) about 4 % of the SIMDs get two of the waves and as many stay empty -- same wave-cycles, 54 % more busy time
+// (profiles/r02_hash_placement.txt), and the hash takes 68 us instead of 45.  The state survives idle time.  This kernel has
+// the hash's launch shape (one wave per workgroup, the same LDS footprint), keeps its waves resident for a few microseconds so
+// that the whole grid is placed at once, and does nothing else; the hash launched behind it gets the even placement.
+// Opt-in (KOSK_HASH_PRIMER=1, with KOSK_HASH_SPLIT=1): alone on the GPU the 44-proof launch then takes 33 / 44 us instead of
+// 49 / 65 us, but with several pipeline slots sharing the GPU other kernels decide the placement anyway and the extra
+// launches cost 6 % of the throughput (profiles/r02_hash_placement.txt).
+template <int NBUF>
+__global__ __launch_bounds__(64) void k_hash_primer(int *sink)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t stage[NBUF][72 * 64];
+    if (threadIdx.x == 0) stage[0][0] = (uint16_t)blockIdx.x; // keep the allocation
+    __builtin_amdgcn_s_sleep(100); // 64 x 100 clocks ~ 2.8 us: longer than the dispatch of the grid
+    if (sink && stage[0][0] == 0xFFFFu && threadIdx.x == 0) *sink = 1; // never: block indices stay below 65 535 here
 }
 
 // SHA3-256 / SHAKE256 of n byte messages of equal length stored message-major.
@@ -1550,8 +1570,11 @@ static void launch_hash_t(const HashArgs &a, int ngroups, hipStream_t st)
     if (dma_ok) {
         // up to ~2 waves per SIMD the next block's DMA runs under this block's permutation (two buffers, 18 KiB per wave);
         // beyond that one buffer (4 waves per SIMD fit) and occupancy hides the landing
-        if (waves <= 2 * 1024 + 256) hipLaunchKernelGGL((k_commit_hash_dma<PW, NR, 2>), grid, dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_commit_hash_dma<PW, NR, 1>), grid, dim3(64), 0, st, a);
+        const dim3 grid1((unsigned)waves);
+        static const bool primer = getenv("KOSK_HASH_PRIMER") && atoi(getenv("KOSK_HASH_PRIMER")) != 0; // opt-in, see k_hash_primer
+        if (primer && waves >= 256 && waves <= 2 * 1024 + 256) hipLaunchKernelGGL((k_hash_primer<2>), grid1, dim3(64), 0, st, (int *)nullptr);
+        if (waves <= 2 * 1024 + 256) hipLaunchKernelGGL((k_commit_hash_dma<PW, NR, 2>), grid1, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_commit_hash_dma<PW, NR, 1>), grid1, dim3(64), 0, st, a);
         return;
     }
     // fewer than ~3 waves per SIMD (1024 SIMDs): nothing else hides the row loads -> pipelined variant

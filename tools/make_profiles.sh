@@ -38,14 +38,17 @@ with open("%s/%s_pmc_fetch_write.csv" % (out, tag), "w", newline="") as fo:
         w = W.get(k, [1, 0.0])
         f_kb, w_kb = v / n, w[1] / max(1, w[0])
         wr.writerow([k[0], k[1], n, "%.0f" % f_kb, "%.0f" % w_kb, "%.1f" % ((2 * f_kb + w_kb) / 1024)])
-# in-pipeline view hash: the k_commit_hash<16,220,...> dispatch with 46 proofs (grid 1472 x 46 threads)
-hv = [(k, v) for k, v in F.items() if "k_commit_hash" in k[0] and "<16, 220" in k[0] and k[1] == 1472 * 46]
+# in-pipeline view hash: the largest k_commit_hash_dma<16,220,...> dispatch of the 46-proof batch (a multiple of 1472 threads per proof;
+# 46 proofs are hashed as 44 + 2, see kosk_commit_launch_groups); the 65 536-lane calibration dispatch has a different grid
+hv = [(k, v) for k, v in F.items() if "k_commit_hash" in k[0] and "<16, 220" in k[0] and k[1] % 1472 == 0 and k[1] // 1472 <= 46]
 if hv:
-    k, (n, v) = hv[0]
+    k, (n, v) = max(hv, key=lambda kv: kv[0][1])
     w = W[k]
+    proofs = k[1] // 1472
     traffic = int(round((2 * v / n + w[1] / w[0]) * 1024))
     json.dump({"source": "profiles/%s_pmc_fetch_write.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md, calibrated on k_ntt256)" % tag,
-               "hash_view_hbm_bytes_per_launch": traffic, "hash_view_algorithmic_bytes_per_launch": 46 * 1454 * 504}, open(out + "/traffic.json", "w"), indent=1)
-    print("view hash traffic per launch:", traffic, "algorithmic", 46 * 1454 * 504)
+               "hash_view_lanes_per_launch": proofs * 1454,
+               "hash_view_hbm_bytes_per_launch": traffic, "hash_view_algorithmic_bytes_per_launch": proofs * 1454 * 504}, open(out + "/traffic.json", "w"), indent=1)
+    print("view hash traffic per launch:", traffic, "algorithmic", proofs * 1454 * 504, "proofs", proofs)
 PY
 echo "pmc done"
