@@ -264,7 +264,7 @@ static int build_tables(Ctx &c)
 
     // wire image fields (mlwe_prover.hpp:57-75): element e of a party's record <- row
     auto add = [&](int fid, int sel, int width, auto rowfn) {
-        FieldDesc fd;
+        FieldDesc fd{};
         fd.off = (uint32_t)P.off[fid];
         fd.sel = sel;
         fd.width = width;

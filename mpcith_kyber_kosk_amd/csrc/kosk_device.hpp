@@ -111,6 +111,10 @@ struct FieldDesc {
     int sel;   // 0: opened parties in I order, 1: unopened ascending
     int width; // u16 per party
     int rowtab_off;
+    // verifier, fields of unopened parties: which records the reference's verify() ever reads -- record i (party p = rest[i]) is
+    // read iff (limit_by_party ? p : i) < limit.  What it never reads is not range-checked either (any bytes there are accepted
+    // by the reference, mlwe_verifier.cpp:106-107, :321-323, :390-394, :503-507).  0 = every record.
+    int limit, limit_by_party;
 };
 
 // which (field, chunk) a block of the assemble / disassemble kernels works on: blocks [0, nrest * NWIN) walk the

@@ -78,36 +78,38 @@ int ensure_verify_workspace(Ctx &c)
     // where each proof field lands in the verifier's row matrix
     std::vector<FieldDesc> vf;
     std::vector<int16_t> rt;
-    auto add = [&](int fid, int sel, int width, auto rowfn) {
-        FieldDesc fd;
+    auto add = [&](int fid, int sel, int width, auto rowfn, int limit = 0, int by_party = 0) {
+        FieldDesc fd{};
         fd.off = (uint32_t)P.off[fid];
         fd.sel = sel;
         fd.width = width;
+        fd.limit = limit;
+        fd.limit_by_party = by_party;
         fd.rowtab_off = (int)rt.size();
         for (int e = 0; e < width; e++) rt.push_back((int16_t)rowfn(e));
         vf.push_back(fd);
     };
     add(F_F, 0, M, [&](int e) { return rm.f + e; });
     add(F_NTTF, 0, M, [&](int e) { return rm.tf + e; });
-    add(F_BETA, 1, NCHK, [&](int e) { return rm.beta(e); });
-    add(F_GAMMA, 1, NCHK, [&](int e) { return rm.gamma(e); });
+    add(F_BETA, 1, NCHK, [&](int e) { return rm.beta(e); }, DEG + 1, 1);   // recon_secrets_ddeg: shares of parties 0..406  :106-107
+    add(F_GAMMA, 1, NCHK, [&](int e) { return rm.gamma(e); }, DEG + 1, 1);
     add(F_S, 0, K, [&](int e) { return rm.s + e; });
     add(F_E, 0, K, [&](int e) { return rm.e + e; });
-    add(F_T, 1, K, [&](int e) { return rm.t_in + e; });
+    add(F_T, 1, K, [&](int e) { return rm.t_in + e; }, DEG + 1);            // interpolation nodes: the first 407 unopened parties  :321-323
     add(F_NTTS, 0, K, [&](int e) { return rm.ntts + e; });
     add(F_NTTE, 0, K, [&](int e) { return rm.ntte + e; });
     add(F_NTTAR, 0, K, [&](int e) { return rm.nttar + e; });
     add(F_NTTAS, 0, K, [&](int e) { return rm.nttas + e; });
     add(F_SR, 1, K, [&](int e) { return rm.sr_in + e; });
     add(F_ER, 1, K, [&](int e) { return rm.er_in + e; });
-    add(F_SETA, 1, K * E, [&](int e) { return rm.seta_in + e; });
-    add(F_EETA, 1, K * E, [&](int e) { return rm.eeta_in + e; });
+    add(F_SETA, 1, K * E, [&](int e) { return rm.seta_in + e; }, DEG + 1); // :390-394
+    add(F_EETA, 1, K * E, [&](int e) { return rm.eeta_in + e; }, DEG + 1);
     add(F_SSUB, 0, K * E, [&](int e) { return rm.ssub + e; });
     add(F_ESUB, 0, K * E, [&](int e) { return rm.esub + e; });
     add(F_ZS, 0, K * Z, [&](int e) { return rm.zs(e / Z, e % Z); });
     add(F_ZE, 0, K * Z, [&](int e) { return rm.ze(e / Z, e % Z); });
-    add(F_US, 1, K * Z, [&](int e) { return rm.us(e / Z, e % Z); });
-    add(F_UE, 1, K * Z, [&](int e) { return rm.ue(e / Z, e % Z); });
+    add(F_US, 1, K * Z, [&](int e) { return rm.us(e / Z, e % Z); }, DEG2 + 1); // nodes: the first 813 unopened parties; recon: parties 0..812  :503-507, :555-556
+    add(F_UE, 1, K * Z, [&](int e) { return rm.ue(e / Z, e % Z); }, DEG2 + 1);
     c.n_vfields = (int)vf.size();
     c.vplan = make_field_plan(vf.data(), c.n_vfields);
     if (upload_vec(c, &c.d_vfields, vf)) return -1;

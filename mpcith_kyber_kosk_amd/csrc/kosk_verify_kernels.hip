@@ -91,7 +91,9 @@ __global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const F
     const int head = (int)((reinterpret_cast<uintptr_t>(in) >> 1) & 1);
     const int body = (n16 - head) >> 1;
     bool bad = false;
-    auto canon = [&](uint32_t x_) { if (x_ >= (uint32_t)Q) { bad = true; x_ %= Q; } return (uint16_t)x_; };
+    // folded mod q, with bit 15 marking a non-canonical element: whether that makes the proof malformed is decided per record
+    // below (records the reference never reads are not range-checked)
+    auto canon = [&](uint32_t x_) { return (uint16_t)(x_ >= (uint32_t)Q ? (x_ % Q) | 0x8000u : x_); };
     if (lane == 0 && head) tile[0] = canon(in[0]);
     const uint32_t *in32 = reinterpret_cast<const uint32_t *>(in + head);
     for (int q0 = 0; q0 < body; q0 += 64 * 8) { // eight independent loads in flight per lane
@@ -117,16 +119,20 @@ __global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const F
     if (lane < cnt) {
         const int16_t *rt = rowtab + fd.rowtab_off;
         const uint16_t *t = tile + lane * fd.width;
+        uint32_t marks = 0;
         if (kind) {
-            uint16_t *dst = v.P + (size_t)b * v.proof_stride + NSEC + sel[i0 + lane];
+            const int party = sel[i0 + lane];
+            uint16_t *dst = v.P + (size_t)b * v.proof_stride + NSEC + party;
 #pragma unroll 8
-            for (int e = 0; e < fd.width; e++) dst[(size_t)rt[e] * RS] = t[e];
+            for (int e = 0; e < fd.width; e++) { marks |= t[e]; dst[(size_t)rt[e] * RS] = t[e] & 0x7FFFu; }
+            if (fd.limit && (fd.limit_by_party ? party : i0 + lane) >= fd.limit) marks = 0; // never read by the reference
         } else {
             // records of the opened parties: into the opened matrix, consecutive lanes = consecutive entries of a row
             uint16_t *dst = v.O + (size_t)b * v.o_stride + i0 + lane;
 #pragma unroll 8
-            for (int e = 0; e < fd.width; e++) dst[(size_t)rt[e] * OS] = t[e];
+            for (int e = 0; e < fd.width; e++) { marks |= t[e]; dst[(size_t)rt[e] * OS] = t[e] & 0x7FFFu; }
         }
+        bad = (marks & 0x8000u) != 0;
     }
     if (bad) atomicOr(&v.fail[b], 1u << FB_MALFORMED);
 }
