@@ -94,3 +94,43 @@ def test_batch_of_one_on_a_large_context_and_full_context(oracle, torch_cuda):
     assert (pks[4], sks[4], pis[4]) == (opk, osk, opi)
     assert ctx.verify(pis, pks) == [True] * 5
     ctx.close()
+
+
+@pytest.mark.parametrize("k", [2, 3])
+def test_degenerate_randomness_tapes(k, oracle, torch_cuda):
+    """Tapes of constant bytes: every BE16 % q draw, every seed and every sampler sees its extreme input (0x0000 and 0xFFFF words,
+    identical seeds for d, z and all PRF keys, all-equal share randoms).  Byte for byte against the oracle, and verified."""
+    from mpcith_kyber_kosk_amd import api
+    ctx = api.Kosk(kyber_k=k, max_batch=4)
+    n = ctx.tape_bytes
+    tapes = [b"\x00" * n, b"\xff" * n, (b"\x0d\x00" * n)[:n], bytes((i * 251 + 7) & 0xFF for i in range(n))]
+    pks, sks, pis = ctx.verifiable_keygen(tapes)
+    for b in range(len(tapes)):
+        opk, osk, opi, _, _ = oracle.verifiable_keygen(k, tapes[b])
+        assert pks[b] == opk and sks[b] == osk, b
+        assert pis[b] == opi, b
+    assert ctx.verify(pis, pks) == [True] * len(tapes)
+    ctx.close()
+
+
+def test_split_commitment_launches_give_identical_proofs(oracle, torch_cuda, monkeypatch):
+    """KOSK_HASH_SPLIT=1 + KOSK_HASH_PRIMER=1 (opt-in): 46 proofs are hashed as 44 + 2 behind a placement primer.  Same bytes as
+    the default single launch; the two proofs of the second launch also against the oracle."""
+    from mpcith_kyber_kosk_amd import api
+    k, n = 3, 46
+    tapes = [oracle.tape_bytes_for(k, 300 + b) for b in range(n)]
+    plain = api.Kosk(kyber_k=k, max_batch=n)
+    assert plain.commit_launch_groups(n) == n
+    ref = plain.verifiable_keygen(tapes)
+    plain.close()
+    monkeypatch.setenv("KOSK_HASH_SPLIT", "1")
+    monkeypatch.setenv("KOSK_HASH_PRIMER", "1")
+    ctx = api.Kosk(kyber_k=k, max_batch=n)
+    assert ctx.commit_launch_groups(n) == 44 and ctx.commit_launch_groups(44) == 44 and ctx.commit_launch_groups(3) == 3
+    got = ctx.verifiable_keygen(tapes)
+    assert got == ref
+    for b in (44, 45):
+        opk, osk, opi, _, _ = oracle.verifiable_keygen(k, tapes[b])
+        assert (got[0][b], got[1][b], got[2][b]) == (opk, osk, opi)
+    assert ctx.verify(got[2], got[0]) == [True] * n
+    ctx.close()
