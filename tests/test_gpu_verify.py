@@ -76,7 +76,7 @@ def test_verify_malformed_opened_list(oracle, torch_cuda):
 BYTE_FIELDS = (4, 23)  # Tcomm, comm digests; field 5 is the list I; every other field holds u16 elements of GF(3329)
 
 
-@pytest.mark.parametrize("k", [3, 4])
+@pytest.mark.parametrize("k", [2, 3, 4])
 def test_verify_random_corruptions_match_oracle(k, oracle, torch_cuda):
     """Differential test at random positions: single-bit flips and substitutions of whole elements, anywhere in the proof
     image, always leaving CANONICAL field elements (< q) behind.  Whatever the reference's verifier does not read (see
