@@ -48,8 +48,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 
 CONFIGS = {  # 1-based config number -> (kyber_k, proofs per GPU per step, default slots, host threads per slot)
-    2: dict(k=2, batch=46, slots=6, threads=4, what="Kyber-512 (KYBER_K=2), 46 proofs = 66 884 party lanes per GPU per step"),
-    3: dict(k=3, batch=46, slots=6, threads=4, what="Kyber-768 (KYBER_K=3), 46 proofs = 66 884 party lanes per GPU per step"),
+    2: dict(k=2, batch=46, slots=6, threads=6, what="Kyber-512 (KYBER_K=2), 46 proofs = 66 884 party lanes per GPU per step"),
+    3: dict(k=3, batch=46, slots=6, threads=6, what="Kyber-768 (KYBER_K=3), 46 proofs = 66 884 party lanes per GPU per step"),
     4: dict(k=4, batch=91, slots=4, threads=6, what="Kyber-1024 (KYBER_K=4), 91 proofs = 132 314 party lanes per GPU per step "
                                                     "(2^20 lanes over 8 GPUs, proof-aligned), digest tables all-gathered after each commitment round"),
     5: dict(k=3, batch=512, slots=4, threads=8, what="Kyber-768 (KYBER_K=3), 512 verifiable keygens per GPU per step (4096 over 8 GPUs, throughput mode)"),
