@@ -102,18 +102,6 @@ static int upload_table(Ctx &c, GemmTable &t, const std::vector<uint16_t> &A, in
     return 0;
 }
 
-GemmArgs gemm_args_small(const uint8_t *A, size_t a_gstride, int Mpad, int M, int KS, const GemmSrc &s, const GemmDst &d, int npg,
-                         int ngroups, bool grouped)
-{
-    GemmArgs ga{};
-    ga.A = A; ga.a_gstride = a_gstride; ga.Mpad = Mpad; ga.M = M; ga.KS = KS;
-    ga.C = d.C; ga.c_gstride = d.gstride; ga.c_rows = d.rows; ga.c_rstride = d.rstride; ga.c_off = d.off;
-    ga.npg = npg; ga.npg_pad = grouped ? (npg + 63) / 64 * 64 : npg; ga.ngroups = ngroups; ga.grouped = grouped ? 1 : 0;
-    ga.B = nullptr; ga.BRT = 0;
-    ga.src = s.src; ga.src_gstride = s.gstride; ga.src_rows = s.rows; ga.src_rstride = s.rstride; ga.src_koff = s.koff;
-    return ga;
-}
-
 // The commitment hashes run one party lane per thread, 23 waves per proof.  A SIMD with ONE such wave finishes a batch in
 // about 60 % of the time a SIMD with two needs, so a launch of r whole rounds of waves plus a few more
 // (46 proofs: 1 058 waves on 1 024 SIMDs) costs r + 1 rounds.  With KOSK_HASH_SPLIT=1 such a batch is hashed in two

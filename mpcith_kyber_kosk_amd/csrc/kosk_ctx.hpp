@@ -228,9 +228,6 @@ hipError_t stream_sync(Ctx &c);
 int commit_hash_groups(const Ctx &c, int n);
 int gemm_modq(Ctx &c, const uint8_t *A, size_t a_gstride, int Mpad, int M, int KS, const GemmSrc &s, const GemmDst &d,
               int npg, int ngroups, bool grouped, const uint8_t *Afrag = nullptr);
-// argument block of a small product (data operand converted inside the kernel), for launch_gemm_batch
-GemmArgs gemm_args_small(const uint8_t *A, size_t a_gstride, int Mpad, int M, int KS, const GemmSrc &s, const GemmDst &d, int npg,
-                         int ngroups, bool grouped);
 inline int gemm_modq(Ctx &c, const GemmTable &t, const GemmSrc &s, const GemmDst &d, int npg, int ngroups)
 {
     return gemm_modq(c, t.d, 0, t.Mpad, t.M, t.KS, s, d, npg, ngroups, false, t.dfrag);

@@ -260,13 +260,6 @@ hipError_t launch_relation_ntt(const NttArgs &na, const int16_t *A, size_t A_str
                                int nproofs, hipStream_t st);
 hipError_t launch_matvec_ntt(const int16_t *A, size_t A_stride, uint16_t *P, size_t proof_stride, int v_row0, int row0, int K,
                              int nproofs, hipStream_t st);
-// several independent products in ONE launch (the small ones are latency-bound: run them side by side)
-struct GemmBatch {
-    GemmArgs g[3];
-    int nblk[3]; // workgroups of each product
-    int count;
-};
-hipError_t launch_gemm_batch(const GemmArgs *list, int count, hipStream_t st);
 hipError_t launch_rows_to_limbs(const LimbArgs &a, hipStream_t st);
 hipError_t launch_gemm(const GemmArgs &a, hipStream_t st);
 // table products (shared table, 407-wide u16 input rows) with the data rows resident in LDS; `sink` = 4 KiB of scratch

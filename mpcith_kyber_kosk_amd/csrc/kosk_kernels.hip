@@ -1119,20 +1119,6 @@ __global__ __launch_bounds__(512, KS <= 7 ? 2 : 1) void k_table_gemm(GemmArgs a,
     }
 }
 
-// up to three independent products (data operand as u16 rows) side by side in one launch
-__global__ __launch_bounds__(256) void k_gemm_modq_batch(GemmBatch bt)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t lds[2][GM_A_BYTES + GM_B_BYTES];
-    int id = blockIdx.x, d = 0;
-    while (d + 1 < bt.count && id >= bt.nblk[d]) { id -= bt.nblk[d]; d++; }
-    const GemmArgs &a = bt.g[d];
-    const int mt = a.Mpad / GM_TM;
-    const int ntot = a.grouped ? a.npg : a.npg * a.ngroups;
-    const int nt = (ntot + GM_TN - 1) / GM_TN;
-    const int bx = id % mt, by = (id / mt) % nt, bz = id / (mt * nt);
-    gemm_modq_block<false>(a, bx, by, bz, lds);
-}
-
 // ---- K3 (prover) on the matrix cores: out_j[x] = sum_k Coef[j][k] * in_k[x] as the same GEMM -----
 // "A" operand: the 77 f (or NTT f) rows of one proof transposed: limb-matrix row = evaluation point x,
 // k = row index (padded to 128).  Loads are coalesced along x.
@@ -1686,22 +1672,6 @@ hipError_t launch_rows_to_limbs(const LimbArgs &a, hipStream_t st)
 {
     if (a.RT <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_rows_to_limbs, dim3((a.KS + 3) / 4, a.RT), dim3(256), 0, st, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_gemm_batch(const GemmArgs *list, int count, hipStream_t st)
-{
-    GemmBatch bt{};
-    bt.count = count;
-    int total = 0;
-    for (int d = 0; d < count; d++) {
-        bt.g[d] = list[d];
-        const int ntot = list[d].grouped ? list[d].npg : list[d].npg * list[d].ngroups;
-        bt.nblk[d] = (list[d].Mpad / GM_TM) * ((ntot + GM_TN - 1) / GM_TN) * (list[d].grouped ? list[d].ngroups : 1);
-        total += bt.nblk[d];
-    }
-    if (total <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_gemm_modq_batch, dim3(total), dim3(256), 0, st, bt);
     return hipGetLastError();
 }
 
