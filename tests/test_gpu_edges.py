@@ -134,3 +134,26 @@ def test_split_commitment_launches_give_identical_proofs(oracle, torch_cuda, mon
         assert (got[0][b], got[1][b], got[2][b]) == (opk, osk, opi)
     assert ctx.verify(got[2], got[0]) == [True] * n
     ctx.close()
+
+
+@pytest.mark.parametrize("knob", ["KOSK_TABLE_GEMM=0", "KOSK_HASH_DMA=0", "KOSK_LINCOMB_FUSED=0", "KOSK_NTT_FP32=1", "KOSK_BLOCKING_SYNC=1",
+                                  "KOSK_GRAPHS=1"])
+def test_documented_knobs_do_not_change_results(knob, oracle, torch_cuda, monkeypatch):
+    """Every runtime knob of INTEGRATION.md 5 selects another kernel or another way of waiting, never other bytes: proofs, keys
+    and verify bits equal the default context's (which the other tests pin to the oracle), for K = 3 and a K = 4 spot check."""
+    from mpcith_kyber_kosk_amd import api
+    name, val = knob.split("=")
+    for k, n in ((3, 3), (4, 1)):
+        tapes = [oracle.tape_bytes_for(k, 500 + b) for b in range(n)]
+        base = api.Kosk(kyber_k=k, max_batch=n)
+        ref = base.verifiable_keygen(tapes)
+        base.close()
+        monkeypatch.setenv(name, val)
+        ctx = api.Kosk(kyber_k=k, max_batch=n)
+        monkeypatch.delenv(name)
+        got = ctx.verifiable_keygen(tapes)
+        assert got == ref
+        assert ctx.verify(got[2], got[0]) == [True] * n
+        bad = bytearray(got[2][0]); bad[oracle.params(k).off[0] + 7] ^= 4  # an f share of an opened party: always read
+        assert ctx.verify([bytes(bad)], [got[0][0]]) == [False]
+        ctx.close()
