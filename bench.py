@@ -297,7 +297,9 @@ def main():
     threads = cfg["threads"]
     if cores_per_rank < S * (threads + 1):
         os.environ.setdefault("KOSK_BLOCKING_SYNC", "1")
-        threads = max(1, min(threads, cores_per_rank // S))
+        # the pool threads sleep between the four hash rounds of a step, so twice as many of them as cores is harmless; fewer than
+        # three per slot would stretch every round (46 proofs = 6 groups of 8 AVX-512 lanes)
+        threads = max(3, min(threads, 2 * cores_per_rank // S))
     os.environ.setdefault("KOSK_HOST_THREADS", str(threads))
     # stdout carries exactly ONE line (the JSON): whatever libraries print there (RCCL's version banner on the first
     # communicator, for one) goes to stderr instead
