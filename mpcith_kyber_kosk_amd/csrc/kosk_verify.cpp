@@ -317,7 +317,6 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool);
     t1 = now_sec(); c.phase_sec[PH_V_FS_ALPHA] = t1 - t0; t0 = t1;
     if (run_segment(c, Ctx::SEG_V2, n, [&]() -> int {
-    NttArgs na{};
     HIPCHK(hipMemcpyAsync(c.d_alpha, c.h_alpha, (size_t)n * 80 * 2, hipMemcpyHostToDevice, st));
 
     // ---- V2/V3: beta, gamma, r, NTT_r on the opened columns; reconstruction and NTT check
