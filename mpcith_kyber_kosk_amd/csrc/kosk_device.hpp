@@ -104,6 +104,7 @@ struct LincombArgs {
     int ncols;
     const uint16_t *col_map; // optional party list (verifier: opened parties)
     int col_map_stride;
+    int nxb, njc, ngroups; // grid decomposition (set by launch_lincomb)
 };
 
 struct FieldDesc {

@@ -990,13 +990,19 @@ constexpr int TG_NB = 48, TG_WAVES = 8;
 
 // TG_RT = table row tiles (of 16) per chunk
 template <int KS, int TG_RT>
-__global__ __launch_bounds__(512, KS <= 7 ? 2 : 1) void k_table_gemm(GemmArgs a, int nchunks, int chunks_per_block)
+__global__ __launch_bounds__(512, KS <= 7 ? 2 : 1) void k_table_gemm(GemmArgs a, int nchunks, int chunks_per_block, int nblk, int msplit)
 {
     constexpr int TG_CHUNK = 16 * TG_RT;
     __shared__ __attribute__((aligned(16))) uint8_t ldsB[KS * 3 * 2048]; // [k-step][row tile][limb][1 KiB]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ntot = a.npg * a.ngroups;
-    const int n0 = blockIdx.x * TG_NB;
+    // one-dimensional grid in XCD-aware order: the msplit workgroups that share a row block (each converts the same 48 rows) get
+    // consecutive virtual ids, i.e. one XCD and one L2 (as a 2D grid they sat on msplit different XCDs: the rows were fetched
+    // from HBM msplit times)
+    const int vid = xcd_virtual_id();
+    const int bxr = vid / msplit, byr = vid - bxr * msplit;
+    if (bxr >= nblk) return; // grid padding (whole workgroup, before any barrier)
+    const int n0 = bxr * TG_NB;
 
     // ---- prologue: this workgroup's data rows, u16 -> limbs, into LDS (every row is read exactly once from HBM);
     // all loads of a thread are issued before the first conversion
@@ -1029,7 +1035,7 @@ __global__ __launch_bounds__(512, KS <= 7 ? 2 : 1) void k_table_gemm(GemmArgs a,
         }
     }
 
-    const int c_begin = blockIdx.y * chunks_per_block;
+    const int c_begin = byr * chunks_per_block;
     const int c_end = c_begin + chunks_per_block < nchunks ? c_begin + chunks_per_block : nchunks;
     const int c_first = c_begin + w;
     const int nmy = c_first < c_end ? (c_end - c_first + TG_WAVES - 1) / TG_WAVES : 0; // chunks c_first, c_first + 8, ...
@@ -1166,9 +1172,8 @@ __global__ __launch_bounds__(256) void k_lincomb_fused(const uint16_t *P, size_t
     // One-dimensional grid, remapped so that the point blocks of one (proof, f | NTT f) group -- which all read the same 32 KiB of
     // coefficient tiles -- run on ONE XCD (consecutive workgroup ids go round the 8 XCDs, each with its own L2): virtual id =
     // position in this XCD's sequence; with the 2D grid every XCD fetched every group's tiles (PMC: 71 MB for 48 MB algorithmic)
-    constexpr int MB = (NPTS + 127) / 128, NXCD = 8;
-    const int per_xcd = (int)gridDim.x / NXCD; // the launcher pads the grid to a multiple of 8
-    const int vid = ((int)blockIdx.x % NXCD) * per_xcd + (int)blockIdx.x / NXCD;
+    constexpr int MB = (NPTS + 127) / 128;
+    const int vid = xcd_virtual_id(); // the launcher pads the grid to a multiple of 8
     const int g = vid / MB;
     if (g >= ngroups) return;
     const int b = g >> 1, which = g & 1;
@@ -1330,9 +1335,14 @@ __global__ __launch_bounds__(128) void k_pow_table(const uint16_t *__restrict__ 
 
 __global__ __launch_bounds__(256) void k_lincomb(LincombArgs a)
 {
-    const int xi = blockIdx.x * 256 + threadIdx.x;
-    const int jc = blockIdx.y;
-    const int b = blockIdx.z >> 1, which = blockIdx.z & 1;
+    // one-dimensional grid in XCD-aware order: the workgroups of a (proof, f | NTT f) group read the same input rows
+    const int vid = xcd_virtual_id();
+    const int per_group = a.nxb * a.njc;
+    const int grp = vid / per_group, rem = vid - grp * per_group;
+    if (grp >= a.ngroups) return;
+    const int jc = rem / a.nxb;
+    const int xi = (rem - jc * a.nxb) * 256 + threadIdx.x;
+    const int b = grp >> 1, which = grp & 1;
     if (xi >= a.ncols) return;
     // verifier (a.O): entry xi of the opened matrix's rows -- consecutive threads, consecutive addresses; otherwise column
     // `col` of the row matrix
@@ -1476,12 +1486,19 @@ constexpr int ASM_TILE = 64 * 80; // u16 per tile: 64 parties x the widest field
 // One wave per (field, 64 parties): for the fields of unopened parties the 64 parties are those of one ALIGNED window of
 // 64 party columns (a single 128-byte line per row read, PMC: 125 -> 35 MB fetched), for opened fields 64 entries of I.
 // No workgroup barrier: the wave gathers its whole tile (independent loads), then streams it out.
-__global__ __launch_bounds__(64) void k_assemble_fields(AssembleArgs a, uint32_t off_tcomm, uint32_t off_comm, uint32_t off_I)
+__global__ __launch_bounds__(64) void k_assemble_fields(AssembleArgs a, uint32_t off_tcomm, uint32_t off_comm, uint32_t off_I,
+                                                        int blocks_per_proof, int nproofs)
 {
+    // One-dimensional grid in XCD-aware order (xcd_virtual_id): the three 64-party chunks of an opened field gather scattered
+    // columns of the SAME rows; on three different XCDs each L2 fetched nearly every line of those rows (PMC: 100 MB for 33 MB
+    // of rows), on one XCD the lines are fetched once.
+    const int vid = xcd_virtual_id();
+    const int b = vid / blocks_per_proof, bx = vid - b * blocks_per_proof;
+    if (b >= nproofs) return;
     { // blocks past the field tiles: Tcomm / comm of the unopened parties and the list I itself (64 u16 per block)
         const int nfield_blocks = a.plan.nrest * NWIN + a.plan.nopen * ((NOPEN + 63) / 64);
-        if ((int)blockIdx.x >= nfield_blocks) {
-            const int q = ((int)blockIdx.x - nfield_blocks) * 64 + threadIdx.x, b = blockIdx.y;
+        if (bx >= nfield_blocks) {
+            const int q = (bx - nfield_blocks) * 64 + threadIdx.x;
             uint8_t *img = a.proof + (size_t)b * a.image_stride;
             if (q < NREST * 16) {
                 const int i = q >> 4, w = q & 15;
@@ -1495,7 +1512,7 @@ __global__ __launch_bounds__(64) void k_assemble_fields(AssembleArgs a, uint32_t
     }
     // the tile is kept in IMAGE order (party-major, no padding): the second phase is a straight copy.
     __shared__ __attribute__((aligned(16))) uint16_t tile[ASM_TILE];
-    const int b = blockIdx.y, x = blockIdx.x, lane = threadIdx.x;
+    const int x = bx, lane = threadIdx.x;
     const bool kind = x < a.plan.nrest * NWIN; // unopened parties
     const uint16_t *orow = a.opened + (size_t)b * a.sel_stride;
     int i0, cnt, f;
@@ -1705,8 +1722,9 @@ hipError_t launch_table_gemm(const GemmArgs &a, uint16_t *sink, hipStream_t st)
     const int cpb = (nchunks + msplit - 1) / msplit;
     msplit = (nchunks + cpb - 1) / cpb;
     (void)sink;
-    if (a.KS == 7) hipLaunchKernelGGL((k_table_gemm<7, 1>), dim3(nblk, msplit), dim3(512), 0, st, a, nchunks, cpb);
-    else hipLaunchKernelGGL((k_table_gemm<13, 1>), dim3(nblk, msplit), dim3(512), 0, st, a, nchunks, cpb);
+    const dim3 grid((unsigned)((nblk * msplit + 7) / 8 * 8));
+    if (a.KS == 7) hipLaunchKernelGGL((k_table_gemm<7, 1>), grid, dim3(512), 0, st, a, nchunks, cpb, nblk, msplit);
+    else hipLaunchKernelGGL((k_table_gemm<13, 1>), grid, dim3(512), 0, st, a, nchunks, cpb, nblk, msplit);
     return hipGetLastError();
 }
 
@@ -1748,8 +1766,11 @@ hipError_t launch_pow_table(const uint16_t *alpha, int J, int M, int32_t *pwT, i
 
 hipError_t launch_lincomb(const LincombArgs &a, int nproofs, hipStream_t st)
 {
-    dim3 grid((a.ncols + 255) / 256, (a.J + LC_JC - 1) / LC_JC, nproofs * 2);
-    hipLaunchKernelGGL(k_lincomb, grid, dim3(256), 0, st, a);
+    LincombArgs b = a;
+    b.nxb = (a.ncols + 255) / 256;
+    b.njc = (a.J + LC_JC - 1) / LC_JC;
+    b.ngroups = nproofs * 2;
+    hipLaunchKernelGGL(k_lincomb, dim3((unsigned)((b.nxb * b.njc * b.ngroups + 7) / 8 * 8)), dim3(256), 0, st, b);
     return hipGetLastError();
 }
 
@@ -1779,8 +1800,10 @@ hipError_t launch_post_relation(uint16_t *P, size_t proof_stride, const RowMap &
 hipError_t launch_assemble(const AssembleArgs &a, int nfields, size_t off_tcomm, size_t off_comm, size_t off_I,
                            int nproofs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_assemble_fields, dim3(a.plan.nrest * NWIN + a.plan.nopen * ((NOPEN + 63) / 64) + (NREST * 16 + 63) / 64, nproofs), dim3(64),
-                       0, st, a, (uint32_t)off_tcomm, (uint32_t)off_comm, (uint32_t)off_I);
+    const int bpp = a.plan.nrest * NWIN + a.plan.nopen * ((NOPEN + 63) / 64) + (NREST * 16 + 63) / 64;
+    const long nwg = ((long)bpp * nproofs + 7) / 8 * 8;
+    hipLaunchKernelGGL(k_assemble_fields, dim3((unsigned)nwg), dim3(64), 0, st, a, (uint32_t)off_tcomm, (uint32_t)off_comm, (uint32_t)off_I, bpp,
+                       nproofs);
     return hipGetLastError();
 }
 

@@ -10,6 +10,16 @@ namespace kosk {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
+// XCD-aware workgroup order for one-dimensional grids whose size is a multiple of 8: consecutive workgroup ids go round the
+// 8 XCDs (each with its own L2), so workgroups that read the same data are given CONSECUTIVE virtual ids, which this maps to
+// ids of one XCD: virtual id = position in this XCD's sequence.
+__device__ __forceinline__ int xcd_virtual_id()
+{
+    constexpr int NXCD = 8;
+    const int per_xcd = (int)gridDim.x / NXCD;
+    return ((int)blockIdx.x % NXCD) * per_xcd + (int)blockIdx.x / NXCD;
+}
+
 // 16 canonical u16 (two uint4) -> 16 low-limb bytes + 16 high-limb bytes of the centred representatives
 __device__ __forceinline__ void gm_split16(const uint4 &x0, const uint4 &x1, uint4 &lo, uint4 &hi)
 {

@@ -485,11 +485,14 @@ __device__ __forceinline__ void interp_apply_block(const InterpApplyArgs &g, con
 }
 
 // blocks per proof: 7 (degree d: 407 points in groups of 64) + 4 (degree 2d: 256 points)
-__global__ __launch_bounds__(256) void k_interp_apply(InterpApplyArgs g)
+__global__ __launch_bounds__(256) void k_interp_apply(InterpApplyArgs g, int nproofs)
 {
     __shared__ __attribute__((aligned(4))) uint16_t tab_s[IA_TAB + 2];
     __shared__ __attribute__((aligned(16))) uint16_t rest_s[IA_KS2 * 64];
-    const int b = blockIdx.x / 11, m = blockIdx.x % 11;
+    // XCD-aware order: the 11 workgroups of a proof read the same fragment tiles of weighted shares (108 KB)
+    const int vid = xcd_virtual_id();
+    const int b = vid / 11, m = vid % 11;
+    if (b >= nproofs) return;
     if (m < 7) interp_apply_block<0>(g, b, m, tab_s, rest_s);
     else interp_apply_block<1>(g, b, m - 7, tab_s, rest_s);
 }
@@ -695,7 +698,7 @@ hipError_t launch_interp_apply(const InterpArgs &a, uint16_t *P, size_t proof_st
     g.n2 = n2;
     g.y2 = y2;
     g.out2 = out2;
-    hipLaunchKernelGGL(k_interp_apply, dim3(11 * nproofs), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(k_interp_apply, dim3((11 * nproofs + 7) / 8 * 8), dim3(256), 0, st, g, nproofs);
     return hipGetLastError();
 }
 hipError_t launch_check_opened(const VerifyArgs &v, int nproofs, hipStream_t st)
