@@ -81,8 +81,31 @@ def cpu_baseline(k, tapes, nproofs):
                       % (nproofs, tp.value, tv.value, os.cpu_count(), len(os.sched_getaffinity(0)))}
 
 
+def _sample(n, count=64):
+    import numpy as np
+    rng = np.random.default_rng(n)
+    return sorted(set([0, 1, 63, 64, n - 65, n - 1] + rng.integers(0, n, count - 6).tolist()))
+
+
+def _ntt_by_definition(f):
+    """Kyber's NTT from its definition (ntt.c:80-95 computes exactly this): outputs 2i, 2i+1 = the even / odd coefficients'
+    polynomials evaluated at zeta^(2 br7(i) + 1), zeta = 17, mod q.  f: 256 ints; returns 256 ints in [0, q)."""
+    import numpy as np
+    q = 3329
+    f = np.asarray(f, dtype=np.int64) % q
+    out = np.zeros(256, np.int64)
+    for i in range(128):
+        z = pow(17, 2 * int("{:07b}".format(i)[::-1], 2) + 1, q)
+        pw = np.array([pow(z, j, q) for j in range(128)], dtype=np.int64)
+        out[2 * i] = int((f[0::2] * pw % q).sum() % q)
+        out[2 * i + 1] = int((f[1::2] * pw % q).sum() % q)
+    return out
+
+
 def kernel_microbench(ctx, torch, k, lanes=65536, reps=20):
-    """Graded kernels at exactly `lanes` lanes (BASELINE.json configs[1..2]); hipEvent pairs on the ctx stream."""
+    """Graded kernels at exactly `lanes` lanes (BASELINE.json configs[1..2]); hipEvent pairs on the ctx stream.  The outputs of
+    the very launches that were timed are checked on 64 sampled lanes (hashlib.sha3_256; the NTT's definition mod q)."""
+    import numpy as np
     out = {}
     tc_words = {2: 154, 3: 160, 4: 166}[k]
     vw_words = {2: 210, 3: 220, 4: 246}[k]
@@ -95,14 +118,24 @@ def kernel_microbench(ctx, torch, k, lanes=65536, reps=20):
         for _ in range(3):
             ctx.commit_hash_lanes(rows.data_ptr(), lanes, lanes, pre.data_ptr(), wp, dig.data_ptr())
         ctx.synchronize()
+        dig.zero_()
+        torch.cuda.synchronize()
         ctx.timer_start()
         for _ in range(reps):
             ctx.commit_hash_lanes(rows.data_ptr(), lanes, lanes, pre.data_ptr(), wp, dig.data_ptr())
         ms = ctx.timer_stop_ms() / reps
+        smp = _sample(lanes)
+        h_rows = rows[:words][:, smp].cpu().numpy().astype("<u2")
+        h_pre, h_dig = pre[smp].cpu().numpy(), dig[smp].cpu().numpy()
+        for j, l in enumerate(smp):
+            msg = (h_pre[j].tobytes() if wp else b"") + h_rows[:, j].tobytes()
+            if h_dig[j].tobytes() != hashlib.sha3_256(msg).digest():
+                raise RuntimeError("%s: digest of lane %d differs from hashlib.sha3_256" % (name, l))
         nbytes = lanes * (2 * words + 32 * wp + 32)
         perms = lanes * ((2 * words + 32 * wp) // 136 + 1)
         out[name] = {"lanes": lanes, "msg_bytes": 2 * words + 32 * wp, "us": ms * 1e3, "GBps": nbytes / ms / 1e6,
-                     "frac_hbm_peak": nbytes / ms / 1e6 / HBM_PEAK_GBS, "keccak_f_per_s": perms / ms * 1e3}
+                     "frac_hbm_peak": nbytes / ms / 1e6 / HBM_PEAK_GBS, "keccak_f_per_s": perms / ms * 1e3,
+                     "checked": "%d sampled lanes of the timed launches' output == hashlib.sha3_256" % len(smp)}
     for big in (262144, 1048576):  # the same view-hash kernel with several waves per SIMD (its saturated rate)
         rows_b = torch.randint(0, 3329, (vw_words, big), dtype=torch.int16, device="cuda", generator=g)
         pre_b = torch.randint(0, 256, (big, 32), dtype=torch.uint8, device="cuda", generator=g)
@@ -128,8 +161,18 @@ def kernel_microbench(ctx, torch, k, lanes=65536, reps=20):
     for _ in range(reps):
         ctx.ntt256_batch(polys.data_ptr(), outp.data_ptr(), lanes)
     ms = ctx.timer_stop_ms() / reps
+
+    def check_ntt(what):
+        smp = _sample(lanes, 24)
+        h_in, h_out = polys[smp].cpu().numpy(), outp[smp].cpu().numpy()
+        for j, l in enumerate(smp):
+            if not np.array_equal(h_out[j].astype(np.int64) % 3329, _ntt_by_definition(h_in[j])) or abs(int(h_out[j].min())) > 1664 or int(h_out[j].max()) > 1664:
+                raise RuntimeError("%s: polynomial %d differs from the NTT's definition" % (what, l))
+        return "%d sampled polynomials of the timed launches' output == the NTT by definition (mod q, centred range)" % len(smp)
     out["ntt256"] = {"polys": lanes, "us": ms * 1e3, "GBps": lanes * 1024 / ms / 1e6,
-                     "frac_hbm_peak": lanes * 1024 / ms / 1e6 / HBM_PEAK_GBS, "arithmetic": "integer Montgomery (default)"}
+                     "frac_hbm_peak": lanes * 1024 / ms / 1e6 / HBM_PEAK_GBS, "arithmetic": "integer Montgomery (default)",
+                     "checked": check_ntt("ntt256")}
+    outp.zero_()
     # the opt-in packed-fp32 butterflies (KOSK_NTT_FP32=1; operands pinned to VGPRs, see k_ntt256_fp32's HAZARD note)
     from mpcith_kyber_kosk_amd import api
     old = os.environ.get("KOSK_NTT_FP32")
@@ -148,7 +191,8 @@ def kernel_microbench(ctx, torch, k, lanes=65536, reps=20):
     ms = cf.timer_stop_ms() / reps
     cf.close()
     out["ntt256_packed_fp32"] = {"polys": lanes, "us": ms * 1e3, "GBps": lanes * 1024 / ms / 1e6,
-                                 "frac_hbm_peak": lanes * 1024 / ms / 1e6 / HBM_PEAK_GBS, "arithmetic": "packed fp32, opt-in (KOSK_NTT_FP32=1)"}
+                                 "frac_hbm_peak": lanes * 1024 / ms / 1e6 / HBM_PEAK_GBS, "arithmetic": "packed fp32, opt-in (KOSK_NTT_FP32=1)",
+                                 "checked": check_ntt("ntt256_packed_fp32")}
     return out
 
 
@@ -212,6 +256,18 @@ def pcie_inclusive(api, k, B, tapes):
     return out
 
 
+def host_budget(usable_cores, local_world, slots, threads):
+    """(host threads per slot, sleep instead of spin) for a rank that shares `usable_cores` with local_world - 1 other ranks and
+    runs `slots` pipeline slots.  With a core for every slot thread nothing changes; when cores are scarce (an 8-GPU node with
+    few cores per GPU) the slots' waits sleep on events and the Fiat-Shamir pools shrink -- but never below three threads per
+    slot: the pool threads sleep between the four hash rounds of a step, so twice as many of them as cores is harmless, while
+    fewer than three would stretch every round (46 proofs = 6 groups of 8 AVX-512 lanes)."""
+    cores_per_rank = max(1, usable_cores // max(1, local_world))
+    if cores_per_rank >= slots * (threads + 1):
+        return threads, False
+    return max(3, min(threads, 2 * cores_per_rank // slots)), True
+
+
 class Slot:
     """One pipeline slot: a library context with its tape bank in HBM (and, for config 4, its own process group)."""
 
@@ -248,18 +304,25 @@ class Slot:
             raise RuntimeError("verifier rejected %d of %d honest proofs (masks %s)" % (ok.count(False), B, c.fail_masks(B)[:8]))
         self.steps_done += 1
 
-    def enable_gather(self, api, torch, dist, group, world):
+    def enable_gather(self, api, torch, dist, group, world, host_staged=False):
+        """host_staged (KOSK_BENCH_REHEARSE=1: several ranks on ONE GPU over gloo, which RCCL cannot do): the table is copied to
+        the host and all-gathered there -- same hook order, same static step dealing, same pending.wait() ordering as the RCCL
+        path, so that config 4's multi-rank control flow can run on a one-GPU box."""
         B = self.B
         # concatenation form [world * B][1454][32] (rank-major = global proof order of the contiguous partition)
-        outs = [torch.empty((world * B, 1454, 32), dtype=torch.uint8, device=self.bank.device) for _ in range(2)]
+        outs = [torch.empty((world * B, 1454, 32), dtype=torch.uint8, device="cpu" if host_staged else self.bank.device) for _ in range(2)]
         self.gather = (dist, group, outs, world)
+        self.gathers_issued = 0
 
         def hook(role, rnd, ptr, nbytes):
             if role != 0:
                 return  # the verifier's tables are the prover's again (opened digests recomputed, the rest from the proof)
             assert nbytes == B * 1454 * 32
             src = torch.as_tensor(api.DeviceView(ptr, (B, 1454, 32)), device=self.bank.device)
+            if host_staged:
+                src = src.cpu()  # the table is complete in HBM when the hook fires; a blocking D2H on torch's stream
             self.pending.append(dist.all_gather_into_tensor(outs[rnd], src, group=group, async_op=True))
+            self.gathers_issued += 1
         self.c.set_round_hook(hook)
 
 
@@ -293,13 +356,10 @@ def main():
         usable_cores = len(os.sched_getaffinity(0))
     except AttributeError:
         usable_cores = os.cpu_count() or 1
-    cores_per_rank = max(1, usable_cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))))
-    threads = cfg["threads"]
-    if cores_per_rank < S * (threads + 1):
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    threads, blocking = host_budget(usable_cores, local_world, S, cfg["threads"])
+    if blocking:
         os.environ.setdefault("KOSK_BLOCKING_SYNC", "1")
-        # the pool threads sleep between the four hash rounds of a step, so twice as many of them as cores is harmless; fewer than
-        # three per slot would stretch every round (46 proofs = 6 groups of 8 AVX-512 lanes)
-        threads = max(3, min(threads, 2 * cores_per_rank // S))
     os.environ.setdefault("KOSK_HOST_THREADS", str(threads))
     # stdout carries exactly ONE line (the JSON): whatever libraries print there (RCCL's version banner on the first
     # communicator, for one) goes to stderr instead
@@ -339,10 +399,8 @@ def main():
     ctx = slots[0].c
     tapes = slots[0].first_tapes
     if want_gather:
-        if rehearse:
-            raise SystemExit("config 4 gathers device tensors over RCCL: no gloo rehearsal")
         for sl in slots:  # one communicator per slot: each slot issues its collectives in its own fixed order
-            sl.enable_gather(api, torch, dist, dist.new_group(list(range(world))), world)
+            sl.enable_gather(api, torch, dist, dist.new_group(list(range(world))), world, host_staged=rehearse)
     for sl in slots:  # setup, not a benchmark step: first use allocates the verifier workspace and builds its tables
         sl.step(torch, 0)
 
@@ -456,11 +514,25 @@ def main():
         for w_ in sl.pending:
             w_.wait()
         torch.cuda.synchronize()
-        same = all(bool(torch.equal(outs[r].view(world, B, 1454, 32)[rank], torch.as_tensor(sl.c.resident_digests(r, B), device=outs[r].device))) for r in (0, 1))
+        mine = [torch.as_tensor(sl.c.resident_digests(r, B), device=sl.bank.device).to(outs[r].device) for r in (0, 1)]
+        same = all(bool(torch.equal(outs[r].view(world, B, 1454, 32)[rank], mine[r])) for r in (0, 1))
         if not same:
             raise RuntimeError("all-gathered digest table differs from the resident one")
-        gather_info = {"collective": "all_gather_into_tensor (RCCL)", "tables_per_step": 2, "bytes_per_rank_per_table": B * 1454 * 32,
-                       "gathered_shape": list(outs[0].shape), "own_block_matches_resident_table": True}
+        # every rank's block of MY gathered tables must be what THAT rank holds: one sha3_256 per (rank, round), all-gathered
+        peers_ok = True
+        for r in (0, 1):
+            own = torch.frombuffer(bytearray(hashlib.sha3_256(mine[r].cpu().numpy().tobytes()).digest()), dtype=torch.uint8).reshape(1, 32).to(outs[r].device)
+            table = sharding.allgather_digest_table(own, world, dist)
+            for q_ in range(world):
+                blk = outs[r].view(world, B, 1454, 32)[q_].cpu().numpy().tobytes()
+                peers_ok &= bytes(table[q_].tolist()) == hashlib.sha3_256(blk).digest()
+        if not peers_ok:
+            raise RuntimeError("a peer's block of the all-gathered digest table differs from that peer's resident table")
+        gather_info = {"collective": "all_gather_into_tensor (%s)" % ("gloo, host-staged rehearsal" if rehearse else "RCCL"),
+                       "tables_per_step": 2, "bytes_per_rank_per_table": B * 1454 * 32,
+                       "gathered_shape": list(outs[0].shape), "own_block_matches_resident_table": True,
+                       "peer_blocks_match_their_resident_tables": True,
+                       "gathers_issued_per_slot": [s_.gathers_issued for s_ in slots], "steps_per_slot": [s_.steps_done for s_ in slots]}
     if dist is not None:
         cdev = "cpu" if rehearse else "cuda"
         t = torch.tensor([dt, dt_drained], dtype=torch.float64, device=cdev)

@@ -46,7 +46,10 @@ int kosk_set_randombytes(kosk_ctx *ctx, kosk_randombytes_fn fn, void *user); /* 
 /* void kyber_verifiable_keygen(kyber_keypair *keypair, uint8_t *pi)   kosk.hpp:20-21, kosk.cpp:72-86
  * n independent instances; pk/sk/pi are n consecutive records of kosk_*_bytes().
  * `tapes` == NULL draws randomness through the randombytes callback; otherwise
- * proof b consumes tapes[b*tape_stride ..] (kosk_tape_bytes() bytes each). */
+ * proof b consumes tapes[b*tape_stride ..] (kosk_tape_bytes() bytes each).
+ * Error containment (all entry points): no C++ exception and no abort leaves the library -- a failed allocation, thread or
+ * HIP call is rc -1 + kosk_last_error(); the only abort is the reference's own, an OS entropy failure
+ * (kyber/randombytes.c:49-52).  A batch call creates no threads (kosk_create made them). */
 int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride,
                                  uint8_t *pk, uint8_t *sk, uint8_t *pi);
 
@@ -55,7 +58,7 @@ int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, siz
  * false (mlwe_verifier.cpp:120 etc.); here kosk_verify_fail_masks() reports
  * which checks failed (bit i = check i of DESIGN.md's verifier table). */
 int kosk_verify_batch(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk, uint8_t *ok);
-int kosk_verify_fail_masks(const kosk_ctx *ctx, uint32_t *masks, int n);
+int kosk_verify_fail_masks(const kosk_ctx *ctx, uint32_t *masks, int n); /* n <= proofs of the last completed verify call */
 
 /* ---- Second-level entry points of the reference (mlwe_prover.hpp:77-99, mlwe_verifier.hpp:14-15; used directly by
  * main.cpp:21-47) on n instances at a time.  The buffers are arrays of the reference's structs for this kyber_k, byte for
@@ -93,7 +96,9 @@ int kosk_verify_resident(kosk_ctx *ctx, int n, uint8_t *ok);
  * memory (a device buffer whose base and tape_stride are multiples of 8 is read in place) or NULL (randombytes callback).
  * kyber_kosk_verify (kosk.cpp:88-117) on the resident proofs -- polyvec_frombytes(t) + gen_matrix (kosk.cpp:94-99) run at
  * the head of the verifier's first segment from `pk` (host or device memory), or, with pk == NULL, from the pk bytes the
- * key generation left in HBM. */
+ * key generation (or a verifier staging call) of at least n proofs left in HBM on this handle -- an error otherwise.
+ * A DEVICE tape buffer that is read in place must stay valid and unmodified until the prove call that consumes it has
+ * returned (kosk_verifiable_keygen_resident itself, or kosk_prove_resident after kosk_stage_prover_inputs). */
 int kosk_verifiable_keygen_resident(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk);
 int kosk_verify_resident_pk(kosk_ctx *ctx, int n, const uint8_t *pk, uint8_t *ok);
 /* ---- Compact wire format (no reference counterpart: the reference ships the raw image of
@@ -107,6 +112,16 @@ int kosk_proof_compress(int kyber_k, const uint8_t *pi, uint8_t *out);   /* host
 int kosk_proof_decompress(int kyber_k, const uint8_t *in, uint8_t *pi);
 int kosk_fetch_proofs_compact(kosk_ctx *ctx, int n, uint8_t *out);        /* like kosk_fetch_proofs */
 int kosk_stage_verifier_inputs_compact(kosk_ctx *ctx, int n, const uint8_t *in, const uint8_t *pk); /* like kosk_stage_verifier_inputs */
+
+/* Which of the alternative kernel / copy paths ran on this handle since kosk_create (the runtime knobs of INTEGRATION.md 5 are
+ * read from the environment by kosk_create, per handle).  ids: 0 commitment hash with LDS-DMA staging, 1 without (KOSK_HASH_DMA=0
+ * or a layout it cannot take), 2 placement primer launches (KOSK_HASH_PRIMER=1), 3 shared-table products on k_table_gemm,
+ * 4 products on the generic limb GEMM (KOSK_TABLE_GEMM=0, grouped products), 5 proof images copied straight between HBM and
+ * page-locked caller memory, 6 through the pinned staging buffer (KOSK_REGISTER=0, head / tail chunks, single-chunk calls),
+ * 7 hipGraph segment replays (KOSK_GRAPHS=1), 8 / 9 NTT launches of the packed-fp32 / integer kernel. */
+int kosk_path_count(const kosk_ctx *ctx, int id, long *count);
+/* host worker threads per sub-context (<= 8, <= CPUs of the process / KOSK_STREAMS; all created by kosk_create) */
+int kosk_host_threads(const kosk_ctx *ctx);
 
 /* wall seconds of the phases of the last prove / verify on this context (16 values: host_pre, gpu_commit,
  * fs_alpha, gpu_relation, fs_open, gpu_assemble, d2h, then the host time spent issuing the prover's three

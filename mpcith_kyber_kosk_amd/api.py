@@ -55,6 +55,8 @@ def _load():
         "kosk_resident_digests": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(sz)]),
         "kosk_set_round_hook": (C.c_int, [vp, vp, vp]),
         "kosk_phase_seconds": (C.c_int, [vp, C.POINTER(C.c_double), C.c_int]),
+        "kosk_path_count": (C.c_int, [vp, C.c_int, C.POINTER(C.c_long)]),
+        "kosk_host_threads": (C.c_int, [vp]),
         "kosk_sha3_256_batch": (C.c_int, [vp, vp, sz, sz, vp, C.c_int]),
         "kosk_shake256_batch": (C.c_int, [vp, vp, sz, sz, vp, sz, C.c_int]),
         "kosk_commit_hash_lanes": (C.c_int, [vp, vp, sz, C.c_int, vp, C.c_int, vp]),
@@ -91,7 +93,7 @@ EXPORTS = ["kosk_pk_bytes", "kosk_sk_bytes", "kosk_proof_bytes", "kosk_tape_byte
            "kosk_prepare_randomness", "kosk_prepare_range_proof", "kosk_prove_prepared", "kosk_verify_inst", "kosk_compact_proof_bytes",
            "kosk_proof_compress", "kosk_proof_decompress", "kosk_fetch_proofs_compact", "kosk_stage_verifier_inputs_compact", "kosk_stage_prover_inputs", "kosk_prove_resident", "kosk_fetch_proofs",
            "kosk_stage_verifier_inputs", "kosk_verify_resident", "kosk_verifiable_keygen_resident", "kosk_verify_resident_pk",
-           "kosk_resident_digests", "kosk_set_round_hook", "kosk_phase_seconds", "kosk_sha3_256_batch",
+           "kosk_resident_digests", "kosk_set_round_hook", "kosk_phase_seconds", "kosk_path_count", "kosk_host_threads", "kosk_sha3_256_batch",
            "kosk_shake256_batch", "kosk_commit_hash_lanes", "kosk_ntt256_batch", "kosk_lagrange_expand",
            "kosk_recon_secrets", "kosk_profile_enable", "kosk_profile_read", "kosk_stream_timer_start", "kosk_stream_timer_stop", "kosk_device_synchronize", "kosk_streams", "kosk_commit_launch_groups", "kosk_resident_proofs", "kosk_keygen", "kosk_fs_alpha",
            "kosk_fs_opened", "kosk_host_sha3_256", "kosk_host_shake256", "kosk_host_sha3_256_multi", "kosk_lagrange_table"]
@@ -358,6 +360,22 @@ class Kosk:
             lib.kosk_profile_read(self._h, i, C.byref(ms), C.byref(cnt))
             out[name] = (ms.value, cnt.value)
         return out
+
+    PATH_IDS = ["hash_dma", "hash_plain", "hash_primer", "table_gemm", "limb_gemm", "copy_direct", "copy_staged", "graph_replay",
+                "ntt_fp32", "ntt_int"]
+
+    def path_counts(self):
+        """{name: launches / copies} of the alternative kernel and copy paths on this handle since it was created"""
+        out = {}
+        for i, name in enumerate(self.PATH_IDS):
+            v = C.c_long()
+            self._chk(lib.kosk_path_count(self._h, i, C.byref(v)), "path_count")
+            out[name] = v.value
+        return out
+
+    @property
+    def host_threads(self):
+        return lib.kosk_host_threads(self._h)
 
     def timer_start(self):
         self._chk(lib.kosk_stream_timer_start(self._h), "timer_start")

@@ -1,13 +1,30 @@
 // extern "C" boundary (include/kosk_mi355x.h) over kosk::Ctx.
+//
+// Containment rules of this file (the reference's API is void / bool and never kills its caller except on RNG failure,
+// kosk.hpp:18-24, kyber/randombytes.c:49-52):
+//   * no C++ exception leaves an extern "C" function: every entry point runs inside guard(), which turns std::exception /
+//     anything else into rc -1 + kosk_last_error() text;
+//   * no thread is created inside a batch call: the S - 1 lane threads of a handle (KOSK_STREAMS = S) and every
+//     sub-context's host workers are created by kosk_create(), whose failure is an ordinary -1;
+//   * caller memory is page-locked only over whole pages the caller's buffer fully covers, every HIP result of that is
+//     checked, and any failure falls back to the pinned staging buffers.
 #include "../../include/kosk_mi355x.h"
 
+#include <unistd.h>
+
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <exception>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "kosk_ctx.hpp"
+#include "kosk_lanes.hpp"
 
 using namespace kosk;
 
@@ -16,18 +33,17 @@ using namespace kosk;
 // Fiat-Shamir round trip the GPU works on the other, and kernels of different streams share the CUs.
 struct kosk_ctx {
     std::vector<Ctx *> sub;
-    Ctx *c; // sub[0]: kernel-level entry points, error text, sizes
-    int max_batch;
+    LaneSet lanes; // lane i runs sub[i]; lane 0 is the caller's thread (kosk_lanes.hpp)
+    Ctx *c = nullptr; // sub[0]: kernel-level entry points, error text, sizes
+    int max_batch = 0;
     std::string err;
     std::vector<uint32_t> masks; // fail masks of the last verify call, in the caller's proof order
+    int masks_n = 0;             // proofs of the last verify call (kosk_verify_fail_masks serves exactly these)
 
-    // [first, count) of sub-batch i of an n-proof call
-    void split(int n, int i, int &first, int &count) const
+    ~kosk_ctx()
     {
-        const int S = (int)sub.size();
-        const int base = n / S, rem = n % S;
-        count = base + (i < rem ? 1 : 0);
-        first = i * base + (i < rem ? i : rem);
+        lanes.lanes.clear(); // join the lane threads before their sub-contexts go
+        for (Ctx *x : sub) delete x;
     }
     // every entry point starts from a clean error state (kosk_last_error never reports a stale message)
     void clear_err()
@@ -35,27 +51,61 @@ struct kosk_ctx {
         err.clear();
         for (Ctx *x : sub) x->err.clear();
     }
+    int run_lanes(std::vector<std::function<int()>> &jobs)
+    {
+        std::vector<int> rc;
+        std::vector<std::string> what;
+        lanes.run(jobs, rc, what);
+        for (int i = 0; i < (int)sub.size(); i++)
+            if (rc[i]) {
+                if (rc[i] == -2) sub[i]->err = "exception in a batch job: " + what[i];
+                err = sub[i]->err;
+                c->err = err;
+                return -1;
+            }
+        return 0;
+    }
+    // an n-proof call (n <= max_batch) as S contiguous sub-batches: fn(sub-context, first, count)
     template <typename F>
     int run(int n, F &&fn)
     {
         clear_err();
-        const int S = (int)sub.size();
-        std::vector<int> rc(S, 0);
-        std::vector<std::thread> th;
-        for (int i = 1; i < S; i++) {
-            int first, count;
-            split(n, i, first, count);
-            if (count > 0) th.emplace_back([&, i, first, count] { rc[i] = fn(*sub[i], first, count); });
-        }
-        int first, count;
-        split(n, 0, first, count);
-        if (count > 0) rc[0] = fn(*sub[0], first, count);
-        for (auto &t : th) t.join();
-        for (int i = 0; i < S; i++)
-            if (rc[i]) { err = sub[i]->err; c->err = err; return -1; }
-        return 0;
+        auto on_lane = [&](int i, int first, int count) { return fn(*sub[i], first, count); };
+        std::vector<std::function<int()>> jobs;
+        deal_split((int)sub.size(), n, on_lane, jobs);
+        return run_lanes(jobs);
     }
 };
+
+// Every extern "C" entry point's body runs in here: nothing thrown below (std::bad_alloc, std::system_error, an exception
+// out of a host worker job) reaches the caller's frames.
+template <typename F>
+static int guard(kosk_ctx *ctx, const char *fn, F &&body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::exception &e) {
+        try {
+            if (ctx) { ctx->err = std::string(fn) + ": " + e.what(); if (ctx->c) ctx->c->err = ctx->err; }
+        } catch (...) {}
+    } catch (...) {
+        try {
+            if (ctx) { ctx->err = std::string(fn) + ": unknown exception"; if (ctx->c) ctx->c->err = ctx->err; }
+        } catch (...) {}
+    }
+    return -1;
+}
+template <typename F>
+static int guard(const kosk_ctx *, const char *, F &&body) noexcept // read-only entry points leave the error string alone
+{
+    try {
+        return body();
+    } catch (...) {
+    }
+    return -1;
+}
+#define GUARD(ctx) return guard(ctx, __func__, [&]() -> int {
+#define GUARD_END });
 
 // argument validation failed: the call has done nothing; kosk_last_error(ctx) says which entry point refused
 static int bad_args(const kosk_ctx *, const char *) { return -1; } // read-only entry points leave the error string alone
@@ -70,34 +120,70 @@ static int bad_args(kosk_ctx *ctx, const char *fn)
 }
 
 // Batches larger than a sub-context: the chunks (of a sub-context's capacity each) are dealt round-robin to the S
-// sub-contexts, which work through theirs concurrently on S host threads.  With KOSK_STREAMS >= 2 one chunk's PCIe
-// transfers (tapes in, 0.68 MB of proof image out per proof; proofs and keys in for the verifier) and host hashing run
+// sub-contexts, which work through theirs concurrently on the handle's lane threads.  With KOSK_STREAMS >= 2 one chunk's
+// PCIe transfers (tapes in, 0.68 MB of proof image out per proof; proofs and keys in for the verifier) and host hashing run
 // under another chunk's kernels: the streaming write-back of SURVEY.md 8 f4 for a single caller thread.
 template <typename F>
 static int run_chunks(kosk_ctx *h, int n, F &&fn)
 {
     h->clear_err();
-    const int S = (int)h->sub.size(), per = h->sub[0]->max_batch, nchunks = (n + per - 1) / per;
-    std::vector<int> rc(S, 0);
-    auto lane = [&](int i) {
-        for (int j = i; j < nchunks && !rc[i]; j += S) {
-            const int first = j * per, count = (n - first) < per ? (n - first) : per;
-            rc[i] = fn(*h->sub[i], first, count);
-        }
-    };
-    std::vector<std::thread> th;
-    for (int i = 1; i < S && i < nchunks; i++) th.emplace_back(lane, i);
-    lane(0);
-    for (auto &t : th) t.join();
-    for (int i = 0; i < S; i++)
-        if (rc[i]) { h->err = h->sub[i]->err; h->c->err = h->err; return -1; }
-    return 0;
+    auto on_lane = [&](int i, int first, int count) { return fn(*h->sub[i], first, count); };
+    std::vector<std::function<int()>> jobs;
+    deal_chunks((int)h->sub.size(), h->sub[0]->max_batch, n, on_lane, jobs);
+    return h->run_lanes(jobs);
 }
 
-static bool register_enabled()
+// Caller memory page-locked for the duration of one multi-chunk call, so that proof images cross PCIe straight from / to
+// it.  Only the whole pages INSIDE the buffer are locked (never a page shared with a neighbouring allocation); records
+// that touch the unlocked head or tail go through the pinned staging buffer like everything does with KOSK_REGISTER=0.
+struct HostSpan {
+    uint8_t *lo = nullptr, *hi = nullptr;
+    bool covers(const uint8_t *p, size_t len) const { return lo && p >= lo && p + len <= hi; }
+};
+static HostSpan lock_span(const kosk_ctx *h, const uint8_t *p, size_t bytes)
 {
-    static const bool on = !(getenv("KOSK_REGISTER") && atoi(getenv("KOSK_REGISTER")) == 0);
-    return on;
+    HostSpan s;
+    if (!h->c->host_register || !p) return s;
+    const long pg = sysconf(_SC_PAGESIZE);
+    const uintptr_t page = pg > 0 ? (uintptr_t)pg : 4096;
+    const uintptr_t a = (reinterpret_cast<uintptr_t>(p) + page - 1) & ~(page - 1), b = (reinterpret_cast<uintptr_t>(p) + bytes) & ~(page - 1);
+    if (b <= a || b - a < ((size_t)1 << 20)) return s; // under 1 MiB the two driver calls cost more than the staging copy
+    if (hipSetDevice(h->c->device) != hipSuccess ||
+        hipHostRegister(reinterpret_cast<void *>(a), b - a, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError(); // e.g. a read-only mapping, memory that is already registered, a locked-memory limit: stage instead
+        return s;
+    }
+    s.lo = reinterpret_cast<uint8_t *>(a);
+    s.hi = reinterpret_cast<uint8_t *>(b);
+    return s;
+}
+// after every lane has synchronised its stream (run_lanes has returned): nothing is in flight on the span any more
+static int unlock_span(kosk_ctx *h, HostSpan &s)
+{
+    if (!s.lo) return 0;
+    const hipError_t e = hipHostUnregister(s.lo);
+    s = HostSpan{};
+    if (e == hipSuccess) return 0;
+    (void)hipGetLastError();
+    h->err = std::string("hipHostUnregister of the caller's buffer failed (the results are complete; the pages stay locked): ") + hipGetErrorString(e);
+    h->c->err = h->err;
+    return -1;
+}
+
+// draw n proofs' worth of randomness through the (stateful) callback / OS entropy, sequentially in proof order and in the
+// reference's call order and lengths (kosk.cpp:12, mlwe_prover.cpp:9, ss.cpp:5)
+static void draw_tapes(const kosk_ctx *ctx, int n, std::vector<uint8_t> &drawn)
+{
+    const Params &P = ctx->c->P;
+    drawn.resize((size_t)n * P.tape_bytes);
+    const Ctx &c0 = *ctx->c;
+    uint8_t *tp = drawn.data();
+    auto draw = [&](size_t len) { if (c0.rb) c0.rb(c0.rb_user, tp, len); else os_randombytes(tp, len); tp += len; };
+    for (int b = 0; b < n; b++) {
+        draw(64);
+        for (int i = 0; i < P.M; i++) draw(32);
+        for (int i = 0; i < P.nfresh; i++) draw(302);
+    }
 }
 
 static thread_local std::string g_create_err; // error text of the last failed kosk_create on this thread
@@ -129,39 +215,49 @@ int kosk_proof_field(int k, int idx, size_t *offset, size_t *size)
 int kosk_create(kosk_ctx **ctx, int device, int kyber_k, int max_batch)
 {
     if (!ctx) return -1;
-    g_create_err.clear();
-    if (const char *e = getenv("AMD_DIRECT_DISPATCH"))
-        if (atoi(e) == 0 && e[0] != '\0') {
-            // measured on ROCm 7.2 (tools/stress.py): with direct dispatch off, hipStreamSynchronize returned before
-            // device-to-host copies into pinned memory had landed; the host then hashed stale digests
-            g_create_err = "AMD_DIRECT_DISPATCH=0 is not supported: stream synchronisation does not cover D2H copies in that mode";
-            return -1;
+    *ctx = nullptr;
+    kosk_ctx *h = nullptr;
+    try {
+        g_create_err.clear();
+        if (const char *e = getenv("AMD_DIRECT_DISPATCH"))
+            if (atoi(e) == 0 && e[0] != '\0') {
+                // measured on ROCm 7.2 (tools/stress.py): with direct dispatch off, hipStreamSynchronize returned before
+                // device-to-host copies into pinned memory had landed; the host then hashed stale digests
+                g_create_err = "AMD_DIRECT_DISPATCH=0 is not supported: stream synchronisation does not cover D2H copies in that mode";
+                return -1;
+            }
+        int S = 1; // KOSK_STREAMS: sub-batches in flight per handle (1 measured best at 46 proofs: kernels sit on latency floors)
+        if (const char *e = getenv("KOSK_STREAMS")) S = atoi(e) > 0 ? atoi(e) : S;
+        if (S > max_batch) S = max_batch > 0 ? max_batch : 1;
+        if (S > 8) S = 8;
+        h = new kosk_ctx();
+        h->max_batch = max_batch;
+        const int per = (max_batch + S - 1) / S;
+        for (int i = 0; i < S; i++) {
+            Ctx *c = nullptr;
+            if (ctx_create(&c, device, kyber_k, per, g_create_err, S)) {
+                delete h;
+                return -1;
+            }
+            h->sub.push_back(c);
         }
-    int S = 1; // KOSK_STREAMS: sub-batches in flight per handle (1 measured best at 46 proofs: kernels sit on latency floors)
-    if (const char *e = getenv("KOSK_STREAMS")) S = atoi(e) > 0 ? atoi(e) : S;
-    if (S > max_batch) S = max_batch > 0 ? max_batch : 1;
-    if (S > 8) S = 8;
-    kosk_ctx *h = new kosk_ctx();
-    h->max_batch = max_batch;
-    const int per = (max_batch + S - 1) / S;
-    for (int i = 0; i < S; i++) {
-        Ctx *c = nullptr;
-        if (ctx_create(&c, device, kyber_k, per, g_create_err)) {
-            for (Ctx *x : h->sub) delete x;
-            delete h;
-            return -1;
-        }
-        h->sub.push_back(c);
+        h->c = h->sub[0];
+        // the lane threads live as long as the handle: a batch call never creates a thread
+        h->lanes.create(S - 1);
+        *ctx = h;
+        return 0;
+    } catch (const std::exception &e) {
+        try { g_create_err = std::string("kosk_create: ") + e.what(); } catch (...) {}
+    } catch (...) {
+        try { g_create_err = "kosk_create: unknown exception"; } catch (...) {}
     }
-    h->c = h->sub[0];
-    *ctx = h;
-    return 0;
+    try { delete h; } catch (...) {}
+    return -1;
 }
 void kosk_destroy(kosk_ctx *ctx)
 {
     if (!ctx) return;
-    for (Ctx *c : ctx->sub) delete c;
-    delete ctx;
+    try { delete ctx; } catch (...) {}
 }
 const char *kosk_last_error(const kosk_ctx *ctx)
 {
@@ -178,109 +274,120 @@ int kosk_set_randombytes(kosk_ctx *ctx, kosk_randombytes_fn fn, void *user)
 int kosk_stage_prover_inputs(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk)
 {
     if (!ctx || n < 1 || n > ctx->max_batch) return bad_args(ctx, __func__);
+    GUARD(ctx)
     const Params &P = ctx->c->P;
-    if (!tapes) {
-        // the randombytes callback is stateful: draw every tape sequentially, in proof order, then stage in parallel
-        std::vector<uint8_t> drawn((size_t)n * P.tape_bytes);
-        Ctx &c0 = *ctx->c;
-        uint8_t *tp = drawn.data();
-        auto draw = [&](size_t len) { if (c0.rb) c0.rb(c0.rb_user, tp, len); else os_randombytes(tp, len); tp += len; };
-        for (int b = 0; b < n; b++) { // reference call order: kosk.cpp:12, mlwe_prover.cpp:9, ss.cpp:5
-            draw(64);
-            for (int i = 0; i < P.M; i++) draw(32);
-            for (int i = 0; i < P.nfresh; i++) draw(302);
-        }
-        return ctx->run(n, [&](Ctx &c, int first, int count) {
-            return stage_prover_inputs(c, count, drawn.data() + (size_t)first * P.tape_bytes, P.tape_bytes,
-                                       pk + (size_t)first * P.pk_bytes, sk + (size_t)first * P.sk_bytes);
-        });
+    std::vector<uint8_t> drawn;
+    if (!tapes) { // the randombytes callback is stateful: draw every tape sequentially, then stage in parallel
+        draw_tapes(ctx, n, drawn);
+        tapes = drawn.data();
+        tape_stride = P.tape_bytes;
     }
     return ctx->run(n, [&](Ctx &c, int first, int count) {
         return stage_prover_inputs(c, count, tapes + (size_t)first * tape_stride, tape_stride,
                                    pk + (size_t)first * P.pk_bytes, sk + (size_t)first * P.sk_bytes);
     });
+    GUARD_END
 }
 int kosk_prove_resident(kosk_ctx *ctx, int n)
 {
     if (!ctx || n < 1 || n > ctx->max_batch) return bad_args(ctx, __func__);
+    GUARD(ctx)
     return ctx->run(n, [&](Ctx &c, int, int count) { return prove_resident(c, count); });
+    GUARD_END
 }
 int kosk_fetch_proofs(kosk_ctx *ctx, int n, uint8_t *pi)
 {
-    if (!ctx || n < 1 || n > ctx->max_batch) return bad_args(ctx, __func__);
+    if (!ctx || n < 1 || n > ctx->max_batch || !pi) return bad_args(ctx, __func__);
+    GUARD(ctx)
     const Params &P = ctx->c->P;
     return ctx->run(n, [&](Ctx &c, int first, int count) { return fetch_proofs(c, count, pi + (size_t)first * P.proof_bytes); });
+    GUARD_END
 }
 int kosk_stage_verifier_inputs(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk)
 {
-    if (!ctx || n < 1 || n > ctx->max_batch) return bad_args(ctx, __func__);
+    if (!ctx || n < 1 || n > ctx->max_batch || !pi || !pk) return bad_args(ctx, __func__);
+    GUARD(ctx)
     const Params &P = ctx->c->P;
     return ctx->run(n, [&](Ctx &c, int first, int count) {
         return stage_verifier_inputs(c, count, pi + (size_t)first * P.proof_bytes, pk + (size_t)first * P.pk_bytes);
     });
+    GUARD_END
 }
+
+// verify `count` resident proofs of sub-context c and file their fail masks at the caller's proof index `first`
+static int verify_into(kosk_ctx *ctx, Ctx &c, int first, int count, uint8_t *ok, int pk_mode, const uint8_t *pk)
+{
+    if (verify_resident(c, count, ok + first, pk_mode, pk)) return -1;
+    memcpy(ctx->masks.data() + first, c.h_fail, sizeof(uint32_t) * (size_t)count);
+    return 0;
+}
+// every verify entry point: the masks of an earlier call are gone, whatever happens next
+static void reset_masks(kosk_ctx *ctx, int n)
+{
+    ctx->masks_n = 0;
+    ctx->masks.assign((size_t)n, 0);
+}
+
 int kosk_verify_resident(kosk_ctx *ctx, int n, uint8_t *ok)
 {
-    if (!ctx || n < 1 || n > ctx->max_batch) return bad_args(ctx, __func__);
-    ctx->masks.assign((size_t)n, 0);
-    return ctx->run(n, [&](Ctx &c, int first, int count) {
-        if (verify_resident(c, count, ok + first)) return -1;
-        memcpy(ctx->masks.data() + first, c.h_fail, sizeof(uint32_t) * (size_t)count);
-        return 0;
-    });
+    if (!ctx || n < 1 || n > ctx->max_batch || !ok) return bad_args(ctx, __func__);
+    GUARD(ctx)
+    reset_masks(ctx, n);
+    if (ctx->run(n, [&](Ctx &c, int first, int count) { return verify_into(ctx, c, first, count, ok, 0, nullptr); })) return -1;
+    ctx->masks_n = n;
+    return 0;
+    GUARD_END
 }
 
 int kosk_verifiable_keygen_resident(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk)
 {
     if (!ctx || n < 1 || n > ctx->max_batch || !pk || !sk) return bad_args(ctx, __func__);
+    GUARD(ctx)
     const Params &P = ctx->c->P;
-    if (!tapes && ctx->sub.size() > 1) {
-        // the randombytes callback is stateful: draw sequentially in proof order, then prove the sub-batches in parallel
-        std::vector<uint8_t> drawn((size_t)n * P.tape_bytes);
-        Ctx &c0 = *ctx->c;
-        uint8_t *tp = drawn.data();
-        auto draw = [&](size_t len) { if (c0.rb) c0.rb(c0.rb_user, tp, len); else os_randombytes(tp, len); tp += len; };
-        for (int b = 0; b < n; b++) {
-            draw(64);
-            for (int i = 0; i < P.M; i++) draw(32);
-            for (int i = 0; i < P.nfresh; i++) draw(302);
-        }
-        return ctx->run(n, [&](Ctx &c, int first, int count) {
-            const KeygenIn kg{drawn.data() + (size_t)first * P.tape_bytes, P.tape_bytes, pk + (size_t)first * P.pk_bytes, sk + (size_t)first * P.sk_bytes};
-            return prove_resident(c, count, false, &kg);
-        });
+    std::vector<uint8_t> drawn;
+    if (!tapes && ctx->sub.size() > 1) { // stateful callback: draw sequentially in proof order, then prove the sub-batches in parallel
+        draw_tapes(ctx, n, drawn);
+        tapes = drawn.data();
+        tape_stride = P.tape_bytes;
     }
     return ctx->run(n, [&](Ctx &c, int first, int count) {
         const KeygenIn kg{tapes ? tapes + (size_t)first * tape_stride : nullptr, tape_stride, pk + (size_t)first * P.pk_bytes,
                           sk + (size_t)first * P.sk_bytes};
         return prove_resident(c, count, false, &kg);
     });
+    GUARD_END
 }
 int kosk_verify_resident_pk(kosk_ctx *ctx, int n, const uint8_t *pk, uint8_t *ok)
 {
     if (!ctx || n < 1 || n > ctx->max_batch || !ok) return bad_args(ctx, __func__);
+    GUARD(ctx)
     const Params &P = ctx->c->P;
-    ctx->masks.assign((size_t)n, 0);
-    return ctx->run(n, [&](Ctx &c, int first, int count) {
-        if (verify_resident(c, count, ok + first, pk ? 1 : 2, pk ? pk + (size_t)first * P.pk_bytes : nullptr)) return -1;
-        memcpy(ctx->masks.data() + first, c.h_fail, sizeof(uint32_t) * (size_t)count);
-        return 0;
-    });
+    reset_masks(ctx, n);
+    if (ctx->run(n, [&](Ctx &c, int first, int count) {
+            return verify_into(ctx, c, first, count, ok, pk ? 1 : 2, pk ? pk + (size_t)first * P.pk_bytes : nullptr);
+        })) return -1;
+    ctx->masks_n = n;
+    return 0;
+    GUARD_END
 }
 int kosk_set_round_hook(kosk_ctx *ctx, kosk_round_fn fn, void *user)
 {
     if (!ctx) return -1;
+    GUARD(ctx)
     if (fn && ctx->sub.size() > 1) { ctx->err = "kosk_set_round_hook needs KOSK_STREAMS=1 (one digest table per round)"; return -1; }
     for (Ctx *c : ctx->sub) { c->round_hook = fn; c->round_user = user; }
     return 0;
+    GUARD_END
 }
 int kosk_resident_digests(kosk_ctx *ctx, int round, void **d_digests, size_t *stride)
 {
     if (!ctx || round < 0 || round > 1) return bad_args(ctx, __func__);
+    GUARD(ctx)
     if (ctx->sub.size() > 1) { ctx->err = "kosk_resident_digests needs KOSK_STREAMS=1 (sub-batches keep separate tables)"; return -1; }
     if (d_digests) *d_digests = round ? ctx->c->d_dig2 : ctx->c->d_dig1;
     if (stride) *stride = (size_t)NPARTY * 32;
     return 0;
+    GUARD_END
 }
 
 int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride,
@@ -288,54 +395,59 @@ int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, siz
 {
     if (!ctx || n < 0 || !pk || !sk || !pi) return bad_args(ctx, __func__);
     if (n == 0) return 0;
+    GUARD(ctx)
     const Params &P = ctx->c->P;
     std::vector<uint8_t> drawn;
-    if (!tapes) {
-        // the randombytes callback is stateful: draw every tape sequentially, in proof order (reference call order:
-        // kosk.cpp:12, mlwe_prover.cpp:9, ss.cpp:5), then work through the chunks in parallel
-        drawn.resize((size_t)n * P.tape_bytes);
-        Ctx &c0 = *ctx->c;
-        uint8_t *tp = drawn.data();
-        auto draw = [&](size_t len) { if (c0.rb) c0.rb(c0.rb_user, tp, len); else os_randombytes(tp, len); tp += len; };
-        for (int b = 0; b < n; b++) {
-            draw(64);
-            for (int i = 0; i < P.M; i++) draw(32);
-            for (int i = 0; i < P.nfresh; i++) draw(302);
-        }
+    if (!tapes) { // stateful callback: every tape sequentially, in proof order, then the chunks in parallel
+        draw_tapes(ctx, n, drawn);
         tapes = drawn.data();
         tape_stride = P.tape_bytes;
     }
-    // several chunks: page-lock the caller's proof buffer for the call so that the images are copied straight into it
-    // (KOSK_REGISTER=0 keeps the pinned staging buffer + host memcpy)
-    const bool reg = n > ctx->sub[0]->max_batch && register_enabled() &&
-                     hipHostRegister(pi, (size_t)n * P.proof_bytes, hipHostRegisterDefault) == hipSuccess;
-    const int rc = run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
-        const KeygenIn kg{tapes + (size_t)first * tape_stride, tape_stride, pk + (size_t)first * P.pk_bytes, sk + (size_t)first * P.sk_bytes};
-        if (prove_resident(c, count, false, &kg)) return -1;
-        return fetch_proofs(c, count, pi + (size_t)first * P.proof_bytes, reg);
-    });
-    if (reg) (void)hipHostUnregister(pi);
-    else (void)hipGetLastError();
+    // several chunks: the whole pages of the caller's proof buffer are page-locked for the call and the images of the
+    // chunks inside them are copied straight there (KOSK_REGISTER=0, or any failure: pinned staging buffer + host memcpy)
+    HostSpan span;
+    if (n > ctx->sub[0]->max_batch) span = lock_span(ctx, pi, (size_t)n * P.proof_bytes);
+    int rc = -1;
+    try {
+        rc = run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
+            const KeygenIn kg{tapes + (size_t)first * tape_stride, tape_stride, pk + (size_t)first * P.pk_bytes, sk + (size_t)first * P.sk_bytes};
+            if (prove_resident(c, count, false, &kg)) return -1;
+            uint8_t *dst = pi + (size_t)first * P.proof_bytes;
+            return fetch_proofs(c, count, dst, span.covers(dst, (size_t)count * P.proof_bytes));
+        });
+    } catch (...) {
+        (void)unlock_span(ctx, span);
+        throw;
+    }
+    if (unlock_span(ctx, span) && !rc) rc = -1;
     return rc;
+    GUARD_END
 }
 
 int kosk_verify_batch(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk, uint8_t *ok)
 {
     if (!ctx || n < 0 || !pi || !pk || !ok) return bad_args(ctx, __func__);
-    if (n == 0) return 0;
+    if (n == 0) { ctx->masks_n = 0; return 0; }
+    GUARD(ctx)
     const Params &P = ctx->c->P;
-    ctx->masks.assign((size_t)n, 0);
-    const bool reg = n > ctx->sub[0]->max_batch && register_enabled() &&
-                     hipHostRegister(const_cast<uint8_t *>(pi), (size_t)n * P.proof_bytes, hipHostRegisterDefault) == hipSuccess;
-    const int rc = run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
-        if (stage_verifier_inputs(c, count, pi + (size_t)first * P.proof_bytes, pk + (size_t)first * P.pk_bytes, reg)) return -1;
-        if (verify_resident(c, count, ok + first)) return -1;
-        memcpy(ctx->masks.data() + first, c.h_fail, sizeof(uint32_t) * (size_t)count);
-        return 0;
-    });
-    if (reg) (void)hipHostUnregister(const_cast<uint8_t *>(pi));
-    else (void)hipGetLastError();
+    reset_masks(ctx, n);
+    HostSpan span;
+    if (n > ctx->sub[0]->max_batch) span = lock_span(ctx, pi, (size_t)n * P.proof_bytes);
+    int rc = -1;
+    try {
+        rc = run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
+            const uint8_t *src = pi + (size_t)first * P.proof_bytes;
+            if (stage_verifier_inputs(c, count, src, pk + (size_t)first * P.pk_bytes, span.covers(src, (size_t)count * P.proof_bytes))) return -1;
+            return verify_into(ctx, c, first, count, ok, 0, nullptr);
+        });
+    } catch (...) {
+        (void)unlock_span(ctx, span);
+        throw;
+    }
+    if (unlock_span(ctx, span) && !rc) rc = -1;
+    if (!rc) ctx->masks_n = n;
     return rc;
+    GUARD_END
 }
 
 // ---- second-level entry points (kosk_split.cpp) -----------------------------------------------------------
@@ -346,6 +458,7 @@ size_t kosk_mlwe_inst_bytes(int k) { Params p; return make_params(k, p) ? mlwe_i
 int kosk_prepare_randomness(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *rand_out)
 {
     if (!ctx || n < 0 || !rand_out) return bad_args(ctx, __func__);
+    GUARD(ctx)
     Ctx &c = *ctx->c;
     ctx->clear_err();
     for (int done = 0; done < n;) {
@@ -355,10 +468,12 @@ int kosk_prepare_randomness(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t t
         done += m;
     }
     return 0;
+    GUARD_END
 }
 int kosk_prepare_range_proof(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *range_out)
 {
     if (!ctx || n < 0 || !range_out) return bad_args(ctx, __func__);
+    GUARD(ctx)
     Ctx &c = *ctx->c;
     ctx->clear_err();
     for (int done = 0; done < n;) {
@@ -368,11 +483,13 @@ int kosk_prepare_range_proof(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t 
         done += m;
     }
     return 0;
+    GUARD_END
 }
 int kosk_prove_prepared(kosk_ctx *ctx, int n, const uint8_t *inst, const uint8_t *rand_in, const uint8_t *range_in,
                         const uint8_t *tapes, size_t tape_stride, uint8_t *pi)
 {
     if (!ctx || n < 0 || !inst || !rand_in || !range_in || !pi) return bad_args(ctx, __func__);
+    GUARD(ctx)
     Ctx &c = *ctx->c;
     ctx->clear_err();
     for (int done = 0; done < n;) {
@@ -383,21 +500,24 @@ int kosk_prove_prepared(kosk_ctx *ctx, int n, const uint8_t *inst, const uint8_t
         done += m;
     }
     return 0;
+    GUARD_END
 }
 int kosk_verify_inst(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *inst, uint8_t *ok)
 {
     if (!ctx || n < 0 || !pi || !inst || !ok) return bad_args(ctx, __func__);
+    GUARD(ctx)
     Ctx &c = *ctx->c;
     ctx->clear_err();
+    reset_masks(ctx, n);
     for (int done = 0; done < n;) {
         const int m = (n - done) < c.max_batch ? (n - done) : c.max_batch;
         if (stage_verifier_inst(c, m, pi + (size_t)done * c.P.proof_bytes, inst + (size_t)done * mlwe_inst_bytes(c.P))) return -1;
-        if (verify_resident(c, m, ok + done)) return -1;
-        if (ctx->masks.size() < (size_t)n) ctx->masks.resize((size_t)n, 0);
-        memcpy(ctx->masks.data() + done, c.h_fail, sizeof(uint32_t) * (size_t)m);
+        if (verify_into(ctx, c, done, m, ok, 0, nullptr)) return -1;
         done += m;
     }
+    ctx->masks_n = n;
     return 0;
+    GUARD_END
 }
 
 // ---- compact wire format (kosk_compact.hip) ------------------------------------------------------------------
@@ -406,41 +526,60 @@ int kosk_proof_compress(int k, const uint8_t *pi, uint8_t *out)
 {
     Params p;
     if (!make_params(k, p) || !pi || !out) return -1;
+    return guard(static_cast<const kosk_ctx *>(nullptr), __func__, [&]() -> int {
     return compact_encode(p, pi, out);
+    GUARD_END
 }
 int kosk_proof_decompress(int k, const uint8_t *in, uint8_t *pi)
 {
     Params p;
     if (!make_params(k, p) || !pi || !in) return -1;
+    return guard(static_cast<const kosk_ctx *>(nullptr), __func__, [&]() -> int {
     compact_decode(p, in, pi);
     return 0;
+    GUARD_END
 }
 int kosk_fetch_proofs_compact(kosk_ctx *ctx, int n, uint8_t *out)
 {
     if (!ctx || n < 0 || n > ctx->max_batch || !out) return bad_args(ctx, __func__);
+    GUARD(ctx)
     const size_t cb = make_compact_plan(ctx->c->P).bytes;
     return ctx->run(n, [&](Ctx &c, int first, int count) { return fetch_proofs_compact(c, count, out + (size_t)first * cb); });
+    GUARD_END
 }
 int kosk_stage_verifier_inputs_compact(kosk_ctx *ctx, int n, const uint8_t *in, const uint8_t *pk)
 {
     if (!ctx || n < 0 || n > ctx->max_batch || !in || !pk) return bad_args(ctx, __func__);
+    GUARD(ctx)
     const Params &P = ctx->c->P;
     const size_t cb = make_compact_plan(P).bytes;
     return ctx->run(n, [&](Ctx &c, int first, int count) {
         return stage_verifier_inputs_compact(c, count, in + (size_t)first * cb, pk + (size_t)first * P.pk_bytes);
     });
+    GUARD_END
 }
 
 int kosk_verify_fail_masks(const kosk_ctx *ctx, uint32_t *masks, int n)
 {
-    if (!ctx || !masks || n < 0 || (size_t)n > ctx->masks.size()) return bad_args(ctx, __func__);
+    // only the masks of the LAST verify call, and only if it completed: never stale entries of an earlier, larger batch
+    if (!ctx || !masks || n < 0 || n > ctx->masks_n) return bad_args(ctx, __func__);
     memcpy(masks, ctx->masks.data(), sizeof(uint32_t) * (size_t)n);
     return 0;
 }
 
+int kosk_path_count(const kosk_ctx *ctx, int id, long *count)
+{
+    if (!ctx || id < 0 || id >= PATH_COUNT || !count) return bad_args(ctx, __func__);
+    long v = 0;
+    for (const Ctx *c : ctx->sub) v += c->path_n[id];
+    *count = v;
+    return 0;
+}
+int kosk_host_threads(const kosk_ctx *ctx) { return ctx ? ctx->c->nthreads : -1; }
+
 int kosk_phase_seconds(const kosk_ctx *ctx, double *out, int n)
 {
-    if (!ctx) return -1;
+    if (!ctx || !out) return -1;
     for (int i = 0; i < n && i < PH_COUNT; i++) out[i] = ctx->c->phase_sec[i];
     return 0;
 }
@@ -448,12 +587,14 @@ int kosk_phase_seconds(const kosk_ctx *ctx, double *out, int n)
 int kosk_profile_enable(kosk_ctx *ctx, int on)
 {
     if (!ctx) return -1;
+    GUARD(ctx)
     for (Ctx *cp : ctx->sub) {
         Ctx &c = *cp;
         c.prof_on = on < 0 ? 0 : (on > 2 ? 2 : on);
         for (int i = 0; i < PR_COUNT; i++) { c.prof_ms[i] = 0; c.prof_n[i] = 0; c.prof_used[i] = false; }
     }
     return 0;
+    GUARD_END
 }
 int kosk_profile_read(const kosk_ctx *ctx, int id, double *total_ms, long *launches)
 {
@@ -469,16 +610,19 @@ int kosk_profile_read(const kosk_ctx *ctx, int id, double *total_ms, long *launc
 int kosk_stream_timer_start(kosk_ctx *ctx)
 {
     if (!ctx) return -1;
+    GUARD(ctx)
     Ctx &c = *ctx->c;
     ctx->clear_err();
     HIPCHK_C(hipSetDevice(c.device));
     if (!c.timer_ev[0]) { HIPCHK_C(hipEventCreate(&c.timer_ev[0])); HIPCHK_C(hipEventCreate(&c.timer_ev[1])); }
     HIPCHK_C(hipEventRecord(c.timer_ev[0], c.stream));
     return 0;
+    GUARD_END
 }
 int kosk_stream_timer_stop(kosk_ctx *ctx, double *ms)
 {
     if (!ctx || !ctx->c->timer_ev[0]) return bad_args(ctx, __func__);
+    GUARD(ctx)
     Ctx &c = *ctx->c;
     ctx->clear_err();
     HIPCHK_C(hipSetDevice(c.device));
@@ -488,11 +632,13 @@ int kosk_stream_timer_stop(kosk_ctx *ctx, double *ms)
     HIPCHK_C(hipEventElapsedTime(&f, c.timer_ev[0], c.timer_ev[1]));
     if (ms) *ms = f;
     return 0;
+    GUARD_END
 }
 
 int kosk_device_synchronize(kosk_ctx *ctx)
 {
     if (!ctx) return -1;
+    GUARD(ctx)
     ctx->clear_err();
     for (Ctx *cp : ctx->sub) {
         Ctx &c = *cp;
@@ -500,6 +646,7 @@ int kosk_device_synchronize(kosk_ctx *ctx)
         HIPCHK_C(hipStreamSynchronize(c.stream));
     }
     return 0;
+    GUARD_END
 }
 int kosk_commit_launch_groups(const kosk_ctx *ctx, int n, int *main_groups)
 {
@@ -512,10 +659,12 @@ int kosk_streams(const kosk_ctx *ctx) { return ctx ? (int)ctx->sub.size() : -1; 
 int kosk_resident_proofs(kosk_ctx *ctx, void **d_proofs, size_t *stride)
 {
     if (!ctx) return -1;
+    GUARD(ctx)
     if (ctx->sub.size() > 1) { ctx->err = "kosk_resident_proofs needs KOSK_STREAMS=1 (sub-batches keep separate images)"; return -1; }
     if (d_proofs) *d_proofs = ctx->c->d_proof;
     if (stride) *stride = ctx->c->image_stride;
     return 0;
+    GUARD_END
 }
 
 // ---- kernel-level entry points -------------------------------------------------
@@ -523,26 +672,31 @@ int kosk_resident_proofs(kosk_ctx *ctx, void **d_proofs, size_t *stride)
 int kosk_sha3_256_batch(kosk_ctx *ctx, const uint8_t *d_in, size_t in_stride, size_t inlen, uint8_t *d_out, int n)
 {
     if (!ctx) return -1;
+    GUARD(ctx)
     Ctx &c = *ctx->c;
     ctx->clear_err();
     HIPCHK_C(hipSetDevice(c.device));
     HIPCHK_C(launch_sha3_msgs(d_in, in_stride, (int)inlen, d_out, 32, 32, n, 0x06, c.stream));
     return 0;
+    GUARD_END
 }
 int kosk_shake256_batch(kosk_ctx *ctx, const uint8_t *d_in, size_t in_stride, size_t inlen, uint8_t *d_out, size_t outlen, int n)
 {
     if (!ctx) return -1;
+    GUARD(ctx)
     Ctx &c = *ctx->c;
     ctx->clear_err();
     HIPCHK_C(hipSetDevice(c.device));
     HIPCHK_C(launch_sha3_msgs(d_in, in_stride, (int)inlen, d_out, outlen, (int)outlen, n, 0x1F, c.stream));
     return 0;
+    GUARD_END
 }
 
 int kosk_commit_hash_lanes(kosk_ctx *ctx, const uint16_t *d_rows, size_t row_stride, int n_lanes,
                            const uint8_t *d_prefix, int with_prefix, uint8_t *d_out)
 {
     if (!ctx) return -1;
+    GUARD(ctx)
     Ctx &c = *ctx->c;
     ctx->clear_err();
     HIPCHK_C(hipSetDevice(c.device));
@@ -556,13 +710,18 @@ int kosk_commit_hash_lanes(kosk_ctx *ctx, const uint16_t *d_rows, size_t row_str
     ha.prefix = d_prefix;
     ha.out = d_out;
     ha.out_lanes_per_group = n_lanes;
-    HIPCHK_C(launch_commit_hash(ha, 1, c.P.K, with_prefix != 0, c.stream));
+    int variant = 0;
+    HIPCHK_C(launch_commit_hash(ha, 1, c.P.K, with_prefix != 0, c.stream, c.hash_opts(), &variant));
+    c.path_n[(variant & 1) ? PATH_HASH_DMA : PATH_HASH_PLAIN]++;
+    if (variant & 2) c.path_n[PATH_HASH_PRIMER]++;
     return 0;
+    GUARD_END
 }
 
 int kosk_ntt256_batch(kosk_ctx *ctx, const int16_t *d_in, int16_t *d_out, int n)
 {
     if (!ctx) return -1;
+    GUARD(ctx)
     Ctx &c = *ctx->c;
     ctx->clear_err();
     HIPCHK_C(hipSetDevice(c.device));
@@ -573,12 +732,15 @@ int kosk_ntt256_batch(kosk_ctx *ctx, const int16_t *d_in, int16_t *d_out, int n)
     na.npoly = n;
     na.out_canonical = 0; na.fp32 = c.ntt_fp32;
     HIPCHK_C(launch_ntt(na, c.stream));
+    c.path_n[c.ntt_fp32 ? PATH_NTT_FP32 : PATH_NTT_INT]++;
     return 0;
+    GUARD_END
 }
 
 int kosk_lagrange_expand(kosk_ctx *ctx, const uint16_t *d_y407, uint16_t *d_shares, int n)
 {
     if (!ctx) return -1;
+    GUARD(ctx)
     Ctx &c = *ctx->c;
     ctx->clear_err();
     HIPCHK_C(hipSetDevice(c.device));
@@ -594,11 +756,13 @@ int kosk_lagrange_expand(kosk_ctx *ctx, const uint16_t *d_y407, uint16_t *d_shar
         done += m;
     }
     return 0;
+    GUARD_END
 }
 
 int kosk_recon_secrets(kosk_ctx *ctx, const uint16_t *d_shares, uint16_t *d_secrets, int n, int two_d)
 {
     if (!ctx) return -1;
+    GUARD(ctx)
     Ctx &c = *ctx->c;
     ctx->clear_err();
     HIPCHK_C(hipSetDevice(c.device));
@@ -615,6 +779,7 @@ int kosk_recon_secrets(kosk_ctx *ctx, const uint16_t *d_shares, uint16_t *d_secr
         done += m;
     }
     return 0;
+    GUARD_END
 }
 
 // ---- host-only entry points -----------------------------------------------------
@@ -623,29 +788,35 @@ int kosk_keygen(int kyber_k, const uint8_t seed64[64], uint8_t *pk, uint8_t *sk,
 {
     Params P;
     if (!make_params(kyber_k, P) || !seed64 || !pk || !sk) return -1;
-    HostKey *key = new HostKey();
+    return guard(static_cast<const kosk_ctx *>(nullptr), __func__, [&]() -> int {
+    std::unique_ptr<HostKey> key(new HostKey());
     host_keygen(P, seed64, pk, sk, *key);
     const int K = P.K;
     if (A) memcpy(A, key->A, sizeof(int16_t) * K * K * 256);
     if (s) memcpy(s, key->se, sizeof(int16_t) * K * 256);
     if (e) memcpy(e, key->se + K * 256, sizeof(int16_t) * K * 256);
     if (t) memcpy(t, key->t, sizeof(int16_t) * K * 256);
-    delete key;
     return 0;
+    GUARD_END
 }
 
 int kosk_fs_alpha(int kyber_k, const uint8_t *tcomm_all, uint16_t *alpha)
 {
     Params P;
-    if (!make_params(kyber_k, P)) return -1;
+    if (!make_params(kyber_k, P) || !tcomm_all || !alpha) return -1;
+    return guard(static_cast<const kosk_ctx *>(nullptr), __func__, [&]() -> int {
     fs_alpha(P, tcomm_all, alpha);
     return 0;
+    GUARD_END
 }
 
 int kosk_fs_opened(const uint8_t *digests_all, uint16_t *I, uint16_t *rest)
 {
+    if (!digests_all || !I || !rest) return -1;
+    return guard(static_cast<const kosk_ctx *>(nullptr), __func__, [&]() -> int {
     fs_opened(digests_all, I, rest);
     return 0;
+    GUARD_END
 }
 
 void kosk_host_sha3_256(uint8_t out[32], const uint8_t *in, size_t inlen) { sha3_256(out, in, inlen); }
@@ -654,12 +825,8 @@ void kosk_host_shake256(uint8_t *out, size_t outlen, const uint8_t *in, size_t i
 int kosk_host_sha3_256_multi(uint8_t *out, const uint8_t *in, size_t in_stride, size_t inlen, int count, int nthreads)
 {
     // same code path as the batched Fiat-Shamir rounds: SIMD groups spread over the pool
-    if (inlen == (size_t)NPARTY * 32) {
-        Params P;
-        make_params(2, P);
-        std::vector<uint16_t> I((size_t)count * 1312), rest((size_t)count * 1312);
-        (void)P;
-    }
+    if (!out || !in || count < 0) return -1;
+    return guard(static_cast<const kosk_ctx *>(nullptr), __func__, [&]() -> int {
     std::vector<const uint8_t *> ptr(count);
     for (int i = 0; i < count; i++) ptr[i] = in + (size_t)i * in_stride;
     const int w = sha3_multi_width();
@@ -670,10 +837,13 @@ int kosk_host_sha3_256_multi(uint8_t *out, const uint8_t *in, size_t in_stride, 
         sha3_256_multi(out + 32 * (size_t)lo, ptr.data() + lo, inlen, n);
     });
     return w;
+    GUARD_END
 }
 
 int kosk_lagrange_table(int which, uint16_t *out)
 {
+    if (!out) return -1;
+    return guard(static_cast<const kosk_ctx *>(nullptr), __func__, [&]() -> int {
     if (which == 0) {
         for (int x = 0; x < NPARTY - NOPEN - 1; x++) lagrange_row(out + (size_t)x * XLEN, XLEN, 0, XLEN + x);
     } else if (which == 1) {
@@ -684,6 +854,7 @@ int kosk_lagrange_table(int which, uint16_t *out)
         return -1;
     }
     return 0;
+    GUARD_END
 }
 
 } // extern "C"

@@ -187,6 +187,7 @@ int stage_verifier_inputs_compact(Ctx &c, int n, const uint8_t *in, const uint8_
         memcpy(c.h_compact + (size_t)b * c.compact_stride, in + (size_t)b * c.cplan.bytes, c.cplan.bytes);
     });
     HIPCHK(hipMemcpyAsync(c.d_pk, c.h_pk, (size_t)n * c.pk_stride, hipMemcpyHostToDevice, c.stream));
+    c.resident_pk_n = n;
     HIPCHK(hipMemcpyAsync(c.d_compact, c.h_compact, (size_t)n * c.compact_stride, hipMemcpyHostToDevice, c.stream));
     hipLaunchKernelGGL(k_unpack_proofs, dim3(16, NFIELDS, n), dim3(256), 0, c.stream, c.d_compact, c.compact_stride, c.d_proof, c.image_stride, c.cplan);
     HIPCHK(hipGetLastError());

@@ -119,7 +119,14 @@ static hipError_t commit_hash_batch(Ctx &c, const HashArgs &ha, int n, int K, bo
 {
     const int n_main = commit_hash_groups(c, n);
     c.prof_begin(view ? PR_HASH_VIEW : PR_HASH_TCOMM);
-    hipError_t e = launch_commit_hash(ha, n_main, K, view, st);
+    int variant = 0;
+    auto count = [&]() {
+        if (c.capturing) return; // a captured launch runs at replay time (PATH_GRAPH_REPLAY counts those)
+        c.path_n[(variant & 1) ? PATH_HASH_DMA : PATH_HASH_PLAIN]++;
+        if (variant & 2) c.path_n[PATH_HASH_PRIMER]++;
+    };
+    hipError_t e = launch_commit_hash(ha, n_main, K, view, st, c.hash_opts(), &variant);
+    count();
     c.prof_end(view ? PR_HASH_VIEW : PR_HASH_TCOMM);
     if (e != hipSuccess || n_main == n) return e;
     HashArgs t = ha;
@@ -128,7 +135,8 @@ static hipError_t commit_hash_batch(Ctx &c, const HashArgs &ha, int n, int K, bo
     t.out += (size_t)n_main * ha.out_lanes_per_group * 32;
     if (t.lane_map) t.lane_map += (size_t)n_main * ha.lane_map_stride;
     c.prof_begin(view ? PR_HASH_VIEW_TAIL : PR_HASH_TCOMM_TAIL);
-    e = launch_commit_hash(t, n - n_main, K, view, st);
+    e = launch_commit_hash(t, n - n_main, K, view, st, c.hash_opts(), &variant);
+    count();
     c.prof_end(view ? PR_HASH_VIEW_TAIL : PR_HASH_TCOMM_TAIL);
     return e;
 }
@@ -154,8 +162,9 @@ int gemm_modq(Ctx &c, const uint8_t *A, size_t a_gstride, int Mpad, int M, int K
         GemmArgs ta = ga;
         ta.B = nullptr; ta.BRT = 0;
         ta.src = s.src; ta.src_gstride = s.gstride; ta.src_rows = s.rows; ta.src_rstride = s.rstride; ta.src_koff = s.koff;
-        if (table_gemm_usable(ta)) {
+        if (c.table_gemm && table_gemm_usable(ta)) {
             HIPCHK(launch_table_gemm(ta, reinterpret_cast<uint16_t *>(c.d_limbs), c.stream));
+            if (!c.capturing) c.path_n[PATH_TABLE_GEMM]++;
             return 0;
         }
     }
@@ -174,6 +183,7 @@ int gemm_modq(Ctx &c, const uint8_t *A, size_t a_gstride, int Mpad, int M, int K
         ga.src = s.src; ga.src_gstride = s.gstride; ga.src_rows = s.rows; ga.src_rstride = s.rstride; ga.src_koff = s.koff;
     }
     HIPCHK(launch_gemm(ga, c.stream));
+    if (!c.capturing) c.path_n[PATH_LIMB_GEMM]++;
     return 0;
 }
 
@@ -288,7 +298,7 @@ static int build_tables(Ctx &c)
     return 0;
 }
 
-int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &err)
+int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &err, int host_share)
 {
     Ctx *cp = new Ctx();
     Ctx &c = *cp;
@@ -303,15 +313,22 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     c.device = device;
     c.max_batch = max_batch;
     c.rm = make_rowmap(c.P);
+    // host threads per context: at most 8, and never more than this process's CPUs (sched_getaffinity) divided by the
+    // sub-contexts of the handle; the workers exist before the first call (no thread is ever created inside a batch call)
+    const int cpus = host_cpu_count() / (host_share > 0 ? host_share : 1);
+    c.nthreads = cpus > 8 ? 8 : (cpus < 1 ? 1 : cpus);
+    if (const char *e = getenv("KOSK_HOST_THREADS")) c.nthreads = atoi(e) > 0 ? (atoi(e) > 64 ? 64 : atoi(e)) : c.nthreads;
     c.pool = pool_create();
-    unsigned hc = std::thread::hardware_concurrency();
-    c.nthreads = hc ? (int)(hc > 8 ? 8 : hc) : 1; // per context; several contexts (pipeline slots) share the host
-    if (const char *e = getenv("KOSK_HOST_THREADS")) c.nthreads = atoi(e) > 0 ? atoi(e) : c.nthreads;
+    c.nthreads = pool_reserve(c.pool, c.nthreads);
     if (const char *e = getenv("KOSK_GRAPHS")) c.use_graphs = atoi(e) != 0;
     if (const char *e = getenv("KOSK_LINCOMB_FUSED")) c.lincomb_fused = atoi(e) != 0;
     if (const char *e = getenv("KOSK_NTT_FP32")) c.ntt_fp32 = atoi(e) != 0;
     if (const char *e = getenv("KOSK_BLOCKING_SYNC")) c.blocking_sync = atoi(e) != 0;
     if (const char *e = getenv("KOSK_HASH_SPLIT")) c.hash_split = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_HASH_DMA")) c.hash_dma = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_HASH_PRIMER")) c.hash_primer = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_TABLE_GEMM")) c.table_gemm = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_REGISTER")) c.host_register = atoi(e) != 0;
 
     auto body = [&]() -> int {
         HIPCHK(hipSetDevice(device));
@@ -442,6 +459,7 @@ int issue_keygen(Ctx &c, int n, bool sampled)
     HIPCHK(launch_keygen_pack(c.d_A, c.key_stride, c.d_sehat, c.se_stride, c.d_seeds, c.kg_rec, c.d_t, c.d_pk, c.pk_stride, c.d_sb,
                               c.sb_stride, K, n, c.stream));
     HIPCHK(hipMemcpyAsync(c.h_kg, c.d_kg, (size_t)n * c.kg_rec, hipMemcpyDeviceToHost, c.stream)); // pk, NTT(s) bytes, seeds: one copy
+    c.resident_pk_n = n;
     return 0;
 }
 
@@ -503,6 +521,7 @@ int issue_sharing_front(Ctx &c, int n, FrontPart part, bool with_keygen)
         na.out_canonical = 1; na.fp32 = c.ntt_fp32;
         c.prof_begin(PR_NTT_F);
         HIPCHK(launch_ntt(na, st));
+        if (!c.capturing) c.path_n[c.ntt_fp32 ? PATH_NTT_FP32 : PATH_NTT_INT]++;
         c.prof_end(PR_NTT_F);
     }
     if (matvec) HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_P, c.proof_stride, rm.shat, rm.nttas, K, n, st)); // :284-285
@@ -547,7 +566,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         HIPCHK(commit_hash_batch(c, h1, n, K, false, st));
         HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig1, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
         return 0;
-    })) return -1;
+    }, c.tape_cur, c.tape_cur_stride)) return -1; // the tape pointer is baked into the captured launch: part of the graph's key
     HIPCHK(hipEventRecord(c.ev, st)); // the Tcomm digests are on the host once this event has passed
     c.phase_sec[PH_P1_ISSUE] = now_sec() - t0;
 
@@ -583,6 +602,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
             ga.C = c.d_P; ga.c_gstride = c.proof_stride; ga.c_rows = c.d_lin_rows; ga.c_rstride = RS; ga.c_off = 0;
             ga.npg = P.J; ga.npg_pad = 128; ga.ngroups = 2 * n; ga.grouped = 1; ga.c_gdiv = 2; ga.c_rows_gstride = 128;
             HIPCHK(launch_gemm(ga, st));
+            if (!c.capturing) c.path_n[PATH_LIMB_GEMM]++;
         }
         c.prof_end(PR_LINCOMB);
         if (!c.lincomb_fused) HIPCHK(launch_post_open(c.d_P, c.proof_stride, rm, n, st));
@@ -672,7 +692,9 @@ int fetch_proofs(Ctx &c, int n, uint8_t *pi, bool registered)
         // the caller's buffer is page-locked for the duration of the call (kosk_capi.cpp): the images go straight there
         HIPCHK(hipMemcpy2DAsync(pi, c.P.proof_bytes, c.d_proof, c.image_stride, c.P.proof_bytes, n, hipMemcpyDeviceToHost, c.stream));
         HIPCHK(stream_sync(c));
+        c.path_n[PATH_COPY_DIRECT]++;
     } else {
+        c.path_n[PATH_COPY_STAGED]++;
         HIPCHK(hipMemcpyAsync(c.h_proof, c.d_proof, (size_t)n * c.image_stride, hipMemcpyDeviceToHost, c.stream));
         HIPCHK(stream_sync(c));
         parallel_for(c.pool, n, c.nthreads, [&](int b) { memcpy(pi + (size_t)b * c.P.proof_bytes, c.h_proof + (size_t)b * c.image_stride, c.P.proof_bytes); });

@@ -35,6 +35,9 @@ enum ProfId { PR_HASH_TCOMM = 0, PR_HASH_VIEW, PR_GEMM_EXPAND1, PR_GEMM_EXPAND2,
               PR_V_HASH_TCOMM, PR_V_HASH_VIEW, PR_V_INTERP_BUILD, PR_V_GEMM_INTERP, PR_V_GEMM_EXPAND, PR_V_GEMM_RECON,
               PR_V_LINCOMB, PR_HASH_TCOMM_TAIL, PR_HASH_VIEW_TAIL, PR_COUNT };
 
+enum PathId { PATH_HASH_DMA = 0, PATH_HASH_PLAIN, PATH_HASH_PRIMER, PATH_TABLE_GEMM, PATH_LIMB_GEMM, PATH_COPY_DIRECT, PATH_COPY_STAGED,
+              PATH_GRAPH_REPLAY, PATH_NTT_FP32, PATH_NTT_INT, PATH_COUNT };
+
 struct GemmTable {
     uint8_t *d = nullptr; // limb matrix (kosk_device.hpp)
     uint8_t *dfrag = nullptr; // the same in fragment-linear tile order (k_table_gemm), tables with Kdim <= 448 only
@@ -112,6 +115,7 @@ struct Ctx {
     size_t kg_rec = 0, sb_bytes = 0;
     uint8_t *d_seeds = nullptr, *d_pk = nullptr, *d_sb = nullptr; // sha3_512 output, packed pk, packed NTT(s)
     int16_t *d_sehat = nullptr;
+    int resident_pk_n = 0; // pk records valid in d_pk (written by the key generation or a verifier staging call): pk_mode 2 needs >= n
     size_t pk_stride = 0, sb_stride = 0;
     uint8_t *h_seeds = nullptr, *h_pk = nullptr, *h_sb = nullptr;
     uint16_t *d_t = nullptr; // pk's t, canonical (verifier)
@@ -165,12 +169,23 @@ struct Ctx {
     struct SegGraph {
         hipGraphExec_t exec = nullptr;
         int n = 0;
+        // caller-owned pointers baked into the captured launches (SEG_P1: the tape buffer read in place): part of the cache key
+        const void *key_ptr = nullptr;
+        size_t key_stride = 0;
     };
     SegGraph seg[SEG_COUNT];
     bool use_graphs = false; // KOSK_GRAPHS=1 turns them on (measured on ROCm 7.2: no gain over plain launches)
     bool capturing = false;
     int ntt_fp32 = 0; // KOSK_NTT_FP32=1: packed-fp32 NTT kernel (see its HAZARD note in kosk_kernels.hip); default integer
     bool lincomb_fused = true; // KOSK_LINCOMB_FUSED=0: separate transposition pass + generic GEMM
+    // kernel / copy path choices, read from the environment when the context is created (per handle, never per process)
+    bool hash_dma = true;      // KOSK_HASH_DMA=0: commitment hashes without the LDS-DMA staging (k_commit_hash)
+    bool hash_primer = false;  // KOSK_HASH_PRIMER=1: placement primer in front of a commitment launch (k_hash_primer)
+    bool table_gemm = true;    // KOSK_TABLE_GEMM=0: shared-table products through the generic limb GEMM
+    bool host_register = true; // KOSK_REGISTER=0: multi-chunk host-buffer calls never page-lock caller memory (staging copies only)
+    unsigned hash_opts() const { return (hash_dma ? HASH_OPT_DMA : 0u) | (hash_primer ? HASH_OPT_PRIMER : 0u); }
+    // which of those paths really ran on this context (kosk_path_count): the tests of the knobs assert on these
+    long path_n[PATH_COUNT] = {0};
 
     double phase_sec[PH_COUNT] = {0};
     int prof_on = 0; // 1: the graded kernel only (graphs stay on); 2: every profiled id (plain launches)
@@ -188,11 +203,11 @@ struct Ctx {
 // Run `body` (stream launches on c.stream only: kernels, pinned-memory copies, memsets) as segment `seg`:
 // captured into a graph on first use for this batch size, replayed afterwards.
 template <class F>
-int run_segment(Ctx &c, int seg, int n, F &&body)
+int run_segment(Ctx &c, int seg, int n, F &&body, const void *key_ptr = nullptr, size_t key_stride = 0)
 {
     if (seg < 0 || !c.use_graphs || c.prof_on == 2) return body();
     Ctx::SegGraph &g = c.seg[seg];
-    if (g.exec && g.n != n) {
+    if (g.exec && (g.n != n || g.key_ptr != key_ptr || g.key_stride != key_stride)) {
         (void)hipGraphExecDestroy(g.exec);
         g.exec = nullptr;
     }
@@ -213,13 +228,17 @@ int run_segment(Ctx &c, int seg, int n, F &&body)
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) { g.exec = nullptr; c.err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e); return -1; }
         g.n = n;
+        g.key_ptr = key_ptr;
+        g.key_stride = key_stride;
     }
     const hipError_t e = hipGraphLaunch(g.exec, c.stream);
     if (e != hipSuccess) { c.err = std::string("hipGraphLaunch: ") + hipGetErrorString(e); return -1; }
+    c.path_n[PATH_GRAPH_REPLAY]++;
     return 0;
 }
 
-int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &err);
+// host_share: sub-contexts of the same handle that share this process's CPUs (divides the host thread budget)
+int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &err, int host_share = 1);
 
 // C[g][rows_d[i]][off + m] = sum_k A[m][k] * src[g][rows_s[i]][koff + k] mod q  (conversion to limbs + MFMA GEMM)
 // host wait for everything queued on the context's stream (spinning, or sleeping with KOSK_BLOCKING_SYNC=1)

@@ -236,7 +236,11 @@ hipError_t launch_keygen_pack(const int16_t *A, size_t A_stride, const int16_t *
                               hipStream_t st);
 hipError_t launch_decode_pk(const uint8_t *pk, size_t pk_stride, uint16_t *t_out, int16_t *A, size_t A_stride, int K, int n, hipStream_t st);
 
-hipError_t launch_commit_hash(const HashArgs &a, int ngroups, int K, bool view, hipStream_t st);
+// opts: HASH_OPT_DMA = LDS-DMA staged kernel where the layout allows it (KOSK_HASH_DMA, default on), HASH_OPT_PRIMER = placement
+// primer launch in front (KOSK_HASH_PRIMER, default off); *variant: bit 0 the DMA kernel ran, bit 1 the primer was launched
+enum : unsigned { HASH_OPT_DMA = 1u, HASH_OPT_PRIMER = 2u };
+hipError_t launch_commit_hash(const HashArgs &a, int ngroups, int K, bool view, hipStream_t st, unsigned opts = HASH_OPT_DMA,
+                              int *variant = nullptr);
 hipError_t launch_sha3_msgs(const uint8_t *in, size_t in_stride, int len, uint8_t *out, size_t out_stride,
                             int outlen, int n, int domain, hipStream_t st);
 hipError_t launch_rows_copy(const uint16_t *src, size_t src_stride, uint16_t *dst, size_t dst_stride, int count,

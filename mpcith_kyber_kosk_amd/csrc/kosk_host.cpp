@@ -1,6 +1,7 @@
 // Host-side crypto and helpers of the product path (see kosk_host.hpp).
 #include "kosk_host.hpp"
 
+#include <sched.h>
 #include <sys/random.h>
 #include <unistd.h>
 
@@ -9,6 +10,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <stdexcept>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -532,6 +534,7 @@ public:
         cur_.store(nullptr);
         // a worker may still hold &job between its pick-up and its first (failing) index fetch
         while (inside_.load() != 0) __builtin_ia32_pause();
+        if (job.failed.load()) throw std::runtime_error("exception in a host worker job");
     }
 
 private:
@@ -539,14 +542,22 @@ private:
         const std::function<void(int)> *fn;
         int n, want;
         std::atomic<int> next{0}, done{0};
+        std::atomic<bool> failed{false};
         Job(const std::function<void(int)> *f, int n_, int w) : fn(f), n(n_), want(w) {}
     };
-    void grow(int want)
+    // Workers are created up front (pool_create) and on demand; a failed thread creation (pid / thread limit, no memory) is
+    // not an error: the job's indices are claimed dynamically, so the pool simply runs on the threads it has (the caller
+    // always works too).  Nothing here may throw across run(): the C ABI above must never terminate its caller.
+    void grow(int want) noexcept
     {
-        while ((int)th_.size() < want && th_.size() < 255) {
+        while ((int)th_.size() < want && th_.size() < 255 && !grow_failed_) {
             const int id = (int)th_.size();
             const uint64_t g = gen_.load(); // never pick up a job published before we existed
-            th_.emplace_back([this, id, g] { loop(id, g); });
+            try {
+                th_.emplace_back([this, id, g] { loop(id, g); });
+            } catch (...) {
+                grow_failed_ = true;
+            }
         }
     }
     static void work(Job &j)
@@ -554,7 +565,11 @@ private:
         for (;;) {
             const int i = j.next.fetch_add(1, std::memory_order_relaxed);
             if (i >= j.n) break;
-            (*j.fn)(i);
+            try {
+                (*j.fn)(i);
+            } catch (...) {
+                j.failed.store(true, std::memory_order_relaxed); // rethrown by run() on the calling thread once the job is over
+            }
             j.done.fetch_add(1, std::memory_order_release);
         }
     }
@@ -593,9 +608,31 @@ private:
     std::atomic<int> inside_{0};
     std::atomic<Job *> cur_{nullptr};
     std::atomic<bool> stop_{false};
+    bool grow_failed_ = false;
+
+public:
+    int reserve(int nthreads) noexcept
+    {
+        std::lock_guard<std::mutex> job_lock(job_mu_);
+        grow(nthreads - 1);
+        return (int)th_.size() + 1;
+    }
 };
 
 Pool *pool_create() { return new Pool(); }
+int pool_reserve(Pool *p, int nthreads) { return p ? p->reserve(nthreads) : 1; }
+
+int host_cpu_count()
+{
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+        const int n = CPU_COUNT(&set);
+        if (n > 0) return n;
+    }
+    const long n = sysconf(_SC_NPROCESSORS_ONLN);
+    return n > 0 ? (int)n : 1;
+}
 void pool_destroy(Pool *p) { delete p; }
 
 void parallel_for(Pool *pool, int n, int nthreads, const std::function<void(int)> &fn)

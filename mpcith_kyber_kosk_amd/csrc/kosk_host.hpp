@@ -50,6 +50,11 @@ void pack_frag_table(const std::vector<uint16_t> &A, int M, int Kdim, int Mpad, 
 class Pool;
 Pool *pool_create();
 void pool_destroy(Pool *);
+// create the workers for jobs of up to `nthreads` threads now; returns the threads such a job will really run on (>= 1:
+// thread creation may fail under a pid / thread limit, the pool then works with what it has)
+int pool_reserve(Pool *, int nthreads);
+// CPUs this process may run on (sched_getaffinity), the cap for every host thread count in the library
+int host_cpu_count();
 // run fn(i) for i in [0,n) on up to nthreads threads of `pool` (nullptr: a process-wide default pool)
 void parallel_for(Pool *pool, int n, int nthreads, const std::function<void(int)> &fn);
 inline void parallel_for(int n, int nthreads, const std::function<void(int)> &fn) { parallel_for(nullptr, n, nthreads, fn); }

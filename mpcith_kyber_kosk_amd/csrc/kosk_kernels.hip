@@ -1562,49 +1562,46 @@ __global__ __launch_bounds__(256) void k_rows_copy(const uint16_t *__restrict__ 
 // =========================================================================
 // host-side launchers
 // =========================================================================
-static bool hash_dma_enabled()
-{
-    static const bool on = !(getenv("KOSK_HASH_DMA") && atoi(getenv("KOSK_HASH_DMA")) == 0);
-    return on;
-}
-
 template <int PW, int NR>
-static void launch_hash_t(const HashArgs &a, int ngroups, hipStream_t st)
+static int launch_hash_t(const HashArgs &a, int ngroups, hipStream_t st, unsigned opts)
 {
     dim3 grid((a.lanes_per_group + 63) / 64, ngroups);
     const long waves = (long)grid.x * grid.y;
     // LDS-DMA staging needs 16-byte aligned 128-byte row segments per wave and readable row padding up to the last
     // wave's 64th lane (true for the row matrix: RS = 1728 = 256 + 23 * 64)
-    const bool dma_ok = hash_dma_enabled() && !a.lane_map && a.row_stride % 8 == 0 && a.group_stride % 8 == 0 && a.col_off % 8 == 0 &&
+    const bool dma_ok = (opts & HASH_OPT_DMA) && !a.lane_map && a.row_stride % 8 == 0 && a.group_stride % 8 == 0 && a.col_off % 8 == 0 &&
                         (reinterpret_cast<uintptr_t>(a.rows) & 15) == 0 && a.col_off + (int)grid.x * 64 <= a.row_stride &&
                         (!PW || (reinterpret_cast<uintptr_t>(a.prefix) & 15) == 0);
     if (dma_ok) {
         // up to ~2 waves per SIMD the next block's DMA runs under this block's permutation (two buffers, 18 KiB per wave);
         // beyond that one buffer (4 waves per SIMD fit) and occupancy hides the landing
         const dim3 grid1((unsigned)waves);
-        static const bool primer = getenv("KOSK_HASH_PRIMER") && atoi(getenv("KOSK_HASH_PRIMER")) != 0; // opt-in, see k_hash_primer
-        if (primer && waves >= 256 && waves <= 2 * 1024 + 256) hipLaunchKernelGGL((k_hash_primer<2>), grid1, dim3(64), 0, st, (int *)nullptr);
+        const bool primer = (opts & HASH_OPT_PRIMER) && waves >= 256 && waves <= 2 * 1024 + 256; // opt-in, see k_hash_primer
+        if (primer) hipLaunchKernelGGL((k_hash_primer<2>), grid1, dim3(64), 0, st, (int *)nullptr);
         if (waves <= 2 * 1024 + 256) hipLaunchKernelGGL((k_commit_hash_dma<PW, NR, 2>), grid1, dim3(64), 0, st, a);
         else hipLaunchKernelGGL((k_commit_hash_dma<PW, NR, 1>), grid1, dim3(64), 0, st, a);
-        return;
+        return primer ? 3 : 1;
     }
     // fewer than ~3 waves per SIMD (1024 SIMDs): nothing else hides the row loads -> pipelined variant
     if (waves < 3 * 1024) hipLaunchKernelGGL((k_commit_hash<PW, NR, true>), grid, dim3(64), 0, st, a);
     else hipLaunchKernelGGL((k_commit_hash<PW, NR, false>), grid, dim3(64), 0, st, a);
+    return 0;
 }
 
-hipError_t launch_commit_hash(const HashArgs &a, int ngroups, int K, bool view, hipStream_t st)
+hipError_t launch_commit_hash(const HashArgs &a, int ngroups, int K, bool view, hipStream_t st, unsigned opts, int *variant)
 {
     // rows hashed per party: Tcomm 2(K+M); view (6+8 eta1)K + 2M   (M = 71+2K)
+    int v;
     if (!view) {
-        if (K == 2) launch_hash_t<0, 154>(a, ngroups, st);
-        else if (K == 3) launch_hash_t<0, 160>(a, ngroups, st);
-        else launch_hash_t<0, 166>(a, ngroups, st);
+        if (K == 2) v = launch_hash_t<0, 154>(a, ngroups, st, opts);
+        else if (K == 3) v = launch_hash_t<0, 160>(a, ngroups, st, opts);
+        else v = launch_hash_t<0, 166>(a, ngroups, st, opts);
     } else {
-        if (K == 2) launch_hash_t<16, 210>(a, ngroups, st);
-        else if (K == 3) launch_hash_t<16, 220>(a, ngroups, st);
-        else launch_hash_t<16, 246>(a, ngroups, st);
+        if (K == 2) v = launch_hash_t<16, 210>(a, ngroups, st, opts);
+        else if (K == 3) v = launch_hash_t<16, 220>(a, ngroups, st, opts);
+        else v = launch_hash_t<16, 246>(a, ngroups, st, opts);
     }
+    if (variant) *variant = v;
     return hipGetLastError();
 }
 
@@ -1703,8 +1700,7 @@ hipError_t launch_rows_to_limbs(const LimbArgs &a, hipStream_t st)
 // the table-product kernel: shared table, KS == 7 (407-wide inputs) or 13 (813-wide: recon_secrets_2ddeg), aligned u16 rows
 static bool table_gemm_ok(const GemmArgs &a)
 {
-    static const bool on = !(getenv("KOSK_TABLE_GEMM") && atoi(getenv("KOSK_TABLE_GEMM")) == 0);
-    return on && a.Afrag && !a.grouped && !a.B && (a.KS == 7 || a.KS == 13) && a.M % 32 == 0 && a.c_gdiv <= 1 && a.src_koff % 8 == 0 && a.src_rstride % 8 == 0 &&
+    return a.Afrag && !a.grouped && !a.B && (a.KS == 7 || a.KS == 13) && a.M % 32 == 0 && a.c_gdiv <= 1 && a.src_koff % 8 == 0 && a.src_rstride % 8 == 0 &&
            a.src_gstride % 8 == 0 && (reinterpret_cast<uintptr_t>(a.src) & 15) == 0 && a.c_off % 4 == 0 && a.c_rstride % 4 == 0 &&
            a.c_gstride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C) & 7) == 0;
 }

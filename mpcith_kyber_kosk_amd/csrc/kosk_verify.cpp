@@ -160,6 +160,8 @@ int stage_verifier_inputs(Ctx &c, int n, const uint8_t *pi, const uint8_t *pk, b
         if (!registered) memcpy(c.h_proof + (size_t)b * c.image_stride, pi + (size_t)b * P.proof_bytes, P.proof_bytes);
     });
     HIPCHK(hipMemcpyAsync(c.d_pk, c.h_pk, (size_t)n * c.pk_stride, hipMemcpyHostToDevice, c.stream));
+    c.resident_pk_n = n;
+    c.path_n[registered ? PATH_COPY_DIRECT : PATH_COPY_STAGED]++;
     if (registered) // page-locked caller memory (kosk_capi.cpp): no staging copy
         HIPCHK(hipMemcpy2DAsync(c.d_proof, c.image_stride, pi, P.proof_bytes, P.proof_bytes, n, hipMemcpyHostToDevice, c.stream));
     else
@@ -185,6 +187,10 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
     if (!ok) { c.err = "ok output buffer is required"; return -1; }
     if (pk_mode == 1 && !pk) { c.err = "pk_mode 1 needs the public keys"; return -1; }
+    if (pk_mode == 2 && c.resident_pk_n < n) {
+        c.err = "no resident public keys for this batch: pk == NULL needs a key generation (or a verifier staging call) of at least n proofs on this context";
+        return -1;
+    }
     HIPCHK(hipSetDevice(c.device));
     if (ensure_verify_workspace(c)) return -1;
     if (pk_mode) {
@@ -196,6 +202,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
                 for (int b = 0; b < n; b++) memcpy(c.h_pk + (size_t)b * c.pk_stride, pk + (size_t)b * Pk.pk_bytes, Pk.pk_bytes);
                 HIPCHK(hipMemcpyAsync(c.d_pk, c.h_pk, (size_t)n * c.pk_stride, hipMemcpyHostToDevice, c.stream));
             }
+            c.resident_pk_n = n;
         }
         // the decoding itself (polyvec_frombytes + gen_matrix) is issued with segment V1B: nothing before needs A or t, and
         // there it runs while the host hashes instead of in front of the first digests

@@ -7,6 +7,9 @@
 //
 //   san_driver full  : K = 2,3,4: oracle keygen + prove + verify (+ one tampered proof), host code against the oracle
 //   san_driver pool  : back-to-back small parallel_for calls (the hand-off race of ADVICE r1) + batched Fiat-Shamir
+//   san_driver lanes : the handle's lane threads and chunk dealing (csrc/kosk_lanes.hpp: what kosk_capi.cpp's run_chunks /
+//                      kosk_ctx::run execute) on fake sub-contexts: every unit exactly once, throwing and failing jobs,
+//                      a pool job inside each lane (the nesting of a real batch call), many back-to-back calls
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +18,8 @@
 
 #include "kosk_oracle.h"
 #include "../mpcith_kyber_kosk_amd/csrc/kosk_host.hpp"
+#include "../mpcith_kyber_kosk_amd/csrc/kosk_lanes.hpp"
+#include <stdexcept>
 
 static int fails = 0;
 #define CHECK(cond, ...)                   \
@@ -54,6 +59,62 @@ static void pool_hammer(int rounds)
     }
     kosk::pool_destroy(pool);
     printf("pool: %d back-to-back jobs, %ld indices\n", rounds, total);
+}
+
+// fake sub-context: a capacity, its own worker pool, a record of the units it processed
+struct FakeSub {
+    int per;
+    kosk::Pool *pool;
+    std::vector<int> seen;
+    long calls = 0;
+};
+
+static void lanes_hammer(int rounds)
+{
+    for (int S = 1; S <= 4; S++) {
+        kosk::LaneSet lanes;
+        lanes.create(S - 1);
+        CHECK(lanes.size() == S, "lane count");
+        std::vector<FakeSub> sub(S);
+        for (auto &f : sub) { f.per = 2 + S % 3; f.pool = kosk::pool_create(); kosk::pool_reserve(f.pool, 3); }
+        std::vector<int> hits;
+        for (int r = 0; r < rounds; r++) {
+            const int n = 1 + (r * 7 + S) % 23;          // ragged: n % per != 0 most of the time
+            const int fail_unit = r % 5 == 3 ? (r % n) : -1;   // a failing chunk (rc -1)
+            const int throw_unit = r % 7 == 5 ? (r % n) : -1;  // a throwing chunk (std::runtime_error)
+            hits.assign(n, 0);
+            auto fn = [&](int lane, int first, int count) -> int {
+                FakeSub &f = sub[lane];
+                f.calls++;
+                if (count < 1 || count > f.per || first < 0 || first + count > n) return -7;
+                // the nesting of a real call: a parallel_for on the sub-context's own pool inside the lane job
+                kosk::parallel_for(f.pool, count, 3, [&](int i) { hits[first + i]++; });
+                if (fail_unit >= first && fail_unit < first + count) return -1;
+                if (throw_unit >= first && throw_unit < first + count) throw std::runtime_error("injected");
+                return 0;
+            };
+            std::vector<std::function<int()>> jobs;
+            std::vector<int> rc;
+            std::vector<std::string> what;
+            if (r & 1) kosk::deal_chunks(S, sub[0].per, n, fn, jobs);
+            else if (n <= S * sub[0].per) kosk::deal_split(S, n, fn, jobs);
+            else kosk::deal_chunks(S, sub[0].per, n, fn, jobs);
+            lanes.run(jobs, rc, what);
+            bool any = false;
+            for (int i = 0; i < S; i++) {
+                any |= rc[i] != 0;
+                CHECK(rc[i] == 0 || rc[i] == -1 || rc[i] == -2, "lane rc %d", rc[i]);
+                CHECK(rc[i] != -2 || what[i] == "injected", "exception text '%s'", what[i].c_str());
+                CHECK(rc[i] != -7, "chunk bounds");
+            }
+            CHECK(any == (fail_unit >= 0 || throw_unit >= 0), "round %d: failure reporting (S=%d n=%d)", r, S, n);
+            for (int u = 0; u < n; u++) CHECK(hits[u] <= 1, "unit %d processed %d times", u, hits[u]);
+            if (!any)
+                for (int u = 0; u < n; u++) CHECK(hits[u] == 1, "unit %d of %d not processed (S=%d round %d)", u, n, S, r);
+        }
+        for (auto &f : sub) kosk::pool_destroy(f.pool);
+    }
+    printf("lanes: %d back-to-back batch calls on 1..4 lanes, injected failures and exceptions contained\n", rounds);
 }
 
 static void host_vs_oracle(int K)
@@ -169,6 +230,8 @@ int main(int argc, char **argv)
     if (!strcmp(mode, "pool")) {
         pool_hammer(argc > 2 ? atoi(argv[2]) : 20000);
         host_vs_oracle(2);
+    } else if (!strcmp(mode, "lanes")) {
+        lanes_hammer(argc > 2 ? atoi(argv[2]) : 3000);
     } else {
         primitives();
         for (int K = 2; K <= 4; K++) host_vs_oracle(K);

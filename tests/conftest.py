@@ -22,3 +22,24 @@ def pytest_configure(config):
 def oracle():
     from tests import oracle_lib
     return oracle_lib
+
+
+def run_gpu_child(code, timeout=900, env=None):
+    """Run `code` in a fresh child Python process (never an exec of this one) from the repository root; a crash there -- abort,
+    segfault, GPU fault -- is reported as this test's failure with the head and tail of the child's output."""
+    e = dict(os.environ)
+    e.update(env or {})
+    e["PYTHONFAULTHANDLER"] = "1"
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=timeout)
+    if r.returncode != 0:
+        out = r.stdout
+        if len(out) > 6000:
+            out = out[:3000] + "\n...\n" + out[-3000:]
+        pytest.fail("child process exit code %d\n%s" % (r.returncode, out))
+    return r.stdout
+
+
+@pytest.fixture(scope="session")
+def gpu_child():
+    return run_gpu_child

@@ -1,0 +1,132 @@
+"""Bodies of the GPU tests that run in a FRESH child Python process (tests/conftest.py: run_gpu_child): everything that puts
+several library handles, lane threads and page-locked caller memory in play at once.  A crash in here is one failing test
+with its stderr in the report, not the end of the pytest process and of every test behind it.
+
+    python -c "from tests.gpu_child_cases import streamed_chunks; streamed_chunks(3)"
+"""
+import os
+
+from tests import oracle_lib as oracle
+
+
+def _kosk(k, max_batch, **env):
+    """a handle created under the given environment knobs (read by kosk_create, per handle)"""
+    from mpcith_kyber_kosk_amd import api
+    old = {name: os.environ.get(name) for name in env}
+    os.environ.update({name: str(v) for name, v in env.items()})
+    try:
+        return api.Kosk(kyber_k=k, max_batch=max_batch)
+    finally:
+        for name, v in old.items():
+            if v is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = v
+
+
+def streamed_chunks(k):
+    """KOSK_STREAMS=3: a call longer than one sub-context is cut into chunks that run on three sub-contexts concurrently
+    (whole pages of the caller's buffer page-locked for the call); n = 7 over sub-batches of 2 leaves a ragged last chunk.
+    Same bytes as the single-context path and the oracle, with and without page-locking (KOSK_REGISTER=0)."""
+    from mpcith_kyber_kosk_amd import api
+    n = 7
+    tapes = [oracle.tape_bytes_for(k, 40 + b) for b in range(n)]
+    plain = api.Kosk(kyber_k=k, max_batch=n)
+    pks0, sks0, pis0 = plain.verifiable_keygen(tapes)
+    assert plain.path_counts()["copy_direct"] == 0          # single chunk: always staged
+    st = _kosk(k, 6, KOSK_STREAMS=3)
+    assert st.streams == 3 and st.host_threads >= 1
+    pks, sks, pis = st.verifiable_keygen(tapes)
+    assert pks == pks0 and sks == sks0 and pis == pis0
+    pc = st.path_counts()
+    # 4 chunks of <= 2 proofs: the two inner ones lie inside the page-locked span, the first and last touch its unlocked
+    # head / tail pages (unless the buffer happens to be page aligned) and are staged
+    assert pc["copy_direct"] >= 2 and pc["copy_direct"] + pc["copy_staged"] == 4, pc
+    for b in (0, n - 1):
+        opk, osk, opi, _, _ = oracle.verifiable_keygen(k, tapes[b])
+        assert pks[b] == opk and sks[b] == osk and pis[b] == opi
+    assert st.verify(pis, pks) == [True] * n
+    # one bad proof in the ragged last chunk, one wrong key in the first: exactly those two fail, with the same masks as
+    # on the single context
+    bad = list(pis)
+    p = oracle.params(k)
+    flip = bytearray(bad[n - 1]); flip[p.off[0] + 5] ^= 1; bad[n - 1] = bytes(flip)
+    keys = list(pks); keys[0] = pks[1]
+    want = [False] + [True] * (n - 2) + [False]
+    assert st.verify(bad, keys) == want
+    m_st = st.fail_masks(n)
+    assert plain.verify(bad, keys) == want
+    assert plain.fail_masks(n) == m_st
+    assert all((m != 0) == (not w) for m, w in zip(m_st, want))
+    # the opt-out of page-locking: per handle, gives the same bytes, and really never locks
+    st2 = _kosk(k, 6, KOSK_STREAMS=3, KOSK_REGISTER=0)
+    pks2, sks2, pis2 = st2.verifiable_keygen(tapes)
+    assert pks2 == pks0 and sks2 == sks0 and pis2 == pis0
+    assert st2.verify(bad, keys) == want
+    pc2 = st2.path_counts()
+    assert pc2["copy_direct"] == 0 and pc2["copy_staged"] == 8, pc2
+    # the handle created BEFORE that knob was set still page-locks (the knob is per handle, not per process)
+    before = st.path_counts()["copy_direct"]
+    assert st.verifiable_keygen(tapes)[2] == pis0
+    assert st.path_counts()["copy_direct"] > before
+    for c in (plain, st, st2):
+        c.close()
+    print("streamed_chunks ok", k)
+
+
+def streamed_loop(k, iters):
+    """The round-2 abort's territory, many times over: several live handles (1, 2 and 3 lanes), streamed keygen + verify in
+    a loop, caller buffers allocated and freed every iteration (so page-locked spans come and go at recycled addresses)."""
+    from mpcith_kyber_kosk_amd import api
+    n = 7
+    tapes = [oracle.tape_bytes_for(k, 40 + b) for b in range(n)]
+    plain = api.Kosk(kyber_k=k, max_batch=n)
+    ref = plain.verifiable_keygen(tapes)
+    hs = [_kosk(k, 6, KOSK_STREAMS=3), _kosk(k, 4, KOSK_STREAMS=2), _kosk(k, 6, KOSK_STREAMS=3, KOSK_REGISTER=0), _kosk(k, 3)]
+    for it in range(iters):
+        h = hs[it % len(hs)]
+        got = h.verifiable_keygen(tapes)
+        assert got == ref, it
+        assert h.verify(got[2], got[0]) == [True] * n, it
+        if it % 16 == 5:  # handles come and go while the others stay alive
+            hs[1].close()
+            hs[1] = _kosk(k, 4, KOSK_STREAMS=2)
+    for h in hs + [plain]:
+        h.close()
+    print("streamed_loop ok", k, iters)
+
+
+def errors_do_not_kill(k):
+    """Error containment at the ABI: bad arguments, a handle whose creation fails, a batch call on a destroyed-and-recreated
+    handle -- every failure is a return code with text, and the next call on a live handle works."""
+    import ctypes as C
+    from mpcith_kyber_kosk_amd import api
+    lib = api.lib
+    h = C.c_void_p()
+    assert lib.kosk_create(C.byref(h), 0, 7, 4) != 0 and b"kyber_k" in lib.kosk_last_error(None)
+    assert lib.kosk_create(C.byref(h), 0, k, 0) != 0 and b"max_batch" in lib.kosk_last_error(None)
+    assert lib.kosk_create(C.byref(h), 99, k, 1) != 0 and lib.kosk_last_error(None) != b""
+    st = _kosk(k, 4, KOSK_STREAMS=2)
+    tapes = [oracle.tape_bytes_for(k, 90 + b) for b in range(5)]
+    guard = C.create_string_buffer(64)
+    assert lib.kosk_verifiable_keygen_batch(st.handle, 5, None, 0, None, guard, guard) != 0
+    assert lib.kosk_verify_batch(st.handle, 5, guard, None, guard) != 0
+    # a tape stride smaller than a tape: refused by every lane, reported once, handle still good
+    blob = b"".join(tapes)
+    pk = C.create_string_buffer(st.pk_bytes * 5); sk = C.create_string_buffer(st.sk_bytes * 5); pi = C.create_string_buffer(st.proof_bytes * 5)
+    assert lib.kosk_verifiable_keygen_batch(st.handle, 5, C.c_char_p(blob), 16, pk, sk, pi) != 0
+    assert b"tape_stride" in lib.kosk_last_error(st.handle)
+    got = st.verifiable_keygen(tapes)
+    assert st.verify(got[2], got[0]) == [True] * 5
+    # fail masks: only of the last completed verify call
+    assert st.fail_masks(5) == [0] * 5
+    assert st.verify(got[2][:2], got[0][:2]) == [True, True]
+    m = (C.c_uint32 * 5)()
+    assert lib.kosk_verify_fail_masks(st.handle, m, 5) != 0 and lib.kosk_verify_fail_masks(st.handle, m, 2) == 0
+    # pk == NULL on a handle that never generated keys: an error, not stale keys
+    fresh = api.Kosk(kyber_k=k, max_batch=2)
+    ok = C.create_string_buffer(2)
+    assert lib.kosk_verify_resident_pk(fresh.handle, 2, None, ok) != 0 and b"resident public keys" in lib.kosk_last_error(fresh.handle)
+    fresh.close()
+    st.close()
+    print("errors_do_not_kill ok", k)

@@ -35,45 +35,22 @@ def test_empty_batches_are_no_ops(oracle, torch_cuda):
 
 
 @pytest.mark.parametrize("k", [2, 3])
-def test_streamed_chunks_equal_single_context_and_oracle(k, oracle, torch_cuda, monkeypatch):
-    """KOSK_STREAMS=3: a call longer than one sub-context is cut into chunks that run on three sub-contexts concurrently
-    (caller buffers page-locked for the call); n = 7 over sub-batches of 2 leaves a ragged last chunk."""
-    from mpcith_kyber_kosk_amd import api
-    n = 7
-    tapes = [oracle.tape_bytes_for(k, 40 + b) for b in range(n)]
-    plain = api.Kosk(kyber_k=k, max_batch=n)
-    pks0, sks0, pis0 = plain.verifiable_keygen(tapes)
-    monkeypatch.setenv("KOSK_STREAMS", "3")
-    st = api.Kosk(kyber_k=k, max_batch=6)
-    monkeypatch.delenv("KOSK_STREAMS")
-    assert st.streams == 3
-    pks, sks, pis = st.verifiable_keygen(tapes)
-    assert pks == pks0 and sks == sks0 and pis == pis0
-    for b in (0, n - 1):
-        opk, osk, opi, _, _ = oracle.verifiable_keygen(k, tapes[b])
-        assert pks[b] == opk and sks[b] == osk and pis[b] == opi
-    assert st.verify(pis, pks) == [True] * n
-    # one bad proof in the ragged last chunk, one wrong key in the first: exactly those two fail, with the same masks as
-    # on the single context
-    bad = list(pis)
-    p = oracle.params(k)
-    flip = bytearray(bad[n - 1]); flip[p.off[0] + 5] ^= 1; bad[n - 1] = bytes(flip)
-    keys = list(pks); keys[0] = pks[1]
-    want = [False] + [True] * (n - 2) + [False]
-    assert st.verify(bad, keys) == want
-    m_st = st.fail_masks(n)
-    assert plain.verify(bad, keys) == want
-    assert plain.fail_masks(n) == m_st
-    assert all((m != 0) == (not w) for m, w in zip(m_st, want))
-    # the opt-out of page-locking gives the same bytes
-    monkeypatch.setenv("KOSK_STREAMS", "3")
-    monkeypatch.setenv("KOSK_REGISTER", "0")
-    st2 = api.Kosk(kyber_k=k, max_batch=6)
-    pks2, sks2, pis2 = st2.verifiable_keygen(tapes)
-    assert pks2 == pks0 and sks2 == sks0 and pis2 == pis0
-    assert st2.verify(bad, keys) == want
-    for c in (plain, st, st2):
-        c.close()
+def test_streamed_chunks_equal_single_context_and_oracle(k, torch_cuda, gpu_child):
+    """KOSK_STREAMS=3 host-buffer path (tests/gpu_child_cases.py: streamed_chunks) in a fresh child process: lane threads, page-locked
+    caller memory and three live handles must not be able to take the rest of the suite down."""
+    out = gpu_child("from tests.gpu_child_cases import streamed_chunks; streamed_chunks(%d)" % k)
+    assert "streamed_chunks ok %d" % k in out
+
+
+def test_streamed_calls_in_a_loop_over_live_handles(torch_cuda, gpu_child):
+    """The round-2 SIGABRT's territory 120 times over (tests/gpu_child_cases.py: streamed_loop)."""
+    out = gpu_child("from tests.gpu_child_cases import streamed_loop; streamed_loop(3, 120)")
+    assert "streamed_loop ok 3 120" in out
+
+
+def test_abi_errors_are_return_codes(torch_cuda, gpu_child):
+    out = gpu_child("from tests.gpu_child_cases import errors_do_not_kill; errors_do_not_kill(2)")
+    assert "errors_do_not_kill ok" in out
 
 
 def test_batch_of_one_on_a_large_context_and_full_context(oracle, torch_cuda):
@@ -129,6 +106,8 @@ def test_split_commitment_launches_give_identical_proofs(oracle, torch_cuda, mon
     assert ctx.commit_launch_groups(n) == 44 and ctx.commit_launch_groups(44) == 44 and ctx.commit_launch_groups(3) == 3
     got = ctx.verifiable_keygen(tapes)
     assert got == ref
+    pc = ctx.path_counts()
+    assert pc["hash_primer"] >= 2 and pc["hash_dma"] >= 4, pc   # two rounds x (44-proof launch behind a primer + 2-proof launch)
     for b in (44, 45):
         opk, osk, opi, _, _ = oracle.verifiable_keygen(k, tapes[b])
         assert (got[0][b], got[1][b], got[2][b]) == (opk, osk, opi)
@@ -136,24 +115,84 @@ def test_split_commitment_launches_give_identical_proofs(oracle, torch_cuda, mon
     ctx.close()
 
 
-@pytest.mark.parametrize("knob", ["KOSK_TABLE_GEMM=0", "KOSK_HASH_DMA=0", "KOSK_LINCOMB_FUSED=0", "KOSK_NTT_FP32=1", "KOSK_BLOCKING_SYNC=1",
-                                  "KOSK_GRAPHS=1"])
+KNOBS = {  # knob -> (path counter that must be > 0 on the knob's handle, counter that must stay 0 there)
+    "KOSK_TABLE_GEMM=0": ("limb_gemm", "table_gemm"),
+    "KOSK_HASH_DMA=0": ("hash_plain", "hash_dma"),
+    "KOSK_LINCOMB_FUSED=0": ("limb_gemm", None),
+    "KOSK_NTT_FP32=1": ("ntt_fp32", "ntt_int"),
+    "KOSK_BLOCKING_SYNC=1": (None, None),
+    "KOSK_GRAPHS=1": ("graph_replay", None),
+}
+
+
+@pytest.mark.parametrize("knob", list(KNOBS))
 def test_documented_knobs_do_not_change_results(knob, oracle, torch_cuda, monkeypatch):
     """Every runtime knob of INTEGRATION.md 5 selects another kernel or another way of waiting, never other bytes: proofs, keys
-    and verify bits equal the default context's (which the other tests pin to the oracle), for K = 3 and a K = 4 spot check."""
+    and verify bits equal the default context's (which the other tests pin to the oracle), for K = 3 and a K = 4 spot check.
+    The knobs are per handle (read by kosk_create); kosk_path_count proves that the alternative path is the one that ran."""
     from mpcith_kyber_kosk_amd import api
     name, val = knob.split("=")
+    must, must_not = KNOBS[knob]
     for k, n in ((3, 3), (4, 1)):
         tapes = [oracle.tape_bytes_for(k, 500 + b) for b in range(n)]
         base = api.Kosk(kyber_k=k, max_batch=n)
         ref = base.verifiable_keygen(tapes)
-        base.close()
+        pc0 = base.path_counts()
+        assert pc0["table_gemm"] > 0 and pc0["hash_dma"] > 0 and pc0["ntt_int"] > 0 and pc0["graph_replay"] == 0 and pc0["hash_plain"] == 0
         monkeypatch.setenv(name, val)
         ctx = api.Kosk(kyber_k=k, max_batch=n)
         monkeypatch.delenv(name)
+        # GRAPHS captures at the resident split (the keygen-in-front call never captures its first segment, but P1B.. do)
         got = ctx.verifiable_keygen(tapes)
         assert got == ref
         assert ctx.verify(got[2], got[0]) == [True] * n
+        if knob == "KOSK_GRAPHS=1":
+            got2 = ctx.verifiable_keygen(tapes)   # second call replays the captured segments
+            assert got2 == ref
+        pc = ctx.path_counts()
+        if must:
+            assert pc[must] > 0, (knob, pc)
+        if must_not:
+            assert pc[must_not] == 0, (knob, pc)
+        # the default handle created earlier is unaffected by the knob (per handle, not per process)
+        assert base.verifiable_keygen(tapes) == ref and base.path_counts()["hash_plain"] == 0
+        base.close()
         bad = bytearray(got[2][0]); bad[oracle.params(k).off[0] + 7] ^= 4  # an f share of an opened party: always read
         assert ctx.verify([bytes(bad)], [got[0][0]]) == [False]
         ctx.close()
+
+
+def test_graphs_with_alternating_device_tape_buffers(oracle, torch_cuda, monkeypatch):
+    """KOSK_GRAPHS=1 + kosk_stage_prover_inputs / kosk_prove_resident with tapes read IN PLACE from two different device
+    buffers, then from host memory: the captured first segment must never replay against the previous call's tape pointer
+    (the tape buffer is part of the segment graph's key)."""
+    torch = torch_cuda
+    import numpy as np
+    from mpcith_kyber_kosk_amd import api
+    import ctypes as C
+    k, n = 3, 2
+    monkeypatch.setenv("KOSK_GRAPHS", "1")
+    ctx = api.Kosk(kyber_k=k, max_batch=n)
+    monkeypatch.delenv("KOSK_GRAPHS")
+    stride = (ctx.tape_bytes + 63) // 64 * 64
+    sets = [[oracle.tape_bytes_for(k, 700 + 10 * s + b) for b in range(n)] for s in range(3)]
+    devs = []
+    for tp in sets[:2]:
+        host = np.zeros((n, stride), np.uint8)
+        for b, t in enumerate(tp):
+            host[b, :len(t)] = np.frombuffer(t, np.uint8)
+        devs.append(torch.from_numpy(host).cuda())
+    pk = C.create_string_buffer(ctx.pk_bytes * n); sk = C.create_string_buffer(ctx.sk_bytes * n)
+    order = [0, 1, 0, 0, 1, 2, 0]   # 2 = host tapes (uploaded into the library's own buffer)
+    for s in order:
+        if s < 2:
+            r = api.lib.kosk_stage_prover_inputs(ctx.handle, n, C.c_void_p(devs[s].data_ptr()), stride, pk, sk)
+        else:
+            r = api.lib.kosk_stage_prover_inputs(ctx.handle, n, C.c_char_p(b"".join(sets[2])), ctx.tape_bytes, pk, sk)
+        assert r == 0, api.lib.kosk_last_error(ctx.handle)
+        ctx.prove_resident(n)
+        pis = ctx.fetch_proofs(n)
+        for b in range(n):
+            assert pis[b] == oracle.verifiable_keygen(k, sets[s][b])[2], (s, b)
+    assert ctx.path_counts()["graph_replay"] > 0
+    ctx.close()

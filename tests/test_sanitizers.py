@@ -31,3 +31,15 @@ def test_tsan_thread_pool_and_batched_fiat_shamir():
                        stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "san_driver pool: ok" in r.stdout, r.stdout[-3000:]
     assert "ThreadSanitizer" not in r.stdout
+
+
+@pytest.mark.parametrize("san", ["tsan", "asan"])
+def test_lane_threads_and_chunk_dealing_under_sanitizers(san):
+    """csrc/kosk_lanes.hpp (the lane threads and chunk dealing behind kosk_verifiable_keygen_batch / kosk_verify_batch with
+    KOSK_STREAMS > 1) on fake sub-contexts: every unit exactly once, failing and throwing chunks contained, no data race."""
+    _build(san)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([os.path.join(ROOT, "oracle", "_san", "san_driver_" + san), "lanes", "1500"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "san_driver lanes: ok" in r.stdout, r.stdout[-3000:]
+    assert "ThreadSanitizer" not in r.stdout and "AddressSanitizer" not in r.stdout and "runtime error" not in r.stdout

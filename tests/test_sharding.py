@@ -74,3 +74,49 @@ def test_allgather_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_host_budget_per_rank():
+    """bench.py's host-thread budget: plenty of cores -> the configuration's threads and spinning waits; an 8-rank node with
+    few cores per rank (LOCAL_WORLD_SIZE=8) -> sleeping waits and smaller pools, never fewer than three threads per slot."""
+    import bench
+    assert bench.host_budget(256, 1, 6, 6) == (6, False)
+    assert bench.host_budget(256, 8, 4, 6) == (6, False)      # 32 cores per rank >= 4 x 7
+    assert bench.host_budget(128, 8, 6, 6) == (5, True)       # 16 cores per rank, 6 slots: 2 * 16 // 6 = 5
+    assert bench.host_budget(64, 8, 6, 6) == (3, True)        # 8 cores per rank: the floor of three
+    assert bench.host_budget(8, 8, 4, 8) == (3, True)
+    assert bench.host_budget(1, 1, 1, 6) == (3, True)
+
+
+@pytest.mark.gpu
+def test_config4_two_ranks_on_one_gpu_rehearsal():
+    """BASELINE.json configs[3]'s multi-rank control flow with world = 2 on ONE GPU: static step dealing, the round hook's
+    all-gather per commitment round, pending.wait() before the verifier reuses the tables -- host-staged over gloo
+    (KOSK_BENCH_REHEARSE=1), since RCCL cannot put two ranks on one device.  bench.py itself checks that every rank's block of
+    the gathered tables equals that rank's resident table."""
+    import json
+    import subprocess
+    import sys
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, KOSK_BENCH_REHEARSE="1", LOCAL_WORLD_SIZE="8")  # 8: also drives the scarce-cores branch of host_budget
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--config", "4", "--steps", "6", "--warmup", "2",
+           "--slots", "2", "--no-cpu-baseline", "--no-kernels"]
+    r = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["kyber_k"] == 4 and line["config"]["proofs_per_gpu"] == 91
+    g = line["digest_allgather"]
+    assert g["own_block_matches_resident_table"] and g["peer_blocks_match_their_resident_tables"]
+    assert g["gathered_shape"] == [2 * 91, 1454, 32]
+    # two gathers (Tcomm, view) per step on every slot, the same count on every slot (static dealing)
+    assert all(n == 2 * s for n, s in zip(g["gathers_issued_per_slot"], g["steps_per_slot"])) and len(set(g["steps_per_slot"])) == 1
+    assert line["value"] > 0
