@@ -196,63 +196,154 @@ def kernel_microbench(ctx, torch, k, lanes=65536, reps=20):
     return out
 
 
-def pcie_inclusive(api, k, B, tapes):
-    """For DESIGN.md only (never `value`): the two top-level ABI calls on HOST buffers, one caller thread."""
-    out = {}
-    c = api.Kosk(kyber_k=k, max_batch=B)
-    blob = C.create_string_buffer(b"".join(tapes), c.tape_bytes * B)
-    pk = C.create_string_buffer(c.pk_bytes * B); sk = C.create_string_buffer(c.sk_bytes * B)
-    pi = C.create_string_buffer(c.proof_bytes * B); okb = C.create_string_buffer(B)
-    lib, h = api.lib, c.handle
+def _with_env(env, fn):
+    old = {n_: os.environ.get(n_) for n_ in env}
+    os.environ.update({n_: str(v) for n_, v in env.items()})
+    try:
+        return fn()
+    finally:
+        for n_, v in old.items():
+            if v is None:
+                os.environ.pop(n_, None)
+            else:
+                os.environ[n_] = v
 
-    def once():  # tape H2D, proofs D2H (B x 0.68 MB), proofs + pk H2D for verify
-        assert lib.kosk_verifiable_keygen_batch(h, B, blob, c.tape_bytes, pk, sk, pi) == 0
-        assert lib.kosk_verify_batch(h, B, pi, pk, okb) == 0 and okb.raw == b"\x01" * B
-    once()
-    t0 = time.perf_counter()
-    reps = 5
-    for _ in range(reps):
-        once()
-    out["pcie_inclusive_proofs_per_s"] = reps * B / (time.perf_counter() - t0)
-    cb = lib.kosk_compact_proof_bytes(k)
-    blobs = C.create_string_buffer(cb * B)
 
-    def once_compact():  # the same with the compact wire format (SURVEY 8 f4): 78 % of the image size over PCIe
-        assert lib.kosk_verifiable_keygen_resident(h, B, blob, c.tape_bytes, pk, sk) == 0
-        assert lib.kosk_fetch_proofs_compact(h, B, blobs) == 0
-        assert lib.kosk_stage_verifier_inputs_compact(h, B, blobs, pk) == 0
-        assert lib.kosk_verify_resident(h, B, okb) == 0 and okb.raw == b"\x01" * B
-    once_compact()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        once_compact()
-    out["pcie_inclusive_compact_proofs_per_s"] = reps * B / (time.perf_counter() - t0)
-    out["compact_proof_bytes"] = cb
-    c.close()
-    # streaming write-back from ONE caller thread: a handle with 3 sub-contexts (KOSK_STREAMS=3) works through the chunks of a
-    # 6 x B-proof call concurrently, so a chunk's PCIe transfers and host hashing run under another chunk's kernels
-    old = os.environ.get("KOSK_STREAMS")
-    os.environ["KOSK_STREAMS"] = "3"
-    cs = api.Kosk(kyber_k=k, max_batch=3 * B)
-    if old is None:
-        del os.environ["KOSK_STREAMS"]
-    else:
-        os.environ["KOSK_STREAMS"] = old
+def link_rate(torch, device, mib=256):
+    """Measured PCIe rate of this box (GB/s): page-locked host memory <-> HBM, each direction alone and both at once."""
+    n = mib << 20
+    host_a = torch.empty(n, dtype=torch.uint8).pin_memory()
+    host_b = torch.empty(n, dtype=torch.uint8).pin_memory()
+    dev_a = torch.empty(n, dtype=torch.uint8, device=device)
+    dev_b = torch.empty(n, dtype=torch.uint8, device=device)
+    s1, s2 = torch.cuda.Stream(device), torch.cuda.Stream(device)
+
+    def timed(fn, reps=4):
+        fn(); torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(device)
+        return reps * n / (time.perf_counter() - t0) / 1e9
+
+    def h2d():
+        with torch.cuda.stream(s1):
+            dev_a.copy_(host_a, non_blocking=True)
+
+    def d2h():
+        with torch.cuda.stream(s2):
+            host_b.copy_(dev_b, non_blocking=True)
+
+    def both():
+        h2d(); d2h()
+    out = {"h2d_GBps": timed(h2d), "d2h_GBps": timed(d2h)}
+    out["both_directions_GBps_each"] = timed(both)
+    out["note"] = "%d MiB page-locked host buffers, torch copies on two streams" % mib
+    return out
+
+
+def drop_in(api, torch, k, B, tapes, device):
+    """The reference's two calls on HOST buffers (kosk_verifiable_keygen_batch + kosk_verify_batch and their compact-format
+    twins) -- PCIe-inclusive, never `value`.  (i) one caller thread, plain (pageable) buffers; (ii) one caller thread,
+    page-locked buffers from kosk_host_alloc; (iii) two caller threads, one proving and one verifying the previous call's proofs,
+    so that both directions of the link are busy.  KOSK_STREAMS=3 handles, 6 x B proofs per call in chunks of B."""
+    lib = api.lib
+    out = {"link": link_rate(torch, "cuda:%d" % device)}
     n = 6 * B
-    blob6 = C.create_string_buffer(b"".join(tapes) * 6, cs.tape_bytes * n)
-    pk6 = C.create_string_buffer(cs.pk_bytes * n); sk6 = C.create_string_buffer(cs.sk_bytes * n)
-    pi6 = C.create_string_buffer(cs.proof_bytes * n); ok6 = C.create_string_buffer(n)
+    cb = lib.kosk_compact_proof_bytes(k)
+    mk = lambda: _with_env({"KOSK_STREAMS": "3"}, lambda: api.Kosk(kyber_k=k, max_batch=3 * B, device=device))
+    prover, verifier = mk(), mk()
+    pb, pkb, skb, tb = prover.proof_bytes, prover.pk_bytes, prover.sk_bytes, prover.tape_bytes
+    blob = C.create_string_buffer(b"".join(tapes) * 6, tb * n)
+    pk = [C.create_string_buffer(pkb * n) for _ in range(2)]
+    sk = C.create_string_buffer(skb * n)
+    ok = C.create_string_buffer(n)
+    # per proof over PCIe: image (or compact) out + in, tape in, 2 x 46.5 KB digest tables out per call
+    out["bytes_per_proof"] = {"image": pb, "compact": cb, "tape_h2d": tb, "digest_tables_d2h_per_call": 2 * 1454 * 32, "pk": pkb, "sk": skb}
 
-    def once_stream():
-        assert lib.kosk_verifiable_keygen_batch(cs.handle, n, blob6, cs.tape_bytes, pk6, sk6, pi6) == 0
-        assert lib.kosk_verify_batch(cs.handle, n, pi6, pk6, ok6) == 0 and ok6.raw == b"\x01" * n
-    once_stream()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        once_stream()
-    out["pcie_inclusive_streaming_proofs_per_s"] = 3 * n / (time.perf_counter() - t0)
-    out["pcie_inclusive_streaming_note"] = "one caller thread, KOSK_STREAMS=3, %d proofs per call in chunks of %d" % (n, B)
-    cs.close()
+    def rate(fn, reps):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return reps * n / (time.perf_counter() - t0)
+
+    def pair(buf, compact):
+        def fn():
+            if compact:
+                assert lib.kosk_verifiable_keygen_batch_compact(prover.handle, n, blob, tb, pk[0], sk, buf) == 0
+                assert lib.kosk_verify_batch_compact(prover.handle, n, buf, pk[0], ok) == 0 and ok.raw == b"\x01" * n
+            else:
+                assert lib.kosk_verifiable_keygen_batch(prover.handle, n, blob, tb, pk[0], sk, buf) == 0
+                assert lib.kosk_verify_batch(prover.handle, n, buf, pk[0], ok) == 0 and ok.raw == b"\x01" * n
+        return fn
+    pageable = C.create_string_buffer(pb * n)
+    out["one_thread_pageable_image"] = rate(pair(pageable, False), 2)
+    del pageable
+    pin = [lib.kosk_host_alloc(pb * n) for _ in range(2)]
+    if not all(pin):
+        raise RuntimeError("kosk_host_alloc failed")
+    pinv = [C.c_void_p(p_) for p_ in pin]
+    out["one_thread_pinned_image"] = rate(pair(pinv[0], False), 3)
+    out["one_thread_pinned_compact"] = rate(pair(pinv[0], True), 3)
+
+    def two_threads(compact, rounds=6):
+        """thread A proves call i into buffer i % 2 while thread B verifies call i - 1 from the other buffer"""
+        ready = [threading.Semaphore(0), threading.Semaphore(0)]
+        free = [threading.Semaphore(1), threading.Semaphore(1)]
+        err = []
+        okv = C.create_string_buffer(n)
+
+        def prove():
+            try:
+                for i in range(rounds):
+                    free[i % 2].acquire()
+                    f = lib.kosk_verifiable_keygen_batch_compact if compact else lib.kosk_verifiable_keygen_batch
+                    if f(prover.handle, n, blob, tb, pk[i % 2], sk, pinv[i % 2]):
+                        raise RuntimeError(lib.kosk_last_error(prover.handle))
+                    ready[i % 2].release()
+            except Exception as e:  # noqa: BLE001
+                err.append(e)
+                for r_ in ready:
+                    r_.release()
+
+        def verify():
+            try:
+                for i in range(rounds):
+                    ready[i % 2].acquire()
+                    if err:
+                        return
+                    f = lib.kosk_verify_batch_compact if compact else lib.kosk_verify_batch
+                    if f(verifier.handle, n, pinv[i % 2], pk[i % 2], okv) or okv.raw != b"\x01" * n:
+                        raise RuntimeError("verify: %s" % lib.kosk_last_error(verifier.handle))
+                    free[i % 2].release()
+            except Exception as e:  # noqa: BLE001
+                err.append(e)
+                for f_ in free:
+                    f_.release()
+        ta, tv = threading.Thread(target=prove), threading.Thread(target=verify)
+        t0 = time.perf_counter()
+        ta.start(); tv.start(); ta.join(); tv.join()
+        dt = time.perf_counter() - t0
+        if err:
+            raise err[0]
+        return rounds * n / dt
+    two_threads(False, 2)  # warm both handles (verifier workspace, compact staging)
+    two_threads(True, 2)
+    out["two_threads_pinned_image"] = two_threads(False)
+    out["two_threads_pinned_compact"] = two_threads(True)
+    best = max(out["two_threads_pinned_image"], out["two_threads_pinned_compact"])
+    lk = out["link"]
+    per_dir = {"image": out["two_threads_pinned_image"] * (pb + 2 * 1454 * 32) / 1e9,
+               "compact": out["two_threads_pinned_compact"] * (cb + 2 * 1454 * 32) / 1e9}
+    out["two_threads_GBps_d2h"] = per_dir
+    out["two_threads_fraction_of_link_d2h"] = {k_: v / lk["both_directions_GBps_each"] for k_, v in per_dir.items()}
+    out["proofs_per_s"] = best
+    out["note"] = ("kyber_verifiable_keygen + kyber_kosk_verify through the drop-in calls on host pointers, %d proofs per call in chunks of %d, "
+                   "KOSK_STREAMS=3; unit proofs/s; every verify bit asserted" % (n, B))
+    for p_ in pinv:
+        lib.kosk_host_free(p_)
+    prover.close(); verifier.close()
     return out
 
 
@@ -340,7 +431,7 @@ def main():
     ap.add_argument("--tape-sets", type=int, default=4, help="distinct resident tape sets per slot, rotated step by step")
     ap.add_argument("--cpu-proofs", type=int, default=12, help="bounded CPU baseline sample (about 13 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernels", action="store_true", help="skip the 65 536-lane kernel leg and the PCIe-inclusive extras")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the 65 536-lane kernel leg and the PCIe-inclusive drop-in leg")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     if args.kyber_k:
@@ -634,7 +725,25 @@ def main():
                                "per_proof_us_at_throughput": dt / K / B * 1e6}
         if world == 1 and not args.no_kernels and args.config in (2, 3) and not custom:
             line["kernels_65536_lanes"] = kernel_microbench(ctx, torch, k)
-            line["extras"] = pcie_inclusive(api, k, B, tapes)
+            line["drop_in"] = drop_in(api, torch, k, B, tapes, local_rank)
+        if world == 1 and not args.no_kernels and args.config in (2, 3) and not custom:
+            # the same 276 proofs in flight with TWO steps' batches per launch (3 slots x 92 proofs): what the launches gain
+            # above the 1 024-wave step of the commitment hashes; a separate run, reported NEXT TO the line
+            # of record, never as `value`
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", str(args.config), "--batch", str(2 * B), "--slots", str(max(1, S // 2)),
+                   "--steps", str(max(10, K // 2)), "--warmup", str(max(2, W // 2)), "--no-kernels", "--no-cpu-baseline"]
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            sub = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and sub:
+                j = json.loads(sub[-1])
+                line["two_batches_per_launch"] = {
+                    "proofs_per_s": j["value"], "ms_per_%d_proofs" % B: j["ms_per_step"] / 2, "proofs_per_launch": 2 * B, "slots": max(1, S // 2),
+                    "steps": j["steps"], "roofline_frac": (j.get("roofline") or {}).get("frac"),
+                    "hash_view_avg_us": (j.get("kernels_in_pipeline", {}).get("hash_view") or {}).get("avg_us"),
+                    "note": "python bench.py --batch %d --slots %d: two %d-proof batches share every launch; not the line of record" % (2 * B, max(1, S // 2), B)}
+            else:
+                line["two_batches_per_launch"] = {"error": (r.stderr or "")[-400:]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(k, tapes, min(args.cpu_proofs, B))
         os.write(json_fd, (json.dumps(line) + "\n").encode())  # written here: the RCCL teardown below can end the process without Python's exit flush

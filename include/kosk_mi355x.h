@@ -53,6 +53,14 @@ int kosk_set_randombytes(kosk_ctx *ctx, kosk_randombytes_fn fn, void *user); /* 
 int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride,
                                  uint8_t *pk, uint8_t *sk, uint8_t *pi);
 
+/* Page-locked host memory for the proof buffers of the two host-buffer calls (no reference counterpart: the reference's
+ * caller owns plain arrays, main.cpp:71).  Proof images in such a buffer (or in any memory the caller page-locked itself with
+ * hipHostMalloc / hipHostRegister) cross PCIe straight from / to it: no staging copy on the host and no per-call locking.
+ * Plain (pageable) buffers keep working: a multi-chunk call page-locks the whole pages inside the buffer for its duration,
+ * everything else goes through the library's pinned staging buffers.  NULL on failure. */
+void *kosk_host_alloc(size_t bytes);
+void kosk_host_free(void *p);
+
 /* bool kyber_kosk_verify(const uint8_t *pi, const uint8_t *pk)       kosk.hpp:23-24, kosk.cpp:88-117
  * ok[b] = 1 accept / 0 reject.  The reference prints a diagnostic and returns
  * false (mlwe_verifier.cpp:120 etc.); here kosk_verify_fail_masks() reports
@@ -110,6 +118,11 @@ int kosk_verify_resident_pk(kosk_ctx *ctx, int n, const uint8_t *pk, uint8_t *ok
 size_t kosk_compact_proof_bytes(int kyber_k);
 int kosk_proof_compress(int kyber_k, const uint8_t *pi, uint8_t *out);   /* host codec; -1 if a value >= 4096 */
 int kosk_proof_decompress(int kyber_k, const uint8_t *in, uint8_t *pi);
+/* kosk_verifiable_keygen_batch / kosk_verify_batch with the proofs in the compact format: n records of
+ * kosk_compact_proof_bytes(); any n (chunked like the image calls), host or page-locked host buffers */
+int kosk_verifiable_keygen_batch_compact(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride,
+                                         uint8_t *pk, uint8_t *sk, uint8_t *out);
+int kosk_verify_batch_compact(kosk_ctx *ctx, int n, const uint8_t *in, const uint8_t *pk, uint8_t *ok);
 int kosk_fetch_proofs_compact(kosk_ctx *ctx, int n, uint8_t *out);        /* like kosk_fetch_proofs */
 int kosk_stage_verifier_inputs_compact(kosk_ctx *ctx, int n, const uint8_t *in, const uint8_t *pk); /* like kosk_stage_verifier_inputs */
 

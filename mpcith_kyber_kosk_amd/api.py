@@ -18,9 +18,11 @@ class KoskError(RuntimeError):
 
 
 def _load():
-    if not os.path.exists(LIB_PATH):
+    # KOSK_LIB_PATH: another build of the SAME library (tools/host_asan.sh: host code under AddressSanitizer); never a fallback
+    path = os.environ.get("KOSK_LIB_PATH") or LIB_PATH
+    if path == LIB_PATH and not os.path.exists(LIB_PATH):
         _build.build()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     u8p, u16p, i16p, sz, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), C.POINTER(C.c_int16), C.c_size_t, C.c_void_p
     sig = {
         "kosk_pk_bytes": (sz, [C.c_int]), "kosk_sk_bytes": (sz, [C.c_int]),
@@ -44,6 +46,8 @@ def _load():
         "kosk_proof_compress": (C.c_int, [C.c_int, vp, vp]),
         "kosk_proof_decompress": (C.c_int, [C.c_int, vp, vp]),
         "kosk_fetch_proofs_compact": (C.c_int, [vp, C.c_int, vp]),
+        "kosk_verifiable_keygen_batch_compact": (C.c_int, [vp, C.c_int, vp, sz, vp, vp, vp]),
+        "kosk_verify_batch_compact": (C.c_int, [vp, C.c_int, vp, vp, vp]),
         "kosk_stage_verifier_inputs_compact": (C.c_int, [vp, C.c_int, vp, vp]),
         "kosk_stage_prover_inputs": (C.c_int, [vp, C.c_int, vp, sz, vp, vp]),
         "kosk_prove_resident": (C.c_int, [vp, C.c_int]),
@@ -57,6 +61,8 @@ def _load():
         "kosk_phase_seconds": (C.c_int, [vp, C.POINTER(C.c_double), C.c_int]),
         "kosk_path_count": (C.c_int, [vp, C.c_int, C.POINTER(C.c_long)]),
         "kosk_host_threads": (C.c_int, [vp]),
+        "kosk_host_alloc": (vp, [sz]),
+        "kosk_host_free": (None, [vp]),
         "kosk_sha3_256_batch": (C.c_int, [vp, vp, sz, sz, vp, C.c_int]),
         "kosk_shake256_batch": (C.c_int, [vp, vp, sz, sz, vp, sz, C.c_int]),
         "kosk_commit_hash_lanes": (C.c_int, [vp, vp, sz, C.c_int, vp, C.c_int, vp]),
@@ -93,7 +99,7 @@ EXPORTS = ["kosk_pk_bytes", "kosk_sk_bytes", "kosk_proof_bytes", "kosk_tape_byte
            "kosk_prepare_randomness", "kosk_prepare_range_proof", "kosk_prove_prepared", "kosk_verify_inst", "kosk_compact_proof_bytes",
            "kosk_proof_compress", "kosk_proof_decompress", "kosk_fetch_proofs_compact", "kosk_stage_verifier_inputs_compact", "kosk_stage_prover_inputs", "kosk_prove_resident", "kosk_fetch_proofs",
            "kosk_stage_verifier_inputs", "kosk_verify_resident", "kosk_verifiable_keygen_resident", "kosk_verify_resident_pk",
-           "kosk_resident_digests", "kosk_set_round_hook", "kosk_phase_seconds", "kosk_path_count", "kosk_host_threads", "kosk_sha3_256_batch",
+           "kosk_resident_digests", "kosk_set_round_hook", "kosk_phase_seconds", "kosk_path_count", "kosk_host_threads", "kosk_verifiable_keygen_batch_compact", "kosk_verify_batch_compact", "kosk_host_alloc", "kosk_host_free", "kosk_sha3_256_batch",
            "kosk_shake256_batch", "kosk_commit_hash_lanes", "kosk_ntt256_batch", "kosk_lagrange_expand",
            "kosk_recon_secrets", "kosk_profile_enable", "kosk_profile_read", "kosk_stream_timer_start", "kosk_stream_timer_stop", "kosk_device_synchronize", "kosk_streams", "kosk_commit_launch_groups", "kosk_resident_proofs", "kosk_keygen", "kosk_fs_alpha",
            "kosk_fs_opened", "kosk_host_sha3_256", "kosk_host_shake256", "kosk_host_sha3_256_multi", "kosk_lagrange_table"]

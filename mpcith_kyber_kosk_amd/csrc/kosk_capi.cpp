@@ -83,6 +83,9 @@ template <typename F>
 static int guard(kosk_ctx *ctx, const char *fn, F &&body) noexcept
 {
     try {
+        // a stale per-thread HIP error (an earlier failed call of ours, or of the host application) must not be taken for
+        // the result of this call's first kernel launch
+        (void)hipGetLastError();
         return body();
     } catch (const std::exception &e) {
         try {
@@ -170,6 +173,20 @@ static int unlock_span(kosk_ctx *h, HostSpan &s)
     return -1;
 }
 
+// [p, p + bytes) is page-locked host memory already (kosk_host_alloc, hipHostMalloc, hipHostRegister by the caller): the
+// copies can go straight to / from it, no staging and no per-call locking
+static bool span_is_pinned(const void *p, size_t bytes)
+{
+    if (!p || !bytes) return false;
+    hipPointerAttribute_t a0{}, a1{};
+    if (hipPointerGetAttributes(&a0, p) != hipSuccess ||
+        hipPointerGetAttributes(&a1, static_cast<const uint8_t *>(p) + bytes - 1) != hipSuccess) {
+        (void)hipGetLastError(); // plain pageable memory: not an error
+        return false;
+    }
+    return a0.type == hipMemoryTypeHost && a1.type == hipMemoryTypeHost;
+}
+
 // draw n proofs' worth of randomness through the (stateful) callback / OS entropy, sequentially in proof order and in the
 // reference's call order and lengths (kosk.cpp:12, mlwe_prover.cpp:9, ss.cpp:5)
 static void draw_tapes(const kosk_ctx *ctx, int n, std::vector<uint8_t> &drawn)
@@ -188,14 +205,7 @@ static void draw_tapes(const kosk_ctx *ctx, int n, std::vector<uint8_t> &drawn)
 
 static thread_local std::string g_create_err; // error text of the last failed kosk_create on this thread
 
-#define HIPCHK_C(x)                                                        \
-    do {                                                                   \
-        hipError_t e_ = (x);                                               \
-        if (e_ != hipSuccess) {                                            \
-            c.err = std::string(#x) + ": " + hipGetErrorString(e_);        \
-            return -1;                                                     \
-        }                                                                  \
-    } while (0)
+#define HIPCHK_C(x) KOSK_HIPCHK(x)
 
 extern "C" {
 
@@ -406,14 +416,15 @@ int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, siz
     // several chunks: the whole pages of the caller's proof buffer are page-locked for the call and the images of the
     // chunks inside them are copied straight there (KOSK_REGISTER=0, or any failure: pinned staging buffer + host memcpy)
     HostSpan span;
-    if (n > ctx->sub[0]->max_batch) span = lock_span(ctx, pi, (size_t)n * P.proof_bytes);
+    const bool pinned = ctx->c->host_register && span_is_pinned(pi, (size_t)n * P.proof_bytes); // the caller's own page-locked buffer
+    if (!pinned && n > ctx->sub[0]->max_batch) span = lock_span(ctx, pi, (size_t)n * P.proof_bytes);
     int rc = -1;
     try {
         rc = run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
             const KeygenIn kg{tapes + (size_t)first * tape_stride, tape_stride, pk + (size_t)first * P.pk_bytes, sk + (size_t)first * P.sk_bytes};
             if (prove_resident(c, count, false, &kg)) return -1;
             uint8_t *dst = pi + (size_t)first * P.proof_bytes;
-            return fetch_proofs(c, count, dst, span.covers(dst, (size_t)count * P.proof_bytes));
+            return fetch_proofs(c, count, dst, pinned || span.covers(dst, (size_t)count * P.proof_bytes));
         });
     } catch (...) {
         (void)unlock_span(ctx, span);
@@ -432,12 +443,76 @@ int kosk_verify_batch(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk
     const Params &P = ctx->c->P;
     reset_masks(ctx, n);
     HostSpan span;
-    if (n > ctx->sub[0]->max_batch) span = lock_span(ctx, pi, (size_t)n * P.proof_bytes);
+    const bool pinned = ctx->c->host_register && span_is_pinned(pi, (size_t)n * P.proof_bytes);
+    if (!pinned && n > ctx->sub[0]->max_batch) span = lock_span(ctx, pi, (size_t)n * P.proof_bytes);
     int rc = -1;
     try {
         rc = run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
             const uint8_t *src = pi + (size_t)first * P.proof_bytes;
-            if (stage_verifier_inputs(c, count, src, pk + (size_t)first * P.pk_bytes, span.covers(src, (size_t)count * P.proof_bytes))) return -1;
+            if (stage_verifier_inputs(c, count, src, pk + (size_t)first * P.pk_bytes, pinned || span.covers(src, (size_t)count * P.proof_bytes))) return -1;
+            return verify_into(ctx, c, first, count, ok, 0, nullptr);
+        });
+    } catch (...) {
+        (void)unlock_span(ctx, span);
+        throw;
+    }
+    if (unlock_span(ctx, span) && !rc) rc = -1;
+    if (!rc) ctx->masks_n = n;
+    return rc;
+    GUARD_END
+}
+
+// The two host-buffer calls with the proofs in the compact wire format: packed / unpacked on the GPU, so PCIe
+// carries 78 % of the image bytes in each direction.  Same chunking, lanes and page-locking as the calls above.
+int kosk_verifiable_keygen_batch_compact(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride,
+                                         uint8_t *pk, uint8_t *sk, uint8_t *out)
+{
+    if (!ctx || n < 0 || !pk || !sk || !out) return bad_args(ctx, __func__);
+    if (n == 0) return 0;
+    GUARD(ctx)
+    const Params &P = ctx->c->P;
+    const size_t cb = make_compact_plan(P).bytes;
+    std::vector<uint8_t> drawn;
+    if (!tapes) {
+        draw_tapes(ctx, n, drawn);
+        tapes = drawn.data();
+        tape_stride = P.tape_bytes;
+    }
+    HostSpan span;
+    const bool pinned = ctx->c->host_register && span_is_pinned(out, (size_t)n * cb);
+    if (!pinned && n > ctx->sub[0]->max_batch) span = lock_span(ctx, out, (size_t)n * cb);
+    int rc = -1;
+    try {
+        rc = run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
+            const KeygenIn kg{tapes + (size_t)first * tape_stride, tape_stride, pk + (size_t)first * P.pk_bytes, sk + (size_t)first * P.sk_bytes};
+            if (prove_resident(c, count, false, &kg)) return -1;
+            uint8_t *dst = out + (size_t)first * cb;
+            return fetch_proofs_compact(c, count, dst, pinned || span.covers(dst, (size_t)count * cb));
+        });
+    } catch (...) {
+        (void)unlock_span(ctx, span);
+        throw;
+    }
+    if (unlock_span(ctx, span) && !rc) rc = -1;
+    return rc;
+    GUARD_END
+}
+int kosk_verify_batch_compact(kosk_ctx *ctx, int n, const uint8_t *in, const uint8_t *pk, uint8_t *ok)
+{
+    if (!ctx || n < 0 || !in || !pk || !ok) return bad_args(ctx, __func__);
+    if (n == 0) { ctx->masks_n = 0; return 0; }
+    GUARD(ctx)
+    const Params &P = ctx->c->P;
+    const size_t cb = make_compact_plan(P).bytes;
+    reset_masks(ctx, n);
+    HostSpan span;
+    const bool pinned = ctx->c->host_register && span_is_pinned(in, (size_t)n * cb);
+    if (!pinned && n > ctx->sub[0]->max_batch) span = lock_span(ctx, in, (size_t)n * cb);
+    int rc = -1;
+    try {
+        rc = run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
+            const uint8_t *src = in + (size_t)first * cb;
+            if (stage_verifier_inputs_compact(c, count, src, pk + (size_t)first * P.pk_bytes, pinned || span.covers(src, (size_t)count * cb))) return -1;
             return verify_into(ctx, c, first, count, ok, 0, nullptr);
         });
     } catch (...) {
@@ -565,6 +640,20 @@ int kosk_verify_fail_masks(const kosk_ctx *ctx, uint32_t *masks, int n)
     if (!ctx || !masks || n < 0 || n > ctx->masks_n) return bad_args(ctx, __func__);
     memcpy(masks, ctx->masks.data(), sizeof(uint32_t) * (size_t)n);
     return 0;
+}
+
+void *kosk_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (!bytes || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void kosk_host_free(void *p)
+{
+    if (p && hipHostFree(p) != hipSuccess) (void)hipGetLastError();
 }
 
 int kosk_path_count(const kosk_ctx *ctx, int id, long *count)

@@ -14,14 +14,7 @@
 
 namespace kosk {
 
-#define HIPCHK(x)                                                                       \
-    do {                                                                                \
-        hipError_t e_ = (x);                                                            \
-        if (e_ != hipSuccess) {                                                         \
-            c.err = std::string(#x) + ": " + hipGetErrorString(e_);                     \
-            return -1;                                                                  \
-        }                                                                               \
-    } while (0)
+#define HIPCHK(x) KOSK_HIPCHK(x)
 
 CompactPlan make_compact_plan(const Params &P)
 {
@@ -156,7 +149,7 @@ static int ensure_compact(Ctx &c)
     return 0;
 }
 
-int fetch_proofs_compact(Ctx &c, int n, uint8_t *out)
+int fetch_proofs_compact(Ctx &c, int n, uint8_t *out, bool direct)
 {
     if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
     HIPCHK(hipSetDevice(c.device));
@@ -166,16 +159,20 @@ int fetch_proofs_compact(Ctx &c, int n, uint8_t *out)
     hipLaunchKernelGGL(k_pack_proofs, dim3(16, NFIELDS, n), dim3(256), 0, c.stream, c.d_proof, c.image_stride, c.d_compact, c.compact_stride,
                        c.cplan, c.d_compact_bad);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c.h_compact, c.d_compact, (size_t)n * c.compact_stride, hipMemcpyDeviceToHost, c.stream));
+    // direct: `out` is page-locked host memory (the caller's own, or locked for this call by kosk_capi.cpp): no staging copy
+    if (direct) HIPCHK(hipMemcpy2DAsync(out, c.cplan.bytes, c.d_compact, c.compact_stride, c.cplan.bytes, n, hipMemcpyDeviceToHost, c.stream));
+    else HIPCHK(hipMemcpyAsync(c.h_compact, c.d_compact, (size_t)n * c.compact_stride, hipMemcpyDeviceToHost, c.stream));
     HIPCHK(hipMemcpyAsync(c.h_compact_bad, c.d_compact_bad, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c.stream));
-    HIPCHK(hipStreamSynchronize(c.stream));
+    HIPCHK(stream_sync(c));
+    c.path_n[direct ? PATH_COPY_DIRECT : PATH_COPY_STAGED]++;
     for (int b = 0; b < n; b++)
         if (c.h_compact_bad[b]) { c.err = "a resident proof holds a value >= 4096: not representable in the compact format"; return -1; }
-    parallel_for(c.pool, n, c.nthreads, [&](int b) { memcpy(out + (size_t)b * c.cplan.bytes, c.h_compact + (size_t)b * c.compact_stride, c.cplan.bytes); });
+    if (!direct)
+        parallel_for(c.pool, n, c.nthreads, [&](int b) { memcpy(out + (size_t)b * c.cplan.bytes, c.h_compact + (size_t)b * c.compact_stride, c.cplan.bytes); });
     return 0;
 }
 
-int stage_verifier_inputs_compact(Ctx &c, int n, const uint8_t *in, const uint8_t *pk)
+int stage_verifier_inputs_compact(Ctx &c, int n, const uint8_t *in, const uint8_t *pk, bool direct)
 {
     if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
     HIPCHK(hipSetDevice(c.device));
@@ -184,15 +181,17 @@ int stage_verifier_inputs_compact(Ctx &c, int n, const uint8_t *in, const uint8_
     const Params &P = c.P;
     parallel_for(c.pool, n, c.nthreads, [&](int b) {
         memcpy(c.h_pk + (size_t)b * c.pk_stride, pk + (size_t)b * P.pk_bytes, P.pk_bytes);
-        memcpy(c.h_compact + (size_t)b * c.compact_stride, in + (size_t)b * c.cplan.bytes, c.cplan.bytes);
+        if (!direct) memcpy(c.h_compact + (size_t)b * c.compact_stride, in + (size_t)b * c.cplan.bytes, c.cplan.bytes);
     });
+    c.path_n[direct ? PATH_COPY_DIRECT : PATH_COPY_STAGED]++;
     HIPCHK(hipMemcpyAsync(c.d_pk, c.h_pk, (size_t)n * c.pk_stride, hipMemcpyHostToDevice, c.stream));
     c.resident_pk_n = n;
-    HIPCHK(hipMemcpyAsync(c.d_compact, c.h_compact, (size_t)n * c.compact_stride, hipMemcpyHostToDevice, c.stream));
+    if (direct) HIPCHK(hipMemcpy2DAsync(c.d_compact, c.compact_stride, in, c.cplan.bytes, c.cplan.bytes, n, hipMemcpyHostToDevice, c.stream));
+    else HIPCHK(hipMemcpyAsync(c.d_compact, c.h_compact, (size_t)n * c.compact_stride, hipMemcpyHostToDevice, c.stream));
     hipLaunchKernelGGL(k_unpack_proofs, dim3(16, NFIELDS, n), dim3(256), 0, c.stream, c.d_compact, c.compact_stride, c.d_proof, c.image_stride, c.cplan);
     HIPCHK(hipGetLastError());
     HIPCHK(launch_decode_pk(c.d_pk, c.pk_stride, c.d_t, c.d_A, c.key_stride, P.K, n, c.stream));
-    HIPCHK(hipStreamSynchronize(c.stream));
+    HIPCHK(stream_sync(c));
     return 0;
 }
 

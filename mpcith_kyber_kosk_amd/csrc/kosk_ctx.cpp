@@ -20,14 +20,7 @@
 
 namespace kosk {
 
-#define HIPCHK(x)                                                                       \
-    do {                                                                                \
-        hipError_t e_ = (x);                                                            \
-        if (e_ != hipSuccess) {                                                         \
-            c.err = std::string(#x) + ": " + hipGetErrorString(e_);                     \
-            return -1;                                                                  \
-        }                                                                               \
-    } while (0)
+#define HIPCHK(x) KOSK_HIPCHK(x)
 
 static double now_sec()
 {
@@ -307,7 +300,12 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     if (max_batch < 1) { c.err = "max_batch must be >= 1"; return fail(); }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
         c.err = "no HIP device available: the KOSK path has no CPU fallback";
+        return fail();
+    }
+    if (device < 0 || device >= ndev) {
+        c.err = "device " + std::to_string(device) + " out of range: " + std::to_string(ndev) + " HIP device(s) visible";
         return fail();
     }
     c.device = device;

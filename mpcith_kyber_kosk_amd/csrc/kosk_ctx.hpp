@@ -10,6 +10,20 @@
 #include "kosk_host.hpp"
 #include "kosk_params.hpp"
 
+// Every HIP call of the host code goes through this (needs a `Ctx &c` in scope, returns -1 from the enclosing function).
+// HIP keeps the last error per host thread until somebody reads it, and every kernel launcher reports hipGetLastError():
+// a failure reported here is consumed here, so that it cannot come back as the "result" of the next, healthy launch on this
+// thread (r3: a failed kosk_create on a bad device ordinal made the next handle's first launch fail).
+#define KOSK_HIPCHK(x)                                                      \
+    do {                                                                    \
+        hipError_t e_ = (x);                                                \
+        if (e_ != hipSuccess) {                                             \
+            (void)hipGetLastError();                                        \
+            c.err = std::string(#x) + ": " + hipGetErrorString(e_);         \
+            return -1;                                                      \
+        }                                                                   \
+    } while (0)
+
 namespace kosk {
 
 typedef void (*randombytes_fn)(void *user, uint8_t *out, size_t len);
@@ -276,8 +290,9 @@ int prove_prepared(Ctx &c, int n, const uint8_t *inst, const uint8_t *rand_in, c
                    size_t tape_stride, uint8_t *pi);
 int stage_verifier_inst(Ctx &c, int n, const uint8_t *pi, const uint8_t *inst);
 int ensure_verify_workspace(Ctx &c);
-int fetch_proofs_compact(Ctx &c, int n, uint8_t *out);
-int stage_verifier_inputs_compact(Ctx &c, int n, const uint8_t *in, const uint8_t *pk);
+// direct: the host buffer is page-locked (copied to / from straight, no staging)
+int fetch_proofs_compact(Ctx &c, int n, uint8_t *out, bool direct = false);
+int stage_verifier_inputs_compact(Ctx &c, int n, const uint8_t *in, const uint8_t *pk, bool direct = false);
 // registered: `pi` is page-locked host memory (hipHostRegister): copied to directly, no staging
 int fetch_proofs(Ctx &c, int n, uint8_t *pi, bool registered = false);
 

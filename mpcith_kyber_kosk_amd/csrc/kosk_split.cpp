@@ -18,14 +18,7 @@
 
 namespace kosk {
 
-#define HIPCHK(x)                                                                       \
-    do {                                                                                \
-        hipError_t e_ = (x);                                                            \
-        if (e_ != hipSuccess) {                                                         \
-            c.err = std::string(#x) + ": " + hipGetErrorString(e_);                     \
-            return -1;                                                                  \
-        }                                                                               \
-    } while (0)
+#define HIPCHK(x) KOSK_HIPCHK(x)
 
 static constexpr size_t SHARE_VEC_BYTES = 8 + 2 * 2 * NPARTY; // 5824
 

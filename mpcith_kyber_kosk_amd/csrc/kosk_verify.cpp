@@ -28,14 +28,7 @@ static double now_sec()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-#define HIPCHK(x)                                                   \
-    do {                                                            \
-        hipError_t e_ = (x);                                        \
-        if (e_ != hipSuccess) {                                     \
-            c.err = std::string(#x) + ": " + hipGetErrorString(e_); \
-            return -1;                                              \
-        }                                                           \
-    } while (0)
+#define HIPCHK(x) KOSK_HIPCHK(x)
 
 template <typename T>
 static hipError_t dalloc(T **p, size_t n) { return hipMalloc(reinterpret_cast<void **>(p), (n ? n : 1) * sizeof(T)); }

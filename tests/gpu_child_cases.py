@@ -130,3 +130,67 @@ def errors_do_not_kill(k):
     fresh.close()
     st.close()
     print("errors_do_not_kill ok", k)
+
+
+def pinned_buffers(k):
+    """Proof buffers from kosk_host_alloc: every chunk of a host-buffer call is copied straight to / from the caller's memory
+    (single-chunk calls too), same bytes as through pageable memory; KOSK_REGISTER=0 keeps even those on the staging path."""
+    import ctypes as C
+    from mpcith_kyber_kosk_amd import api
+    lib = api.lib
+    n = 5
+    tapes = [oracle.tape_bytes_for(k, 140 + b) for b in range(n)]
+    plain = api.Kosk(kyber_k=k, max_batch=n)
+    ref = plain.verifiable_keygen(tapes)
+    blob = b"".join(tapes)
+    for streams, cap, reg in ((1, n, 1), (2, 4, 1), (2, 4, 0)):
+        h = _kosk(k, cap, KOSK_STREAMS=streams, KOSK_REGISTER=reg)
+        nbytes = h.proof_bytes * n
+        ptr = lib.kosk_host_alloc(nbytes)
+        assert ptr
+        pk = C.create_string_buffer(h.pk_bytes * n); sk = C.create_string_buffer(h.sk_bytes * n); ok = C.create_string_buffer(n)
+        assert lib.kosk_verifiable_keygen_batch(h.handle, n, C.c_char_p(blob), h.tape_bytes, pk, sk, C.c_void_p(ptr)) == 0, lib.kosk_last_error(h.handle)
+        got = C.string_at(ptr, nbytes)
+        assert got == b"".join(ref[2]) and pk.raw == b"".join(ref[0]) and sk.raw == b"".join(ref[1])
+        assert lib.kosk_verify_batch(h.handle, n, C.c_void_p(ptr), pk, ok) == 0 and ok.raw == b"\x01" * n
+        bad = bytearray(got); bad[h.proof_bytes * 3 + oracle.params(k).off[0] + 5] ^= 1
+        C.memmove(ptr, bytes(bad), nbytes)
+        assert lib.kosk_verify_batch(h.handle, n, C.c_void_p(ptr), pk, ok) == 0 and ok.raw == b"\x01\x01\x01\x00\x01"
+        pc = h.path_counts()
+        chunks = -(-n // (cap // streams if streams > 1 else cap))
+        if reg:
+            assert pc["copy_staged"] == 0 and pc["copy_direct"] == 3 * chunks, (streams, pc)
+        else:
+            assert pc["copy_direct"] == 0 and pc["copy_staged"] == 3 * chunks, (streams, pc)
+        lib.kosk_host_free(C.c_void_p(ptr))
+        h.close()
+    plain.close()
+    print("pinned_buffers ok", k)
+
+
+def big_batches():
+    """The batch shapes of BASELINE configs[2..4] through the host-buffer calls and the resident split (what the suite's big tests
+    run): for tools/host_asan.sh, so that the host paths of large batches run under AddressSanitizer too."""
+    from mpcith_kyber_kosk_amd import api
+    for k, n in ((3, 46), (4, 91), (3, 130)):
+        ctx = api.Kosk(kyber_k=k, max_batch=min(n, 91))
+        tapes = [oracle.tape_bytes_for(k, 1000 + b) for b in range(n)]
+        pks, sks, pis = ctx.verifiable_keygen(tapes)
+        opk, osk, opi, _, _ = oracle.verifiable_keygen(k, tapes[n - 1])
+        assert (pks[-1], sks[-1], pis[-1]) == (opk, osk, opi)
+        assert ctx.verify(pis, pks) == [True] * n
+        m = min(n, 91)
+        ctx.verifiable_keygen_resident(tapes[:m])
+        assert ctx.verify_resident_pk(m) == [True] * m
+        blobs = ctx.fetch_proofs_compact(m)
+        ctx.stage_verifier_inputs_compact(blobs, pks[:m])
+        assert ctx.verify_resident(m) == [True] * m
+        ctx.close()
+    # second-level entry points
+    k = 2
+    ctx = api.Kosk(kyber_k=k, max_batch=2)
+    rnd = ctx.prepare_randomness(n=3)
+    rng = ctx.prepare_range_proof(n=3)
+    assert len(rnd) == 3 and len(rng) == 3
+    ctx.close()
+    print("big_batches ok")

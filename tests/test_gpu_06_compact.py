@@ -50,3 +50,34 @@ def test_compress_rejects_unrepresentable_values(oracle, torch_cuda):
     assert api.lib.kosk_proof_compress(k, bytes(img), out) == 0
     img[1] = 0x10                                        # first u16 = 4096
     assert api.lib.kosk_proof_compress(k, bytes(img), out) == -1
+
+
+def test_compact_host_buffer_calls_chunked(oracle, torch_cuda):
+    """kosk_verifiable_keygen_batch_compact / kosk_verify_batch_compact: n = 5 through a context of 2 (three chunks, the last
+    ragged): the compact bytes equal the host codec of the image call's proofs; the verifier accepts them and rejects a
+    tampered one with the same fail mask as the image path."""
+    from mpcith_kyber_kosk_amd import api
+    lib = api.lib
+    k, n = 3, 5
+    tapes = [oracle.tape_bytes_for(k, 170 + i) for i in range(n)]
+    ref = api.Kosk(kyber_k=k, max_batch=n)
+    pks, sks, pis = ref.verifiable_keygen(tapes)
+    cb = lib.kosk_compact_proof_bytes(k)
+    ctx = api.Kosk(kyber_k=k, max_batch=2)
+    pk = C.create_string_buffer(ctx.pk_bytes * n); sk = C.create_string_buffer(ctx.sk_bytes * n)
+    out = C.create_string_buffer(cb * n); ok = C.create_string_buffer(n)
+    assert lib.kosk_verifiable_keygen_batch_compact(ctx.handle, n, C.c_char_p(b"".join(tapes)), ctx.tape_bytes, pk, sk, out) == 0
+    assert pk.raw == b"".join(pks) and sk.raw == b"".join(sks)
+    for b in range(n):
+        host = C.create_string_buffer(cb)
+        assert lib.kosk_proof_compress(k, pis[b], host) == 0
+        assert out.raw[b * cb:(b + 1) * cb] == host.raw, b
+    assert lib.kosk_verify_batch_compact(ctx.handle, n, out, pk, ok) == 0 and ok.raw == b"\x01" * n
+    bad = bytearray(out.raw); bad[4 * cb + 200] ^= 0x20
+    assert lib.kosk_verify_batch_compact(ctx.handle, n, bytes(bad), pk, ok) == 0 and ok.raw == b"\x01" * 4 + b"\x00"
+    masks = ctx.fail_masks(n)
+    img = C.create_string_buffer(ctx.proof_bytes)
+    assert lib.kosk_proof_decompress(k, bytes(bad[4 * cb:5 * cb]), img) == 0
+    assert ref.verify(pis[:4] + [img.raw], pks) == [True] * 4 + [False] and ref.fail_masks(n) == masks
+    assert lib.kosk_verify_batch_compact(ctx.handle, 0, out, pk, ok) == 0
+    ref.close(); ctx.close()

@@ -48,6 +48,11 @@ def test_streamed_calls_in_a_loop_over_live_handles(torch_cuda, gpu_child):
     assert "streamed_loop ok 3 120" in out
 
 
+def test_pinned_caller_buffers_are_copied_directly(torch_cuda, gpu_child):
+    out = gpu_child("from tests.gpu_child_cases import pinned_buffers; pinned_buffers(3)")
+    assert "pinned_buffers ok 3" in out
+
+
 def test_abi_errors_are_return_codes(torch_cuda, gpu_child):
     out = gpu_child("from tests.gpu_child_cases import errors_do_not_kill; errors_do_not_kill(2)")
     assert "errors_do_not_kill ok" in out

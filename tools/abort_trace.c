@@ -34,7 +34,13 @@ static void on_fatal(int sig, siginfo_t *si, void *uc)
 int sigaction(int sig, const struct sigaction *act, struct sigaction *old)
 {
     if (!real_sigaction) real_sigaction = dlsym(RTLD_NEXT, "sigaction");
-    if (fatal(sig) && act) { // pretend success, keep ours
+    if (fatal(sig) && act) { // pretend success, keep ours; say who asked
+        char buf[128];
+        int n = snprintf(buf, sizeof buf, "[abort_trace] sigaction(%d, handler %p) refused; caller:\n", sig, (void *)act->sa_sigaction);
+        (void)!write(2, buf, (size_t)n);
+        void *bt[12];
+        int d = backtrace(bt, 12);
+        backtrace_symbols_fd(bt, d, 2);
         if (old) memset(old, 0, sizeof *old);
         return 0;
     }
