@@ -18,11 +18,9 @@ class KoskError(RuntimeError):
 
 
 def _load():
-    # KOSK_LIB_PATH: another build of the SAME library (tools/host_asan.sh: host code under AddressSanitizer); never a fallback
-    path = os.environ.get("KOSK_LIB_PATH") or LIB_PATH
-    if path == LIB_PATH and not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH):
         _build.build()
-    lib = C.CDLL(path)
+    lib = C.CDLL(LIB_PATH)
     u8p, u16p, i16p, sz, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), C.POINTER(C.c_int16), C.c_size_t, C.c_void_p
     sig = {
         "kosk_pk_bytes": (sz, [C.c_int]), "kosk_sk_bytes": (sz, [C.c_int]),

@@ -169,8 +169,8 @@ def pinned_buffers(k):
 
 
 def big_batches():
-    """The batch shapes of BASELINE configs[2..4] through the host-buffer calls and the resident split (what the suite's big tests
-    run): for tools/host_asan.sh, so that the host paths of large batches run under AddressSanitizer too."""
+    """The batch shapes of BASELINE configs[2..4] through the host-buffer calls (chunked: n above the context's capacity), the
+    resident split, the compact staging and the second-level entry points, in one fresh process."""
     from mpcith_kyber_kosk_amd import api
     for k, n in ((3, 46), (4, 91), (3, 130)):
         ctx = api.Kosk(kyber_k=k, max_batch=min(n, 91))

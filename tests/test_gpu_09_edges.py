@@ -53,6 +53,16 @@ def test_pinned_caller_buffers_are_copied_directly(torch_cuda, gpu_child):
     assert "pinned_buffers ok 3" in out
 
 
+def test_host_paths_under_glibc_heap_checking(torch_cuda, gpu_child):
+    """The multi-handle cases and the big batch shapes once more in a child whose allocator checks every free()
+    (MALLOC_CHECK_=3: abort with a message on a corrupted chunk header; MALLOC_PERTURB_: freed and fresh memory is filled, so a
+    use-after-free or an uninitialised read changes bytes that the cases compare with the oracle)."""
+    code = ("from tests.gpu_child_cases import *; streamed_chunks(3); pinned_buffers(2); streamed_loop(2, 24); big_batches(); "
+            "print('heap-checked ok')")
+    out = gpu_child(code, env={"MALLOC_CHECK_": "3", "MALLOC_PERTURB_": "165", "LIBC_FATAL_STDERR_": "1"})
+    assert "heap-checked ok" in out
+
+
 def test_abi_errors_are_return_codes(torch_cuda, gpu_child):
     out = gpu_child("from tests.gpu_child_cases import errors_do_not_kill; errors_do_not_kill(2)")
     assert "errors_do_not_kill ok" in out
