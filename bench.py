@@ -362,8 +362,10 @@ def host_budget(usable_cores, local_world, slots, threads):
 class Slot:
     """One pipeline slot: a library context with its tape bank in HBM (and, for config 4, its own process group)."""
 
-    def __init__(self, api, torch, k, B, device, first_tape, nsets):
-        self.c = api.Kosk(kyber_k=k, max_batch=B, device=device)
+    def __init__(self, api, torch, k, B, device, first_tape, nsets, partition=None):
+        # partition = (i, n): the slot's stream may only use CU partition i of n (KOSK_CU_PARTITION, read by kosk_create)
+        env = {"KOSK_CU_PARTITION": "%d/%d" % partition} if partition and partition[1] > 1 else {}
+        self.c = _with_env(env, lambda: api.Kosk(kyber_k=k, max_batch=B, device=device))
         self.B, self.nsets = B, nsets
         self.stride = (self.c.tape_bytes + 63) // 64 * 64
         import numpy as np
@@ -428,6 +430,8 @@ def main():
     ap.add_argument("--slots", type=int, default=int(os.environ.get("KOSK_BENCH_SLOTS", "0")),
                     help="independent batches kept in flight per GPU (own HIP stream + host threads each); 0 = the configuration's "
                          "default.  Never depends on --steps.")
+    ap.add_argument("--partitions", type=int, default=int(os.environ.get("KOSK_BENCH_PARTITIONS", "1")),
+                    help="CU partitions of the GPU (whole XCDs for 2, 4, 8): slot i runs on partition i %% P only")
     ap.add_argument("--tape-sets", type=int, default=4, help="distinct resident tape sets per slot, rotated step by step")
     ap.add_argument("--cpu-proofs", type=int, default=12, help="bounded CPU baseline sample (about 13 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -486,7 +490,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from mpcith_kyber_kosk_amd import api, sharding
-    slots = [Slot(api, torch, k, B, local_rank, ((rank * S + si) * args.tape_sets) * B, args.tape_sets) for si in range(S)]
+    P_ = max(1, args.partitions)
+    slots = [Slot(api, torch, k, B, local_rank, ((rank * S + si) * args.tape_sets) * B, args.tape_sets, partition=(si % P_, P_)) for si in range(S)]
     ctx = slots[0].c
     tapes = slots[0].first_tapes
     if want_gather:
@@ -692,7 +697,7 @@ def main():
                                    ": kyber_verifiable_keygen (GPU key generation + offline + online prover) + kyber_kosk_verify (pk decoding + "
                                    "verifier), randomness tapes resident in HBM, a different tape set every step",
                        "baseline_config": "configs[%d]" % (args.config - 1), "kyber_k": k, "proofs_per_gpu": B, "party_lanes_per_gpu": B * 1454,
-                       "sharding": "by proof", "pipeline_slots_per_gpu": S, "tape_sets_per_slot": args.tape_sets,
+                       "sharding": "by proof", "pipeline_slots_per_gpu": S, "cu_partitions": P_, "tape_sets_per_slot": args.tape_sets,
                        "host_threads_per_slot": os.environ.get("KOSK_HOST_THREADS"), "host_waits": "sleep" if os.environ.get("KOSK_BLOCKING_SYNC") == "1" else "spin",
                        "timing": "steady-state window: completion of step W to completion of step W+K, slots running continuously"},
             "drained_run": {"steps": total, "ms_per_step": dt_drained / total * 1e3, "value": world * total * B / dt_drained,

@@ -327,6 +327,13 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     if (const char *e = getenv("KOSK_HASH_PRIMER")) c.hash_primer = atoi(e) != 0;
     if (const char *e = getenv("KOSK_TABLE_GEMM")) c.table_gemm = atoi(e) != 0;
     if (const char *e = getenv("KOSK_REGISTER")) c.host_register = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_CU_PARTITION")) {
+        int i = 0, n = 0;
+        if (sscanf(e, "%d/%d", &i, &n) != 2 || n < 1 || i < 0 || i >= n) { c.err = "KOSK_CU_PARTITION must be i/n with 0 <= i < n"; return fail(); }
+        c.cu_part_i = i;
+        c.cu_part_n = n;
+    }
+    if (const char *e = getenv("KOSK_CU_MASK_LAYOUT")) c.cu_mask_layout = atoi(e) != 0;
 
     auto body = [&]() -> int {
         HIPCHK(hipSetDevice(device));
@@ -335,7 +342,30 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
             HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
             if (cus > 0) c.n_simd = 4 * cus;
         }
-        HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        if (c.cu_part_n > 1) {
+            // KOSK_CU_PARTITION=i/n: this context's kernels run on partition i of n equal CU partitions only (whole XCDs, each
+            // with its own L2, when n divides 8).  A 46-proof batch that is small for 256 CUs is a large batch for 64 of them:
+            // its launches sit well above the one-wave-per-SIMD step of the commitment hashes, and contexts on different
+            // partitions do not stretch each other's kernels.
+            int cus = 0;
+            HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+            const int nx = 8, per_xcd = cus / nx;
+            if (cus <= 0 || cus % nx || c.cu_part_n > cus) { c.err = "KOSK_CU_PARTITION: unsupported CU count / partition count"; return -1; }
+            std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+            int mine = 0;
+            for (int bit = 0; bit < cus; bit++) {
+                // bit -> (XCD, CU inside it): layout 0 deals consecutive bits round the XCDs (how workgroups are dealt),
+                // layout 1 numbers the CUs XCD after XCD (KOSK_CU_MASK_LAYOUT; which one the driver uses is measured by
+                // tools/cu_mask_probe.py)
+                const int xcd = c.cu_mask_layout ? bit / per_xcd : bit % nx, idx = c.cu_mask_layout ? bit % per_xcd : bit / nx;
+                const int ordered = xcd * per_xcd + idx;
+                if ((long)ordered * c.cu_part_n / cus == c.cu_part_i) { mask[(size_t)bit >> 5] |= 1u << (bit & 31); mine++; }
+            }
+            HIPCHK(hipExtStreamCreateWithCUMask(&c.stream, (uint32_t)mask.size(), mask.data()));
+            c.n_simd = 4 * mine;
+        } else {
+            HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        }
         HIPCHK(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
         if (c.blocking_sync) HIPCHK(hipEventCreateWithFlags(&c.ev_sync, hipEventDisableTiming | hipEventBlockingSync));
         for (auto &pe : c.prof_ev)

@@ -197,6 +197,8 @@ struct Ctx {
     bool hash_primer = false;  // KOSK_HASH_PRIMER=1: placement primer in front of a commitment launch (k_hash_primer)
     bool table_gemm = true;    // KOSK_TABLE_GEMM=0: shared-table products through the generic limb GEMM
     bool host_register = true; // KOSK_REGISTER=0: multi-chunk host-buffer calls never page-lock caller memory (staging copies only)
+    int cu_part_i = 0, cu_part_n = 1; // KOSK_CU_PARTITION=i/n: the stream is restricted to partition i of n CU partitions
+    int cu_mask_layout = 0;           // KOSK_CU_MASK_LAYOUT: how CU-mask bits map to XCDs (0 round-robin, 1 XCD-major)
     unsigned hash_opts() const { return (hash_dma ? HASH_OPT_DMA : 0u) | (hash_primer ? HASH_OPT_PRIMER : 0u); }
     // which of those paths really ran on this context (kosk_path_count): the tests of the knobs assert on these
     long path_n[PATH_COUNT] = {0};
