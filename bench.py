@@ -381,18 +381,24 @@ class Slot:
         self.gather = None  # config 4: (dist, group, [out0, out1], world)
         self.pending = []
         self.steps_done = 0
+        self.t_prove = self.t_verify = 0.0  # wall seconds inside the two library calls (the rest of a step is the harness)
 
     def step(self, torch, index):
         c, B = self.c, self.B
         ptr = self.bank[index % self.nsets].data_ptr()
+        t_a = time.perf_counter()
         c.verifiable_keygen_resident(ptr, n=B, tape_stride=self.stride)
+        t_b = time.perf_counter()
+        self.t_prove += t_b - t_a
         if self.pending:
             # the verifier reuses the digest tables: the all-gathers that read them must have completed
             for w in self.pending:
                 w.wait()
             torch.cuda.current_stream().synchronize()
             self.pending = []
+        t_c = time.perf_counter()
         ok = c.verify_resident_pk(B)
+        self.t_verify += time.perf_counter() - t_c
         if not all(ok):
             raise RuntimeError("verifier rejected %d of %d honest proofs (masks %s)" % (ok.count(False), B, c.fail_masks(B)[:8]))
         self.steps_done += 1
@@ -703,6 +709,8 @@ def main():
             "drained_run": {"steps": total, "ms_per_step": dt_drained / total * 1e3, "value": world * total * B / dt_drained,
                             "note": "the same run from first issue to last completion, barrier + synchronize on both sides (fill and drain included)"},
             "step_latency_ms": {"median": lats[len(lats) // 2] * 1e3, "p90": lats[int(len(lats) * 0.9)] * 1e3,
+                                "mean_in_keygen_call": sum(s_.t_prove for s_ in slots) / max(1, sum(s_.steps_done for s_ in slots)) * 1e3,
+                                "mean_in_verify_call": sum(s_.t_verify for s_ in slots) / max(1, sum(s_.steps_done for s_ in slots)) * 1e3,
                                 "note": "one slot's keygen + prove + verify of its %d proofs while the other slots run" % B},
             "roofline": roof,
             "host_cpu_cores_busy": round(host_cpu_s / max(dt_drained, 1e-9), 2),
@@ -711,6 +719,9 @@ def main():
             "profiled_kernel_ms_per_step": round(sum(v["total_ms"] for v in kern.values()) / max(1, (hv or {}).get("launches", 0)), 4),
             "prove_phase_ms": dict(zip(["host_pre", "gpu_commit", "fs_alpha_host", "gpu_relation", "fs_open_host", "gpu_assemble", "d2h"],
                                        [round(x * 1e3, 3) for x in phases])),
+            "prove_issue_ms": dict(zip(["p1", "p2", "p3"], [round(x * 1e3, 3) for x in phases[7:10]])),
+            "verify_phase_ms": dict(zip(["issue1", "wait1", "fs_alpha_host", "issue2", "wait2", "fs_open_host_and_masks"],
+                                        [round(x * 1e3, 3) for x in phases[10:16]])),
         }
         if gather_info:
             line["digest_allgather"] = gather_info

@@ -161,6 +161,10 @@ int kosk_stream_timer_stop(kosk_ctx *ctx, double *ms);
 /* sha3_256(h, in, inlen) for n equal-length messages        kyber/fips202.c:745-754
  * message-major layout: message i at in + i*in_stride; digest i at out + 32*i */
 int kosk_sha3_256_batch(kosk_ctx *ctx, const uint8_t *d_in, size_t in_stride, size_t inlen, uint8_t *d_out, int n);
+/* the same function computed by the lane-pair ("warp-cooperative") sponge: one Keccak state spread over two adjacent lanes of a
+ * wave, 64-bit rotations exchanged by DPP, 32 messages per wave (csrc/kosk_keccak_split_dev.hpp; BASELINE.json north_star names
+ * this layout; the pipeline's hashes use one lane per state, which is faster at its wave counts -- DESIGN.md 8) */
+int kosk_sha3_256_batch_pair(kosk_ctx *ctx, const uint8_t *d_in, size_t in_stride, size_t inlen, uint8_t *d_out, int n);
 /* shake256(out, outlen, in, inlen)                           kyber/fips202.c:723-734 */
 int kosk_shake256_batch(kosk_ctx *ctx, const uint8_t *d_in, size_t in_stride, size_t inlen,
                         uint8_t *d_out, size_t outlen, int n);

@@ -63,6 +63,7 @@ def _load():
         "kosk_host_free": (None, [vp]),
         "kosk_sha3_256_batch": (C.c_int, [vp, vp, sz, sz, vp, C.c_int]),
         "kosk_shake256_batch": (C.c_int, [vp, vp, sz, sz, vp, sz, C.c_int]),
+        "kosk_sha3_256_batch_pair": (C.c_int, [vp, vp, sz, sz, vp, C.c_int]),
         "kosk_commit_hash_lanes": (C.c_int, [vp, vp, sz, C.c_int, vp, C.c_int, vp]),
         "kosk_ntt256_batch": (C.c_int, [vp, vp, vp, C.c_int]),
         "kosk_lagrange_expand": (C.c_int, [vp, vp, vp, C.c_int]),
@@ -97,7 +98,7 @@ EXPORTS = ["kosk_pk_bytes", "kosk_sk_bytes", "kosk_proof_bytes", "kosk_tape_byte
            "kosk_prepare_randomness", "kosk_prepare_range_proof", "kosk_prove_prepared", "kosk_verify_inst", "kosk_compact_proof_bytes",
            "kosk_proof_compress", "kosk_proof_decompress", "kosk_fetch_proofs_compact", "kosk_stage_verifier_inputs_compact", "kosk_stage_prover_inputs", "kosk_prove_resident", "kosk_fetch_proofs",
            "kosk_stage_verifier_inputs", "kosk_verify_resident", "kosk_verifiable_keygen_resident", "kosk_verify_resident_pk",
-           "kosk_resident_digests", "kosk_set_round_hook", "kosk_phase_seconds", "kosk_path_count", "kosk_host_threads", "kosk_verifiable_keygen_batch_compact", "kosk_verify_batch_compact", "kosk_host_alloc", "kosk_host_free", "kosk_sha3_256_batch",
+           "kosk_resident_digests", "kosk_set_round_hook", "kosk_phase_seconds", "kosk_path_count", "kosk_host_threads", "kosk_sha3_256_batch_pair", "kosk_verifiable_keygen_batch_compact", "kosk_verify_batch_compact", "kosk_host_alloc", "kosk_host_free", "kosk_sha3_256_batch",
            "kosk_shake256_batch", "kosk_commit_hash_lanes", "kosk_ntt256_batch", "kosk_lagrange_expand",
            "kosk_recon_secrets", "kosk_profile_enable", "kosk_profile_read", "kosk_stream_timer_start", "kosk_stream_timer_stop", "kosk_device_synchronize", "kosk_streams", "kosk_commit_launch_groups", "kosk_resident_proofs", "kosk_keygen", "kosk_fs_alpha",
            "kosk_fs_opened", "kosk_host_sha3_256", "kosk_host_shake256", "kosk_host_sha3_256_multi", "kosk_lagrange_table"]
@@ -405,6 +406,9 @@ class Kosk:
     # kernel-level (device pointers as ints, e.g. torch tensor .data_ptr())
     def sha3_256_batch(self, d_in, in_stride, inlen, d_out, n):
         self._chk(lib.kosk_sha3_256_batch(self._h, d_in, in_stride, inlen, d_out, n), "sha3_256_batch")
+
+    def sha3_256_batch_pair(self, d_in, in_stride, inlen, d_out, n):
+        self._chk(lib.kosk_sha3_256_batch_pair(self._h, d_in, in_stride, inlen, d_out, n), "sha3_256_batch_pair")
 
     def shake256_batch(self, d_in, in_stride, inlen, d_out, outlen, n):
         self._chk(lib.kosk_shake256_batch(self._h, d_in, in_stride, inlen, d_out, outlen, n), "shake256_batch")

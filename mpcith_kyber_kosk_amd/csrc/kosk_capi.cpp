@@ -781,6 +781,18 @@ int kosk_shake256_batch(kosk_ctx *ctx, const uint8_t *d_in, size_t in_stride, si
     GUARD_END
 }
 
+int kosk_sha3_256_batch_pair(kosk_ctx *ctx, const uint8_t *d_in, size_t in_stride, size_t inlen, uint8_t *d_out, int n)
+{
+    if (!ctx) return -1;
+    GUARD(ctx)
+    Ctx &c = *ctx->c;
+    ctx->clear_err();
+    HIPCHK_C(hipSetDevice(c.device));
+    HIPCHK_C(launch_sha3_msgs_pair(d_in, in_stride, (int)inlen, d_out, 32, 32, n, 0x06, c.stream));
+    return 0;
+    GUARD_END
+}
+
 int kosk_commit_hash_lanes(kosk_ctx *ctx, const uint16_t *d_rows, size_t row_stride, int n_lanes,
                            const uint8_t *d_prefix, int with_prefix, uint8_t *d_out)
 {

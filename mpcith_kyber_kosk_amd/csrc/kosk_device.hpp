@@ -243,6 +243,9 @@ hipError_t launch_commit_hash(const HashArgs &a, int ngroups, int K, bool view, 
                               int *variant = nullptr);
 hipError_t launch_sha3_msgs(const uint8_t *in, size_t in_stride, int len, uint8_t *out, size_t out_stride,
                             int outlen, int n, int domain, hipStream_t st);
+// the same on the lane-pair sponge (32 messages per wave; kosk_keccak_split_dev.hpp)
+hipError_t launch_sha3_msgs_pair(const uint8_t *in, size_t in_stride, int len, uint8_t *out, size_t out_stride, int outlen, int n,
+                                 int domain, hipStream_t st);
 hipError_t launch_rows_copy(const uint16_t *src, size_t src_stride, uint16_t *dst, size_t dst_stride, int count,
                             int nrows, hipStream_t st);
 // expand_f + tape randoms + witness secrets (the kernels that only read the tape / the key) in one launch

@@ -19,6 +19,7 @@
 
 #include "kosk_device.hpp"
 #include "kosk_keccak_dev.hpp"
+#include "kosk_keccak_split_dev.hpp"
 #include "kosk_keygen_dev.hpp"
 #include "kosk_math.hpp"
 #include "kosk_limb_dev.hpp"
@@ -301,6 +302,58 @@ __global__ __launch_bounds__(64) void k_sha3_msgs(const uint8_t *__restrict__ in
             for (int k = 0; k < 17; k++)
                 if (k == w) lanev = s[k];
             o[produced + b] = (uint8_t)(lanev >> (8 * (b & 7)));
+        }
+        produced += take;
+    }
+}
+
+// The "warp-cooperative" sponge of BASELINE.json's north_star in its cheapest form (kosk_keccak_split_dev.hpp): one state spread
+// over a LANE PAIR -- the even lane holds the low halves of the 25 words, the odd lane the high halves, the 64-bit rotations
+// exchange halves by DPP.  32 messages per wave.  SHA3-256 / SHAKE of message-major input like k_sha3_msgs; kernel-level entry
+// kosk_sha3_256_batch_pair.  The pipeline keeps the one-lane layout (this one has 1.28x less single-wave latency but fewer
+// states per issue slot: DESIGN.md 8).  All 64 lanes stay active: the DPP exchange reads the partner's registers.
+__global__ __launch_bounds__(64) void k_sha3_msgs_pair(const uint8_t *__restrict__ in, size_t in_stride, int len,
+                                                       uint8_t *__restrict__ out, size_t out_stride, int outlen, int n, int domain)
+{
+    const int msg = blockIdx.x * 32 + (threadIdx.x >> 1);
+    const bool hi = threadIdx.x & 1;
+    const bool live = msg < n;
+    const uint8_t *m = in + (size_t)(live ? msg : n - 1) * in_stride; // idle pairs hash the last message and store nothing
+    KHalf s;
+#pragma unroll
+    for (int k = 0; k < 25; k++) s.w[k] = 0;
+    // byte `pos` of the 136-byte rate block belongs to word pos >> 3, half (pos >> 2) & 1, bits 8 (pos & 3)
+    auto absorb_byte = [&](int pos, uint32_t byte) {
+        if ((((pos >> 2) & 1) != 0) != hi) return;
+        const uint32_t v = byte << (8 * (pos & 3));
+        const int w = pos >> 3;
+#pragma unroll
+        for (int k = 0; k < 17; k++)
+            if (k == w) s.w[k] ^= v;
+    };
+    int pos = 0;
+    for (int b = 0; b < len; b++) {
+        absorb_byte(pos, m[b]);
+        if (++pos == 136) {
+            keccak_f1600_split(s, hi);
+            pos = 0;
+        }
+    }
+    absorb_byte(pos, (uint32_t)domain);
+    if (hi) s.w[16] ^= 0x80000000u;
+    uint8_t *o = out + (size_t)(live ? msg : 0) * out_stride;
+    int produced = 0;
+    while (produced < outlen) {
+        keccak_f1600_split(s, hi);
+        const int take = min(136, outlen - produced);
+        for (int b = 0; b < take; b++) {
+            if ((((b >> 2) & 1) != 0) != hi) continue;
+            uint32_t v = 0;
+            const int w = b >> 3;
+#pragma unroll
+            for (int k = 0; k < 17; k++)
+                if (k == w) v = s.w[k];
+            if (live) o[produced + b] = (uint8_t)(v >> (8 * (b & 3)));
         }
         produced += take;
     }
@@ -1209,8 +1262,12 @@ __global__ __launch_bounds__(256) void k_lincomb_fused(const uint16_t *P, size_t
                 lo[q >> 2] |= ((uint32_t)c0 & 0xFFu) << (8 * (q & 3));
                 hi[q >> 2] |= ((uint32_t)c1 & 0xFFu) << (8 * (q & 3));
             }
+            // point x of the 128 goes to MFMA row tile 2 (x >> 5) + ((x >> 2) & 1), row 4 ((x >> 3) & 3) + (x & 3): an output
+            // lane (row group g = lane >> 4) then holds points 8 g .. 8 g + 3 in the even tile of a pair and 8 g + 4 .. 8 g + 7
+            // in the odd one -- eight consecutive points, ONE 16-byte store per output row instead of two 8-byte ones
             const int x = xl + pt;
-            uint8_t *d = lds + ((ch >> 2) * 8 + (x >> 4)) * 2048 + (x & 15) * 64 + (((ch & 3) ^ limb_swz(x & 15)) << 4);
+            const int xt = (x >> 5) * 2 + ((x >> 2) & 1), xr = ((x >> 3) & 3) * 4 + (x & 3);
+            uint8_t *d = lds + ((ch >> 2) * 8 + xt) * 2048 + xr * 64 + (((ch & 3) ^ limb_swz(xr)) << 4);
             *reinterpret_cast<uint4 *>(d) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
             *reinterpret_cast<uint4 *>(d + 1024) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
         }
@@ -1257,20 +1314,25 @@ __global__ __launch_bounds__(256) void k_lincomb_fused(const uint16_t *P, size_t
             if (jo >= J) continue;
             uint16_t *crow = Cb + (size_t)lin_rows[which * 128 + jo] * RS;
 #pragma unroll
-            for (int ib = 0; ib < 4; ib++) {
-                const int m = m0 + wm * 64 + ib * 16 + (lane >> 4) * 4;
-                if (m >= NPTS) continue;
-                uint32_t v[4];
+            for (int ip = 0; ip < 2; ip++) { // tile pair: eight consecutive points per lane (see the staging above)
+                const int m = m0 + wm * 64 + ip * 32 + (lane >> 4) * 8;
+                if (m >= NPTS) continue; // the last live group (1704..1711) ends two points inside the row padding (RS = 1728), as before
+                uint32_t v[8];
 #pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = gf_from_i32(s0[ib][j][r] + 64 * s1[ib][j][r] + 767 * s2[ib][j][r]);
-                *reinterpret_cast<uint2 *>(crow + m) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        v[4 * h + r] = gf_from_i32(s0[2 * ip + h][j][r] + 64 * s1[2 * ip + h][j][r] + 767 * s2[2 * ip + h][j][r]);
+                *reinterpret_cast<uint4 *>(crow + m) = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
                 if (which == 0 && jo >= NCHK) { // r rows: s + r_i, e + r_{K+i} on the spot (mlwe_prover.cpp:222-245)
                     const int idx = jo - NCHK;
                     const int src_row = idx < K ? row_s + idx : row_e + (idx - K), dst_row = idx < K ? row_sr + idx : row_er + (idx - K);
-                    const uint2 sv = *reinterpret_cast<const uint2 *>(Cb + (size_t)src_row * RS + m);
-                    const uint32_t a0 = gf_add(sv.x & 0xFFFFu, v[0]), a1 = gf_add(sv.x >> 16, v[1]);
-                    const uint32_t a2 = gf_add(sv.y & 0xFFFFu, v[2]), a3 = gf_add(sv.y >> 16, v[3]);
-                    *reinterpret_cast<uint2 *>(Cb + (size_t)dst_row * RS + m) = make_uint2(a0 | (a1 << 16), a2 | (a3 << 16));
+                    const uint4 sv = *reinterpret_cast<const uint4 *>(Cb + (size_t)src_row * RS + m);
+                    const uint32_t sw[4] = {sv.x, sv.y, sv.z, sv.w};
+                    uint32_t ow[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) ow[q] = gf_add(sw[q] & 0xFFFFu, v[2 * q]) | (gf_add(sw[q] >> 16, v[2 * q + 1]) << 16);
+                    *reinterpret_cast<uint4 *>(Cb + (size_t)dst_row * RS + m) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
                 }
             }
         }
@@ -1610,6 +1672,14 @@ hipError_t launch_sha3_msgs(const uint8_t *in, size_t in_stride, int len, uint8_
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_sha3_msgs, dim3((n + 63) / 64), dim3(64), 0, st, in, in_stride, len, out, out_stride, outlen, n, domain);
+    return hipGetLastError();
+}
+
+hipError_t launch_sha3_msgs_pair(const uint8_t *in, size_t in_stride, int len, uint8_t *out, size_t out_stride, int outlen, int n,
+                                 int domain, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sha3_msgs_pair, dim3((n + 31) / 32), dim3(64), 0, st, in, in_stride, len, out, out_stride, outlen, n, domain);
     return hipGetLastError();
 }
 

@@ -46,6 +46,24 @@ def test_sha3_256_and_shake256_message_major(length, torch, ctx):
         assert xof[i].tobytes() == hashlib.shake_256(m).digest(200)
 
 
+@pytest.mark.parametrize("length", [0, 1, 3, 4, 5, 135, 136, 137, 271, 272, 320, 472, 1000])
+def test_sha3_256_lane_pair_sponge(length, torch, ctx):
+    """kosk_sha3_256_batch_pair: the lane-pair ("warp-cooperative") Keccak layout, 32 messages per wave, ragged counts (idle
+    pairs in the last wave, a single message, one more than a wave) against hashlib."""
+    rng = np.random.default_rng(1000 + length)
+    stride = max(8, (length + 7) // 8 * 8)
+    for n in (257, 1, 33):
+        msgs = rng.integers(0, 256, size=(n, stride), dtype=np.uint8)
+        d_in = _dev(torch, msgs)
+        d_out = torch.zeros((n + 1, 32), dtype=torch.uint8, device="cuda")   # one guard row behind the last digest
+        ctx.sha3_256_batch_pair(d_in.data_ptr(), stride, length, d_out.data_ptr(), n)
+        ctx.synchronize()
+        out = d_out.cpu().numpy()
+        for i in range(n):
+            assert out[i].tobytes() == hashlib.sha3_256(msgs[i, :length].tobytes()).digest(), (n, i)
+        assert not out[n].any()
+
+
 @pytest.mark.parametrize("k", [2, 3, 4])
 @pytest.mark.parametrize("with_prefix", [0, 1])
 def test_commit_hash_column_layout(k, with_prefix, torch, oracle):
