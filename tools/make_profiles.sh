@@ -2,7 +2,7 @@
 # Regenerates the files under profiles/ (run on the MI355X box from the repo root; outputs under gpurun_out/prof).
 # usage: tools/make_profiles.sh <tag>        e.g. r01b
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/prof
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
