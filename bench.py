@@ -381,6 +381,7 @@ class Slot:
         self.gather = None  # config 4: (dist, group, [out0, out1], world)
         self.pending = []
         self.steps_done = 0
+        self.ph_sum = None
         self.t_prove = self.t_verify = 0.0  # wall seconds inside the two library calls (the rest of a step is the harness)
 
     def step(self, torch, index):
@@ -399,6 +400,9 @@ class Slot:
         t_c = time.perf_counter()
         ok = c.verify_resident_pk(B)
         self.t_verify += time.perf_counter() - t_c
+        if self.ph_sum is not None:  # --phase-stats: the library's phase clocks of THIS step (prove phases are still the last prove's)
+            for i_, v_ in enumerate(c.phase_seconds()):
+                self.ph_sum[i_] += v_
         if not all(ok):
             raise RuntimeError("verifier rejected %d of %d honest proofs (masks %s)" % (ok.count(False), B, c.fail_masks(B)[:8]))
         self.steps_done += 1
@@ -438,6 +442,7 @@ def main():
                          "default.  Never depends on --steps.")
     ap.add_argument("--partitions", type=int, default=int(os.environ.get("KOSK_BENCH_PARTITIONS", "1")),
                     help="CU partitions of the GPU (whole XCDs for 2, 4, 8): slot i runs on partition i %% P only")
+    ap.add_argument("--phase-stats", action="store_true", help="mean of the library's phase clocks over every step (diagnostic; one extra ABI call per step)")
     ap.add_argument("--tape-sets", type=int, default=4, help="distinct resident tape sets per slot, rotated step by step")
     ap.add_argument("--cpu-proofs", type=int, default=12, help="bounded CPU baseline sample (about 13 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -589,6 +594,9 @@ def main():
             run(2 * S)
     for sl in slots:
         sl.c.profile_enable(True)
+        if args.phase_stats:
+            sl.ph_sum = [0.0] * 16
+            sl.steps_at_stats = sl.steps_done
     import resource
     barrier()
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
@@ -723,6 +731,11 @@ def main():
             "verify_phase_ms": dict(zip(["issue1", "wait1", "fs_alpha_host", "issue2", "wait2", "fs_open_host_and_masks"],
                                         [round(x * 1e3, 3) for x in phases[10:16]])),
         }
+        if args.phase_stats:
+            names = ["host_pre", "gpu_commit", "fs_alpha_host", "gpu_relation", "fs_open_host", "gpu_assemble", "d2h", "issue_p1", "issue_p2", "issue_p3",
+                     "v_issue1", "v_wait1", "v_fs_alpha_host", "v_issue2", "v_wait2", "v_fs_open_host_and_masks"]
+            nst = max(1, sum(s_.steps_done - s_.steps_at_stats for s_ in slots))
+            line["phase_means_ms"] = {nm: round(sum(s_.ph_sum[i_] for s_ in slots) / nst * 1e3, 4) for i_, nm in enumerate(names)}
         if gather_info:
             line["digest_allgather"] = gather_info
         if args.config == 5 and not custom:
