@@ -268,14 +268,40 @@ def drop_in(api, torch, k, B, tapes, device):
             fn()
         return reps * n / (time.perf_counter() - t0)
 
+    def chk(rc, h, what, okbuf=None):
+        if rc:
+            raise RuntimeError("%s: %s" % (what, lib.kosk_last_error(h.handle).decode()))
+        if okbuf is not None and okbuf.raw != b"\x01" * n:
+            bad = [i for i, b_ in enumerate(okbuf.raw) if b_ != 1]
+            if os.environ.get("KOSK_BENCH_DIAG"):
+                masks = h.fail_masks(n)
+                sys.stderr.write("DIAG %s: rejected %d: %s\n" % (what, len(bad), [(i, masks[i]) for i in bad][:8]))
+                sys.stderr.write("DIAG path counts %s\n" % h.path_counts())
+                if diag_buf[0] is not None:
+                    # are the proofs themselves good?  prove the same tapes on a fresh single-stream handle, compare, and verify
+                    # the suspect buffer there
+                    fresh = api.Kosk(kyber_k=k, max_batch=B, device=device)
+                    img = C.string_at(diag_buf[0], pb * n) if not isinstance(diag_buf[0], C.Array) else diag_buf[0].raw
+                    ref = fresh.verifiable_keygen(tapes)
+                    diff = [i for i in range(n) if img[i * pb:(i + 1) * pb] != ref[2][i % B]]
+                    sys.stderr.write("DIAG proofs differing from a fresh handle's: %d %s\n" % (len(diff), diff[:12]))
+                    okf = fresh.verify([img[i * pb:(i + 1) * pb] for i in range(B)], ref[0])
+                    sys.stderr.write("DIAG fresh handle verifies chunk 0 of the buffer: %s\n" % (okf.count(True),))
+                    rc2 = lib.kosk_verify_batch(h.handle, n, diag_buf[0], pk[0], okbuf)
+                    sys.stderr.write("DIAG same handle, second try: rc %d rejected %d\n" % (rc2, sum(1 for b_ in okbuf.raw if b_ != 1)))
+            raise RuntimeError("%s rejected %d of %d honest proofs: indices %s, fail masks %s" % (what, len(bad), n, bad[:12], h.fail_masks(n)[bad[0]:bad[0] + 4]))
+
+    diag_buf = [None]
+
     def pair(buf, compact):
         def fn():
+            diag_buf[0] = None if compact else buf
             if compact:
-                assert lib.kosk_verifiable_keygen_batch_compact(prover.handle, n, blob, tb, pk[0], sk, buf) == 0
-                assert lib.kosk_verify_batch_compact(prover.handle, n, buf, pk[0], ok) == 0 and ok.raw == b"\x01" * n
+                chk(lib.kosk_verifiable_keygen_batch_compact(prover.handle, n, blob, tb, pk[0], sk, buf), prover, "keygen_batch_compact")
+                chk(lib.kosk_verify_batch_compact(prover.handle, n, buf, pk[0], ok), prover, "verify_batch_compact", ok)
             else:
-                assert lib.kosk_verifiable_keygen_batch(prover.handle, n, blob, tb, pk[0], sk, buf) == 0
-                assert lib.kosk_verify_batch(prover.handle, n, buf, pk[0], ok) == 0 and ok.raw == b"\x01" * n
+                chk(lib.kosk_verifiable_keygen_batch(prover.handle, n, blob, tb, pk[0], sk, buf), prover, "keygen_batch")
+                chk(lib.kosk_verify_batch(prover.handle, n, buf, pk[0], ok), prover, "verify_batch", ok)
         return fn
     pageable = C.create_string_buffer(pb * n)
     out["one_thread_pageable_image"] = rate(pair(pageable, False), 2)

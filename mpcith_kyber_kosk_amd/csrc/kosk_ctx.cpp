@@ -86,11 +86,13 @@ static int upload_table(Ctx &c, GemmTable &t, const std::vector<uint16_t> &A, in
     std::vector<uint8_t> pk;
     pack_limb_table(A, M, Kdim, t.Mpad, t.KS, pk);
     HIPCHK(dalloc(&t.d, pk.size()));
-    HIPCHK(hipMemcpy(t.d, pk.data(), pk.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(t.d, pk.data(), pk.size(), hipMemcpyHostToDevice, c.stream)); // c.stream, not the legacy null stream
+    HIPCHK(hipStreamSynchronize(c.stream));
     if (t.KS == 7 || t.KS == 13) {
         pack_frag_table(A, M, Kdim, t.Mpad, t.KS, pk);
         HIPCHK(dalloc(&t.dfrag, pk.size()));
-        HIPCHK(hipMemcpy(t.dfrag, pk.data(), pk.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(t.dfrag, pk.data(), pk.size(), hipMemcpyHostToDevice, c.stream));
+        HIPCHK(hipStreamSynchronize(c.stream));
     }
     return 0;
 }
@@ -184,7 +186,10 @@ template <typename T>
 static int upload_vec(Ctx &c, T **d, const std::vector<T> &v)
 {
     HIPCHK(dalloc(d, v.size() ? v.size() : 1));
-    if (!v.empty()) HIPCHK(hipMemcpy(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (!v.empty()) {
+        HIPCHK(hipMemcpyAsync(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c.stream)); // c.stream, not the legacy null stream
+        HIPCHK(hipStreamSynchronize(c.stream));
+    }
     return 0;
 }
 

@@ -78,7 +78,8 @@ int prepare_randomness(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride, 
     if (rm.tf != rm.f + M) { c.err = "internal: f / NTT f rows not adjacent"; return -1; }
     std::vector<uint16_t> rows((size_t)2 * M * RS);
     for (int b = 0; b < n; b++) {
-        HIPCHK(hipMemcpy(rows.data(), c.d_P + (size_t)b * c.proof_stride + (size_t)rm.f * RS, rows.size() * 2, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(rows.data(), c.d_P + (size_t)b * c.proof_stride + (size_t)rm.f * RS, rows.size() * 2, hipMemcpyDeviceToHost, c.stream));
+        HIPCHK(hipStreamSynchronize(c.stream));
         uint8_t *o = out + (size_t)b * randomness_bytes(P);
         uint8_t *of = o, *ontt = o + (size_t)M * 512, *ofs = o + (size_t)M * 1024, *onfs = ofs + (size_t)M * SHARE_VEC_BYTES;
         for (int i = 0; i < M; i++) {
@@ -104,7 +105,8 @@ int prepare_range_proof(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride,
     if (rm.eeta != rm.seta + KE) { c.err = "internal: eta rows not adjacent"; return -1; }
     std::vector<uint16_t> rows((size_t)2 * KE * RS);
     for (int b = 0; b < n; b++) {
-        HIPCHK(hipMemcpy(rows.data(), c.d_P + (size_t)b * c.proof_stride + (size_t)rm.seta * RS, rows.size() * 2, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(rows.data(), c.d_P + (size_t)b * c.proof_stride + (size_t)rm.seta * RS, rows.size() * 2, hipMemcpyDeviceToHost, c.stream));
+        HIPCHK(hipStreamSynchronize(c.stream));
         uint8_t *o = out + (size_t)b * range_proof_bytes(P);
         for (int r = 0; r < 2 * KE; r++) put_share_vec(o + (size_t)r * SHARE_VEC_BYTES, &rows[(size_t)r * RS]); // s rows [i][j], then e rows
     }
@@ -131,9 +133,12 @@ static int upload_inst(Ctx &c, int n, const uint8_t *inst, bool with_se, bool wi
         for (int i = 0; i < K * 256; i++) t[(size_t)b * K * 256 + i] = (uint16_t)(((int)ts[i] % Q + Q) % Q); // encode_to_gf3329
         memcpy(&se[(size_t)b * c.se_stride], ss, (size_t)2 * K * 512);
     }
-    HIPCHK(hipMemcpy(c.d_A, A.data(), A.size() * 2, hipMemcpyHostToDevice));
-    if (with_se) HIPCHK(hipMemcpy(c.d_se, se.data(), se.size() * 2, hipMemcpyHostToDevice));
-    if (with_t) HIPCHK(hipMemcpy(c.d_t, t.data(), t.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(c.d_A, A.data(), A.size() * 2, hipMemcpyHostToDevice, c.stream));
+        HIPCHK(hipStreamSynchronize(c.stream));
+    if (with_se) HIPCHK(hipMemcpyAsync(c.d_se, se.data(), se.size() * 2, hipMemcpyHostToDevice, c.stream));
+        HIPCHK(hipStreamSynchronize(c.stream));
+    if (with_t) HIPCHK(hipMemcpyAsync(c.d_t, t.data(), t.size() * 2, hipMemcpyHostToDevice, c.stream));
+        HIPCHK(hipStreamSynchronize(c.stream));
     return 0;
 }
 
@@ -160,7 +165,8 @@ int prove_prepared(Ctx &c, int n, const uint8_t *inst, const uint8_t *rand_in, c
         }
         for (uint16_t v : rows)
             if (v >= Q) { c.err = "mpcith_randomness holds a non-canonical value"; return -1; }
-        HIPCHK(hipMemcpy(c.d_P + (size_t)b * c.proof_stride + (size_t)rm.f * RS, rows.data(), rows.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(c.d_P + (size_t)b * c.proof_stride + (size_t)rm.f * RS, rows.data(), rows.size() * 2, hipMemcpyHostToDevice, c.stream));
+        HIPCHK(hipStreamSynchronize(c.stream));
         const uint8_t *g = range_in + (size_t)b * range_proof_bytes(P);
         std::fill(erows.begin(), erows.end(), 0);
         for (int q = 0; q < 2 * KE; q++) {
@@ -171,7 +177,8 @@ int prove_prepared(Ctx &c, int n, const uint8_t *inst, const uint8_t *rand_in, c
         }
         for (uint16_t v : erows)
             if (v >= Q) { c.err = "mpcith_range_proof holds a non-canonical value"; return -1; }
-        HIPCHK(hipMemcpy(c.d_P + (size_t)b * c.proof_stride + (size_t)rm.seta * RS, erows.data(), erows.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(c.d_P + (size_t)b * c.proof_stride + (size_t)rm.seta * RS, erows.data(), erows.size() * 2, hipMemcpyHostToDevice, c.stream));
+        HIPCHK(hipStreamSynchronize(c.stream));
     }
     if (fill_tape_part(c, n, false, 2 * M + 2 * KE, P.nfresh, tapes, tape_stride)) return -1;
     if (prove_resident(c, n, true)) return -1;

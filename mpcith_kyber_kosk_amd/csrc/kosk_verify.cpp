@@ -36,7 +36,12 @@ template <typename T>
 static int upload_vec(Ctx &c, T **d, const std::vector<T> &v)
 {
     HIPCHK(dalloc(d, v.size()));
-    if (!v.empty()) HIPCHK(hipMemcpy(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    // on the context's own stream (a non-blocking stream is NOT ordered against the legacy null stream that a plain hipMemcpy /
+    // hipMemset uses), and complete before `v` goes away: the caller synchronises the stream before it returns
+    if (!v.empty()) {
+        HIPCHK(hipMemcpyAsync(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c.stream));
+        HIPCHK(hipStreamSynchronize(c.stream));
+    }
     return 0;
 }
 
@@ -127,7 +132,7 @@ int ensure_verify_workspace(Ctx &c)
 
     c.o_stride = (size_t)rm.nrows * OS;
     HIPCHK(dalloc(&c.d_O, B * c.o_stride));
-    HIPCHK(hipMemset(c.d_O, 0, B * c.o_stride * sizeof(uint16_t)));
+    HIPCHK(hipMemsetAsync(c.d_O, 0, B * c.o_stride * sizeof(uint16_t), c.stream));
     HIPCHK(dalloc(&c.d_w, B * 2 * 832));
     HIPCHK(dalloc(&c.d_ell, B * 416));
     HIPCHK(dalloc(&c.d_node_of, B * 416));
@@ -139,6 +144,7 @@ int ensure_verify_workspace(Ctx &c)
     HIPCHK(dalloc(&c.d_sec_u1, B * c.n_interp_2d * 256));
     HIPCHK(dalloc(&c.d_sec_u2, B * c.n_interp_2d * 256));
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c.h_Iimg), B * 2 * NOPEN, hipHostMallocDefault));
+    HIPCHK(hipStreamSynchronize(c.stream)); // every table and the zeroed opened matrix are in HBM before the first verifier kernel is queued
     c.verify_ready = true;
     return 0;
 }

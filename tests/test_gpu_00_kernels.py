@@ -35,8 +35,10 @@ def test_sha3_256_and_shake256_message_major(length, torch, ctx):
     msgs = rng.integers(0, 256, size=(n, stride), dtype=np.uint8)
     d_in = _dev(torch, msgs)
     d_out = torch.zeros((n, 32), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # torch fills / copies run on the null stream; the library streams are not ordered against it
     ctx.sha3_256_batch(d_in.data_ptr(), stride, length, d_out.data_ptr(), n)
     d_x = torch.zeros((n, 200), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # torch fills / copies run on the null stream; the library streams are not ordered against it
     ctx.shake256_batch(d_in.data_ptr(), stride, length, d_x.data_ptr(), 200, n)
     ctx.synchronize()
     out, xof = d_out.cpu().numpy(), d_x.cpu().numpy()
@@ -56,6 +58,7 @@ def test_sha3_256_lane_pair_sponge(length, torch, ctx):
         msgs = rng.integers(0, 256, size=(n, stride), dtype=np.uint8)
         d_in = _dev(torch, msgs)
         d_out = torch.zeros((n + 1, 32), dtype=torch.uint8, device="cuda")   # one guard row behind the last digest
+        torch.cuda.synchronize()  # torch fills / copies run on the null stream; the library streams are not ordered against it
         ctx.sha3_256_batch_pair(d_in.data_ptr(), stride, length, d_out.data_ptr(), n)
         ctx.synchronize()
         out = d_out.cpu().numpy()
@@ -78,6 +81,7 @@ def test_commit_hash_column_layout(k, with_prefix, torch, oracle):
     c = api.Kosk(kyber_k=k, max_batch=1)
     d_rows, d_pre = _dev(torch, rows), _dev(torch, prefix)
     d_out = torch.zeros((n, 32), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # torch fills / copies run on the null stream; the library streams are not ordered against it
     c.commit_hash_lanes(d_rows.data_ptr(), stride, n, d_pre.data_ptr(), with_prefix, d_out.data_ptr())
     c.synchronize()
     out = d_out.cpu().numpy()
@@ -95,6 +99,7 @@ def test_ntt256_matches_oracle(torch, ctx, oracle):
     a[3] = np.arange(256) % 3329
     d_in = _dev(torch, a)
     d_out = torch.zeros_like(d_in)
+    torch.cuda.synchronize()  # torch fills / copies run on the null stream; the library streams are not ordered against it
     ctx.ntt256_batch(d_in.data_ptr(), d_out.data_ptr(), n)
     ctx.synchronize()
     out = d_out.cpu().numpy()
@@ -115,6 +120,7 @@ def test_ntt256_packed_fp32_variant(torch, oracle, monkeypatch):
     a[0] = 3328; a[1] = -3328; a[2] = 0; a[3] = np.arange(256) % 3329
     d_in = _dev(torch, a)
     d_out = torch.zeros_like(d_in)
+    torch.cuda.synchronize()  # torch fills / copies run on the null stream; the library streams are not ordered against it
     c.ntt256_batch(d_in.data_ptr(), d_out.data_ptr(), n)
     c.synchronize()
     out = d_out.cpu().numpy()
@@ -137,8 +143,10 @@ def test_lagrange_expand_and_recon_match_oracle(torch, ctx, oracle):
     y[0] = 0; y[1] = 3328
     d_y = _dev(torch, y)
     d_sh = torch.zeros((n, 1454), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()  # torch fills / copies run on the null stream; the library streams are not ordered against it
     ctx.lagrange_expand(d_y.data_ptr(), d_sh.data_ptr(), n)
     d_sec = torch.zeros((n, 256), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()  # torch fills / copies run on the null stream; the library streams are not ordered against it
     ctx.recon_secrets(d_sh.data_ptr(), d_sec.data_ptr(), n, False)
     ctx.synchronize()
     sh = d_sh.cpu().numpy().view(np.uint16)
@@ -151,6 +159,7 @@ def test_lagrange_expand_and_recon_match_oracle(torch, ctx, oracle):
     prod = (sh.astype(np.uint32)[0::2] * sh.astype(np.uint32)[1::2] % 3329).astype(np.uint16)
     d_p = _dev(torch, prod)
     d_s2 = torch.zeros((prod.shape[0], 256), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()  # torch fills / copies run on the null stream; the library streams are not ordered against it
     ctx.recon_secrets(d_p.data_ptr(), d_s2.data_ptr(), prod.shape[0], True)
     ctx.synchronize()
     s2 = d_s2.cpu().numpy().view(np.uint16)

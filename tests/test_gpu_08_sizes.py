@@ -44,7 +44,9 @@ def test_commit_hash_at_65536_lanes(k, torch_cuda, oracle):
     d_tc = torch.zeros((LANES, 32), dtype=torch.uint8, device="cuda")
     d_vw = torch.zeros((LANES, 32), dtype=torch.uint8, device="cuda")
     c = api.Kosk(kyber_k=k, max_batch=1)
+    torch_cuda.cuda.synchronize()  # torch fills / copies run on the null stream; the library streams are not ordered against it
     c.commit_hash_lanes(d_rows.data_ptr(), LANES, LANES, 0, 0, d_tc.data_ptr())          # rows 0..tc_words-1
+    torch_cuda.cuda.synchronize()  # torch fills / copies run on the null stream; the library streams are not ordered against it
     c.commit_hash_lanes(d_rows.data_ptr(), LANES, LANES, d_tc.data_ptr(), 1, d_vw.data_ptr())
     c.synchronize()
     assert c.path_counts()["hash_dma"] == 2          # the kernel the bench times (LDS-DMA staged), not a fallback
@@ -74,6 +76,7 @@ def test_ntt256_at_65536_polynomials(fp32, torch_cuda, oracle, monkeypatch):
     for x in (a, b, s):
         d_in = torch.from_numpy(np.ascontiguousarray(x)).cuda()
         d_out = torch.zeros_like(d_in)
+        torch_cuda.cuda.synchronize()  # torch fills / copies run on the null stream; the library streams are not ordered against it
         c.ntt256_batch(d_in.data_ptr(), d_out.data_ptr(), LANES)
         c.synchronize()
         outs.append(d_out.cpu().numpy())
