@@ -677,15 +677,9 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     if (c.round_hook) c.round_hook(c.round_user, 0, 1, c.d_dig2, (size_t)n * NPARTY * 32);
 
     // ---- Fiat-Shamir round 2 on the host
-    fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, c.h_I, c.h_rest, c.sel_stride, c.nthreads, c.pool);
-    for (int b = 0; b < n; b++) { // complement entries owned by each aligned 64-party window (k_assemble_fields)
-        const uint16_t *rest = c.h_rest + (size_t)b * c.sel_stride;
-        uint16_t *win = c.h_I + (size_t)b * c.sel_stride + SEL_WIN;
-        for (int w = 0, j = 0; w <= NWIN; w++) {
-            while (j < NREST && rest[j] < 64 * w) j++;
-            win[w] = (uint16_t)j;
-        }
-    }
+    // I, its complement, and the complement entries owned by each aligned 64-party window (k_assemble_fields), all derived by
+    // the worker that hashed the proof's table
+    fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, c.h_I, c.h_rest, c.sel_stride, c.nthreads, c.pool, true);
     t1 = now_sec(); c.phase_sec[PH_FS_OPEN] = t1 - t0; t0 = t1;
 
     // ---- P3: wire image

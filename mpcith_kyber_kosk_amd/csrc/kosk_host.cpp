@@ -367,7 +367,11 @@ void sha3_256_multi(uint8_t *out, const uint8_t *const *in, size_t len, int coun
 
 // the SIMD width is chosen so that the groups roughly fill the available threads: the 343-permutation
 // chains are sequential per proof, so latency = one chain whatever the width
-static void sha3_digest_tables(int n, const uint8_t *digs, size_t dig_stride, uint8_t *out, int nthreads, Pool *pool)
+// `then(b)` (optional) runs for every proof b of a group on the worker that has just hashed the group: the per-proof
+// derivations (a SHAKE PRF and a few hundred scalar steps each) ride with the hashing instead of forming a serial tail of
+// n of them on the calling thread (r3: that tail was ~60 us of each of the four Fiat-Shamir rounds of a 46-proof step)
+static void sha3_digest_tables(int n, const uint8_t *digs, size_t dig_stride, uint8_t *out, int nthreads, Pool *pool,
+                               const std::function<void(int)> *then = nullptr)
 {
     std::vector<const uint8_t *> in(n);
     for (int b = 0; b < n; b++) in[b] = digs + (size_t)b * dig_stride;
@@ -377,19 +381,23 @@ static void sha3_digest_tables(int n, const uint8_t *digs, size_t dig_stride, ui
     else if (w == 8 && n <= 4 * nthreads && n < 16) w = 4; // few proofs: shorter chains per group beat fewer groups
     if (w > 1 && n <= nthreads && !caps().avx512f) w = 1;
     const int groups = (n + w - 1) / w;
-    parallel_for(pool, groups, nthreads, [&](int g) { sha3_group(out, in.data(), (size_t)NPARTY * 32, n, w, g); });
+    parallel_for(pool, groups, nthreads, [&](int g) {
+        sha3_group(out, in.data(), (size_t)NPARTY * 32, n, w, g);
+        if (then)
+            for (int b = g * w; b < n && b < (g + 1) * w; b++) (*then)(b);
+    });
 }
 
 void fs_alpha_batch(const Params &P, int n, const uint8_t *digs, size_t dig_stride, uint16_t *alpha, size_t alpha_stride, int nthreads, Pool *pool)
 {
     std::vector<uint8_t> h((size_t)n * 32);
-    sha3_digest_tables(n, digs, dig_stride, h.data(), nthreads, pool);
-    for (int b = 0; b < n; b++) {
+    const std::function<void(int)> derive = [&](int b) {
         uint8_t a_[2 * MAXJ];
         shake256_prf(a_, (size_t)2 * P.J, &h[(size_t)b * 32], 1);
         uint16_t *al = alpha + (size_t)b * alpha_stride;
         for (int i = 0; i < P.J; i++) al[i] = (uint16_t)(((a_[2 * i] << 8) | a_[2 * i + 1]) % Q);
-    }
+    };
+    sha3_digest_tables(n, digs, dig_stride, h.data(), nthreads, pool, &derive);
 }
 
 static void opened_from_ch(const uint8_t ch[32], uint16_t I[NOPEN], uint16_t rest[NREST])
@@ -409,11 +417,22 @@ static void opened_from_ch(const uint8_t ch[32], uint16_t I[NOPEN], uint16_t res
         if (!used[p]) rest[j++] = (uint16_t)p;
 }
 
-void fs_opened_batch(int n, const uint8_t *digs, size_t dig_stride, uint16_t *I, uint16_t *rest, size_t sel_stride, int nthreads, Pool *pool)
+void fs_opened_batch(int n, const uint8_t *digs, size_t dig_stride, uint16_t *I, uint16_t *rest, size_t sel_stride, int nthreads, Pool *pool,
+                     bool windows)
 {
     std::vector<uint8_t> h((size_t)n * 32);
-    sha3_digest_tables(n, digs, dig_stride, h.data(), nthreads, pool);
-    for (int b = 0; b < n; b++) opened_from_ch(&h[(size_t)b * 32], I + (size_t)b * sel_stride, rest + (size_t)b * sel_stride);
+    const std::function<void(int)> derive = [&](int b) {
+        uint16_t *Ib = I + (size_t)b * sel_stride, *rb = rest + (size_t)b * sel_stride;
+        opened_from_ch(&h[(size_t)b * 32], Ib, rb);
+        if (windows) { // complement entries owned by each aligned 64-party window (k_assemble_fields), stored behind the list I
+            uint16_t *win = Ib + SEL_WIN;
+            for (int w = 0, j = 0; w <= NWIN; w++) {
+                while (j < NREST && rb[j] < 64 * w) j++;
+                win[w] = (uint16_t)j;
+            }
+        }
+    };
+    sha3_digest_tables(n, digs, dig_stride, h.data(), nthreads, pool, &derive);
 }
 
 // ------------------------------------------------------------------- tables --

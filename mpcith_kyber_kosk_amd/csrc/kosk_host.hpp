@@ -67,7 +67,9 @@ int sha3_multi_width(); // 8 (AVX-512F), 4 (AVX2) or 1
 
 // batch forms of fs_alpha / fs_opened over n proofs whose digest tables are dig_stride bytes apart
 void fs_alpha_batch(const Params &P, int n, const uint8_t *digs, size_t dig_stride, uint16_t *alpha, size_t alpha_stride, int nthreads, Pool *pool = nullptr);
-void fs_opened_batch(int n, const uint8_t *digs, size_t dig_stride, uint16_t *I, uint16_t *rest, size_t sel_stride, int nthreads, Pool *pool = nullptr);
+// windows: also write, behind each proof's list I (at I + SEL_WIN), the NWIN + 1 boundaries of the complement's aligned 64-party windows
+void fs_opened_batch(int n, const uint8_t *digs, size_t dig_stride, uint16_t *I, uint16_t *rest, size_t sel_stride, int nthreads, Pool *pool = nullptr,
+                     bool windows = false);
 
 // OS entropy (kyber/randombytes.c:44-57, Linux branch)
 void os_randombytes(uint8_t *out, size_t len);

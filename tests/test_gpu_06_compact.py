@@ -52,13 +52,14 @@ def test_compress_rejects_unrepresentable_values(oracle, torch_cuda):
     assert api.lib.kosk_proof_compress(k, bytes(img), out) == -1
 
 
-def test_compact_host_buffer_calls_chunked(oracle, torch_cuda):
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_compact_host_buffer_calls_chunked(k, oracle, torch_cuda):
     """kosk_verifiable_keygen_batch_compact / kosk_verify_batch_compact: n = 5 through a context of 2 (three chunks, the last
     ragged): the compact bytes equal the host codec of the image call's proofs; the verifier accepts them and rejects a
     tampered one with the same fail mask as the image path."""
     from mpcith_kyber_kosk_amd import api
     lib = api.lib
-    k, n = 3, 5
+    n = 5
     tapes = [oracle.tape_bytes_for(k, 170 + i) for i in range(n)]
     ref = api.Kosk(kyber_k=k, max_batch=n)
     pks, sks, pis = ref.verifiable_keygen(tapes)
