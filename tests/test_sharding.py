@@ -120,3 +120,34 @@ def test_config4_two_ranks_on_one_gpu_rehearsal():
     # two gathers (Tcomm, view) per step on every slot, the same count on every slot (static dealing)
     assert all(n == 2 * s for n, s in zip(g["gathers_issued_per_slot"], g["steps_per_slot"])) and len(set(g["steps_per_slot"])) == 1
     assert line["value"] > 0
+
+
+@pytest.mark.gpu
+def test_config3_two_ranks_on_one_gpu_rehearsal():
+    """The line the driver's scaling run produces (bench.py --gpus N, default configuration, by-proof sharding, no data-path
+    collective) with world = 2 on one GPU over gloo: barrier + MAX-reduction of the window, the result gather of one digest per
+    rank, value = proofs of BOTH ranks over the slower rank's window, exactly one JSON line on rank 0's stdout."""
+    import json
+    import subprocess
+    import sys
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, KOSK_BENCH_REHEARSE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--slots", "3"]
+    r = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 12 and line["warmup"] == 3 and line["scaling"] == "weak"
+    assert line["config"]["baseline_config"] == "configs[2]" and line["config"]["proofs_per_gpu"] == 46
+    # whole-job value: both ranks' proofs over the MAX window
+    assert abs(line["value"] - 2 * 12 * 46 / (line["ms_per_step"] * 12 / 1e3)) < 1e-6 * line["value"]
+    assert "drop_in" not in line and "cpu_baseline" not in line   # N = 1 extras only
+    assert line["roofline"]["frac"] > 0
