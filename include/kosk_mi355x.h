@@ -156,7 +156,10 @@ int kosk_stream_timer_start(kosk_ctx *ctx);
 int kosk_stream_timer_stop(kosk_ctx *ctx, double *ms);
 
 /* ---- kernel-level entry points on DEVICE pointers (stream 0 of the ctx) ----
- * Used by the parity tests and by bench.py's roofline leg. */
+ * Used by the parity tests and by bench.py's roofline leg.  Every stream of the library is a NON-BLOCKING HIP stream: it is not
+ * ordered against the legacy null stream (nor against any other stream of the caller).  Device buffers handed to these entry
+ * points -- and device tapes / keys handed to the resident calls -- must be complete before the call (synchronise the stream
+ * that produced them), and kosk_device_synchronize() must have returned before another stream reads the outputs. */
 
 /* sha3_256(h, in, inlen) for n equal-length messages        kyber/fips202.c:745-754
  * message-major layout: message i at in + i*in_stride; digest i at out + 32*i */
