@@ -47,9 +47,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 
-CONFIGS = {  # 1-based config number -> (kyber_k, proofs per GPU per step, default slots, host threads per slot)
-    2: dict(k=2, batch=46, slots=6, threads=6, what="Kyber-512 (KYBER_K=2), 46 proofs = 66 884 party lanes per GPU per step"),
-    3: dict(k=3, batch=46, slots=6, threads=6, what="Kyber-768 (KYBER_K=3), 46 proofs = 66 884 party lanes per GPU per step"),
+CONFIGS = {  # 1-based config number -> (kyber_k, proofs per GPU per step, default slots, host threads per slot, handles per cohort)
+    # configs 2 and 3: nine caller threads, each with its own handle and its own 46-proof calls; the library serves the calls of
+    # a cohort of three handles with one pipeline run (KOSK_COMBINE=3, include/kosk_mi355x.h), i.e. three merged runs in flight
+    2: dict(k=2, batch=46, slots=9, threads=6, combine=3, what="Kyber-512 (KYBER_K=2), 46 proofs = 66 884 party lanes per GPU per step"),
+    3: dict(k=3, batch=46, slots=9, threads=6, combine=3, what="Kyber-768 (KYBER_K=3), 46 proofs = 66 884 party lanes per GPU per step"),
     4: dict(k=4, batch=91, slots=4, threads=6, what="Kyber-1024 (KYBER_K=4), 91 proofs = 132 314 party lanes per GPU per step "
                                                     "(2^20 lanes over 8 GPUs, proof-aligned), digest tables all-gathered after each commitment round"),
     5: dict(k=3, batch=512, slots=4, threads=8, what="Kyber-768 (KYBER_K=3), 512 verifiable keygens per GPU per step (4096 over 8 GPUs, throughput mode)"),
@@ -388,9 +390,11 @@ def host_budget(usable_cores, local_world, slots, threads):
 class Slot:
     """One pipeline slot: a library context with its tape bank in HBM (and, for config 4, its own process group)."""
 
-    def __init__(self, api, torch, k, B, device, first_tape, nsets, partition=None):
+    def __init__(self, api, torch, k, B, device, first_tape, nsets, partition=None, combine=1):
         # partition = (i, n): the slot's stream may only use CU partition i of n (KOSK_CU_PARTITION, read by kosk_create)
         env = {"KOSK_CU_PARTITION": "%d/%d" % partition} if partition and partition[1] > 1 else {}
+        # combine = C > 1: the handle joins a cohort of C handles whose resident calls the library merges (KOSK_COMBINE)
+        env["KOSK_COMBINE"] = str(combine)
         self.c = _with_env(env, lambda: api.Kosk(kyber_k=k, max_batch=B, device=device))
         self.B, self.nsets = B, nsets
         self.stride = (self.c.tape_bytes + 63) // 64 * 64
@@ -466,6 +470,9 @@ def main():
     ap.add_argument("--slots", type=int, default=int(os.environ.get("KOSK_BENCH_SLOTS", "0")),
                     help="independent batches kept in flight per GPU (own HIP stream + host threads each); 0 = the configuration's "
                          "default.  Never depends on --steps.")
+    ap.add_argument("--combine", type=int, default=int(os.environ.get("KOSK_BENCH_COMBINE", "0")),
+                    help="handles per cohort (KOSK_COMBINE): the resident calls of the slots of a cohort are served by one merged pipeline "
+                         "run; 0 = the configuration's default, 1 = every slot on its own (the round-3 arrangement)")
     ap.add_argument("--partitions", type=int, default=int(os.environ.get("KOSK_BENCH_PARTITIONS", "1")),
                     help="CU partitions of the GPU (whole XCDs for 2, 4, 8): slot i runs on partition i %% P only")
     ap.add_argument("--phase-stats", action="store_true", help="mean of the library's phase clocks over every step (diagnostic; one extra ABI call per step)")
@@ -482,6 +489,9 @@ def main():
     custom = bool(args.kyber_k or args.batch)
     k, B = cfg["k"], cfg["batch"]
     S = args.slots if args.slots > 0 else cfg["slots"]
+    CMB = args.combine if args.combine > 0 else (cfg.get("combine", 1) if not args.batch else 1)
+    if args.partitions > 1:
+        CMB = 1
     # host cores this rank can count on: when they are scarce (an 8-GPU node with few cores per GPU), the slots' waits sleep on
     # events instead of spinning and the Fiat-Shamir pools shrink; with 32+ cores per rank nothing changes
     try:
@@ -489,7 +499,8 @@ def main():
     except AttributeError:
         usable_cores = os.cpu_count() or 1
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
-    threads, blocking = host_budget(usable_cores, local_world, S, cfg["threads"])
+    threads, blocking = host_budget(usable_cores, local_world, -(-S // CMB), cfg["threads"] * CMB)
+    threads = max(3, threads // CMB)  # per handle; a merged run uses the threads of all its members
     if blocking:
         os.environ.setdefault("KOSK_BLOCKING_SYNC", "1")
     os.environ.setdefault("KOSK_HOST_THREADS", str(threads))
@@ -528,7 +539,7 @@ def main():
 
     from mpcith_kyber_kosk_amd import api, sharding
     P_ = max(1, args.partitions)
-    slots = [Slot(api, torch, k, B, local_rank, ((rank * S + si) * args.tape_sets) * B, args.tape_sets, partition=(si % P_, P_)) for si in range(S)]
+    slots = [Slot(api, torch, k, B, local_rank, ((rank * S + si) * args.tape_sets) * B, args.tape_sets, partition=(si % P_, P_), combine=CMB) for si in range(S)]
     ctx = slots[0].c
     tapes = slots[0].first_tapes
     if want_gather:
@@ -637,10 +648,11 @@ def main():
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     prof = {}
     for sl in slots:
-        for name, (ms, cnt_) in sl.c.profile_read().items():
-            a, b = prof.get(name, (0.0, 0))
-            prof[name] = (a + ms, b + cnt_)
+        for name, (ms, cnt_, units_) in sl.c.profile_read_units().items():
+            a, b, u = prof.get(name, (0.0, 0, 0))
+            prof[name] = (a + ms, b + cnt_, u + units_)
         sl.c.profile_enable(False)
+    cstats = [sl.c.combine_stats() for sl in slots]
     phases = ctx.phase_seconds()
     gather_info = None
     if want_gather:
@@ -683,50 +695,47 @@ def main():
 
     if rank == 0:
         kern = {}
-        for name, (ms, cnt_) in prof.items():
+        for name, (ms, cnt_, units_) in prof.items():
             if cnt_:
-                kern[name] = {"avg_us": ms / cnt_ * 1e3, "launches": cnt_, "total_ms": ms}
+                kern[name] = {"avg_us": ms / cnt_ * 1e3, "launches": cnt_, "total_ms": ms, "proofs_per_launch": units_ / cnt_}
         # graded kernel: the SHA3-256 view commitment (K4); algorithmic bytes = message + digest per party lane
         hv = kern.get("hash_view")
         roof = None
         if hv:
-            # a commitment round of B proofs is one launch, or two when B x 23 waves would spill a few waves into another
-            # round of the SIMDs (46 proofs on 1 024 SIMDs: 44 proofs = 1 012 waves, then 2 proofs = 46 waves):
-            # `roofline` is the first launch, the second one is reported beside it
-            b_main = ctx.commit_launch_groups(B)
-            lanes_per_launch = b_main * 1454
+            # every launch of the view-commitment kernel inside the timed run, whatever it served: a merged run of a cohort hashes
+            # the batches of 1..C callers with one launch (`proofs_per_launch` is the mean), and with KOSK_HASH_SPLIT=1 a round is
+            # two launches (ids hash_view / hash_view_tail).  achieved = bytes those launches served / time they took.
+            ppl = hv["proofs_per_launch"]
+            lanes_per_launch = ppl * 1454
             nbytes = lanes_per_launch * (VIEW_MSG[k] + 32)
             ach = nbytes / (hv["avg_us"] * 1e-6) / 1e9
             traffic, tsrc = None, None
             tfile = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tfile) and k == 3 and B == 46:
                 tj = json.load(open(tfile))
-                if tj.get("hash_view_lanes_per_launch", 46 * 1454) == lanes_per_launch:
+                if abs(tj.get("hash_view_lanes_per_launch", 0) - lanes_per_launch) < 0.02 * lanes_per_launch:
                     traffic, tsrc = tj.get("hash_view_hbm_bytes_per_launch"), tj.get("source")
-            roof = {"kernel": "k_commit_hash_dma (SHA3-256 view commitment, prover, %d party lanes per launch)" % lanes_per_launch,
+            roof = {"kernel": "k_commit_hash_dma (SHA3-256 view commitment, prover; %.1f callers' batches = %.0f party lanes per launch on average)"
+                              % (ppl / B, lanes_per_launch),
                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": hv["avg_us"],
-                    "lanes_per_launch": lanes_per_launch,
-                    "note": "HIP events on the slot's stream inside the run; %d slots share the GPU, so a launch's duration includes "
-                            "co-running kernels of other slots" % S}
+                    "lanes_per_launch": lanes_per_launch, "launches": hv["launches"],
+                    "note": "HIP events on the stream of the handle that led the (merged) run, inside the timed run; %d handles in %d cohorts "
+                            "share the GPU, so a launch's duration includes co-running kernels of other runs" % (S, -(-S // CMB))}
             hvt = kern.get("hash_view_tail")
-            if hvt and b_main < B:
-                tl = (B - b_main) * 1454
+            if hvt:
+                tl = hvt["proofs_per_launch"] * 1454
                 roof["second_launch"] = {"lanes_per_launch": tl, "avg_launch_us": hvt["avg_us"],
                                          "achieved": tl * (VIEW_MSG[k] + 32) / (hvt["avg_us"] * 1e-6) / 1e9,
-                                         "note": "the batch's last %d proofs, %d waves: latency-bound, runs behind the first launch while "
-                                                 "other slots' kernels use the GPU" % (B - b_main, (B - b_main) * 23)}
-                roof["whole_round"] = {"lanes": B * 1454, "us": hv["avg_us"] + hvt["avg_us"],
-                                       "achieved": B * 1454 * (VIEW_MSG[k] + 32) / ((hv["avg_us"] + hvt["avg_us"]) * 1e-6) / 1e9,
-                                       "note": "both launches back to back (stream time of the round; the GPU is shared meanwhile)"}
+                                         "note": "KOSK_HASH_SPLIT=1: the round's last proofs, latency-bound, behind the first launch"}
             ht = kern.get("hash_tcomm")
             if ht:
-                ht["GBps"] = b_main * 1454 * (TCOMM_MSG[k] + 32) / (ht["avg_us"] * 1e-6) / 1e9
+                ht["GBps"] = ht["proofs_per_launch"] * 1454 * (TCOMM_MSG[k] + 32) / (ht["avg_us"] * 1e-6) / 1e9
             hv["GBps"] = ach
         g1 = kern.get("gemm_expand1")
         if g1:
             rows = {2: 214 - 6, 3: 226 - 9, 4: 254 - 12}[k]
-            g1["useful_GMACps"] = B * rows * 1303 * 407 / (g1["avg_us"] * 1e-6) / 1e9
+            g1["useful_GMACps"] = g1["proofs_per_launch"] * rows * 1303 * 407 / (g1["avg_us"] * 1e-6) / 1e9
         lats.sort()
         line = {
             "metric": "kyber768_kosk_proofs_per_sec_prove_plus_verify" if k == 3 else "kyber%d_kosk_proofs_per_sec_prove_plus_verify" % (256 * k),
@@ -737,7 +746,10 @@ def main():
                                    ": kyber_verifiable_keygen (GPU key generation + offline + online prover) + kyber_kosk_verify (pk decoding + "
                                    "verifier), randomness tapes resident in HBM, a different tape set every step",
                        "baseline_config": "configs[%d]" % (args.config - 1), "kyber_k": k, "proofs_per_gpu": B, "party_lanes_per_gpu": B * 1454,
-                       "sharding": "by proof", "pipeline_slots_per_gpu": S, "cu_partitions": P_, "tape_sets_per_slot": args.tape_sets,
+                       "sharding": "by proof", "pipeline_slots_per_gpu": S, "handles_per_cohort": CMB,
+                       "call_combining": ("KOSK_COMBINE=%d: %d caller threads, one handle and one %d-proof call each; the library serves the "
+                                          "calls of a cohort of %d handles with one pipeline run" % (CMB, S, B, CMB)) if CMB > 1 else "off",
+                       "cu_partitions": P_, "tape_sets_per_slot": args.tape_sets,
                        "host_threads_per_slot": os.environ.get("KOSK_HOST_THREADS"), "host_waits": "sleep" if os.environ.get("KOSK_BLOCKING_SYNC") == "1" else "spin",
                        "timing": "steady-state window: completion of step W to completion of step W+K, slots running continuously"},
             "drained_run": {"steps": total, "ms_per_step": dt_drained / total * 1e3, "value": world * total * B / dt_drained,
@@ -747,6 +759,9 @@ def main():
                                 "mean_in_verify_call": sum(s_.t_verify for s_ in slots) / max(1, sum(s_.steps_done for s_ in slots)) * 1e3,
                                 "note": "one slot's keygen + prove + verify of its %d proofs while the other slots run" % B},
             "roofline": roof,
+            "combining": {"calls": sum(c_[0] for c_ in cstats), "mean_callers_per_run": (sum(c_[1] for c_ in cstats) / max(1, sum(c_[0] for c_ in cstats))),
+                          "note": "resident calls that went through the combiner since the handles were created, and the mean number of "
+                                  "callers served by the run a call ended up in"} if CMB > 1 else None,
             "host_cpu_cores_busy": round(host_cpu_s / max(dt_drained, 1e-9), 2),
             "host_cpus_usable": len(os.sched_getaffinity(0)),
             "kernels_in_pipeline": kern,
@@ -778,38 +793,57 @@ def main():
             c1.close()
             line["latency"] = {"batch_of_512_ms_median": lats[len(lats) // 2] * 1e3, "batch_of_1_ms_median": t1s[len(t1s) // 2] * 1e3,
                                "per_proof_us_at_throughput": dt / K / B * 1e6}
-        if world == 1 and not args.no_kernels and args.config in (2, 3) and not custom:
-            line["kernels_65536_lanes"] = kernel_microbench(ctx, torch, k)
-            line["drop_in"] = drop_in(api, torch, k, B, tapes, local_rank)
-        if world == 1 and not args.no_kernels and args.config in (2, 3) and not custom:
-            # the same 276 proofs in flight with TWO steps' batches per launch (3 slots x 92 proofs): what the launches gain
-            # above the 1 024-wave step of the commitment hashes; a separate run, reported NEXT TO the line
-            # of record, never as `value`
-            import subprocess
-            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", str(args.config), "--batch", str(2 * B), "--slots", str(max(1, S // 2)),
-                   "--steps", str(max(10, K // 2)), "--warmup", str(max(2, W // 2)), "--no-kernels", "--no-cpu-baseline"]
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-            sub = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            if r.returncode == 0 and sub:
-                j = json.loads(sub[-1])
-                line["two_batches_per_launch"] = {
-                    "proofs_per_s": j["value"], "ms_per_%d_proofs" % B: j["ms_per_step"] / 2, "proofs_per_launch": 2 * B, "slots": max(1, S // 2),
-                    "steps": j["steps"], "roofline_frac": (j.get("roofline") or {}).get("frac"),
-                    "hash_view_avg_us": (j.get("kernels_in_pipeline", {}).get("hash_view") or {}).get("avg_us"),
-                    "note": "python bench.py --batch %d --slots %d: two %d-proof batches share every launch; not the line of record" % (2 * B, max(1, S // 2), B)}
-            else:
-                line["two_batches_per_launch"] = {"error": (r.stderr or "")[-400:]}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(k, tapes, min(args.cpu_proofs, B))
-        os.write(json_fd, (json.dumps(line) + "\n").encode())  # written here: the RCCL teardown below can end the process without Python's exit flush
+        aux = world == 1 and not args.no_kernels and args.config in (2, 3) and not custom
+        if aux:
+            try:
+                line["kernels_65536_lanes"] = kernel_microbench(ctx, torch, k)
+            except Exception as e:  # noqa: BLE001  -- an auxiliary leg never costs the line of record
+                line["kernels_65536_lanes"] = {"error": repr(e)[:400]}
+    # the measured run is over: stop the slot threads and free the slots' HBM, host threads and streams BEFORE the auxiliary legs
     state["limit"] = -1
     for g_ in gos:
         g_.set()
+    if dist is None:
+        for sl in slots:
+            sl.c.close()
+    if rank == 0:
+        if aux:
+            try:
+                line["drop_in"] = drop_in(api, torch, k, B, tapes, local_rank)
+            except Exception as e:  # noqa: BLE001
+                line["drop_in"] = {"error": repr(e)[:400]}
+            # the same workload WITHOUT call combining (every handle on its own: the round-3 arrangement, 6 slots), as a
+            # fresh child process with its own host-thread budget; reported NEXT TO the line of record, never as `value`
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", str(args.config), "--combine", "1", "--slots", "6",
+                   "--steps", str(max(20, K // 2)), "--warmup", str(max(4, W // 2)), "--no-kernels", "--no-cpu-baseline"]
+            env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("KOSK_HOST_THREADS", "KOSK_BLOCKING_SYNC", "KOSK_COMBINE", "KOSK_BENCH_COMBINE", "KOSK_BENCH_SLOTS")}
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+                sub = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                if r.returncode != 0 or not sub:
+                    raise RuntimeError("rc %d: %s" % (r.returncode, (r.stderr or "")[-300:]))
+                j = json.loads(sub[-1])
+                line["uncombined"] = {
+                    "proofs_per_s": j["value"], "ms_per_step": j["ms_per_step"], "slots": 6, "steps": j["steps"],
+                    "roofline_frac": (j.get("roofline") or {}).get("frac"),
+                    "hash_view_avg_us": (j.get("kernels_in_pipeline", {}).get("hash_view") or {}).get("avg_us"),
+                    "step_latency_ms_median": (j.get("step_latency_ms") or {}).get("median"),
+                    "note": "python bench.py --combine 1 --slots 6: six independent handles, every launch serves one 46-proof call (round 3's "
+                            "line of record); not the line of record"}
+            except Exception as e:  # noqa: BLE001  (TimeoutExpired, a missing key, bad JSON ...)
+                line["uncombined"] = {"error": repr(e)[:400]}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(k, tapes, min(args.cpu_proofs, B))
+            except Exception as e:  # noqa: BLE001
+                line["cpu_baseline"] = {"error": repr(e)[:400]}
+        os.write(json_fd, (json.dumps(line) + "\n").encode())  # written here: the RCCL teardown below can end the process without Python's exit flush
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    for sl in slots:
-        sl.c.close()
+        for sl in slots:
+            sl.c.close()
 
 
 if __name__ == "__main__":

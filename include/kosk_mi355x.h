@@ -150,6 +150,27 @@ int kosk_phase_seconds(const kosk_ctx *ctx, double *out, int n);
  * instead of graphs (diagnostic: changes the launch overhead being measured).  on = 0: off. */
 int kosk_profile_enable(kosk_ctx *ctx, int on);
 int kosk_profile_read(const kosk_ctx *ctx, int id, double *total_ms, long *launches);
+/* the same plus the proofs those launches served: a merged run of a cohort (KOSK_COMBINE, below) serves several callers'
+ * batches per launch, and its launches are timed on the handle that led the run */
+int kosk_profile_read_units(const kosk_ctx *ctx, int id, double *total_ms, long *launches, long *proofs);
+
+/* ---- Call combining (no reference counterpart: the reference is one call, one proof, one thread -- kosk.hpp:18-24).
+ * With KOSK_COMBINE = C (2..8, needs KOSK_STREAMS=1) in the environment of kosk_create, handles of equal (device, kyber_k,
+ * max_batch) are grouped into cohorts of C that share one workspace, and the resident calls kosk_verifiable_keygen_resident /
+ * kosk_verify_resident_pk that neighbouring members of a cohort make at about the same time -- each from its own thread --
+ * are served by ONE pipeline run over all their proofs: every launch then covers 2..C callers' batches, which is what the
+ * chip-filling kernels need (a 46-proof launch leaves the commitment hash at one and a bit rounds of waves per SIMD).  Per
+ * call nothing changes: same arguments, same results byte for byte, each caller gets its own pk / sk / verify bits / fail
+ * masks / resident proofs (kosk_resident_proofs, kosk_resident_digests point at the member's own block).  A member's call
+ * waits at most KOSK_COMBINE_WAIT_US (default 5000) for the other members, and only for those that are inside a call or left
+ * one less than KOSK_COMBINE_IDLE_US (default 1000) ago: a lone caller is never delayed, callers that loop fall into step after
+ * one or two calls (a request whose kind is in the minority of its window is held back once, so that callers alternating
+ * keygen / verify in opposite phase meet).  Calls that draw randomness through
+ * the callback (tapes == NULL), handles with a round hook, and every other entry point run unmerged on the member's own
+ * block.  All handles of a cohort must be destroyed before the process ends (the last one frees the workspace).
+ * kosk_combine_stats: resident calls of THIS handle that went through the combiner, and the sum over those calls of the
+ * members their run served (members / calls = mean callers per launch; both 0 for a handle outside a cohort). */
+int kosk_combine_stats(const kosk_ctx *ctx, long *calls, long *members);
 
 /* hipEvent pair on the ctx stream around caller-issued kernel-level calls (micro-benchmarks) */
 int kosk_stream_timer_start(kosk_ctx *ctx);

@@ -70,6 +70,8 @@ def _load():
         "kosk_recon_secrets": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
         "kosk_profile_enable": (C.c_int, [vp, C.c_int]),
         "kosk_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+        "kosk_profile_read_units": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+        "kosk_combine_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
         "kosk_stream_timer_start": (C.c_int, [vp]),
         "kosk_stream_timer_stop": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "kosk_device_synchronize": (C.c_int, [vp]),
@@ -100,7 +102,7 @@ EXPORTS = ["kosk_pk_bytes", "kosk_sk_bytes", "kosk_proof_bytes", "kosk_tape_byte
            "kosk_stage_verifier_inputs", "kosk_verify_resident", "kosk_verifiable_keygen_resident", "kosk_verify_resident_pk",
            "kosk_resident_digests", "kosk_set_round_hook", "kosk_phase_seconds", "kosk_path_count", "kosk_host_threads", "kosk_sha3_256_batch_pair", "kosk_verifiable_keygen_batch_compact", "kosk_verify_batch_compact", "kosk_host_alloc", "kosk_host_free", "kosk_sha3_256_batch",
            "kosk_shake256_batch", "kosk_commit_hash_lanes", "kosk_ntt256_batch", "kosk_lagrange_expand",
-           "kosk_recon_secrets", "kosk_profile_enable", "kosk_profile_read", "kosk_stream_timer_start", "kosk_stream_timer_stop", "kosk_device_synchronize", "kosk_streams", "kosk_commit_launch_groups", "kosk_resident_proofs", "kosk_keygen", "kosk_fs_alpha",
+           "kosk_recon_secrets", "kosk_profile_enable", "kosk_profile_read", "kosk_profile_read_units", "kosk_combine_stats", "kosk_stream_timer_start", "kosk_stream_timer_stop", "kosk_device_synchronize", "kosk_streams", "kosk_commit_launch_groups", "kosk_resident_proofs", "kosk_keygen", "kosk_fs_alpha",
            "kosk_fs_opened", "kosk_host_sha3_256", "kosk_host_shake256", "kosk_host_sha3_256_multi", "kosk_lagrange_table"]
 
 
@@ -365,6 +367,22 @@ class Kosk:
             lib.kosk_profile_read(self._h, i, C.byref(ms), C.byref(cnt))
             out[name] = (ms.value, cnt.value)
         return out
+
+    def profile_read_units(self):
+        """{name: (total_ms, launches, proofs served by those launches)}: a merged run of a cohort (KOSK_COMBINE) serves several
+        callers' batches per launch and is timed on the handle that led it"""
+        out = {}
+        for i, name in enumerate(self.PROFILE_IDS):
+            ms, cnt, units = C.c_double(), C.c_long(), C.c_long()
+            lib.kosk_profile_read_units(self._h, i, C.byref(ms), C.byref(cnt), C.byref(units))
+            out[name] = (ms.value, cnt.value, units.value)
+        return out
+
+    def combine_stats(self):
+        """(resident calls of this handle served through the combiner, sum over them of the members their run served)"""
+        a, b = C.c_long(), C.c_long()
+        self._chk(lib.kosk_combine_stats(self._h, C.byref(a), C.byref(b)), "combine_stats")
+        return a.value, b.value
 
     PATH_IDS = ["hash_dma", "hash_plain", "hash_primer", "table_gemm", "limb_gemm", "copy_direct", "copy_staged", "graph_replay",
                 "ntt_fp32", "ntt_int"]

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <exception>
 #include <functional>
@@ -23,10 +24,24 @@
 #include <thread>
 #include <vector>
 
+#include "kosk_combine.hpp"
 #include "kosk_ctx.hpp"
 #include "kosk_lanes.hpp"
 
 using namespace kosk;
+
+struct kosk_ctx;
+// A cohort (KOSK_COMBINE = C): up to C handles of equal (device, kyber_k, max_batch) are views of ONE arena context, and their
+// resident calls are served by merged pipeline runs (kosk_combine.hpp)
+struct Cohort {
+    int device = 0, k = 0, per = 0;
+    Ctx *arena = nullptr;
+    std::unique_ptr<Combiner> comb;
+    std::vector<kosk_ctx *> member;
+};
+static std::mutex g_cohort_mu; // creation / destruction of cohorts and their members
+static std::vector<Cohort *> g_cohorts;
+enum CombineKind { CK_ALONE = -1, CK_KEYGEN = 0, CK_VERIFY_PK_GIVEN = 1, CK_VERIFY_PK_RESIDENT = 2 };
 
 // A handle owns S sub-contexts (own stream + HBM workspace each).  A batch call splits its proofs into S
 // contiguous sub-batches that run concurrently on S host threads: while one sub-batch sits in a host
@@ -39,11 +54,25 @@ struct kosk_ctx {
     std::string err;
     std::vector<uint32_t> masks; // fail masks of the last verify call, in the caller's proof order
     int masks_n = 0;             // proofs of the last verify call (kosk_verify_fail_masks serves exactly these)
+    Cohort *cohort = nullptr;    // KOSK_COMBINE: this handle is member `member_i` of a cohort, sub[0] a view of its arena
+    int member_i = -1;
+    long merged_calls = 0, merged_members = 0; // resident calls of this handle served by a run, and the members those runs served
 
     ~kosk_ctx()
     {
         lanes.lanes.clear(); // join the lane threads before their sub-contexts go
         for (Ctx *x : sub) delete x;
+        if (cohort) {
+            std::lock_guard<std::mutex> lk(g_cohort_mu);
+            cohort->member[member_i] = nullptr;
+            if (const char *e = getenv("KOSK_COMBINE_TRACE"))
+                if (atoi(e)) fprintf(stderr, "[kosk combine] cohort %p %s\n", (void *)cohort, cohort->comb->trace(member_i).c_str());
+            if (cohort->comb->leave(member_i) == 0) { // the last member frees the arena
+                delete cohort->arena;
+                g_cohorts.erase(std::remove(g_cohorts.begin(), g_cohorts.end(), cohort), g_cohorts.end());
+                delete cohort;
+            }
+        }
     }
     // every entry point starts from a clean error state (kosk_last_error never reports a stale message)
     void clear_err()
@@ -242,6 +271,53 @@ int kosk_create(kosk_ctx **ctx, int device, int kyber_k, int max_batch)
         if (S > 8) S = 8;
         h = new kosk_ctx();
         h->max_batch = max_batch;
+        int W = 1; // KOSK_COMBINE: handles per cohort (needs KOSK_STREAMS=1)
+        if (const char *e = getenv("KOSK_COMBINE")) W = atoi(e) > 1 ? (atoi(e) > 8 ? 8 : atoi(e)) : 1;
+        if (W > 1 && S == 1 && max_batch >= 1) {
+            std::lock_guard<std::mutex> lk(g_cohort_mu);
+            Cohort *co = nullptr;
+            int idx = -1;
+            for (Cohort *x : g_cohorts)
+                if (x->device == device && x->k == kyber_k && x->per == max_batch && x->comb->width() == W && (idx = x->comb->join()) >= 0) { co = x; break; }
+            if (!co) {
+                std::unique_ptr<Cohort> fresh(new Cohort());
+                fresh->device = device; fresh->k = kyber_k; fresh->per = max_batch;
+                int wait_us = 5000, idle_us = 1000;
+                if (const char *e = getenv("KOSK_COMBINE_WAIT_US")) wait_us = atoi(e) >= 0 ? atoi(e) : wait_us;
+                if (const char *e = getenv("KOSK_COMBINE_IDLE_US")) idle_us = atoi(e) >= 0 ? atoi(e) : idle_us;
+                fresh->comb.reset(new Combiner(W, wait_us, idle_us));
+                fresh->member.assign((size_t)W, nullptr);
+                if ((long)W * max_batch > 1 << 20) { g_create_err = "KOSK_COMBINE x max_batch too large"; delete h; return -1; }
+                if (ctx_create(&fresh->arena, device, kyber_k, W * max_batch, g_create_err, 1)) { delete h; return -1; }
+                if (ensure_verify_workspace(*fresh->arena)) { // views share it: allocated with the arena, not on first use
+                    g_create_err = fresh->arena->err;
+                    delete fresh->arena;
+                    delete h;
+                    return -1;
+                }
+                idx = fresh->comb->join();
+                co = fresh.release();
+                g_cohorts.push_back(co);
+            }
+            Ctx *v = nullptr;
+            // a run led by member idx serves at most the members idx .. W - 1: that many callers' worth of host workers
+            if (ctx_make_view(*co->arena, idx * max_batch, max_batch, co->arena->base_threads * (W - idx), &v, g_create_err)) {
+                if (co->comb->leave(idx) == 0) {
+                    delete co->arena;
+                    g_cohorts.erase(std::remove(g_cohorts.begin(), g_cohorts.end(), co), g_cohorts.end());
+                    delete co;
+                }
+                delete h;
+                return -1;
+            }
+            h->sub.push_back(v);
+            h->c = v;
+            h->cohort = co;
+            h->member_i = idx;
+            co->member[idx] = h;
+            *ctx = h;
+            return 0;
+        }
         const int per = (max_batch + S - 1) / S;
         for (int i = 0; i < S; i++) {
             Ctx *c = nullptr;
@@ -349,10 +425,112 @@ int kosk_verify_resident(kosk_ctx *ctx, int n, uint8_t *ok)
     GUARD_END
 }
 
+// ---- merged resident calls of a cohort (KOSK_COMBINE) ----
+struct KeygenCall { const uint8_t *tapes; size_t tape_stride; uint8_t *pk, *sk; };
+struct VerifyCall { const uint8_t *pk; uint8_t *ok; };
+
+// what every member of a finished run takes over from the run's leader
+static void run_epilogue(Cohort &co, int first, int count, int rc, const Ctx &lead)
+{
+    for (int k = 0; k < count; k++) {
+        kosk_ctx *m = co.member[first + k];
+        m->merged_calls++;
+        m->merged_members += count;
+        if (k) memcpy(m->c->phase_sec, lead.phase_sec, sizeof(lead.phase_sec));
+        if (rc) { m->err = lead.err; m->c->err = lead.err; }
+    }
+}
+
+static int combined_keygen(kosk_ctx *h, int n, const KeygenCall &call)
+{
+    Cohort &co = *h->cohort;
+    h->clear_err();
+    CombineReq r;
+    r.kind = (call.tapes && !h->c->round_hook) ? CK_KEYGEN : CK_ALONE; // the stateful randombytes callback and round hooks are per handle
+    r.n = n;
+    r.full = n == co.per;
+    r.args = const_cast<KeygenCall *>(&call);
+    std::string what;
+    const int rc = co.comb->call(h->member_i, r, [&co](int first, int count, const CombineReq *const *reqs) -> int {
+        Ctx &c = *co.member[first]->c; // the run leader's view: this thread is its caller
+        std::vector<KeygenIn> segs((size_t)count);
+        int total = 0;
+        for (int k = 0; k < count; k++) {
+            const KeygenCall *a = static_cast<const KeygenCall *>(reqs[k]->args);
+            segs[k] = KeygenIn{a->tapes, a->tape_stride, a->pk, a->sk, reqs[k]->n, k + 1 < count ? &segs[k + 1] : nullptr};
+            total += reqs[k]->n;
+        }
+        c.nthreads = c.base_threads * count; // reserved when the view was made
+        const int rc = prove_resident(c, total, false, &segs[0]);
+        c.nthreads = c.base_threads;
+        for (int k = 0; k < count; k++) {
+            Ctx &v = *co.member[first + k]->c;
+            v.resident_pk_n = rc ? 0 : reqs[k]->n;
+            if (count > 1) { v.tape_cur = v.d_tape; v.tape_cur_stride = v.tape_stride; } // a merged run copies every member's tapes into its own block
+        }
+        run_epilogue(co, first, count, rc, c);
+        return rc;
+    }, &what);
+    if (rc == -2) { h->err = "exception in a merged call: " + what; h->c->err = h->err; return -1; }
+    return rc;
+}
+
+static int combined_verify(kosk_ctx *h, int n, const VerifyCall &call)
+{
+    Cohort &co = *h->cohort;
+    h->clear_err();
+    h->masks_n = 0;
+    if (!call.pk && h->c->resident_pk_n < n) {
+        h->err = "no resident public keys for this batch: pk == NULL needs a key generation (or a verifier staging call) of at least n proofs on this context";
+        h->c->err = h->err;
+        return -1;
+    }
+    CombineReq r;
+    r.kind = h->c->round_hook ? CK_ALONE : (call.pk ? CK_VERIFY_PK_GIVEN : CK_VERIFY_PK_RESIDENT);
+    r.n = n;
+    r.full = n == co.per;
+    r.args = const_cast<VerifyCall *>(&call);
+    std::string what;
+    const int rc = co.comb->call(h->member_i, r, [&co](int first, int count, const CombineReq *const *reqs) -> int {
+        Ctx &c = *co.member[first]->c;
+        std::vector<VerifySeg> segs((size_t)count);
+        int total = 0;
+        bool given = false;
+        for (int k = 0; k < count; k++) {
+            const VerifyCall *a = static_cast<const VerifyCall *>(reqs[k]->args);
+            segs[k] = VerifySeg{reqs[k]->n, a->pk, a->ok, k + 1 < count ? &segs[k + 1] : nullptr};
+            total += reqs[k]->n;
+            given = a->pk != nullptr;
+        }
+        const int keep = c.resident_pk_n;
+        if (!given) c.resident_pk_n = total; // every member checked its own keys before it posted
+        c.nthreads = c.base_threads * count;
+        const int rc = verify_resident(c, total, nullptr, given ? 1 : 2, nullptr, &segs[0]);
+        c.nthreads = c.base_threads;
+        if (!given) c.resident_pk_n = keep;
+        int off = 0;
+        for (int k = 0; k < count; k++) {
+            kosk_ctx *m = co.member[first + k];
+            m->masks.assign((size_t)reqs[k]->n, 0);
+            if (!rc) {
+                memcpy(m->masks.data(), c.h_fail + off, sizeof(uint32_t) * (size_t)reqs[k]->n);
+                m->masks_n = reqs[k]->n;
+                if (given) m->c->resident_pk_n = reqs[k]->n;
+            }
+            off += reqs[k]->n;
+        }
+        run_epilogue(co, first, count, rc, c);
+        return rc;
+    }, &what);
+    if (rc == -2) { h->err = "exception in a merged call: " + what; h->c->err = h->err; return -1; }
+    return rc;
+}
+
 int kosk_verifiable_keygen_resident(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk)
 {
     if (!ctx || n < 1 || n > ctx->max_batch || !pk || !sk) return bad_args(ctx, __func__);
     GUARD(ctx)
+    if (ctx->cohort) return combined_keygen(ctx, n, KeygenCall{tapes, tape_stride, pk, sk});
     const Params &P = ctx->c->P;
     std::vector<uint8_t> drawn;
     if (!tapes && ctx->sub.size() > 1) { // stateful callback: draw sequentially in proof order, then prove the sub-batches in parallel
@@ -371,6 +549,7 @@ int kosk_verify_resident_pk(kosk_ctx *ctx, int n, const uint8_t *pk, uint8_t *ok
 {
     if (!ctx || n < 1 || n > ctx->max_batch || !ok) return bad_args(ctx, __func__);
     GUARD(ctx)
+    if (ctx->cohort) return combined_verify(ctx, n, VerifyCall{pk, ok});
     const Params &P = ctx->c->P;
     reset_masks(ctx, n);
     if (ctx->run(n, [&](Ctx &c, int first, int count) {
@@ -680,7 +859,7 @@ int kosk_profile_enable(kosk_ctx *ctx, int on)
     for (Ctx *cp : ctx->sub) {
         Ctx &c = *cp;
         c.prof_on = on < 0 ? 0 : (on > 2 ? 2 : on);
-        for (int i = 0; i < PR_COUNT; i++) { c.prof_ms[i] = 0; c.prof_n[i] = 0; c.prof_used[i] = false; }
+        for (int i = 0; i < PR_COUNT; i++) { c.prof_ms[i] = 0; c.prof_n[i] = 0; c.prof_units[i] = 0; c.prof_used[i] = false; }
     }
     return 0;
     GUARD_END
@@ -693,6 +872,25 @@ int kosk_profile_read(const kosk_ctx *ctx, int id, double *total_ms, long *launc
     for (const Ctx *c : ctx->sub) { ms += c->prof_ms[id]; cnt += c->prof_n[id]; }
     if (total_ms) *total_ms = ms;
     if (launches) *launches = cnt;
+    return 0;
+}
+
+int kosk_profile_read_units(const kosk_ctx *ctx, int id, double *total_ms, long *launches, long *proofs)
+{
+    if (!ctx || id < 0 || id >= PR_COUNT) return bad_args(ctx, __func__);
+    double ms = 0;
+    long cnt = 0, units = 0;
+    for (const Ctx *c : ctx->sub) { ms += c->prof_ms[id]; cnt += c->prof_n[id]; units += c->prof_units[id]; }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = cnt;
+    if (proofs) *proofs = units;
+    return 0;
+}
+int kosk_combine_stats(const kosk_ctx *ctx, long *calls, long *members)
+{
+    if (!ctx) return -1;
+    if (calls) *calls = ctx->merged_calls;
+    if (members) *members = ctx->merged_members;
     return 0;
 }
 

@@ -142,16 +142,17 @@ static int ensure_compact(Ctx &c)
     if (c.d_compact) return 0;
     c.cplan = make_compact_plan(c.P);
     c.compact_stride = (c.cplan.bytes + 63) / 64 * 64;
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c.d_compact), (size_t)c.max_batch * c.compact_stride));
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c.d_compact_bad), sizeof(uint32_t) * c.max_batch));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c.h_compact), (size_t)c.max_batch * c.compact_stride, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c.h_compact_bad), sizeof(uint32_t) * c.max_batch, hipHostMallocDefault));
+    // a view keeps its own staging, sized for its own callers' batches (the compact calls are never merged)
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c.d_compact), (size_t)c.own_batch * c.compact_stride));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c.d_compact_bad), sizeof(uint32_t) * c.own_batch));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c.h_compact), (size_t)c.own_batch * c.compact_stride, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c.h_compact_bad), sizeof(uint32_t) * c.own_batch, hipHostMallocDefault));
     return 0;
 }
 
 int fetch_proofs_compact(Ctx &c, int n, uint8_t *out, bool direct)
 {
-    if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
+    if (n < 1 || n > c.own_batch) { c.err = "batch size out of range"; return -1; }
     HIPCHK(hipSetDevice(c.device));
     if (ensure_compact(c)) return -1;
     HIPCHK(hipMemsetAsync(c.d_compact, 0, (size_t)n * c.compact_stride, c.stream)); // padding bytes are zero
@@ -174,7 +175,7 @@ int fetch_proofs_compact(Ctx &c, int n, uint8_t *out, bool direct)
 
 int stage_verifier_inputs_compact(Ctx &c, int n, const uint8_t *in, const uint8_t *pk, bool direct)
 {
-    if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
+    if (n < 1 || n > c.own_batch) { c.err = "batch size out of range"; return -1; }
     HIPCHK(hipSetDevice(c.device));
     if (ensure_verify_workspace(c)) return -1;
     if (ensure_compact(c)) return -1;

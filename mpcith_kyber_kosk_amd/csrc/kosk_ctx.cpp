@@ -44,7 +44,7 @@ void Ctx::prof_collect()
     for (int i = 0; i < PR_COUNT; i++)
         if (prof_used[i]) {
             float ms = 0;
-            if (hipEventElapsedTime(&ms, prof_ev[i][0], prof_ev[i][1]) == hipSuccess) { prof_ms[i] += ms; prof_n[i]++; }
+            if (hipEventElapsedTime(&ms, prof_ev[i][0], prof_ev[i][1]) == hipSuccess) { prof_ms[i] += ms; prof_n[i]++; prof_units[i] += prof_cur_units[i]; }
             prof_used[i] = false;
         }
 }
@@ -57,6 +57,18 @@ Ctx::~Ctx()
         for (auto e : pe)
             if (e) (void)hipEventDestroy(e);
     if (ev_sync) (void)hipEventDestroy(ev_sync);
+    if (is_view) {
+        // a view owns its events, host workers and compact staging; tables, workspace and the stream belong to the arena
+        if (d_compact) (void)hipFree(d_compact);
+        if (d_compact_bad) (void)hipFree(d_compact_bad);
+        if (h_compact) (void)hipHostFree(h_compact);
+        if (h_compact_bad) (void)hipHostFree(h_compact_bad);
+        if (pool) pool_destroy(pool);
+        if (ev) (void)hipEventDestroy(ev);
+        for (auto e : timer_ev)
+            if (e) (void)hipEventDestroy(e);
+        return; // the stream is the arena's
+    }
     void *dev[] = {t_expand.d, t_recon_d.d, t_recon_2d.d, t_expand.dfrag, t_recon_d.dfrag, t_recon_2d.dfrag, d_fresh_rows, d_gemm1_rows, d_gemm2_rows, d_off, d_fields,
                    d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_kg, d_sehat, d_t, d_alpha, d_I, d_pwT, d_limbs, d_linA, d_coef, d_lin_rows,
                    d_gather, d_gather2, d_O, d_w, d_ell, d_sec, d_sec_u1, d_sec_u2, d_fail, d_inv, d_invlimb, d_vfields,
@@ -113,7 +125,7 @@ int commit_hash_groups(const Ctx &c, int n)
 static hipError_t commit_hash_batch(Ctx &c, const HashArgs &ha, int n, int K, bool view, hipStream_t st)
 {
     const int n_main = commit_hash_groups(c, n);
-    c.prof_begin(view ? PR_HASH_VIEW : PR_HASH_TCOMM);
+    c.prof_begin(view ? PR_HASH_VIEW : PR_HASH_TCOMM, n_main);
     int variant = 0;
     auto count = [&]() {
         if (c.capturing) return; // a captured launch runs at replay time (PATH_GRAPH_REPLAY counts those)
@@ -129,7 +141,7 @@ static hipError_t commit_hash_batch(Ctx &c, const HashArgs &ha, int n, int K, bo
     if (t.prefix) t.prefix += (size_t)n_main * ha.out_lanes_per_group * 32;
     t.out += (size_t)n_main * ha.out_lanes_per_group * 32;
     if (t.lane_map) t.lane_map += (size_t)n_main * ha.lane_map_stride;
-    c.prof_begin(view ? PR_HASH_VIEW_TAIL : PR_HASH_TCOMM_TAIL);
+    c.prof_begin(view ? PR_HASH_VIEW_TAIL : PR_HASH_TCOMM_TAIL, n - n_main);
     e = launch_commit_hash(t, n - n_main, K, view, st, c.hash_opts(), &variant);
     count();
     c.prof_end(view ? PR_HASH_VIEW_TAIL : PR_HASH_TCOMM_TAIL);
@@ -323,6 +335,8 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     if (const char *e = getenv("KOSK_HOST_THREADS")) c.nthreads = atoi(e) > 0 ? (atoi(e) > 64 ? 64 : atoi(e)) : c.nthreads;
     c.pool = pool_create();
     c.nthreads = pool_reserve(c.pool, c.nthreads);
+    c.base_threads = c.nthreads;
+    c.own_batch = max_batch;
     if (const char *e = getenv("KOSK_GRAPHS")) c.use_graphs = atoi(e) != 0;
     if (const char *e = getenv("KOSK_LINCOMB_FUSED")) c.lincomb_fused = atoi(e) != 0;
     if (const char *e = getenv("KOSK_NTT_FP32")) c.ntt_fp32 = atoi(e) != 0;
@@ -384,47 +398,112 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
         c.key_stride = (size_t)P.K * P.K * 256;
         c.se_stride = (size_t)2 * P.K * 256;
         c.sel_stride = 1312;
-        HIPCHK(dalloc(&c.d_P, B * c.proof_stride));
+        // per-proof buffers: allocated for B proofs and registered with their bytes per proof (views, kosk_combine.hpp)
+        auto dev = [&](auto **p, size_t per) -> hipError_t {
+            const hipError_t e = dalloc(p, B * per);
+            if (e == hipSuccess) c.reg_pp(p, per * sizeof(**p));
+            return e;
+        };
+        auto host = [&](auto **p, size_t per) -> hipError_t {
+            const hipError_t e = halloc(p, B * per);
+            if (e == hipSuccess) c.reg_pp(p, per * sizeof(**p));
+            return e;
+        };
+        HIPCHK(dev(&c.d_P, c.proof_stride));
         HIPCHK(hipMemsetAsync(c.d_P, 0, B * c.proof_stride * 2, c.stream));
-        HIPCHK(dalloc(&c.d_tape, B * c.tape_stride));
-        HIPCHK(dalloc(&c.d_dig1, B * NPARTY * 32));
-        HIPCHK(dalloc(&c.d_dig2, B * NPARTY * 32));
-        HIPCHK(dalloc(&c.d_proof, B * c.image_stride));
-        HIPCHK(dalloc(&c.d_A, B * c.key_stride));
-        HIPCHK(dalloc(&c.d_se, B * c.se_stride));
-        HIPCHK(dalloc(&c.d_t, B * P.K * 256));
+        HIPCHK(dev(&c.d_tape, c.tape_stride));
+        HIPCHK(dev(&c.d_dig1, (size_t)NPARTY * 32));
+        HIPCHK(dev(&c.d_dig2, (size_t)NPARTY * 32));
+        HIPCHK(dev(&c.d_proof, c.image_stride));
+        HIPCHK(dev(&c.d_A, c.key_stride));
+        HIPCHK(dev(&c.d_se, c.se_stride));
+        HIPCHK(dev(&c.d_t, (size_t)P.K * 256));
         const size_t pkpad = (P.pk_bytes + 15) / 16 * 16;
         c.sb_bytes = (size_t)384 * P.K;
         c.kg_rec = pkpad + c.sb_bytes + 64;
         c.pk_stride = c.sb_stride = c.kg_rec;
-        HIPCHK(dalloc(&c.d_kg, B * c.kg_rec));
-        HIPCHK(halloc(&c.h_kg, B * c.kg_rec));
+        HIPCHK(dev(&c.d_kg, c.kg_rec));
+        HIPCHK(host(&c.h_kg, c.kg_rec));
         c.d_pk = c.d_kg; c.d_sb = c.d_kg + pkpad; c.d_seeds = c.d_kg + pkpad + c.sb_bytes;
         c.h_pk = c.h_kg; c.h_sb = c.h_kg + pkpad; c.h_seeds = c.h_kg + pkpad + c.sb_bytes;
-        HIPCHK(dalloc(&c.d_sehat, B * c.se_stride));
-        HIPCHK(dalloc(&c.d_alpha, B * 80));
+        c.reg_pp(&c.d_pk, c.kg_rec); c.reg_pp(&c.d_sb, c.kg_rec); c.reg_pp(&c.d_seeds, c.kg_rec);
+        c.reg_pp(&c.h_pk, c.kg_rec); c.reg_pp(&c.h_sb, c.kg_rec); c.reg_pp(&c.h_seeds, c.kg_rec);
+        HIPCHK(dev(&c.d_sehat, c.se_stride));
+        HIPCHK(dev(&c.d_alpha, 80));
         HIPCHK(dalloc(&c.d_I, 2 * B * c.sel_stride)); // I rows then complement rows: one upload
         c.d_rest = c.d_I + B * c.sel_stride;
-        HIPCHK(dalloc(&c.d_pwT, B * MAXM * 80));
+        c.reg_pp(&c.d_I, (size_t)c.sel_stride * 2); c.reg_pp(&c.d_rest, (size_t)c.sel_stride * 2);
+        HIPCHK(dev(&c.d_pwT, (size_t)MAXM * 80));
         // data operand of the largest GEMM: every fresh sharing of every proof (<= 256 per proof), 13 k-steps
         c.limb_cap = ((B * 256 + 63) / 64 * 64 / 16) * (size_t)13 * 2048;
-        HIPCHK(dalloc(&c.d_limbs, c.limb_cap));
-        if (!c.lincomb_fused) HIPCHK(dalloc(&c.d_linA, B * 2 * (size_t)(1792 / 16) * 2 * 2048)); // only the unfused path stores the transposed f rows
-        HIPCHK(dalloc(&c.d_coef, B * 2 * (size_t)8 * 2 * 2048));
-        HIPCHK(dalloc(&c.d_fail, B));
-        HIPCHK(halloc(&c.h_tape, B * c.tape_stride));
-        HIPCHK(halloc(&c.h_dig, B * NPARTY * 32));
-        HIPCHK(halloc(&c.h_proof, B * c.image_stride));
-        HIPCHK(halloc(&c.h_alpha, B * 80));
+        HIPCHK(dev(&c.d_limbs, (size_t)(256 / 16) * 13 * 2048));
+        if (!c.lincomb_fused) HIPCHK(dev(&c.d_linA, 2 * (size_t)(1792 / 16) * 2 * 2048)); // only the unfused path stores the transposed f rows
+        HIPCHK(dev(&c.d_coef, 2 * (size_t)8 * 2 * 2048));
+        HIPCHK(dev(&c.d_fail, 1));
+        HIPCHK(host(&c.h_tape, c.tape_stride));
+        HIPCHK(host(&c.h_dig, (size_t)NPARTY * 32));
+        HIPCHK(host(&c.h_proof, c.image_stride));
+        HIPCHK(host(&c.h_alpha, 80));
         HIPCHK(halloc(&c.h_I, 2 * B * c.sel_stride));
         c.h_rest = c.h_I + B * c.sel_stride;
-        HIPCHK(halloc(&c.h_fail, B));
+        c.reg_pp(&c.h_I, (size_t)c.sel_stride * 2); c.reg_pp(&c.h_rest, (size_t)c.sel_stride * 2);
+        HIPCHK(host(&c.h_fail, 1));
         memset(c.h_alpha, 0, B * 80 * sizeof(uint16_t));
         HIPCHK(stream_sync(c));
         return 0;
     };
     if (body()) return fail();
     *out = cp;
+    return 0;
+}
+
+// A view of `arena` (kosk_ctx.hpp): same tables, same workspace, proofs [first, first + reach) of it, own stream / events / workers.
+int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx **out, std::string &err)
+{
+    if (arena.is_view || first < 0 || own_batch < 1 || first + own_batch > arena.max_batch) { err = "internal: bad view range"; return -1; }
+    Ctx *vp = new Ctx(arena); // memberwise copy: constants, strides, table pointers, knobs
+    Ctx &c = *vp;
+    c.is_view = true;
+    c.view_first = first;
+    c.max_batch = arena.max_batch - first;
+    c.own_batch = own_batch;
+    c.err.clear();
+    // what the copy must not share with the arena.  The STREAM is shared on purpose: one HIP stream per cohort.  In steady state
+    // a cohort has one merged run in flight, so nothing is lost -- and the number of streams that carry work stays at the
+    // number of cohorts: ROCm deals streams to its (four) hardware queues in creation order, and with a stream per member the
+    // streams of the run leaders of three cohorts of three all landed on the SAME hardware queue (measured: 138-proof runs
+    // took 2.8 ms instead of 1.6).  Calls end with a stream synchronisation, so members never leave work behind for each other.
+    c.use_graphs = false; // stream capture is per stream: not with several callers on one
+    c.ev = nullptr; c.ev_sync = nullptr; c.pool = nullptr;
+    for (auto &e : c.timer_ev) e = nullptr;
+    for (auto &pe : c.prof_ev) for (auto &e : pe) e = nullptr;
+    for (auto &g : c.seg) g = Ctx::SegGraph{};
+    c.d_compact = nullptr; c.h_compact = nullptr; c.d_compact_bad = nullptr; c.h_compact_bad = nullptr;
+    for (auto &x : c.path_n) x = 0;
+    for (int i = 0; i < PR_COUNT; i++) { c.prof_ms[i] = 0; c.prof_n[i] = 0; c.prof_units[i] = 0; c.prof_used[i] = false; }
+    c.tape_cur = nullptr;
+    c.resident_pk_n = 0;
+    c.rb = nullptr; c.rb_user = nullptr; c.round_hook = nullptr; c.round_user = nullptr;
+    for (const Ctx::PerProof &pp : arena.per_proof) {
+        char *base = *reinterpret_cast<char *const *>(reinterpret_cast<const char *>(&arena) + pp.field_off);
+        *reinterpret_cast<char **>(reinterpret_cast<char *>(&c) + pp.field_off) = base ? base + (size_t)first * pp.stride_bytes : nullptr;
+    }
+    c.limb_cap = (size_t)c.max_batch * (256 / 16) * 13 * 2048;
+    auto fail = [&]() { err = c.err; delete vp; return -1; };
+    auto body = [&]() -> int {
+        HIPCHK(hipSetDevice(c.device));
+        HIPCHK(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
+        if (c.blocking_sync) HIPCHK(hipEventCreateWithFlags(&c.ev_sync, hipEventDisableTiming | hipEventBlockingSync));
+        for (auto &pe : c.prof_ev)
+            for (auto &e : pe) HIPCHK(hipEventCreate(&e));
+        return 0;
+    };
+    if (body()) return fail();
+    c.pool = pool_create();
+    c.base_threads = arena.base_threads;
+    const int got = pool_reserve(c.pool, reserve_threads > c.base_threads ? reserve_threads : c.base_threads);
+    c.nthreads = got < c.base_threads ? got : c.base_threads;
+    *out = vp;
     return 0;
 }
 
@@ -438,18 +517,21 @@ static bool is_device_pointer(const void *p)
     return at.type == hipMemoryTypeDevice;
 }
 
-int upload_tapes(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride)
+// one caller's tapes for proofs [first, first + n): copied into the context's own tape buffer (merged calls, host memory,
+// the callback) -- or, for a single caller whose aligned device buffer can be read in place, just noted
+static int upload_tapes_part(Ctx &c, int first, int n, const uint8_t *tapes, size_t tape_stride, bool in_place_ok)
 {
     const Params &P = c.P;
     if (tapes && tape_stride < P.tape_bytes) { c.err = "tape_stride smaller than kosk_tape_bytes"; return -1; }
+    uint8_t *d_dst = c.d_tape + (size_t)first * c.tape_stride, *h_dst = c.h_tape + (size_t)first * c.tape_stride;
     if (tapes && is_device_pointer(tapes)) {
         // the caller keeps its randomness in HBM: use it in place when the kernels' 8-byte loads are aligned, else one D2D copy
-        if (tape_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(tapes) & 7) == 0) {
+        if (in_place_ok && tape_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(tapes) & 7) == 0) {
             c.tape_cur = tapes;
             c.tape_cur_stride = tape_stride;
             return 0;
         }
-        HIPCHK(hipMemcpy2DAsync(c.d_tape, c.tape_stride, tapes, tape_stride, P.tape_bytes, n, hipMemcpyDeviceToDevice, c.stream));
+        HIPCHK(hipMemcpy2DAsync(d_dst, c.tape_stride, tapes, tape_stride, P.tape_bytes, n, hipMemcpyDeviceToDevice, c.stream));
         c.tape_cur = c.d_tape;
         c.tape_cur_stride = c.tape_stride;
         return 0;
@@ -458,7 +540,7 @@ int upload_tapes(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride)
         // draw through the randombytes callback in the reference's call order and
         // lengths (kosk.cpp:12, mlwe_prover.cpp:9, ss.cpp:5), proof after proof
         for (int b = 0; b < n; b++) {
-            uint8_t *tp = c.h_tape + (size_t)b * c.tape_stride;
+            uint8_t *tp = h_dst + (size_t)b * c.tape_stride;
             auto draw = [&](size_t len) {
                 if (c.rb) c.rb(c.rb_user, tp, len);
                 else os_randombytes(tp, len);
@@ -469,11 +551,31 @@ int upload_tapes(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride)
             for (int i = 0; i < P.nfresh; i++) draw(302);
         }
     } else {
-        parallel_for(c.pool, n, c.nthreads, [&](int b) { memcpy(c.h_tape + (size_t)b * c.tape_stride, tapes + (size_t)b * tape_stride, P.tape_bytes); });
+        parallel_for(c.pool, n, c.nthreads, [&](int b) { memcpy(h_dst + (size_t)b * c.tape_stride, tapes + (size_t)b * tape_stride, P.tape_bytes); });
     }
-    HIPCHK(hipMemcpyAsync(c.d_tape, c.h_tape, (size_t)n * c.tape_stride, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipMemcpyAsync(d_dst, h_dst, (size_t)n * c.tape_stride, hipMemcpyHostToDevice, c.stream));
     c.tape_cur = c.d_tape;
     c.tape_cur_stride = c.tape_stride;
+    return 0;
+}
+
+int upload_tapes(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride)
+{
+    return upload_tapes_part(c, 0, n, tapes, tape_stride, true);
+}
+
+// the tapes of every caller of a (possibly merged) call, segment after segment
+static int upload_tapes_segs(Ctx &c, int n, const KeygenIn &kg)
+{
+    if (!kg.next && (kg.count == 0 || kg.count == n)) return upload_tapes(c, n, kg.tapes, kg.tape_stride);
+    int first = 0;
+    for (const KeygenIn *s = &kg; s; s = s->next) {
+        const int cnt = s->count ? s->count : n - first;
+        if (cnt < 1 || first + cnt > n) { c.err = "internal: merged call segments do not add up"; return -1; }
+        if (upload_tapes_part(c, first, cnt, s->tapes, s->tape_stride, false)) return -1;
+        first += cnt;
+    }
+    if (first != n) { c.err = "internal: merged call segments do not add up"; return -1; }
     return 0;
 }
 
@@ -496,17 +598,33 @@ int issue_keygen(Ctx &c, int n, bool sampled)
     return 0;
 }
 
-void finish_keygen_host(Ctx &c, int n, uint8_t *pk, uint8_t *sk)
+static void finish_keygen_part(Ctx &c, int first, int n, uint8_t *pk, uint8_t *sk)
 {
     const Params &P = c.P;
-    parallel_for(c.pool, n, c.nthreads, [&](int b) { // sk = NTT(s) bytes || pk || H(pk) || z, z = noise seed   kosk.cpp:62-69
-        uint8_t *pkb = pk + (size_t)b * P.pk_bytes, *skb = sk + (size_t)b * P.sk_bytes;
+    parallel_for(c.pool, n, c.nthreads, [&](int i) { // sk = NTT(s) bytes || pk || H(pk) || z, z = noise seed   kosk.cpp:62-69
+        const int b = first + i;
+        uint8_t *pkb = pk + (size_t)i * P.pk_bytes, *skb = sk + (size_t)i * P.sk_bytes;
         memcpy(pkb, c.h_pk + (size_t)b * c.pk_stride, P.pk_bytes);
         memcpy(skb, c.h_sb + (size_t)b * c.sb_stride, c.sb_bytes);
         memcpy(skb + c.sb_bytes, pkb, P.pk_bytes);
         sha3_256(skb + P.sk_bytes - 64, pkb, P.pk_bytes);
         memcpy(skb + P.sk_bytes - 32, c.h_seeds + (size_t)b * c.kg_rec + 32, 32);
     });
+}
+
+void finish_keygen_host(Ctx &c, int n, uint8_t *pk, uint8_t *sk)
+{
+    finish_keygen_part(c, 0, n, pk, sk);
+}
+
+static void finish_keygen_segs(Ctx &c, int n, const KeygenIn &kg)
+{
+    int first = 0;
+    for (const KeygenIn *s = &kg; s && first < n; s = s->next) {
+        const int cnt = s->count ? s->count : n - first;
+        finish_keygen_part(c, first, cnt, s->pk, s->sk);
+        first += cnt;
+    }
 }
 
 int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk)
@@ -552,7 +670,7 @@ int issue_sharing_front(Ctx &c, int n, FrontPart part, bool with_keygen)
         na.npg = ntt_count;
         na.npoly = ntt_count * n;
         na.out_canonical = 1; na.fp32 = c.ntt_fp32;
-        c.prof_begin(PR_NTT_F);
+        c.prof_begin(PR_NTT_F, n);
         HIPCHK(launch_ntt(na, st));
         if (!c.capturing) c.path_n[c.ntt_fp32 ? PATH_NTT_FP32 : PATH_NTT_INT]++;
         c.prof_end(PR_NTT_F);
@@ -560,7 +678,7 @@ int issue_sharing_front(Ctx &c, int n, FrontPart part, bool with_keygen)
     if (matvec) HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_P, c.proof_stride, rm.shat, rm.nttas, K, n, st)); // :284-285
     const GemmSrc xsrc{c.d_P, c.proof_stride, c.d_gemm1_rows + s0, RS, 0, XLEN};
     const GemmDst xdst{c.d_P, c.proof_stride, c.d_gemm1_rows + s0, RS, EXP_OFF};
-    c.prof_begin(PR_GEMM_EXPAND1);
+    c.prof_begin(PR_GEMM_EXPAND1, n);
     if (gemm_modq(c, c.t_expand, xsrc, xdst, s1 - s0, n)) return -1;
     c.prof_end(PR_GEMM_EXPAND1);
     return 0;
@@ -569,7 +687,8 @@ int issue_sharing_front(Ctx &c, int n, FrontPart part, bool with_keygen)
 int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
 {
     if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
-    if (keygen && (!keygen->pk || !keygen->sk)) { c.err = "pk / sk output buffers are required"; return -1; }
+    for (const KeygenIn *s = keygen; s; s = s->next)
+        if (!s->pk || !s->sk) { c.err = "pk / sk output buffers are required"; return -1; }
     if (!keygen && !c.tape_cur) { c.err = "no resident prover inputs: call kosk_stage_prover_inputs first"; return -1; }
     HIPCHK(hipSetDevice(c.device));
     const Params &P = c.P;
@@ -589,7 +708,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     ha.out_lanes_per_group = NPARTY;
 
     // ---- key generation rides in the first launch of P1 (tape pointers may change from call to call: never part of a captured graph)
-    if (keygen && upload_tapes(c, n, keygen->tapes, keygen->tape_stride)) return -1;
+    if (keygen && upload_tapes_segs(c, n, *keygen)) return -1;
     // ---- P1: offline phase + witness sharing (secrets, randoms, one expansion GEMM), Tcomm of every party
     if (run_segment(c, (online_only || keygen) ? -1 : (int)Ctx::SEG_P1, n, [&]() -> int {
         if (issue_sharing_front(c, n, online_only ? FRONT_ONLINE : FRONT_FULL, keygen != nullptr)) return -1;
@@ -616,7 +735,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     if (c.round_hook) c.round_hook(c.round_user, 0, 0, c.d_dig1, (size_t)n * NPARTY * 32);
 
     // ---- Fiat-Shamir round 1 on the host (and the host half of the key generation)
-    if (keygen) finish_keygen_host(c, n, keygen->pk, keygen->sk);
+    if (keygen) finish_keygen_segs(c, n, *keygen);
     fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool);
     t1 = now_sec(); c.phase_sec[PH_FS_ALPHA] = t1 - t0; t0 = t1;
 
@@ -624,7 +743,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     // s + r / e + r (:222-245), then the view commitments, which read nothing else of the relation phase
     if (run_segment(c, Ctx::SEG_P2, n, [&]() -> int {
         HIPCHK(hipMemcpyAsync(c.d_alpha, c.h_alpha, (size_t)n * 80 * 2, hipMemcpyHostToDevice, st));
-        c.prof_begin(PR_LINCOMB);
+        c.prof_begin(PR_LINCOMB, n);
         HIPCHK(launch_coef_limbs(c.d_alpha, P.J, P.M, c.d_coef, n, st));
         if (c.lincomb_fused) {
             HIPCHK(launch_lincomb_fused(c.d_P, c.proof_stride, rm, c.d_coef, c.d_P, c.d_lin_rows, P.J, n, st)); // includes s + r, e + r
@@ -665,7 +784,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         HIPCHK(launch_relation_ntt(na, c.d_A, c.key_stride, c.d_P, c.proof_stride, rm, n, st)); // NTT, A o NTT(s+r) (:287-288), tails
         const GemmSrc x2src{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, 0, XLEN};
         const GemmDst x2dst{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, EXP_OFF};
-        c.prof_begin(PR_GEMM_EXPAND2);
+        c.prof_begin(PR_GEMM_EXPAND2, n);
         if (gemm_modq(c, c.t_expand, x2src, x2dst, c.n_gemm2, n)) return -1; // recompute_share_secrets_ddeg x 3K   :298-299,:315
         c.prof_end(PR_GEMM_EXPAND2);
         HIPCHK(launch_post_relation(c.d_P, c.proof_stride, rm, n, st));
@@ -684,7 +803,12 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
 
     // ---- P3: wire image
     if (run_segment(c, Ctx::SEG_P3, n, [&]() -> int {
-        HIPCHK(hipMemcpyAsync(c.d_I, c.h_I, ((size_t)c.max_batch + n) * c.sel_stride * 2, hipMemcpyHostToDevice, st)); // I and its complement
+        if (!c.is_view) {
+            HIPCHK(hipMemcpyAsync(c.d_I, c.h_I, ((size_t)c.max_batch + n) * c.sel_stride * 2, hipMemcpyHostToDevice, st)); // I and its complement
+        } else { // a view's lists sit inside the arena's two blocks: other views' lists lie between them
+            HIPCHK(hipMemcpyAsync(c.d_I, c.h_I, (size_t)n * c.sel_stride * 2, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(c.d_rest, c.h_rest, (size_t)n * c.sel_stride * 2, hipMemcpyHostToDevice, st));
+        }
         AssembleArgs aa{};
         aa.P = c.d_P;
         aa.proof_stride = c.proof_stride;
@@ -698,7 +822,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         aa.proof = c.d_proof;
         aa.image_stride = c.image_stride;
         aa.plan = c.pplan;
-        c.prof_begin(PR_ASSEMBLE);
+        c.prof_begin(PR_ASSEMBLE, n);
         HIPCHK(launch_assemble(aa, c.nfields, P.off[F_TCOMM], P.off[F_COMM], P.off[F_I], n, st));
         c.prof_end(PR_ASSEMBLE);
         return 0;

@@ -37,6 +37,17 @@ struct KeygenIn {
     const uint8_t *tapes; // host or device memory; nullptr: the randombytes callback
     size_t tape_stride;
     uint8_t *pk, *sk;     // host, n records each
+    // a merged call (kosk_combine.hpp): several callers' batches back to back in one pipeline run.  This segment covers the
+    // next `count` proofs (0: all the remaining ones), `next` the ones behind it
+    int count = 0;
+    const KeygenIn *next = nullptr;
+};
+// the verifier's per-caller parts of a merged call: `count` proofs each, own key source and own result bytes
+struct VerifySeg {
+    int count;
+    const uint8_t *pk; // pk_mode 1: this caller's public keys (host or device memory)
+    uint8_t *ok;
+    const VerifySeg *next = nullptr;
 };
 
 enum Phase { PH_HOST_PRE = 0, PH_GPU_COMMIT, PH_FS_ALPHA, PH_GPU_RELATION, PH_FS_OPEN, PH_GPU_ASSEMBLE, PH_D2H,
@@ -90,6 +101,21 @@ struct Ctx {
     Params P{};
     RowMap rm{};
     int max_batch = 0;
+    // ---- views (kosk_combine.hpp) ----
+    // Every per-proof buffer is registered (field, bytes per proof) when it is allocated.  A VIEW of a context is a copy of the
+    // struct whose per-proof pointers start `view_first` proofs further: it shares the constant tables and the workspace with
+    // the context it was made from (the arena), has its own stream / events / host workers, and can run the pipeline on proofs
+    // [view_first, view_first + max_batch) of the arena while other views work on other proofs of it.
+    struct PerProof { size_t field_off, stride_bytes; };
+    std::vector<PerProof> per_proof;
+    template <class T> void reg_pp(T **field, size_t stride_bytes)
+    {
+        per_proof.push_back({(size_t)(reinterpret_cast<char *>(field) - reinterpret_cast<char *>(this)), stride_bytes});
+    }
+    bool is_view = false;
+    int view_first = 0;
+    int own_batch = 0;   // proofs of this context's own callers (a view: its member's kosk_create size; else max_batch)
+    int base_threads = 1; // host threads of a call of own_batch proofs (a merged run uses base_threads x members)
     int nthreads = 1;
     Pool *pool = nullptr; // this context's host worker threads
     hipStream_t stream = nullptr;
@@ -209,7 +235,9 @@ struct Ctx {
     bool prof_used[PR_COUNT] = {};
     double prof_ms[PR_COUNT] = {0};
     long prof_n[PR_COUNT] = {0};
-    void prof_begin(int id) { if (prof_on && !capturing) { (void)hipEventRecord(prof_ev[id][0], stream); } }
+    long prof_units[PR_COUNT] = {0}; // proofs served by the timed launches (a merged run serves several callers' batches per launch)
+    int prof_cur_units[PR_COUNT] = {0};
+    void prof_begin(int id, int units = 0) { if (prof_on && !capturing) { (void)hipEventRecord(prof_ev[id][0], stream); prof_cur_units[id] = units; } }
     void prof_end(int id) { if (prof_on && !capturing) { (void)hipEventRecord(prof_ev[id][1], stream); prof_used[id] = true; } }
     void prof_collect(); // call after the stream has been synchronised
 
@@ -255,6 +283,9 @@ int run_segment(Ctx &c, int seg, int n, F &&body, const void *key_ptr = nullptr,
 
 // host_share: sub-contexts of the same handle that share this process's CPUs (divides the host thread budget)
 int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &err, int host_share = 1);
+// a view of `arena` starting at proof `first` whose own callers send up to `own_batch` proofs per call; reserve_threads: host
+// workers created now (a merged run led by this view uses base_threads x members of them)
+int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx **out, std::string &err);
 
 // C[g][rows_d[i]][off + m] = sum_k A[m][k] * src[g][rows_s[i]][koff + k] mod q  (conversion to limbs + MFMA GEMM)
 // host wait for everything queued on the context's stream (spinning, or sleeping with KOSK_BLOCKING_SYNC=1)
@@ -302,6 +333,6 @@ int stage_verifier_inputs(Ctx &c, int n, const uint8_t *pi, const uint8_t *pk, b
 // pk_mode 0: A and t are already resident (stage_verifier_inputs / stage_verifier_inst); 1: decode `pk` (host or
 // device memory, n records of pk_bytes) at the head of the first segment (kosk.cpp:94-99: polyvec_frombytes + gen_matrix);
 // 2: decode the pk bytes the key generation left resident in HBM
-int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode = 0, const uint8_t *pk = nullptr);
+int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode = 0, const uint8_t *pk = nullptr, const VerifySeg *segs = nullptr);
 
 } // namespace kosk

@@ -48,6 +48,7 @@ static int upload_vec(Ctx &c, T **d, const std::vector<T> &v)
 int ensure_verify_workspace(Ctx &c)
 {
     if (c.verify_ready) return 0;
+    if (c.is_view) { c.err = "internal: a view's verifier workspace is allocated with its arena"; return -1; }
     const Params &P = c.P;
     const RowMap &rm = c.rm;
     const int K = P.K, M = P.M, E = P.E, Z = P.Z;
@@ -131,19 +132,26 @@ int ensure_verify_workspace(Ctx &c)
         return -1;
 
     c.o_stride = (size_t)rm.nrows * OS;
-    HIPCHK(dalloc(&c.d_O, B * c.o_stride));
+    // per-proof buffers, registered for views like the ones of ctx_create
+    auto dev = [&](auto **p, size_t per) -> hipError_t {
+        const hipError_t e = dalloc(p, B * per);
+        if (e == hipSuccess) c.reg_pp(p, per * sizeof(**p));
+        return e;
+    };
+    HIPCHK(dev(&c.d_O, c.o_stride));
     HIPCHK(hipMemsetAsync(c.d_O, 0, B * c.o_stride * sizeof(uint16_t), c.stream));
-    HIPCHK(dalloc(&c.d_w, B * 2 * 832));
-    HIPCHK(dalloc(&c.d_ell, B * 416));
-    HIPCHK(dalloc(&c.d_node_of, B * 416));
-    HIPCHK(dalloc(&c.d_isort, B * c.sel_stride));
-    HIPCHK(dalloc(&c.d_hrange, B * 4));
-    HIPCHK(dalloc(&c.d_gather, B * interp_y_bytes(0)));
-    HIPCHK(dalloc(&c.d_gather2, B * interp_y_bytes(1)));
-    HIPCHK(dalloc(&c.d_sec, B * 2 * NCHK * 256));
-    HIPCHK(dalloc(&c.d_sec_u1, B * c.n_interp_2d * 256));
-    HIPCHK(dalloc(&c.d_sec_u2, B * c.n_interp_2d * 256));
+    HIPCHK(dev(&c.d_w, (size_t)2 * 832));
+    HIPCHK(dev(&c.d_ell, 416));
+    HIPCHK(dev(&c.d_node_of, 416));
+    HIPCHK(dev(&c.d_isort, (size_t)c.sel_stride));
+    HIPCHK(dev(&c.d_hrange, 4));
+    HIPCHK(dev(&c.d_gather, interp_y_bytes(0)));
+    HIPCHK(dev(&c.d_gather2, interp_y_bytes(1)));
+    HIPCHK(dev(&c.d_sec, (size_t)2 * NCHK * 256));
+    HIPCHK(dev(&c.d_sec_u1, (size_t)c.n_interp_2d * 256));
+    HIPCHK(dev(&c.d_sec_u2, (size_t)c.n_interp_2d * 256));
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c.h_Iimg), B * 2 * NOPEN, hipHostMallocDefault));
+    c.reg_pp(&c.h_Iimg, (size_t)2 * NOPEN);
     HIPCHK(hipStreamSynchronize(c.stream)); // every table and the zeroed opened matrix are in HBM before the first verifier kernel is queued
     c.verify_ready = true;
     return 0;
@@ -181,11 +189,21 @@ static bool is_device_pointer(const void *p)
     return at.type == hipMemoryTypeDevice;
 }
 
-int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
+int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, const VerifySeg *segs)
 {
     if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
-    if (!ok) { c.err = "ok output buffer is required"; return -1; }
-    if (pk_mode == 1 && !pk) { c.err = "pk_mode 1 needs the public keys"; return -1; }
+    // a merged call (kosk_combine.hpp): `segs` lists the callers' parts, each with its own keys and result bytes
+    const VerifySeg whole{n, pk, ok, nullptr};
+    if (!segs) segs = &whole;
+    {
+        int total = 0;
+        for (const VerifySeg *s = segs; s; s = s->next) {
+            if (!s->ok) { c.err = "ok output buffer is required"; return -1; }
+            if (pk_mode == 1 && !s->pk) { c.err = "pk_mode 1 needs the public keys"; return -1; }
+            total += s->count;
+        }
+        if (total != n) { c.err = "internal: merged call segments do not add up"; return -1; }
+    }
     if (pk_mode == 2 && c.resident_pk_n < n) {
         c.err = "no resident public keys for this batch: pk == NULL needs a key generation (or a verifier staging call) of at least n proofs on this context";
         return -1;
@@ -195,11 +213,18 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     if (pk_mode) {
         const Params &Pk = c.P;
         if (pk_mode == 1) {
-            if (is_device_pointer(pk)) {
-                HIPCHK(hipMemcpy2DAsync(c.d_pk, c.pk_stride, pk, Pk.pk_bytes, Pk.pk_bytes, n, hipMemcpyDeviceToDevice, c.stream));
-            } else {
-                for (int b = 0; b < n; b++) memcpy(c.h_pk + (size_t)b * c.pk_stride, pk + (size_t)b * Pk.pk_bytes, Pk.pk_bytes);
-                HIPCHK(hipMemcpyAsync(c.d_pk, c.h_pk, (size_t)n * c.pk_stride, hipMemcpyHostToDevice, c.stream));
+            int first = 0;
+            for (const VerifySeg *s = segs; s; s = s->next) {
+                if (is_device_pointer(s->pk)) {
+                    HIPCHK(hipMemcpy2DAsync(c.d_pk + (size_t)first * c.pk_stride, c.pk_stride, s->pk, Pk.pk_bytes, Pk.pk_bytes, s->count,
+                                            hipMemcpyDeviceToDevice, c.stream));
+                } else {
+                    for (int b = 0; b < s->count; b++)
+                        memcpy(c.h_pk + (size_t)(first + b) * c.pk_stride, s->pk + (size_t)b * Pk.pk_bytes, Pk.pk_bytes);
+                    HIPCHK(hipMemcpyAsync(c.d_pk + (size_t)first * c.pk_stride, c.h_pk + (size_t)first * c.pk_stride, (size_t)s->count * c.pk_stride,
+                                          hipMemcpyHostToDevice, c.stream));
+                }
+                first += s->count;
             }
             c.resident_pk_n = n;
         }
@@ -248,7 +273,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     const GateOffsets go{(uint32_t)P.off[F_SSUB], (uint32_t)P.off[F_ESUB], (uint32_t)P.off[F_ZS], (uint32_t)P.off[F_ZE]};
     HIPCHK(launch_disassemble(va, c.d_vfields, c.vplan, c.d_vrowtab, c.d_proof, c.image_stride, P.off[F_TCOMM],
                               P.off[F_COMM], c.d_dig1, c.d_dig2, go, n, st)); // + digests + gate outputs of the opened parties
-    c.prof_begin(PR_V_HASH_TCOMM);
+    c.prof_begin(PR_V_HASH_TCOMM, n);
     HIPCHK(launch_opened_hash(oh, K, false, n, st)); // Tcomm of the opened parties, read from the image   :22-35
     c.prof_end(PR_V_HASH_TCOMM);
     HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig1, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
@@ -273,7 +298,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     ia.w = c.d_w;
     ia.ell = c.d_ell;
     ia.node_of = c.d_node_of;
-    c.prof_begin(PR_V_INTERP_BUILD);
+    c.prof_begin(PR_V_INTERP_BUILD, n);
     HIPCHK(launch_interp_setup(ia, n, st));
     c.prof_end(PR_V_INTERP_BUILD);
     HIPCHK(launch_gather_frags(c.d_P, c.proof_stride, c.d_rows_isrc, c.n_interp_d, c.d_gather, c.d_rows_u, c.n_interp_2d, c.d_gather2,
@@ -281,7 +306,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     { // values at points 0..406 of every interpolated sharing (:201-219 etc.) and the 813-node Cauchy sums of the u shares
       // at the packed positions (:523-543) with the per-proof operators built on the fly; recon_secrets_2ddeg of the merged
       // u rows (:555-556) is a product with a fixed table
-        c.prof_begin(PR_V_GEMM_INTERP);
+        c.prof_begin(PR_V_GEMM_INTERP, n);
         HIPCHK(launch_interp_apply(ia, c.d_P, c.proof_stride, c.d_rows_isrc, c.d_rows_idst, c.n_interp_d, c.d_gather, c.n_interp_2d,
                                    c.d_gather2, c.d_sec_u1, n, st));
         c.prof_end(PR_V_GEMM_INTERP);
@@ -290,7 +315,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
         if (gemm_modq(c, c.t_recon_2d, gs3, gd3, c.n_interp_2d, n)) return -1;
         const GemmSrc xs{c.d_P, c.proof_stride, c.d_rows_idst, RS, 0, XLEN};
         const GemmDst xd{c.d_P, c.proof_stride, c.d_rows_idst, RS, EXP_OFF};
-        c.prof_begin(PR_V_GEMM_EXPAND);
+        c.prof_begin(PR_V_GEMM_EXPAND, n);
         if (gemm_modq(c, c.t_expand, xs, xd, c.n_interp_d, n)) return -1; // recompute_share_secrets_ddeg   :224-225, :351, :441-442
         c.prof_end(PR_V_GEMM_EXPAND);
     }
@@ -338,7 +363,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     la.ncols = NOPEN;
     la.col_map = c.d_I;
     la.col_map_stride = c.sel_stride;
-    c.prof_begin(PR_V_LINCOMB);
+    c.prof_begin(PR_V_LINCOMB, n);
     HIPCHK(launch_lincomb(la, n, st));
     c.prof_end(PR_V_LINCOMB);
     return 0;
@@ -347,7 +372,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     // ---- V10: view hashes of the opened parties (plain launch: HIP events can bracket it)
     oh.prefix = c.d_dig1;
     oh.out = c.d_dig2;
-    c.prof_begin(PR_V_HASH_VIEW);
+    c.prof_begin(PR_V_HASH_VIEW, n);
     HIPCHK(launch_opened_hash(oh, K, true, n, st));
     c.prof_end(PR_V_HASH_VIEW);
     HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig2, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
@@ -361,7 +386,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     {
         const GemmSrc gs{c.d_P, c.proof_stride, c.d_rows_bg, RS, NSEC, XLEN};
         const GemmDst gd{c.d_sec, (size_t)2 * NCHK * 256, nullptr, 256, 0};
-        c.prof_begin(PR_V_GEMM_RECON);
+        c.prof_begin(PR_V_GEMM_RECON, n);
         if (gemm_modq(c, c.t_recon_d, gs, gd, 2 * NCHK, n)) return -1; // recon_secrets_ddeg x 140   :106-107
         c.prof_end(PR_V_GEMM_RECON);
     }
@@ -391,11 +416,15 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk)
     fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, I2.data(), rest2.data(), c.sel_stride, c.nthreads, c.pool);
     HIPCHK(stream_sync(c)); // fail masks of V2B
     c.prof_collect();
-    for (int b = 0; b < n; b++) {
-        uint32_t f = c.h_fail[b];
-        if (memcmp(&I2[(size_t)b * c.sel_stride], c.h_Iimg + (size_t)b * NOPEN, sizeof(uint16_t) * NOPEN) != 0) f |= 1u << FB_OPENED_SET;
-        c.h_fail[b] = f;
-        ok[b] = f == 0;
+    {
+        int b = 0;
+        for (const VerifySeg *s = segs; s; s = s->next)
+            for (int i = 0; i < s->count; i++, b++) {
+                uint32_t f = c.h_fail[b];
+                if (memcmp(&I2[(size_t)b * c.sel_stride], c.h_Iimg + (size_t)b * NOPEN, sizeof(uint16_t) * NOPEN) != 0) f |= 1u << FB_OPENED_SET;
+                c.h_fail[b] = f;
+                s->ok[i] = f == 0;
+            }
     }
     c.phase_sec[PH_V_FS_OPEN] = now_sec() - t0;
     return 0;

@@ -10,6 +10,10 @@
 //   san_driver lanes : the handle's lane threads and chunk dealing (csrc/kosk_lanes.hpp: what kosk_capi.cpp's run_chunks /
 //                      kosk_ctx::run execute) on fake sub-contexts: every unit exactly once, throwing and failing jobs,
 //                      a pool job inside each lane (the nesting of a real batch call), many back-to-back calls
+//   san_driver combine : the call combiner of a cohort (csrc/kosk_combine.hpp: what kosk_capi.cpp's merged resident calls go
+//                      through) with fake executors: every call served exactly once by a run of neighbouring members with its
+//                      own kind, short batches only at the end of a run, a throwing run contained, callers that alternate two
+//                      kinds of call in OPPOSITE phase end up in step, a lone caller is not delayed, members that come and go
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -18,8 +22,10 @@
 
 #include "kosk_oracle.h"
 #include "../mpcith_kyber_kosk_amd/csrc/kosk_host.hpp"
+#include "../mpcith_kyber_kosk_amd/csrc/kosk_combine.hpp"
 #include "../mpcith_kyber_kosk_amd/csrc/kosk_lanes.hpp"
 #include <stdexcept>
+#include <thread>
 
 static int fails = 0;
 #define CHECK(cond, ...)                   \
@@ -224,6 +230,108 @@ static void primitives()
     printf("primitives ok\n");
 }
 
+// ---- call combiner ----
+struct FakeCall { int member, seq, kind, n; int served_by = -1, run_first = -1, run_count = 0; };
+
+static void combine_hammer(int rounds)
+{
+    using namespace kosk;
+    const int C = 3, per = 4;
+    // (1) closed loops in opposite phase: members 0,1 start with kind 0, member 2 with kind 1; each alternates 0,1,0,1...
+    {
+        Combiner comb(C, 200000, 100000);
+        for (int i = 0; i < C; i++) CHECK(comb.join() == i, "join order");
+        CHECK(comb.join() == -1, "a full cohort must refuse a fourth member");
+        std::vector<std::vector<FakeCall>> calls(C);
+        std::atomic<long> execs{0}, merged3{0};
+        auto worker = [&](int i) {
+            for (int r = 0; r < rounds; r++) {
+                FakeCall fc{i, r, (r + (i == 2 ? 1 : 0)) & 1, per};
+                CombineReq q;
+                q.kind = fc.kind; q.n = fc.n; q.full = true; q.args = &fc;
+                int rc_count = 0;
+                const int rc = comb.call(i, q, [&](int first, int count, const CombineReq *const *reqs) -> int {
+                    execs++;
+                    if (count == 3) merged3++;
+                    for (int k = 0; k < count; k++) {
+                        FakeCall *f = static_cast<FakeCall *>(reqs[k]->args);
+                        CHECK(f->member == first + k, "run member order");
+                        CHECK(reqs[k]->kind == reqs[0]->kind, "kinds mixed in one run");
+                        CHECK(f->served_by < 0, "a call served twice");
+                        f->served_by = first; f->run_first = first; f->run_count = count;
+                    }
+                    std::this_thread::sleep_for(std::chrono::microseconds(200));
+                    return 0;
+                }, nullptr, &rc_count);
+                CHECK(rc == 0 && fc.served_by >= 0 && fc.run_count == rc_count, "call %d/%d not served (rc %d)", i, r, rc);
+                calls[i].push_back(fc);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int i = 0; i < C; i++) th.emplace_back(worker, i);
+        for (auto &t : th) t.join();
+        // after the first few calls everything runs as runs of three
+        long late3 = 0;
+        for (int i = 0; i < C; i++)
+            for (int r = rounds / 2; r < rounds; r++) late3 += calls[i][r].run_count == 3;
+        CHECK(late3 >= (long)C * (rounds - rounds / 2) * 9 / 10, "opposite-phase callers did not fall into step: %ld of %d late calls in runs of 3",
+              late3, C * (rounds - rounds / 2));
+        long runs = 0, served = 0;
+        comb.stats(&runs, &served);
+        CHECK(served == (long)C * rounds && runs == execs.load(), "stats: %ld served, %ld runs, %ld execs", served, runs, execs.load());
+    }
+    // (2) ragged batches, unmergeable kinds, a throwing run, members that leave and join
+    {
+        Combiner comb(C, 20000, 5000);
+        for (int i = 0; i < C; i++) comb.join();
+        std::atomic<int> bad{0};
+        auto worker = [&](int i) {
+            for (int r = 0; r < rounds; r++) {
+                FakeCall fc{i, r, (r % 7 == 3 && i == 1) ? -1 : 0, (r % 5 == 1 && i == 0) ? per - 1 : per};
+                CombineReq q;
+                q.kind = fc.kind; q.n = fc.n; q.full = fc.n == per; q.args = &fc;
+                std::string what;
+                const bool thrower = r % 11 == 6;
+                const int rc = comb.call(i, q, [&](int first, int count, const CombineReq *const *reqs) -> int {
+                    for (int k = 0; k < count; k++) {
+                        FakeCall *f = static_cast<FakeCall *>(reqs[k]->args);
+                        if (k + 1 < count && f->n != per) bad++;          // a short batch in the middle of a run
+                        if (count > 1 && reqs[k]->kind < 0) bad++;        // an unmergeable request merged
+                        f->served_by = first;
+                    }
+                    if (static_cast<FakeCall *>(reqs[0]->args)->seq % 11 == 6) throw std::runtime_error("boom");
+                    return 0;
+                }, &what);
+                if (rc == -2) CHECK(what == "boom", "exception text lost");
+                else CHECK(rc == 0, "rc %d", rc);
+                (void)thrower;
+                CHECK(fc.served_by >= 0, "call not served");
+                if (i == 2 && r % 50 == 49) { // member 2 leaves and comes back
+                    comb.leave(2);
+                    CHECK(comb.join() == 2, "rejoin");
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int i = 0; i < C; i++) th.emplace_back(worker, i);
+        for (auto &t : th) t.join();
+        CHECK(bad.load() == 0, "%d malformed runs", bad.load());
+    }
+    // (3) a lone caller of a cohort whose other members are idle is not delayed
+    {
+        Combiner comb(C, 2000000, 1000);
+        for (int i = 0; i < C; i++) comb.join();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < 20; r++) {
+            CombineReq q;
+            q.kind = 0; q.n = per; q.full = true;
+            CHECK(comb.call(1, q, [&](int first, int count, const CombineReq *const *) { return (first == 1 && count == 1) ? 0 : -1; }) == 0, "lone call");
+        }
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        CHECK(ms < 1000.0, "20 lone calls took %.1f ms", ms);
+    }
+}
+
 int main(int argc, char **argv)
 {
     const char *mode = argc > 1 ? argv[1] : "full";
@@ -232,6 +340,8 @@ int main(int argc, char **argv)
         host_vs_oracle(2);
     } else if (!strcmp(mode, "lanes")) {
         lanes_hammer(argc > 2 ? atoi(argv[2]) : 3000);
+    } else if (!strcmp(mode, "combine")) {
+        combine_hammer(argc > 2 ? atoi(argv[2]) : 400);
     } else {
         primitives();
         for (int K = 2; K <= 4; K++) host_vs_oracle(K);

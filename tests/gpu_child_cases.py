@@ -194,3 +194,111 @@ def big_batches():
     assert len(rnd) == 3 and len(rng) == 3
     ctx.close()
     print("big_batches ok")
+
+
+def combined_calls(k, threads=6, rounds=4, min_merge=0.5):
+    """KOSK_COMBINE=3: six caller threads, each with its own handle and its own small resident calls.  The calls of a cohort's
+    members are served by merged pipeline runs; every caller must get exactly what an uncombined handle gives it -- pk, sk, proof
+    images, resident digest tables, verify bits and fail masks byte for byte -- with host tapes, device tapes read by a merged
+    run, a short (ragged) batch on one member, and given / resident public keys.  The oracle pins three of the proofs."""
+    import ctypes as C
+    import threading
+    import torch
+    from mpcith_kyber_kosk_amd import api
+    lib = api.lib
+    per = 3
+    plain = api.Kosk(kyber_k=k, max_batch=per)
+    hs = [_kosk(k, per, KOSK_COMBINE=3, KOSK_COMBINE_WAIT_US=200000, KOSK_COMBINE_IDLE_US=100000) for _ in range(threads)]
+    stride = (plain.tape_bytes + 63) // 64 * 64
+    # what every (thread, round) must produce: from the uncombined handle
+    want = {}
+    tapes = {}
+    for t in range(threads):
+        for r in range(rounds):
+            n = per if not (t == threads - 1 and r == 1) else per - 1  # one ragged call: the last member of its cohort, round 1
+            tp = [oracle.tape_bytes_for(k, 5000 + (t * rounds + r) * per + b) for b in range(n)]
+            tapes[t, r] = tp
+            plain.verifiable_keygen_resident(tp)
+            pk, sk = plain.keys(n)
+            assert plain.verify_resident_pk(n) == [True] * n
+            want[t, r] = (pk, sk, plain.fetch_proofs(n),
+                          [torch.as_tensor(plain.resident_digests(i, n), device="cuda").cpu().numpy().tobytes() for i in (0, 1)])
+    for (t, r) in ((0, 0), (threads - 1, 1), (2, rounds - 1)):
+        opk, osk, opi, _, _ = oracle.verifiable_keygen(k, tapes[t, r][-1])
+        assert (want[t, r][0][-1], want[t, r][1][-1], want[t, r][2][-1]) == (opk, osk, opi)
+    errs = []
+    barrier = threading.Barrier(threads)
+
+    base = [None] * threads
+
+    def worker(t):
+        try:
+            h = hs[t]
+            # two unchecked rounds first: nobody is expected at a cohort's very first call, so it cannot merge.  The threads then
+            # run freely (no barriers: a caller parked at a barrier while its cohort waits for it inside the library would only
+            # test this test); the combiner itself brings the members of a cohort into step (tools/combine_diag.py)
+            barrier.wait()
+            for _ in range(2):
+                h.verifiable_keygen_resident(tapes[t, 0])
+                assert h.verify_resident_pk(len(tapes[t, 0])) == [True] * len(tapes[t, 0])
+            base[t] = h.combine_stats()
+            for r in range(rounds):
+                tp = tapes[t, r]
+                n = len(tp)
+                if r % 2 == 0:  # host tapes
+                    h.verifiable_keygen_resident(tp)
+                else:           # device tapes (a merged run copies them into its own tape block; a lone run reads them in place)
+                    import numpy as np
+                    host = np.zeros((n, stride), np.uint8)
+                    for b, x in enumerate(tp):
+                        host[b, :len(x)] = np.frombuffer(x, np.uint8)
+                    dev = torch.from_numpy(host).to("cuda")
+                    torch.cuda.synchronize()
+                    h.verifiable_keygen_resident(dev.data_ptr(), n=n, tape_stride=stride)
+                pk, sk = h.keys(n)
+                assert (pk, sk) == want[t, r][:2], ("keys", t, r)
+                ok = h.verify_resident_pk(n, pks=pk if r == 2 else None)
+                assert ok == [True] * n and h.fail_masks(n) == [0] * n, ("verify", t, r, ok)
+                assert h.fetch_proofs(n) == want[t, r][2], ("proofs", t, r)
+                for i in (0, 1):
+                    got = torch.as_tensor(h.resident_digests(i, n), device="cuda").cpu().numpy().tobytes()
+                    assert got == want[t, r][3][i], ("digests", t, r, i)
+                # a wrong key for this caller only: its own masks say so, the run's other callers are untouched
+                if r == rounds - 1:
+                    keys = list(pk)
+                    if t == 1:
+                        keys[0] = want[0, r][0][0]
+                    ok = h.verify_resident_pk(n, pks=keys)
+                    assert ok == ([False] + [True] * (n - 1) if t == 1 else [True] * n), ("wrong key", t, ok)
+                    assert (h.fail_masks(n)[0] != 0) == (t == 1)
+        except Exception as e:  # noqa: BLE001
+            errs.append((t, repr(e)))
+            try:
+                barrier.abort()
+            except Exception:
+                pass
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+    for x in ths:
+        x.start()
+    for x in ths:
+        x.join()
+    assert not errs, errs
+    calls = sum(h.combine_stats()[0] - base[t][0] for t, h in enumerate(hs))
+    members = sum(h.combine_stats()[1] - base[t][1] for t, h in enumerate(hs))
+    assert calls == threads * (2 * rounds + 1)
+    # the barrier-aligned calls really merged: every cohort's present members in one run (3, 3 for six threads; 3, 2 for five)
+    ideal = sum(min(3, threads - c0) ** 2 for c0 in range(0, threads, 3)) / threads
+    # (how many is a matter of thread timing: the bytes above are what is asserted strictly)
+    assert members / calls >= min_merge * ideal and members > calls, (calls, members, ideal)
+    # entry points that never merge keep working on a member's own block, next to its neighbours' merged state
+    got = hs[1].verifiable_keygen(tapes[1, 0])
+    assert got[2] == want[1, 0][2]
+    assert hs[1].verify(got[2], got[0]) == [True] * per
+    assert hs[0].fetch_proofs(per) == want[0, rounds - 1][2]  # neighbour's resident proofs untouched
+    # pk == NULL without resident keys on a member: an error for that caller alone
+    fresh = _kosk(k, per, KOSK_COMBINE=3)
+    okb = C.create_string_buffer(per)
+    assert lib.kosk_verify_resident_pk(fresh.handle, per, None, okb) != 0 and b"resident public keys" in lib.kosk_last_error(fresh.handle)
+    for h in hs + [plain, fresh]:
+        h.close()
+    print("combined_calls ok", k, "mean callers per run %.2f" % (members / calls))

@@ -43,3 +43,16 @@ def test_lane_threads_and_chunk_dealing_under_sanitizers(san):
                        stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "san_driver lanes: ok" in r.stdout, r.stdout[-3000:]
     assert "ThreadSanitizer" not in r.stdout and "AddressSanitizer" not in r.stdout and "runtime error" not in r.stdout
+
+
+@pytest.mark.parametrize("san", ["tsan", "asan"])
+def test_call_combiner_under_sanitizers(san):
+    """csrc/kosk_combine.hpp (the combiner behind the merged resident calls of a KOSK_COMBINE cohort) with fake executors: every
+    call served once by a run of neighbouring members of its own kind, short batches only at a run's end, exceptions contained,
+    opposite-phase callers fall into step, a lone caller is not delayed; no data race, no leak."""
+    _build(san)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([os.path.join(ROOT, "oracle", "_san", "san_driver_" + san), "combine", "300"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "san_driver combine: ok" in r.stdout, r.stdout[-3000:]
+    assert "ThreadSanitizer" not in r.stdout and "AddressSanitizer" not in r.stdout and "runtime error" not in r.stdout
