@@ -639,8 +639,6 @@ void ko_prepare_range_proof(int K, ko_tape *t, ko_pre *pre)
 
 void ko_keygen(int K, ko_tape *t, uint8_t *pk, uint8_t *sk, ko_mlwe *raw)
 {
-    ko_params P;
-    ko_get_params(K, &P);
     uint8_t buf[64];
     tape_bytes(t, buf, 64);
     buf[32] = (uint8_t)K;
@@ -649,7 +647,16 @@ void ko_keygen(int K, ko_tape *t, uint8_t *pk, uint8_t *sk, ko_mlwe *raw)
         ko_sha3_512(g, buf, 33); /* kosk.cpp:12-14 */
         memcpy(buf, g, 64);
     }
-    const uint8_t *public_seed = buf, *noise_seed = buf + 32;
+    ko_keygen_from_seeds(K, buf, buf + 32, pk, sk, raw);
+}
+
+/* kosk.cpp:16-69: everything after hash_g, from the two seeds it yields.  (The reference hands both back: the public
+ * seed is pk's last 32 bytes, kosk.cpp:58, and -- its quirk -- the noise seed is sk's z, :67-69; tests/test_oracle_vs_ref.py
+ * runs the reference's own kyber_keygen on OS randomness and feeds those two seeds in here.) */
+void ko_keygen_from_seeds(int K, const uint8_t public_seed[32], const uint8_t noise_seed[32], uint8_t *pk, uint8_t *sk, ko_mlwe *raw)
+{
+    ko_params P;
+    ko_get_params(K, &P);
     int16_t A[4 * 4 * 256];
     ko_gen_matrix(A, public_seed, 0, K);
     uint8_t nb[3 * 256 / 4];

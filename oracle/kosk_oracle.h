@@ -141,6 +141,8 @@ typedef struct {
 } ko_trace;
 
 void ko_keygen(int K, ko_tape *t, uint8_t *pk, uint8_t *sk, ko_mlwe *raw);
+/* kosk.cpp:16-69 from the two halves of hash_g's output */
+void ko_keygen_from_seeds(int K, const uint8_t public_seed[32], const uint8_t noise_seed[32], uint8_t *pk, uint8_t *sk, ko_mlwe *raw);
 void ko_prepare_randomness(int K, ko_tape *t, ko_pre *pre);
 void ko_prepare_range_proof(int K, ko_tape *t, ko_pre *pre);
 void ko_prove(int K, ko_tape *t, uint8_t *pi, const ko_mlwe *mlwe, const ko_pre *pre, ko_trace *trace);

@@ -73,6 +73,12 @@ def sha3_256(data):
     return out.raw
 
 
+def sha3_512(data):
+    out = C.create_string_buffer(64)
+    lib.ko_sha3_512(out, C.c_char_p(bytes(data)), len(data))
+    return out.raw
+
+
 def shake256(data, n):
     out = C.create_string_buffer(n)
     lib.ko_shake256(out, n, C.c_char_p(bytes(data)), len(data))

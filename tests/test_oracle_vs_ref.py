@@ -3,7 +3,9 @@
   libkosk_ref_k*.so  : + ss.cpp + mlwe_prover.cpp + our sizeof/offsetof probe (oracle/ref_layout.cpp); the generated
                        utils/precomputed_kyber.c is not mounted, so get_precomputed_* are unresolved and the library is
                        loaded with RTLD_LAZY: only functions that never reach them are called here.
-Skipped when that build is absent (it cannot be rebuilt without /root/reference; oracle/_ref is git-ignored)."""
+Skipped when that build is absent (it cannot be rebuilt without /root/reference; oracle/_ref is git-ignored) -- but a FAILURE
+where the pins are required: KOSK_REQUIRE_REF=1, which tests/conftest.py sets by itself wherever /root/reference exists (the
+build container); the skip count is printed in the suite summary either way."""
 import ctypes as C
 import os
 
@@ -14,10 +16,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {2: "pqcrystals_kyber512_ref_", 3: "pqcrystals_kyber768_ref_", 4: "pqcrystals_kyber1024_ref_"}
 
 
+def _no_ref(path):
+    if os.environ.get("KOSK_REQUIRE_REF") == "1":
+        pytest.fail("KOSK_REQUIRE_REF=1 but %s is missing: run `make -C oracle` where /root/reference is mounted" % path)
+    pytest.skip("oracle/_ref not built (reference tree absent)")
+
+
 def _ref(k):
     path = os.path.join(ROOT, "oracle", "_ref", "libkyber_ref_k%d.so" % k)
     if not os.path.exists(path):
-        pytest.skip("oracle/_ref not built (reference tree absent)")
+        _no_ref(path)
     return C.CDLL(path)
 
 
@@ -105,12 +113,58 @@ def test_fips202_and_gf3329(oracle):
         assert ref.encode_to_gf3329(a) == oracle.lib.ko_gf_encode(a)
 
 
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_kyber_keygen_of_the_reference_on_its_own_randomness(k, oracle):
+    """kosk.cpp:4-70 compiled in place, called as the reference's main.cpp:21-47 would (its own randombytes = OS entropy, so a
+    different key every trial).  It hands both halves of hash_g back -- the public seed is pk[-32:] (kosk.cpp:58) and, the
+    reference's quirk, the noise seed is sk's z (kosk.cpp:67-69) -- so everything after the sha3_512 is checked against the
+    oracle without touching randombytes: pk, sk (incl. H(pk) and the z quirk) and the raw A / s / e / t of mlwe_inst."""
+    ref = _kosk_ref(k)
+    p = oracle.params(k)
+    fn = ref._Z12kyber_keygenP13kyber_keypairP9mlwe_inst
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p]
+    oracle.lib.ko_keygen_from_seeds.restype = None
+    oracle.lib.ko_keygen_from_seeds.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    inst_bytes = 512 * (k * k + 3 * k)  # mlwe_inst { polyvec A[K]; polyvec t, s, e; }  mlwe_prover.hpp:34-37 (layout test above)
+    seen = set()
+    for trial in range(20):
+        pair = C.create_string_buffer(p.pk_bytes + p.sk_bytes)  # kyber_keypair { pk[]; sk[]; }  kosk.hpp:13-16
+        inst = C.create_string_buffer(inst_bytes)
+        fn(pair, inst)
+        pk, sk = pair.raw[:p.pk_bytes], pair.raw[p.pk_bytes:]
+        assert pk not in seen  # the reference really drew fresh randomness
+        seen.add(pk)
+        pub, noise = pk[-32:], sk[-32:]
+        opk, osk = C.create_string_buffer(p.pk_bytes), C.create_string_buffer(p.sk_bytes)
+        raw = oracle.Mlwe()
+        oracle.lib.ko_keygen_from_seeds(k, pub, noise, opk, osk, C.byref(raw))
+        assert opk.raw == pk and osk.raw == sk
+        assert sk[384 * k:384 * k + p.pk_bytes] == pk and sk[-64:-32] == oracle.sha3_256(pk)
+        got = np.frombuffer(inst.raw, np.int16)
+        A = np.ctypeslib.as_array(raw.A).reshape(4, 4, 256)[:k, :k].reshape(-1)
+        t, s_, e = (np.ctypeslib.as_array(getattr(raw, n_)).reshape(4, 256)[:k].reshape(-1) for n_ in "tse")
+        assert np.array_equal(got[:k * k * 256], A)
+        assert np.array_equal(got[k * k * 256:(k * k + k) * 256], t)
+        assert np.array_equal(got[(k * k + k) * 256:(k * k + 2 * k) * 256], s_)
+        assert np.array_equal(got[(k * k + 2 * k) * 256:], e)
+        assert int(np.abs(s_).max()) <= p.eta1 and int(np.abs(e).max()) <= p.eta1
+    # the oracle's tape-driven keygen is the same function behind kosk.cpp:12-14's hash_g
+    tape = oracle.tape_bytes_for(k, 7)
+    g = oracle.sha3_512(tape[:32] + bytes([k]))
+    opk, osk = C.create_string_buffer(p.pk_bytes), C.create_string_buffer(p.sk_bytes)
+    raw = oracle.Mlwe()
+    oracle.lib.ko_keygen_from_seeds(k, g[:32], g[32:], opk, osk, C.byref(raw))
+    pk2, sk2, _, _, _ = oracle.verifiable_keygen(k, tape)
+    assert (opk.raw, osk.raw) == (pk2, sk2)
+
+
 # ---- L2/L3 pieces of the reference that compile without the unmounted Lagrange tables -----------------------------
 
 def _kosk_ref(k):
     path = os.path.join(ROOT, "oracle", "_ref", "libkosk_ref_k%d.so" % k)
     if not os.path.exists(path):
-        pytest.skip("oracle/_ref not built (reference tree absent)")
+        _no_ref(path)
     return C.CDLL(path, mode=os.RTLD_LAZY)  # get_precomputed_* stay unresolved (see the module docstring)
 
 
