@@ -131,7 +131,9 @@ int kosk_stage_verifier_inputs_compact(kosk_ctx *ctx, int n, const uint8_t *in, 
  * or a layout it cannot take), 2 placement primer launches (KOSK_HASH_PRIMER=1), 3 shared-table products on k_table_gemm,
  * 4 products on the generic limb GEMM (KOSK_TABLE_GEMM=0, grouped products), 5 proof images copied straight between HBM and
  * page-locked caller memory, 6 through the pinned staging buffer (KOSK_REGISTER=0, head / tail chunks, single-chunk calls),
- * 7 hipGraph segment replays (KOSK_GRAPHS=1), 8 / 9 NTT launches of the packed-fp32 / integer kernel. */
+ * 7 hipGraph segment replays (KOSK_GRAPHS=1), 8 / 9 NTT launches of the packed-fp32 / integer kernel, 10 prover commitment rounds
+ * whose digest table was written to the host's table by the hash launch itself (KOSK_DIGEST_DIRECT=1), 11 rounds that copied it
+ * behind the launch (default). */
 int kosk_path_count(const kosk_ctx *ctx, int id, long *count);
 /* host worker threads per sub-context (<= 8, <= CPUs of the process / KOSK_STREAMS; all created by kosk_create) */
 int kosk_host_threads(const kosk_ctx *ctx);

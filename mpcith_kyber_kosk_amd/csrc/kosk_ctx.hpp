@@ -61,7 +61,7 @@ enum ProfId { PR_HASH_TCOMM = 0, PR_HASH_VIEW, PR_GEMM_EXPAND1, PR_GEMM_EXPAND2,
               PR_V_LINCOMB, PR_HASH_TCOMM_TAIL, PR_HASH_VIEW_TAIL, PR_COUNT };
 
 enum PathId { PATH_HASH_DMA = 0, PATH_HASH_PLAIN, PATH_HASH_PRIMER, PATH_TABLE_GEMM, PATH_LIMB_GEMM, PATH_COPY_DIRECT, PATH_COPY_STAGED,
-              PATH_GRAPH_REPLAY, PATH_NTT_FP32, PATH_NTT_INT, PATH_COUNT };
+              PATH_GRAPH_REPLAY, PATH_NTT_FP32, PATH_NTT_INT, PATH_DIGEST_DIRECT, PATH_DIGEST_COPY, PATH_COUNT };
 
 struct GemmTable {
     uint8_t *d = nullptr; // limb matrix (kosk_device.hpp)
@@ -199,7 +199,7 @@ struct Ctx {
     uint32_t *d_compact_bad = nullptr, *h_compact_bad = nullptr;
 
     // pinned host staging
-    uint8_t *h_tape = nullptr, *h_dig = nullptr, *h_proof = nullptr;
+    uint8_t *h_tape = nullptr, *h_dig = nullptr, *h_dig2 = nullptr, *h_proof = nullptr; // h_dig / h_dig2: the host's copies of the two digest tables
     uint16_t *h_alpha = nullptr, *h_I = nullptr, *h_rest = nullptr;
     uint32_t *h_fail = nullptr;
 
@@ -222,6 +222,9 @@ struct Ctx {
     bool hash_dma = true;      // KOSK_HASH_DMA=0: commitment hashes without the LDS-DMA staging (k_commit_hash)
     bool hash_primer = false;  // KOSK_HASH_PRIMER=1: placement primer in front of a commitment launch (k_hash_primer)
     bool table_gemm = true;    // KOSK_TABLE_GEMM=0: shared-table products through the generic limb GEMM
+    // KOSK_DIGEST_DIRECT=1: the prover's commitment launches also store every digest into the host's page-locked table (no copy
+    // behind the launch).  Measured slower with merged runs, neutral without (profiles/r04_digest_direct.txt): default off
+    bool digest_direct = false;
     bool host_register = true; // KOSK_REGISTER=0: multi-chunk host-buffer calls never page-lock caller memory (staging copies only)
     int cu_part_i = 0, cu_part_n = 1; // KOSK_CU_PARTITION=i/n: the stream is restricted to partition i of n CU partitions
     int cu_mask_layout = 0;           // KOSK_CU_MASK_LAYOUT: how CU-mask bits map to XCDs (0 round-robin, 1 XCD-major)

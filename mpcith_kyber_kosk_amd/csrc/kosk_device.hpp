@@ -18,6 +18,10 @@ struct HashArgs {
     const uint8_t *prefix;     // [group][out_lanes_per_group][32], read at the output index
     uint8_t *out;              // [group][out_lanes_per_group][32]
     int out_lanes_per_group;
+    // optional second copy of every digest, same layout, in page-locked HOST memory the GPU can write (hipHostMalloc): the
+    // host's Fiat-Shamir round needs the whole table, and stored from here it crosses PCIe while the launch's other waves still
+    // hash -- no device-to-host copy kernel behind the launch (mlwe_prover.cpp:130-135, :445-449 read Tcomm / comm on the CPU)
+    uint8_t *out_host;
 };
 
 struct NttArgs {

@@ -130,6 +130,11 @@ __global__ __launch_bounds__(64) void k_commit_hash(HashArgs a)
     uint4 *o = reinterpret_cast<uint4 *>(a.out + dig);
     o[0] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
     o[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
+    if (a.out_host) {
+        uint4 *oh = reinterpret_cast<uint4 *>(a.out_host + dig);
+        oh[0] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
+        oh[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
+    }
 }
 
 // The same hash with the message rows staged through LDS by LDS-DMA (global_load_lds_dwordx4): one wave-instruction
@@ -234,11 +239,27 @@ __global__ __launch_bounds__(64) void k_commit_hash_dma(HashArgs a)
          ...);
     };
     run(std::make_integer_sequence<int, NBLK>{});
-    if (live) {
-        uint4 *o = reinterpret_cast<uint4 *>(a.out + dig);
-        o[0] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
-        o[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
+    // The wave's 64 digests are 2 KiB of consecutive table bytes.  Through LDS (the staging buffer is free now) so that every
+    // store instruction writes 1 KiB of CONSECUTIVE bytes, 16 per lane -- whole lines for HBM, and full-size posted writes for
+    // the copy that goes straight to the host's table over PCIe (lane l's own 32 bytes would be two half-dense instructions)
+    uint4 *sd = reinterpret_cast<uint4 *>(&stage[0][0]);
+    sd[2 * tl] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
+    sd[2 * tl + 1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
+    __syncthreads(); // one wave per workgroup: orders the LDS writes above against the reads below
+    const size_t base16 = ((size_t)g * a.out_lanes_per_group + (size_t)bx * 64) * 2; // 16-byte units
+    uint4 *o = reinterpret_cast<uint4 *>(a.out) + base16;
+    uint4 *oh = a.out_host ? reinterpret_cast<uint4 *>(a.out_host) + base16 : nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int c = j * 64 + tl; // chunk c = half (c & 1) of the digest of lane c >> 1
+        if (bx * 64 + (c >> 1) < a.lanes_per_group) {
+            const uint4 v = sd[c];
+            o[c] = v;
+            if (oh) oh[c] = v;
+        }
     }
+    (void)live;
+    (void)dig;
 }
 
 // Placement primer for the commitment hashes.  A launch of ~1 000 one-wave workgroups lands one wave per SIMD only when
