@@ -10,7 +10,8 @@ import os
 from . import build as _build
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkosk_mi355x.so")
+# KOSK_LIB_PATH: another build of the same library (A/B measurements of two trees on one GPU box); never a different product
+LIB_PATH = os.environ.get("KOSK_LIB_PATH") or os.path.join(_HERE, "libkosk_mi355x.so")
 
 
 class KoskError(RuntimeError):

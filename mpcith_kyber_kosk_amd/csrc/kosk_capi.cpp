@@ -466,7 +466,9 @@ static int combined_keygen(kosk_ctx *h, int n, const KeygenCall &call)
         for (int k = 0; k < count; k++) {
             Ctx &v = *co.member[first + k]->c;
             v.resident_pk_n = rc ? 0 : reqs[k]->n;
-            if (count > 1) { v.tape_cur = v.d_tape; v.tape_cur_stride = v.tape_stride; } // a merged run copies every member's tapes into its own block
+            // a merged run either copied every member's tapes into its own block of the tape buffer or read the callers' device
+            // buffers in place: either way a later kosk_prove_resident on this member must not assume anything
+            if (count > 1) v.tape_cur = nullptr;
         }
         run_epilogue(co, first, count, rc, c);
         return rc;
@@ -629,6 +631,9 @@ int kosk_verify_batch(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk
         rc = run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
             const uint8_t *src = pi + (size_t)first * P.proof_bytes;
             if (stage_verifier_inputs(c, count, src, pk + (size_t)first * P.pk_bytes, pinned || span.covers(src, (size_t)count * P.proof_bytes))) return -1;
+            // the verifier's host reads the unopened parties' digests straight from the caller's images: nothing to copy back for them
+            c.host_img = src;
+            c.host_img_stride = P.proof_bytes;
             return verify_into(ctx, c, first, count, ok, 0, nullptr);
         });
     } catch (...) {

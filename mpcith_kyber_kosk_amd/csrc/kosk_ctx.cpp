@@ -57,6 +57,8 @@ Ctx::~Ctx()
         for (auto e : pe)
             if (e) (void)hipEventDestroy(e);
     if (ev_sync) (void)hipEventDestroy(ev_sync);
+    for (auto e : ev_img)
+        if (e) (void)hipEventDestroy(e);
     if (is_view) {
         // a view owns its events, host workers and compact staging; tables, workspace and the stream belong to the arena
         if (d_compact) (void)hipFree(d_compact);
@@ -72,10 +74,10 @@ Ctx::~Ctx()
     void *dev[] = {t_expand.d, t_recon_d.d, t_recon_2d.d, t_expand.dfrag, t_recon_d.dfrag, t_recon_2d.dfrag, d_fresh_rows, d_gemm1_rows, d_gemm2_rows, d_off, d_fields,
                    d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_kg, d_sehat, d_t, d_alpha, d_I, d_pwT, d_limbs, d_linA, d_coef, d_lin_rows,
                    d_gather, d_gather2, d_O, d_w, d_ell, d_sec, d_sec_u1, d_sec_u2, d_fail, d_inv, d_invlimb, d_vfields,
-                   d_vrowtab, d_rows_bg, d_rows_isrc, d_rows_idst, d_rows_u, d_fact, d_invfact, d_node_of, d_isort, d_hrange};
+                   d_vrowtab, d_rows_bg, d_rows_isrc, d_rows_idst, d_rows_u, d_fact, d_invfact, d_node_of, d_isort, d_hrange, d_odig};
     for (void *p : dev)
         if (p) (void)hipFree(p);
-    void *host[] = {h_tape, h_dig, h_dig2, h_proof, h_alpha, h_I, h_fail, h_Iimg, h_kg};
+    void *host[] = {h_tape, h_dig, h_dig2, h_proof, h_alpha, h_I, h_fail, h_Iimg, h_kg, h_odig, h_imgdig};
     for (void *p : host)
         if (p) (void)hipHostFree(p);
     if (d_compact) (void)hipFree(d_compact);
@@ -478,6 +480,8 @@ int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx
     // took 2.8 ms instead of 1.6).  Calls end with a stream synchronisation, so members never leave work behind for each other.
     c.use_graphs = false; // stream capture is per stream: not with several callers on one
     c.ev = nullptr; c.ev_sync = nullptr; c.pool = nullptr;
+    for (auto &e : c.ev_img) e = nullptr;
+    c.host_img = nullptr;
     for (auto &e : c.timer_ev) e = nullptr;
     for (auto &pe : c.prof_ev) for (auto &e : pe) e = nullptr;
     for (auto &g : c.seg) g = Ctx::SegGraph{};
@@ -499,6 +503,7 @@ int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx
         if (c.blocking_sync) HIPCHK(hipEventCreateWithFlags(&c.ev_sync, hipEventDisableTiming | hipEventBlockingSync));
         for (auto &pe : c.prof_ev)
             for (auto &e : pe) HIPCHK(hipEventCreate(&e));
+        for (auto &e : c.ev_img) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
         return 0;
     };
     if (body()) return fail();
@@ -564,13 +569,34 @@ static int upload_tapes_part(Ctx &c, int first, int n, const uint8_t *tapes, siz
 
 int upload_tapes(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride)
 {
+    c.tape_segs.count = 0;
     return upload_tapes_part(c, 0, n, tapes, tape_stride, true);
 }
 
 // the tapes of every caller of a (possibly merged) call, segment after segment
 static int upload_tapes_segs(Ctx &c, int n, const KeygenIn &kg)
 {
+    c.tape_segs.count = 0;
     if (!kg.next && (kg.count == 0 || kg.count == n)) return upload_tapes(c, n, kg.tapes, kg.tape_stride);
+    { // every caller keeps aligned tapes in HBM, equal strides, full blocks except the last: read them where they are
+        const int per = kg.count;
+        int j = 0, total = 0;
+        bool ok = per > 0;
+        for (const KeygenIn *s = &kg; s && ok; s = s->next, j++) {
+            const int cnt = s->count ? s->count : n - total;
+            ok = j < 8 && s->tapes && s->tape_stride == kg.tape_stride && s->tape_stride >= c.P.tape_bytes && s->tape_stride % 8 == 0 &&
+                 (reinterpret_cast<uintptr_t>(s->tapes) & 7) == 0 && cnt >= 1 && (cnt == per || (!s->next && cnt < per)) && is_device_pointer(s->tapes);
+            if (ok) c.tape_segs.ptr[j] = s->tapes;
+            total += cnt;
+        }
+        if (ok && total == n) {
+            c.tape_segs.per = per;
+            c.tape_segs.count = j;
+            c.tape_cur = kg.tapes;
+            c.tape_cur_stride = kg.tape_stride;
+            return 0;
+        }
+    }
     int first = 0;
     for (const KeygenIn *s = &kg; s; s = s->next) {
         const int cnt = s->count ? s->count : n - first;
@@ -660,7 +686,7 @@ int issue_sharing_front(Ctx &c, int n, FrontPart part, bool with_keygen)
     else if (part == FRONT_ONLINE) { s0 = noff; expand = false; ntt_first = P.M; ntt_count = K; }
     const KeygenFront kgf{c.d_seeds, c.kg_rec, c.d_A, c.key_stride, c.d_se, c.se_stride};
     HIPCHK(launch_prover_pre(c.tape_cur, c.tape_cur_stride, c.d_P, c.proof_stride, rm.f, P.M, 64 + 32 * P.M, c.d_fresh_rows, s0, s1, expand,
-                             witness, c.d_se, c.se_stride, rm, P.eta1, n, st, with_keygen ? &kgf : nullptr));
+                             witness, c.d_se, c.se_stride, rm, P.eta1, n, st, with_keygen ? &kgf : nullptr, c.tape_segs.count ? &c.tape_segs : nullptr));
     if (with_keygen && issue_keygen(c, n, true)) return -1; // NTT(s), NTT(e), t = A o s + e, pk / sk bytes and their D2H
     if (ntt_count > 0) {
         NttArgs na{};
@@ -693,6 +719,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     for (const KeygenIn *s = keygen; s; s = s->next)
         if (!s->pk || !s->sk) { c.err = "pk / sk output buffers are required"; return -1; }
     if (!keygen && !c.tape_cur) { c.err = "no resident prover inputs: call kosk_stage_prover_inputs first"; return -1; }
+    if (!keygen) c.tape_segs.count = 0;
     HIPCHK(hipSetDevice(c.device));
     const Params &P = c.P;
     const RowMap &rm = c.rm;
@@ -836,6 +863,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         return 0;
     })) return -1;
     c.phase_sec[PH_P3_ISSUE] = now_sec() - t0;
+    c.tape_segs.count = 0; // the callers' tape buffers are only promised for this call
     HIPCHK(stream_sync(c));
     t1 = now_sec(); c.phase_sec[PH_GPU_ASSEMBLE] = t1 - t0;
     c.prof_collect();

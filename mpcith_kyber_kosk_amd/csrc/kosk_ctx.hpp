@@ -147,6 +147,7 @@ struct Ctx {
     // the tapes the kernels read: d_tape after an upload, or the caller's own device buffer used in place
     const uint8_t *tape_cur = nullptr;
     size_t tape_cur_stride = 0;
+    TapeSegs tape_segs{}; // a merged call whose callers' device tapes are read in place (count > 0; valid for that call only)
     int16_t *d_A = nullptr, *d_se = nullptr;
     // key generation on the device (kosk_keygen_kernels.hip)
     // one record per proof [pk | NTT(s) bytes | sha3_512 output], kg_rec bytes apart, so that the key generation's
@@ -186,6 +187,19 @@ struct Ctx {
     uint16_t *d_sec = nullptr, *d_sec_u1 = nullptr, *d_sec_u2 = nullptr;
     uint32_t *d_fail = nullptr;      // [proof] bit mask of failed checks (FailBit)
     uint16_t *h_Iimg = nullptr;      // I fields as read from the proof images
+    // The verifier's host needs both digest tables whole (mlwe_verifier.cpp:40-44, :648-652), but only 150 entries per proof and
+    // round are NEW -- the rest are fields of the proof image.  Those cross PCIe once, on the device's side stream, as soon as the
+    // call starts (or not at all when the caller handed the proofs over in host memory: host_img); behind each round's hash only
+    // the 150 recomputed digests per proof follow (4.8 KB instead of 46.5 KB on the critical path), and the host puts the
+    // table together (assemble_digest_table).  Used when the caller's host images are at hand (no early copy needed at all);
+    // for resident proofs it is opt-in (KOSK_VERIFY_SPLIT=1: measured slower than whole tables behind each hash).
+    uint8_t *d_odig = nullptr, *h_odig = nullptr; // [proof][NOPEN][32] recomputed digests of the opened parties (one round at a time)
+    uint8_t *h_imgdig = nullptr;                  // [proof][2][NREST][32] fields Tcomm and comm of the images
+    hipStream_t side_stream = nullptr;            // process-wide, one per device (side_stream_for): never destroyed
+    hipEvent_t ev_img[2] = {nullptr, nullptr};    // the two fields have landed in h_imgdig
+    bool verify_tables = true; // whole tables behind each hash unless the call has host images (or KOSK_VERIFY_SPLIT=1)
+    const uint8_t *host_img = nullptr;            // the caller's host copy of the proof images of THIS call (kosk_verify_batch)
+    size_t host_img_stride = 0;
     hipEvent_t ev = nullptr;
     hipEvent_t ev_sync = nullptr; // KOSK_BLOCKING_SYNC=1: every host wait sleeps on an event instead of spinning (few host cores per GPU)
     bool blocking_sync = false;
@@ -326,6 +340,8 @@ int prove_prepared(Ctx &c, int n, const uint8_t *inst, const uint8_t *rand_in, c
                    size_t tape_stride, uint8_t *pi);
 int stage_verifier_inst(Ctx &c, int n, const uint8_t *pi, const uint8_t *inst);
 int ensure_verify_workspace(Ctx &c);
+// the device's one side stream of this process (copies that must not queue behind a context's kernels); nullptr on failure
+hipStream_t side_stream_for(int device);
 // direct: the host buffer is page-locked (copied to / from straight, no staging)
 int fetch_proofs_compact(Ctx &c, int n, uint8_t *out, bool direct = false);
 int stage_verifier_inputs_compact(Ctx &c, int n, const uint8_t *in, const uint8_t *pk, bool direct = false);

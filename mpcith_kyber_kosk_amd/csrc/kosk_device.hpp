@@ -213,6 +213,7 @@ struct OpenedHashArgs {
     int sel_stride;
     const uint8_t *prefix; // Tcomm digest table [proof][NPARTY][32] (view hash only)
     uint8_t *out;          // digest table, written at the party's index
+    uint8_t *out_compact;  // optional [proof][NOPEN][32]: the same digests in the order of the list I (what the host still needs)
 };
 hipError_t launch_opened_hash(const OpenedHashArgs &a, int K, bool view, int nproofs, hipStream_t st);
 hipError_t launch_check_batch(const VerifyArgs &v, const uint16_t *t_pk, const uint16_t *u1, const uint16_t *u2, int nu, int nproofs,
@@ -254,6 +255,12 @@ hipError_t launch_rows_copy(const uint16_t *src, size_t src_stride, uint16_t *ds
                             int nrows, hipStream_t st);
 // expand_f + tape randoms + witness secrets (the kernels that only read the tape / the key) in one launch
 // key generation outputs when it runs as roles of the prover's first launch
+// the randomness tapes of a merged call whose callers keep theirs in HBM: caller j's tapes start at ptr[j], `per` proofs each
+// (the last one may hold fewer), all tape_stride apart -- read in place, no copy into one buffer (count == 0: one buffer)
+struct TapeSegs {
+    const uint8_t *ptr[8];
+    int per, count;
+};
 struct KeygenFront {
     uint8_t *seeds;
     size_t seed_stride;
@@ -265,7 +272,7 @@ struct KeygenFront {
 hipError_t launch_prover_pre(const uint8_t *tape, size_t tape_stride, uint16_t *P, size_t proof_stride, int row_f, int M,
                              int slice0_off, const int16_t *fresh_rows, int slice_begin, int slice_end, bool expand_f,
                              int witness_mode, const int16_t *se, size_t se_stride, const RowMap &rm, int eta1, int nproofs,
-                             hipStream_t st, const KeygenFront *kg = nullptr);
+                             hipStream_t st, const KeygenFront *kg = nullptr, const TapeSegs *segs = nullptr);
 hipError_t launch_ntt(const NttArgs &a, hipStream_t st);
 // k_ntt256 (this proof's na.npg = 2K polynomials) + k_matvec_ntt(nttsr -> nttasr) + k_copy_tails in one launch
 hipError_t launch_relation_ntt(const NttArgs &na, const int16_t *A, size_t A_stride, uint16_t *P, size_t proof_stride, const RowMap &rm,

@@ -371,7 +371,7 @@ void sha3_256_multi(uint8_t *out, const uint8_t *const *in, size_t len, int coun
 // derivations (a SHAKE PRF and a few hundred scalar steps each) ride with the hashing instead of forming a serial tail of
 // n of them on the calling thread (r3: that tail was ~60 us of each of the four Fiat-Shamir rounds of a 46-proof step)
 static void sha3_digest_tables(int n, const uint8_t *digs, size_t dig_stride, uint8_t *out, int nthreads, Pool *pool,
-                               const std::function<void(int)> *then = nullptr)
+                               const std::function<void(int)> *then = nullptr, const std::function<void(int)> *prep = nullptr)
 {
     std::vector<const uint8_t *> in(n);
     for (int b = 0; b < n; b++) in[b] = digs + (size_t)b * dig_stride;
@@ -382,13 +382,30 @@ static void sha3_digest_tables(int n, const uint8_t *digs, size_t dig_stride, ui
     if (w > 1 && n <= nthreads && !caps().avx512f) w = 1;
     const int groups = (n + w - 1) / w;
     parallel_for(pool, groups, nthreads, [&](int g) {
+        if (prep)
+            for (int b = g * w; b < n && b < (g + 1) * w; b++) (*prep)(b);
         sha3_group(out, in.data(), (size_t)NPARTY * 32, n, w, g);
         if (then)
             for (int b = g * w; b < n && b < (g + 1) * w; b++) (*then)(b);
     });
 }
 
-void fs_alpha_batch(const Params &P, int n, const uint8_t *digs, size_t dig_stride, uint16_t *alpha, size_t alpha_stride, int nthreads, Pool *pool)
+void assemble_digest_table(uint8_t *table, const uint16_t *I, const uint8_t *unopened, const uint8_t *opened)
+{
+    bool used[NPARTY] = {false};
+    for (int i = 0; i < NOPEN; i++) {
+        const int p = I[i];
+        if (p >= NPARTY) continue;
+        used[p] = true;
+        memcpy(table + (size_t)p * 32, opened + (size_t)i * 32, 32);
+    }
+    int j = 0;
+    for (int p = 0; p < NPARTY && j < NREST; p++)
+        if (!used[p]) memcpy(table + (size_t)p * 32, unopened + (size_t)(j++) * 32, 32);
+}
+
+void fs_alpha_batch(const Params &P, int n, const uint8_t *digs, size_t dig_stride, uint16_t *alpha, size_t alpha_stride, int nthreads, Pool *pool,
+                    const std::function<void(int)> *prep)
 {
     std::vector<uint8_t> h((size_t)n * 32);
     const std::function<void(int)> derive = [&](int b) {
@@ -397,7 +414,7 @@ void fs_alpha_batch(const Params &P, int n, const uint8_t *digs, size_t dig_stri
         uint16_t *al = alpha + (size_t)b * alpha_stride;
         for (int i = 0; i < P.J; i++) al[i] = (uint16_t)(((a_[2 * i] << 8) | a_[2 * i + 1]) % Q);
     };
-    sha3_digest_tables(n, digs, dig_stride, h.data(), nthreads, pool, &derive);
+    sha3_digest_tables(n, digs, dig_stride, h.data(), nthreads, pool, &derive, prep);
 }
 
 static void opened_from_ch(const uint8_t ch[32], uint16_t I[NOPEN], uint16_t rest[NREST])
@@ -418,7 +435,7 @@ static void opened_from_ch(const uint8_t ch[32], uint16_t I[NOPEN], uint16_t res
 }
 
 void fs_opened_batch(int n, const uint8_t *digs, size_t dig_stride, uint16_t *I, uint16_t *rest, size_t sel_stride, int nthreads, Pool *pool,
-                     bool windows)
+                     bool windows, const std::function<void(int)> *prep)
 {
     std::vector<uint8_t> h((size_t)n * 32);
     const std::function<void(int)> derive = [&](int b) {
@@ -432,7 +449,7 @@ void fs_opened_batch(int n, const uint8_t *digs, size_t dig_stride, uint16_t *I,
             }
         }
     };
-    sha3_digest_tables(n, digs, dig_stride, h.data(), nthreads, pool, &derive);
+    sha3_digest_tables(n, digs, dig_stride, h.data(), nthreads, pool, &derive, prep);
 }
 
 // ------------------------------------------------------------------- tables --

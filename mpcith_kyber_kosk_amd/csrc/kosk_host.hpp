@@ -65,11 +65,19 @@ inline void parallel_for(int n, int nthreads, const std::function<void(int)> &fn
 void sha3_256_multi(uint8_t *out, const uint8_t *const *in, size_t len, int count);
 int sha3_multi_width(); // 8 (AVX-512F), 4 (AVX2) or 1
 
+// One proof's digest table [1454][32] on the verifier's host, put together from what the proof itself carries -- the digests of
+// the 1304 unopened parties, ascending (fields Tcomm / comm of mpcith_proof, mlwe_verifier.cpp:36-38, :645-647) -- and the 150
+// digests the verifier recomputed for the opened parties, in the order of the list I (:22-35, :585-632).  Memory-safe for a
+// malformed I (out-of-range or repeated entries: the table is then garbage, and the proof is rejected for the list anyway).
+void assemble_digest_table(uint8_t *table, const uint16_t *I, const uint8_t *unopened, const uint8_t *opened);
+
 // batch forms of fs_alpha / fs_opened over n proofs whose digest tables are dig_stride bytes apart
-void fs_alpha_batch(const Params &P, int n, const uint8_t *digs, size_t dig_stride, uint16_t *alpha, size_t alpha_stride, int nthreads, Pool *pool = nullptr);
+// prep (optional): called for proof b on the worker that hashes it, before the hashing (the verifier assembles the table there)
+void fs_alpha_batch(const Params &P, int n, const uint8_t *digs, size_t dig_stride, uint16_t *alpha, size_t alpha_stride, int nthreads, Pool *pool = nullptr,
+                    const std::function<void(int)> *prep = nullptr);
 // windows: also write, behind each proof's list I (at I + SEL_WIN), the NWIN + 1 boundaries of the complement's aligned 64-party windows
 void fs_opened_batch(int n, const uint8_t *digs, size_t dig_stride, uint16_t *I, uint16_t *rest, size_t sel_stride, int nthreads, Pool *pool = nullptr,
-                     bool windows = false);
+                     bool windows = false, const std::function<void(int)> *prep = nullptr);
 
 // OS entropy (kyber/randombytes.c:44-57, Linux branch)
 void os_randombytes(uint8_t *out, size_t len);

@@ -392,6 +392,7 @@ __global__ __launch_bounds__(64) void k_sha3_msgs_pair(const uint8_t *__restrict
 struct PreArgs {
     const uint8_t *tape;
     size_t tape_stride;
+    TapeSegs segs; // count > 0: proof b's tape is segs.ptr[b / segs.per] + (b % segs.per) * tape_stride
     uint16_t *P;
     size_t proof_stride;
     int row_f, M, nproofs;
@@ -414,12 +415,22 @@ struct PreArgs {
     size_t kg_se_stride;
 };
 constexpr int PRE_SLICES = 8; // fresh sharings per role-B block
+__device__ __forceinline__ const uint8_t *pre_tape(const PreArgs &a, int b)
+{
+    if (a.segs.count == 0) return a.tape + (size_t)b * a.tape_stride;
+    const int j = b / a.segs.per;
+    // static indices only: a run-time index into the by-value argument block would make the compiler copy all of it to scratch
+    const uint8_t *base = a.segs.ptr[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) base = j == k ? a.segs.ptr[k] : base;
+    return base + (size_t)(b - j * a.segs.per) * a.tape_stride;
+}
 
 __device__ __forceinline__ void pre_expand_f(const PreArgs &a, int t)
 {
     if (t >= a.M * a.nproofs) return;
     const int b = t / a.M, i = t % a.M;
-    const uint64_t *seed = reinterpret_cast<const uint64_t *>(a.tape + (size_t)b * a.tape_stride + 64 + 32 * i);
+    const uint64_t *seed = reinterpret_cast<const uint64_t *>(pre_tape(a, b) + 64 + 32 * i);
     KState s;
     kstate_zero(s);
 #pragma unroll
@@ -460,7 +471,7 @@ __device__ __forceinline__ void pre_tape_randoms(const PreArgs &a, int idx, int 
     for (int q = 0; q < PRE_SLICES; q++) {
         const int slice = a.slice_begin + grp * PRE_SLICES + q;
         if (slice >= a.slice_end) break;
-        const uint8_t *src = a.tape + (size_t)b * a.tape_stride + a.slice0_off + 302 * slice + 2 * t;
+        const uint8_t *src = pre_tape(a, b) + a.slice0_off + 302 * slice + 2 * t;
         const uint32_t v = (((uint32_t)src[0] << 8) | src[1]) % (uint32_t)Q;
         a.P[(size_t)b * a.proof_stride + (size_t)a.fresh_rows[slice] * RS + NSEC + t] = (uint16_t)v;
     }
@@ -499,7 +510,7 @@ __device__ __forceinline__ void pre_gen_matrix(const PreArgs &a, int t)
     if (t >= a.nproofs * KK) return;
     const int b = t / KK, ij = t - b * KK, i = ij / a.K, j = ij - i * a.K;
     uint32_t pub[8], noise[8];
-    kg_seed_hash(a.tape + (size_t)b * a.tape_stride, a.K, pub, noise);
+    kg_seed_hash(pre_tape(a, b), a.K, pub, noise);
     kg_gen_matrix(pub, i, j, a.kg_A + (size_t)b * a.kg_A_stride + (size_t)ij * 256);
 }
 
@@ -508,7 +519,7 @@ __device__ __forceinline__ void pre_noise(const PreArgs &a, int t)
     if (t >= a.nproofs * 2 * a.K) return;
     const int b = t / (2 * a.K), nonce = t - b * 2 * a.K;
     uint32_t pub[8], noise[8];
-    kg_seed_hash(a.tape + (size_t)b * a.tape_stride, a.K, pub, noise);
+    kg_seed_hash(pre_tape(a, b), a.K, pub, noise);
     if (nonce == 0) {
         uint32_t *o = reinterpret_cast<uint32_t *>(a.kg_seeds + (size_t)b * a.kg_seed_stride);
 #pragma unroll
@@ -1715,9 +1726,10 @@ hipError_t launch_rows_copy(const uint16_t *src, size_t src_stride, uint16_t *ds
 hipError_t launch_prover_pre(const uint8_t *tape, size_t tape_stride, uint16_t *P, size_t proof_stride, int row_f, int M,
                              int slice0_off, const int16_t *fresh_rows, int slice_begin, int slice_end, bool expand_f,
                              int witness_mode, const int16_t *se, size_t se_stride, const RowMap &rm, int eta1, int nproofs,
-                             hipStream_t st, const KeygenFront *kg)
+                             hipStream_t st, const KeygenFront *kg, const TapeSegs *segs)
 {
     PreArgs a{};
+    if (segs) a.segs = *segs;
     a.tape = tape; a.tape_stride = tape_stride; a.P = P; a.proof_stride = proof_stride;
     a.row_f = row_f; a.M = M; a.nproofs = nproofs;
     a.slice0_off = slice0_off; a.slice_begin = slice_begin; a.slice_end = slice_end; a.fresh_rows = fresh_rows;

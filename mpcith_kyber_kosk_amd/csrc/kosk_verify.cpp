@@ -14,6 +14,9 @@
 //   V10 view hashes of the opened parties -> host: I' == I                :584-683
 // Every check sets a bit of fail[proof]; the verify bit is fail == 0.
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "kosk_ctx.hpp"
@@ -43,6 +46,25 @@ static int upload_vec(Ctx &c, T **d, const std::vector<T> &v)
         HIPCHK(hipStreamSynchronize(c.stream));
     }
     return 0;
+}
+
+hipStream_t side_stream_for(int device)
+{
+    // One extra stream per device for the whole process, created on first use and kept: ROCm deals streams to its few hardware
+    // queues in creation order, and a side stream per context put the MAIN streams of different contexts on the same queue
+    // (what that costs).
+    static std::mutex mu;
+    static std::vector<std::pair<int, hipStream_t>> all;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &p : all)
+        if (p.first == device) return p.second;
+    hipStream_t s = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    all.emplace_back(device, s);
+    return s;
 }
 
 int ensure_verify_workspace(Ctx &c)
@@ -152,6 +174,29 @@ int ensure_verify_workspace(Ctx &c)
     HIPCHK(dev(&c.d_sec_u2, (size_t)c.n_interp_2d * 256));
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c.h_Iimg), B * 2 * NOPEN, hipHostMallocDefault));
     c.reg_pp(&c.h_Iimg, (size_t)2 * NOPEN);
+    HIPCHK(dev(&c.d_odig, (size_t)NOPEN * 32));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c.h_odig), B * NOPEN * 32, hipHostMallocDefault));
+    c.reg_pp(&c.h_odig, (size_t)NOPEN * 32);
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c.h_imgdig), B * 2 * NREST * 32, hipHostMallocDefault));
+    c.reg_pp(&c.h_imgdig, (size_t)2 * NREST * 32);
+    // KOSK_VERIFY_SPLIT=1: also for RESIDENT proofs the host's tables are put together from the images' digest fields (copied
+    // early, beside the first kernels) and the 150 recomputed digests per proof.  Measured slower than copying the whole tables
+    // behind the hashes (profiles/r04_digest_paths.txt: the early copies are blit kernels that run against the verifier's first
+    // kernels), so the default splits only when the caller's host copy of the images makes the early copies unnecessary.
+    c.verify_tables = true;
+    if (const char *e = getenv("KOSK_VERIFY_SPLIT")) c.verify_tables = atoi(e) == 0;
+    // Where the early copies of the images' digest fields run.  Default: the device's legacy NULL stream (hipStream_t 0) -- it
+    // exists anyway and the library's non-blocking streams are not ordered against it.  KOSK_SIDE_STREAM=1: a stream of the
+    // library's own, one per device and process; measured on ROCm 7.2: the mere existence of that fifth stream next to the null
+    // stream and three cohort streams cost 20 % of the throughput (profiles/r04_side_stream.txt), whatever GPU_MAX_HW_QUEUES says.
+    c.side_stream = nullptr;
+    if (!c.verify_tables)
+        if (const char *e = getenv("KOSK_SIDE_STREAM"))
+            if (atoi(e) != 0) {
+                c.side_stream = side_stream_for(c.device);
+                if (!c.side_stream) c.verify_tables = true; // whole tables behind the hashes, as before
+            }
+    for (auto &e : c.ev_img) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
     HIPCHK(hipStreamSynchronize(c.stream)); // every table and the zeroed opened matrix are in HBM before the first verifier kernel is queued
     c.verify_ready = true;
     return 0;
@@ -262,6 +307,31 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     oh.sel_stride = c.sel_stride;
     oh.prefix = nullptr;
     oh.out = c.d_dig1;
+    // how the host gets its two digest tables (see Ctx::h_imgdig): the 1304 digests per proof and table that the proof itself
+    // carries come from the caller's host copy of the images when there is one, else over the side stream, starting now; only the
+    // 150 recomputed ones per proof follow each round's hash on the context's own stream
+    const uint8_t *himg = c.host_img;
+    const bool split_tables = !c.verify_tables || himg != nullptr;
+    const size_t himg_stride = c.host_img_stride;
+    c.host_img = nullptr; // valid for this call only
+    if (split_tables && !himg) {
+        const size_t w = (size_t)NREST * 32;
+        for (int r = 0; r < 2; r++) {
+            HIPCHK(hipMemcpy2DAsync(c.h_imgdig + (size_t)r * w, 2 * w, c.d_proof + P.off[r ? F_COMM : F_TCOMM], c.image_stride, w, n,
+                                    hipMemcpyDeviceToHost, c.side_stream));
+            HIPCHK(hipEventRecord(c.ev_img[r], c.side_stream));
+        }
+    }
+    oh.out_compact = split_tables ? c.d_odig : nullptr;
+    const size_t dig_bytes = split_tables ? (size_t)n * NOPEN * 32 : (size_t)n * NPARTY * 32;
+    // the table of proof b for the host's hash of round r, put together on the worker that hashes it
+    auto table_prep = [&](int r) {
+        return std::function<void(int)>([&c, himg, himg_stride, r](int b) {
+            const size_t w = (size_t)NREST * 32;
+            const uint8_t *unopened = himg ? himg + (size_t)b * himg_stride + c.P.off[r ? F_COMM : F_TCOMM] : c.h_imgdig + (size_t)b * 2 * w + (size_t)r * w;
+            assemble_digest_table(c.h_dig + (size_t)b * NPARTY * 32, c.h_Iimg + (size_t)b * NOPEN, unopened, c.h_odig + (size_t)b * NOPEN * 32);
+        });
+    };
     if (run_segment(c, Ctx::SEG_V1, n, [&]() -> int {
     // ---- V0: opened list from the image, validated and expanded on the GPU (no host round trip); the host
     // only needs the list itself for the final Fiat-Shamir comparison and receives it with the first digests
@@ -276,9 +346,9 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     c.prof_begin(PR_V_HASH_TCOMM, n);
     HIPCHK(launch_opened_hash(oh, K, false, n, st)); // Tcomm of the opened parties, read from the image   :22-35
     c.prof_end(PR_V_HASH_TCOMM);
-    HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig1, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(split_tables ? c.h_odig : c.h_dig, split_tables ? c.d_odig : c.d_dig1, dig_bytes, hipMemcpyDeviceToHost, st));
     return 0;
-    })) return -1;
+    }, split_tables ? c.h_odig : c.h_dig)) return -1; // which table copy the captured segment holds is part of its graph's key
     HIPCHK(hipEventRecord(c.ev, st)); // the opened parties' Tcomm digests are on the host once this event has passed
     t1 = now_sec(); c.phase_sec[PH_V1_ISSUE] = t1 - t0; t0 = t1;
 
@@ -341,11 +411,15 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     })) return -1;
 
     HIPCHK(hipEventSynchronize(c.ev));
+    if (split_tables && !himg) HIPCHK(hipEventSynchronize(c.ev_img[0])); // the images' Tcomm fields (under way since the call began)
     t1 = now_sec(); c.phase_sec[PH_V1_WAIT] = t1 - t0; t0 = t1;
     if (c.round_hook) c.round_hook(c.round_user, 1, 0, c.d_dig1, (size_t)n * NPARTY * 32);
 
     // ---- host: alpha while the GPU works
-    fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool);
+    {
+        const std::function<void(int)> prep = table_prep(0);
+        fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool, split_tables ? &prep : nullptr);
+    }
     t1 = now_sec(); c.phase_sec[PH_V_FS_ALPHA] = t1 - t0; t0 = t1;
     if (run_segment(c, Ctx::SEG_V2, n, [&]() -> int {
     HIPCHK(hipMemcpyAsync(c.d_alpha, c.h_alpha, (size_t)n * 80 * 2, hipMemcpyHostToDevice, st));
@@ -375,7 +449,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     c.prof_begin(PR_V_HASH_VIEW, n);
     HIPCHK(launch_opened_hash(oh, K, true, n, st));
     c.prof_end(PR_V_HASH_VIEW);
-    HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig2, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(split_tables ? c.h_odig : c.h_dig, split_tables ? c.d_odig : c.d_dig2, dig_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c.ev, st));
     t1 = now_sec(); c.phase_sec[PH_V2_ISSUE] = t1 - t0; t0 = t1;
 
@@ -410,10 +484,14 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     })) return -1;
 
     HIPCHK(hipEventSynchronize(c.ev)); // the view digests are on the host; V2B keeps running
+    if (split_tables && !himg) HIPCHK(hipEventSynchronize(c.ev_img[1]));
     t1 = now_sec(); c.phase_sec[PH_V2_WAIT] = t1 - t0; t0 = t1;
     if (c.round_hook) c.round_hook(c.round_user, 1, 1, c.d_dig2, (size_t)n * NPARTY * 32);
     std::vector<uint16_t> I2((size_t)n * c.sel_stride), rest2((size_t)n * c.sel_stride);
-    fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, I2.data(), rest2.data(), c.sel_stride, c.nthreads, c.pool);
+    {
+        const std::function<void(int)> prep = table_prep(1);
+        fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, I2.data(), rest2.data(), c.sel_stride, c.nthreads, c.pool, false, split_tables ? &prep : nullptr);
+    }
     HIPCHK(stream_sync(c)); // fail masks of V2B
     c.prof_collect();
     {

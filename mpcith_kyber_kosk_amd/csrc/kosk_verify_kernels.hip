@@ -224,6 +224,11 @@ __global__ __launch_bounds__(64) void k_opened_hash(OpenedHashArgs a)
     uint4 *o = reinterpret_cast<uint4 *>(a.out + dig);
     o[0] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
     o[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
+    if (a.out_compact) {
+        uint4 *oc = reinterpret_cast<uint4 *>(a.out_compact + ((size_t)b * NOPEN + i) * 32);
+        oc[0] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
+        oc[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
+    }
 }
 
 template <int K>

@@ -1,10 +1,12 @@
 #!/bin/bash
 # GPU-busy time per bench step (sum of kernel durations, 1 slot) -- the stable optimisation metric.
-# usage (on the GPU box, from the repo root): tools/gpu_busy.sh [outdir]
+# usage (on the GPU box, from the repo root): [BUSY_ARGS="--slots 3 --combine 3"] tools/gpu_busy.sh [outdir] [rows]
+# BUSY_ARGS: the slots of the run (default one handle on its own; "--slots 3 --combine 3" = one cohort, every launch serves 138 proofs);
+# a 'step' in the output is one verifier run (one k_opened_setup launch), whatever number of callers it served
 out=${1:-gpurun_out/busy}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --steps 8 --warmup 2 --slots 1 --no-cpu-baseline --no-kernels > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --steps ${BUSY_STEPS:-8} --warmup 2 ${BUSY_ARGS:---slots 1 --combine 1} --no-cpu-baseline --no-kernels > /dev/null 2>&1
 f=$(find $out -name "*kernel_stats.csv" | head -1)
 python3 - $f <<PY
 import csv,sys
