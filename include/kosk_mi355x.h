@@ -49,7 +49,11 @@ int kosk_set_randombytes(kosk_ctx *ctx, kosk_randombytes_fn fn, void *user); /* 
  * proof b consumes tapes[b*tape_stride ..] (kosk_tape_bytes() bytes each).
  * Error containment (all entry points): no C++ exception and no abort leaves the library -- a failed allocation, thread or
  * HIP call is rc -1 + kosk_last_error(); the only abort is the reference's own, an OS entropy failure
- * (kyber/randombytes.c:49-52).  A batch call creates no threads (kosk_create made them). */
+ * (kyber/randombytes.c:49-52).  A batch call creates no threads (kosk_create made them).
+ * gen_matrix's rejection sampling (indcpa.c:124-145) loops without a bound in the reference; on the host this library does the
+ * same, on the GPU it squeezes at most 32 SHAKE128 blocks per matrix entry (three suffice with probability 1 - 2^-40) and a
+ * call that ever reached that limit returns -1 ("block limit") without results -- for key generation and for the verifier's
+ * decoding of a public key alike. */
 int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride,
                                  uint8_t *pk, uint8_t *sk, uint8_t *pi);
 

@@ -191,8 +191,9 @@ int stage_verifier_inputs_compact(Ctx &c, int n, const uint8_t *in, const uint8_
     else HIPCHK(hipMemcpyAsync(c.d_compact, c.h_compact, (size_t)n * c.compact_stride, hipMemcpyHostToDevice, c.stream));
     hipLaunchKernelGGL(k_unpack_proofs, dim3(16, NFIELDS, n), dim3(256), 0, c.stream, c.d_compact, c.compact_stride, c.d_proof, c.image_stride, c.cplan);
     HIPCHK(hipGetLastError());
-    HIPCHK(launch_decode_pk(c.d_pk, c.pk_stride, c.d_t, c.d_A, c.key_stride, P.K, n, c.stream));
+    HIPCHK(launch_decode_pk(c.d_pk, c.pk_stride, c.d_t, c.d_A, c.key_stride, P.K, n, c.stream, c.xof_guard()));
     HIPCHK(stream_sync(c));
+    if (device_error_check(c)) return -1;
     return 0;
 }
 

@@ -60,6 +60,7 @@ Ctx::~Ctx()
     for (auto e : ev_img)
         if (e) (void)hipEventDestroy(e);
     if (is_view) {
+        if (h_err) (void)hipHostFree(h_err);
         // a view owns its events, host workers and compact staging; tables, workspace and the stream belong to the arena
         if (d_compact) (void)hipFree(d_compact);
         if (d_compact_bad) (void)hipFree(d_compact_bad);
@@ -77,7 +78,7 @@ Ctx::~Ctx()
                    d_vrowtab, d_rows_bg, d_rows_isrc, d_rows_idst, d_rows_u, d_fact, d_invfact, d_node_of, d_isort, d_hrange, d_odig};
     for (void *p : dev)
         if (p) (void)hipFree(p);
-    void *host[] = {h_tape, h_dig, h_dig2, h_proof, h_alpha, h_I, h_fail, h_Iimg, h_kg, h_odig, h_imgdig};
+    void *host[] = {h_err, h_tape, h_dig, h_dig2, h_proof, h_alpha, h_I, h_fail, h_Iimg, h_kg, h_odig, h_imgdig};
     for (void *p : host)
         if (p) (void)hipHostFree(p);
     if (d_compact) (void)hipFree(d_compact);
@@ -149,6 +150,18 @@ static hipError_t commit_hash_batch(Ctx &c, const HashArgs &ha, int n, int K, bo
     count();
     c.prof_end(view ? PR_HASH_VIEW_TAIL : PR_HASH_TCOMM_TAIL);
     return e;
+}
+
+int device_error_check(Ctx &c)
+{
+    if (!c.h_err) return 0;
+    const uint32_t e = *reinterpret_cast<volatile uint32_t *>(c.h_err);
+    if (!e) return 0;
+    *reinterpret_cast<volatile uint32_t *>(c.h_err) = 0;
+    c.err = (e & DEVERR_XOF_BLOCKS) ? "gen_matrix: SHAKE128 block limit reached before 256 coefficients were accepted (indcpa.c:124-145 would squeeze on; "
+                                      "probability < 2^-300 with the default limit of 32 blocks): no result was produced"
+                                    : "a kernel reported an internal error";
+    return -1;
 }
 
 hipError_t stream_sync(Ctx &c)
@@ -350,6 +363,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     if (const char *e = getenv("KOSK_TABLE_GEMM")) c.table_gemm = atoi(e) != 0;
     if (const char *e = getenv("KOSK_REGISTER")) c.host_register = atoi(e) != 0;
     if (const char *e = getenv("KOSK_DIGEST_DIRECT")) c.digest_direct = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_DEBUG_XOF_BLOCKS")) c.xof_max_blocks = atoi(e) > 0 ? atoi(e) : c.xof_max_blocks;
     if (const char *e = getenv("KOSK_CU_PARTITION")) {
         int i = 0, n = 0;
         if (sscanf(e, "%d/%d", &i, &n) != 2 || n < 1 || i < 0 || i >= n) { c.err = "KOSK_CU_PARTITION must be i/n with 0 <= i < n"; return fail(); }
@@ -453,6 +467,8 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
         c.h_rest = c.h_I + B * c.sel_stride;
         c.reg_pp(&c.h_I, (size_t)c.sel_stride * 2); c.reg_pp(&c.h_rest, (size_t)c.sel_stride * 2);
         HIPCHK(host(&c.h_fail, 1));
+        HIPCHK(halloc(&c.h_err, 16));
+        memset(c.h_err, 0, 16 * sizeof(uint32_t));
         memset(c.h_alpha, 0, B * 80 * sizeof(uint16_t));
         HIPCHK(stream_sync(c));
         return 0;
@@ -482,6 +498,7 @@ int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx
     c.ev = nullptr; c.ev_sync = nullptr; c.pool = nullptr;
     for (auto &e : c.ev_img) e = nullptr;
     c.host_img = nullptr;
+    c.h_err = nullptr;
     for (auto &e : c.timer_ev) e = nullptr;
     for (auto &pe : c.prof_ev) for (auto &e : pe) e = nullptr;
     for (auto &g : c.seg) g = Ctx::SegGraph{};
@@ -504,6 +521,8 @@ int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx
         for (auto &pe : c.prof_ev)
             for (auto &e : pe) HIPCHK(hipEventCreate(&e));
         for (auto &e : c.ev_img) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
+        HIPCHK(halloc(&c.h_err, 16)); // a view's kernels report to the view's own word
+        memset(c.h_err, 0, 16 * sizeof(uint32_t));
         return 0;
     };
     if (body()) return fail();
@@ -614,7 +633,7 @@ int issue_keygen(Ctx &c, int n, bool sampled)
     const Params &P = c.P;
     const int K = P.K;
     // `sampled`: seeds, A, s, e were already produced as roles of the prover's first launch (issue_sharing_front)
-    if (!sampled) HIPCHK(launch_keygen(c.tape_cur, c.tape_cur_stride, c.d_seeds, c.kg_rec, c.d_A, c.key_stride, c.d_se, c.se_stride, K, P.eta1, n, c.stream));
+    if (!sampled) HIPCHK(launch_keygen(c.tape_cur, c.tape_cur_stride, c.d_seeds, c.kg_rec, c.d_A, c.key_stride, c.d_se, c.se_stride, K, P.eta1, n, c.stream, c.xof_guard()));
     NttArgs na{};
     na.in = c.d_se; na.in_gstride = c.se_stride; na.src_off = nullptr;
     na.out = c.d_sehat; na.out_gstride = c.se_stride; na.dst_off = nullptr;
@@ -665,6 +684,7 @@ int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride,
     if (upload_tapes(c, n, tapes, tape_stride)) return -1;
     if (issue_keygen(c, n)) return -1;
     HIPCHK(stream_sync(c));
+    if (device_error_check(c)) return -1;
     finish_keygen_host(c, n, pk, sk);
     c.phase_sec[PH_HOST_PRE] = now_sec() - t0;
     return 0;
@@ -684,7 +704,7 @@ int issue_sharing_front(Ctx &c, int n, FrontPart part, bool with_keygen)
     if (part == FRONT_RANDOMNESS) { s1 = noff_f; witness = 0; ntt_count = P.M; matvec = false; }
     else if (part == FRONT_RANGE) { s0 = noff_f; s1 = noff; witness = 2; ntt_count = 0; expand = false; matvec = false; }
     else if (part == FRONT_ONLINE) { s0 = noff; expand = false; ntt_first = P.M; ntt_count = K; }
-    const KeygenFront kgf{c.d_seeds, c.kg_rec, c.d_A, c.key_stride, c.d_se, c.se_stride};
+    const KeygenFront kgf{c.d_seeds, c.kg_rec, c.d_A, c.key_stride, c.d_se, c.se_stride, c.xof_guard()};
     HIPCHK(launch_prover_pre(c.tape_cur, c.tape_cur_stride, c.d_P, c.proof_stride, rm.f, P.M, 64 + 32 * P.M, c.d_fresh_rows, s0, s1, expand,
                              witness, c.d_se, c.se_stride, rm, P.eta1, n, st, with_keygen ? &kgf : nullptr, c.tape_segs.count ? &c.tape_segs : nullptr));
     if (with_keygen && issue_keygen(c, n, true)) return -1; // NTT(s), NTT(e), t = A o s + e, pk / sk bytes and their D2H
@@ -867,6 +887,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     HIPCHK(stream_sync(c));
     t1 = now_sec(); c.phase_sec[PH_GPU_ASSEMBLE] = t1 - t0;
     c.prof_collect();
+    if (device_error_check(c)) return -1; // e.g. the key generation's gen_matrix hit its block limit: pk / sk / proofs are not valid
     return 0;
 }
 

@@ -216,6 +216,12 @@ struct Ctx {
     uint8_t *h_tape = nullptr, *h_dig = nullptr, *h_dig2 = nullptr, *h_proof = nullptr; // h_dig / h_dig2: the host's copies of the two digest tables
     uint16_t *h_alpha = nullptr, *h_I = nullptr, *h_rest = nullptr;
     uint32_t *h_fail = nullptr;
+    // device-raised errors (XofGuard): one word of page-locked host memory the kernels store to; checked and cleared by
+    // device_error_check() after a call's last synchronisation.  KOSK_DEBUG_XOF_BLOCKS=n lowers gen_matrix's block limit
+    // (tests force the error path with 1)
+    uint32_t *h_err = nullptr;
+    int xof_max_blocks = 32;
+    XofGuard xof_guard() const { XofGuard g; g.err = h_err; g.max_blocks = xof_max_blocks; return g; }
 
     // hipGraph per pipeline segment (the launches between two host Fiat-Shamir rounds), captured once per
     // batch size and replayed: one API call instead of ~15 launches of kernels that run 3-6 us each.
@@ -307,6 +313,8 @@ int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx
 // C[g][rows_d[i]][off + m] = sum_k A[m][k] * src[g][rows_s[i]][koff + k] mod q  (conversion to limbs + MFMA GEMM)
 // host wait for everything queued on the context's stream (spinning, or sleeping with KOSK_BLOCKING_SYNC=1)
 hipError_t stream_sync(Ctx &c);
+// after the stream has been synchronised: -1 (with c.err set, the word cleared) if a kernel of this context raised an error
+int device_error_check(Ctx &c);
 // proofs of an n-proof batch that the FIRST of the two commitment-hash launches takes (n: a single launch)
 int commit_hash_groups(const Ctx &c, int n);
 int gemm_modq(Ctx &c, const uint8_t *A, size_t a_gstride, int Mpad, int M, int KS, const GemmSrc &s, const GemmDst &d,

@@ -6,6 +6,17 @@
 
 namespace kosk {
 
+// gen_matrix's rejection sampling squeezes SHAKE128 blocks until it has 256 coefficients (indcpa.c:124-145 loops without a
+// bound; three blocks suffice with probability 1 - 2^-40).  A GPU loop needs an exit every wave reaches: after max_blocks
+// blocks the sampler stops, zero-fills the rest and raises *err -- a word in page-locked HOST memory that the host checks after
+// the call's last synchronisation: the call then fails with rc -1 (never a silently wrong matrix, never an abort).
+struct XofGuard {
+    uint32_t *err = nullptr;
+    int max_blocks = 32;
+};
+enum : uint32_t { DEVERR_XOF_BLOCKS = 1u };
+
+
 // K4: lane `l` of group `g` hashes  [prefix(32 B)] || rows[g][r][col_off + col(l)], r = 0..NROWS-1
 struct HashArgs {
     const uint16_t *rows;      // row 0 of group 0
@@ -39,7 +50,9 @@ struct NttArgs {
     uint32_t *cmp_fail;
     int cmp_delta, cmp_bit;
     int fp32; // 1: the packed-fp32 butterflies (k_ntt256_fp32; KOSK_NTT_FP32=1 at kosk_create), 0: integer Montgomery
+    uint32_t npg_magic; // floor(2^32 / npg), filled in by the launchers: polynomial -> (group, index) without an integer division
 };
+inline uint32_t ntt_npg_magic(int npg) { return npg <= 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / (uint32_t)npg); }
 
 // ---- "limb matrix": the MFMA operand format of the mod-q GEMM -------------------------------
 // A matrix X[r][k] of field elements is stored as two int8 limbs of its centred representative
@@ -235,11 +248,12 @@ hipError_t launch_check_opened(const VerifyArgs &v, int nproofs, hipStream_t st)
 
 // ---- key generation (kosk_keygen_kernels.hip) ----
 hipError_t launch_keygen(const uint8_t *tape, size_t tape_stride, uint8_t *seeds, size_t seed_stride, int16_t *A, size_t A_stride,
-                         int16_t *se, size_t se_stride, int K, int eta1, int n, hipStream_t st);
+                         int16_t *se, size_t se_stride, int K, int eta1, int n, hipStream_t st, XofGuard xof = XofGuard());
 hipError_t launch_keygen_pack(const int16_t *A, size_t A_stride, const int16_t *sehat, size_t sehat_stride, const uint8_t *seeds,
                               size_t seed_stride, uint16_t *t_out, uint8_t *pk, size_t pk_stride, uint8_t *shat_bytes, size_t sb_stride, int K, int n,
                               hipStream_t st);
-hipError_t launch_decode_pk(const uint8_t *pk, size_t pk_stride, uint16_t *t_out, int16_t *A, size_t A_stride, int K, int n, hipStream_t st);
+hipError_t launch_decode_pk(const uint8_t *pk, size_t pk_stride, uint16_t *t_out, int16_t *A, size_t A_stride, int K, int n, hipStream_t st,
+                            XofGuard xof = XofGuard());
 
 // opts: HASH_OPT_DMA = LDS-DMA staged kernel where the layout allows it (KOSK_HASH_DMA, default on), HASH_OPT_PRIMER = placement
 // primer launch in front (KOSK_HASH_PRIMER, default off); *variant: bit 0 the DMA kernel ran, bit 1 the primer was launched
@@ -268,6 +282,7 @@ struct KeygenFront {
     size_t A_stride;
     int16_t *se;
     size_t se_stride;
+    XofGuard xof;
 };
 hipError_t launch_prover_pre(const uint8_t *tape, size_t tape_stride, uint16_t *P, size_t proof_stride, int row_f, int M,
                              int slice0_off, const int16_t *fresh_rows, int slice_begin, int slice_end, bool expand_f,

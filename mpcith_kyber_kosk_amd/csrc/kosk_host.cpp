@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 #include <thread>
 
 #include "kosk_math.hpp"
@@ -127,14 +128,15 @@ void poly_tobytes(uint8_t *r, const int16_t *a)
 // indcpa.c:168-193 (gen_matrix, not transposed) with rej_uniform :124-145
 void gen_matrix(int16_t *A, const uint8_t seed[32], int K)
 {
-    uint8_t ext[34], buf[168 * 8];
+    uint8_t ext[34];
+    std::vector<uint8_t> buf(168 * 4);
     memcpy(ext, seed, 32);
     for (int i = 0; i < K; i++)
         for (int j = 0; j < K; j++) {
             ext[32] = (uint8_t)j;
             ext[33] = (uint8_t)i;
             size_t have = 168 * 4;
-            shake128(buf, have, ext, 34);
+            shake128(buf.data(), have, ext, 34);
             int16_t *r = A + ((size_t)i * K + j) * 256;
             int ctr = 0;
             size_t pos = 0;
@@ -146,9 +148,11 @@ void gen_matrix(int16_t *A, const uint8_t seed[32], int K)
                     if (ctr < 256 && v1 < Q) r[ctr++] = (int16_t)v1;
                 }
                 if (ctr == 256) break;
-                if (have == sizeof buf) { fprintf(stderr, "kosk: gen_matrix XOF prefix exhausted\n"); abort(); }
-                have = sizeof buf; // the XOF stream is a prefix-consistent byte stream: re-squeeze longer
-                shake128(buf, have, ext, 34);
+                // like the reference (indcpa.c:139-144) keep squeezing, without a bound: the XOF output is a prefix-consistent
+                // byte stream, so squeezing a longer prefix again continues where the parser stopped (168 = 56 whole triples)
+                have += 168 * 4;
+                if (buf.size() < have) buf.resize(have);
+                shake128(buf.data(), have, ext, 34);
             }
         }
 }

@@ -413,6 +413,7 @@ struct PreArgs {
     size_t kg_A_stride;
     int16_t *kg_se;      // [proof][2K][256] s then e
     size_t kg_se_stride;
+    XofGuard xof;
 };
 constexpr int PRE_SLICES = 8; // fresh sharings per role-B block
 __device__ __forceinline__ const uint8_t *pre_tape(const PreArgs &a, int b)
@@ -511,7 +512,7 @@ __device__ __forceinline__ void pre_gen_matrix(const PreArgs &a, int t)
     const int b = t / KK, ij = t - b * KK, i = ij / a.K, j = ij - i * a.K;
     uint32_t pub[8], noise[8];
     kg_seed_hash(pre_tape(a, b), a.K, pub, noise);
-    kg_gen_matrix(pub, i, j, a.kg_A + (size_t)b * a.kg_A_stride + (size_t)ij * 256);
+    kg_gen_matrix(pub, i, j, a.kg_A + (size_t)b * a.kg_A_stride + (size_t)ij * 256, a.xof);
 }
 
 __device__ __forceinline__ void pre_noise(const PreArgs &a, int t)
@@ -548,6 +549,34 @@ __global__ __launch_bounds__(64) void k_prover_pre(PreArgs a)
 // Barrett.  Global traffic is 16-byte coalesced both ways.
 // =========================================================================
 __constant__ static const ZetaTable kZetasDev = ZetaTable();
+__constant__ static const ZetaTableDot kZetasDot = ZetaTableDot();
+
+// Cooley-Tukey butterfly (ntt.c:86-91) in four full-rate instructions.  A coefficient lives in the low half of its register.
+//   hi.h16 = lo16(hi.l16 * zq)                 m = (int16)(a z QINV), the Montgomery factor (reduce.c:19), into the spare half
+//   t      = hi.l16 * z + hi.h16 * (-q)        one dot product of packed int16 pairs: a z - m q (reduce.c:20 before the shift)
+//   hi     = lo.l16 - t.h16 ;  lo = lo.l16 + t.h16     fqmul(z, a) is t's high half: the SDWA operand selects sign-extend it
+// The three multiplies of the plain form (a z, (a z) QINV, m q) are half-rate 24/32-bit multiplies on gfx950; these four are not.
+__device__ __forceinline__ void ntt_bfly(int32_t &lo, int32_t &hi, int32_t zq, int32_t zz)
+{
+    int32_t t, nlo, nhi;
+    asm("v_mad_u16 %0, %0, %1, 0 op_sel:[0,0,0,1]" : "+v"(hi) : "v"(zq));
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(t) : "v"(hi), "v"(zz));
+    asm("v_sub_u32_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(nhi) : "v"(lo), "v"(t));
+    asm("v_add_u32_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(nlo) : "v"(lo), "v"(t));
+    lo = nlo;
+    hi = nhi;
+}
+// the same with the zeta operands in scalar registers (layers whose zeta is the same for every lane)
+__device__ __forceinline__ void ntt_bfly_s(int32_t &lo, int32_t &hi, int32_t zq, int32_t zz)
+{
+    int32_t t, nlo, nhi;
+    asm("v_mad_u16 %0, %0, %1, 0 op_sel:[0,0,0,1]" : "+v"(hi) : "s"(zq));
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(t) : "v"(hi), "s"(zz));
+    asm("v_sub_u32_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(nhi) : "v"(lo), "v"(t));
+    asm("v_add_u32_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(nlo) : "v"(lo), "v"(t));
+    lo = nlo;
+    hi = nhi;
+}
 
 constexpr int NTT_PPB = 16;
 constexpr int NTT_LSTRIDE = 256 + 16; // int16 per polynomial in LDS (32-byte pad: conflict-free stride reads)
@@ -559,87 +588,162 @@ constexpr int NTT_LSTRIDE = 256 + 16; // int16 per polynomial in LDS (32-byte pa
         (lo) = (lo) + t_;                    \
     }
 
-// one tile of up to 16 polynomials p0 .. p0+15 by a 256-thread workgroup (all threads must call it)
-__device__ __forceinline__ void ntt256_tile(const NttArgs &a, const int p0, int16_t *__restrict__ lds)
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence as well: hipcc waits for EVERY outstanding memory
+// operation (s_waitcnt vmcnt(0)) in front of it, which would make the workgroup wait for the next tile's prefetched global loads
+// and for the previous tile's stores at each of the transform's barriers.
+__device__ __forceinline__ void lds_barrier()
 {
-    const int tid = threadIdx.x;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
-    for (int c = tid; c < NTT_PPB * 32; c += 256) {
+// polynomial p -> (group g, index i inside the group): p = g npg + i.  A 32-bit division costs ~20 vector instructions and the
+// kernel needs three per thread; with floor(2^32 / npg) from the host it is a multiply-high and one correction step.
+__device__ __forceinline__ void ntt_split(const NttArgs &a, int p, int &g, int &i)
+{
+    uint32_t gg = __umulhi((uint32_t)p, a.npg_magic);
+    int r = p - (int)gg * a.npg;
+    if (r >= a.npg) { gg++; r -= a.npg; }
+    g = (int)gg;
+    i = r;
+}
+
+// A tile = up to 16 polynomials p0 .. p0+15, one 256-thread workgroup.  Its input as two 16-byte pieces per thread: loaded into
+// registers (ntt256_fetch), later written to the LDS staging image (ntt256_stage) -- apart, so that a workgroup that walks
+// several tiles has the NEXT tile's loads in flight while it transforms the current one.
+__device__ __forceinline__ void ntt256_fetch(const NttArgs &a, const int p0, uint4 (&x)[2])
+{
+    int g0, i0;
+    ntt_split(a, p0 + ((int)threadIdx.x >> 5), g0, i0);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int c = (int)threadIdx.x + q * 256;
         const int pl = c >> 5, ch = c & 31, p = p0 + pl;
+        x[q] = make_uint4(0, 0, 0, 0);
         if (p < a.npoly) {
-            const int g = p / a.npg, i = p - g * a.npg;
+            int g = g0, i = i0;
+            if (q) { // the thread's second polynomial is 8 further on
+                i += 8;
+                if (a.npg >= 8) { if (i >= a.npg) { i -= a.npg; g++; } }
+                else ntt_split(a, p, g, i);
+            }
             const size_t off = (size_t)g * a.in_gstride + (a.src_off ? (size_t)a.src_off[i] : (size_t)i * 256);
-            *reinterpret_cast<uint4 *>(lds + pl * NTT_LSTRIDE + ch * 8) =
-                *reinterpret_cast<const uint4 *>(a.in + off + ch * 8);
+            x[q] = *reinterpret_cast<const uint4 *>(a.in + off + ch * 8);
         }
     }
-    __syncthreads();
+}
+__device__ __forceinline__ void ntt256_stage(const uint4 (&x)[2], int16_t *__restrict__ lds)
+{
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int c = (int)threadIdx.x + q * 256;
+        *reinterpret_cast<uint4 *>(lds + (c >> 5) * NTT_LSTRIDE + (c & 31) * 8) = x[q];
+    }
+}
+__device__ __forceinline__ void ntt256_transform(const NttArgs &a, const int p0, int16_t *__restrict__ lds);
 
+// one tile by a 256-thread workgroup (all threads must call it)
+__device__ __forceinline__ void ntt256_tile(const NttArgs &a, const int p0, int16_t *__restrict__ lds)
+{
+    uint4 x[2];
+    ntt256_fetch(a, p0, x);
+    ntt256_stage(x, lds);
+    __syncthreads();
+    ntt256_transform(a, p0, lds);
+}
+
+// the staged tile (every thread's ntt256_stage done, barrier passed) -> transformed polynomials in global memory
+__device__ __forceinline__ void ntt256_transform(const NttArgs &a, const int p0, int16_t *__restrict__ lds)
+{
+    const int tid = threadIdx.x;
     const int pl = tid >> 4, l = tid & 15;
     int16_t *mine = lds + pl * NTT_LSTRIDE;
-    int32_t r[16];
+    int32_t r[16]; // a coefficient is the LOW half of its register; the high half is scratch (ntt_bfly)
 #pragma unroll
     for (int i = 0; i < 16; i++) r[i] = mine[l + 16 * i];
 
+#define KOSK_BFLYZ(lo, hi, k) ntt_bfly_s((lo), (hi), (int32_t)kZetasDot.zq[(k)], (int32_t)kZetasDot.zz[(k)])
     // coefficient index j = l + 16 i : len = 128, 64, 32, 16 <-> register distance 8, 4, 2, 1
 #pragma unroll
-    for (int i = 0; i < 8; i++) KOSK_BFLY(r[i], r[i + 8], (int32_t)kZetasDev.z[1]);
+    for (int i = 0; i < 8; i++) KOSK_BFLYZ(r[i], r[i + 8], 1);
 #pragma unroll
     for (int blk = 0; blk < 2; blk++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) KOSK_BFLY(r[8 * blk + i], r[8 * blk + i + 4], (int32_t)kZetasDev.z[2 + blk]);
+        for (int i = 0; i < 4; i++) KOSK_BFLYZ(r[8 * blk + i], r[8 * blk + i + 4], 2 + blk);
 #pragma unroll
     for (int blk = 0; blk < 4; blk++)
 #pragma unroll
-        for (int i = 0; i < 2; i++) KOSK_BFLY(r[4 * blk + i], r[4 * blk + i + 2], (int32_t)kZetasDev.z[4 + blk]);
+        for (int i = 0; i < 2; i++) KOSK_BFLYZ(r[4 * blk + i], r[4 * blk + i + 2], 4 + blk);
 #pragma unroll
-    for (int blk = 0; blk < 8; blk++) KOSK_BFLY(r[2 * blk], r[2 * blk + 1], (int32_t)kZetasDev.z[8 + blk]);
+    for (int blk = 0; blk < 8; blk++) KOSK_BFLYZ(r[2 * blk], r[2 * blk + 1], 8 + blk);
 
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int i = 0; i < 16; i++) mine[l + 16 * i] = (int16_t)r[i];
-    __syncthreads();
+    lds_barrier();
     {
         const uint4 v0 = *reinterpret_cast<const uint4 *>(mine + 16 * l);
         const uint4 v1 = *reinterpret_cast<const uint4 *>(mine + 16 * l + 8);
         const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            r[2 * q] = (int16_t)(w[q] & 0xFFFF);
-            r[2 * q + 1] = (int16_t)(w[q] >> 16);
+            r[2 * q] = (int32_t)w[q];         // low half = coefficient 2q (the high half is ignored)
+            r[2 * q + 1] = (int32_t)(w[q] >> 16);
         }
     }
-    // coefficient index j = 16 l + c : zeta index = 128/len + j/(2 len)
+    // coefficient index j = 16 l + c : zeta index = 128/len + j/(2 len)  (per lane from here on: vector operands)
+#undef KOSK_BFLYZ
+#define KOSK_BFLYZ(lo, hi, zq_, zz_) ntt_bfly((lo), (hi), (zq_), (zz_))
     {
-        const int32_t z8 = kZetasDev.z[16 + l];
+        const int32_t q8 = (int32_t)kZetasDot.zq[16 + l], z8 = (int32_t)kZetasDot.zz[16 + l];
 #pragma unroll
-        for (int c = 0; c < 8; c++) KOSK_BFLY(r[c], r[c + 8], z8);
-        const int32_t z4a = kZetasDev.z[32 + 2 * l], z4b = kZetasDev.z[33 + 2 * l];
+        for (int c = 0; c < 8; c++) KOSK_BFLYZ(r[c], r[c + 8], q8, z8);
+        const int32_t q4a = (int32_t)kZetasDot.zq[32 + 2 * l], z4a = (int32_t)kZetasDot.zz[32 + 2 * l];
+        const int32_t q4b = (int32_t)kZetasDot.zq[33 + 2 * l], z4b = (int32_t)kZetasDot.zz[33 + 2 * l];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            KOSK_BFLY(r[c], r[c + 4], z4a);
-            KOSK_BFLY(r[8 + c], r[12 + c], z4b);
+            KOSK_BFLYZ(r[c], r[c + 4], q4a, z4a);
+            KOSK_BFLYZ(r[8 + c], r[12 + c], q4b, z4b);
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int32_t z2 = kZetasDev.z[64 + 4 * l + q];
-            KOSK_BFLY(r[4 * q], r[4 * q + 2], z2);
-            KOSK_BFLY(r[4 * q + 1], r[4 * q + 3], z2);
+            const int32_t q2 = (int32_t)kZetasDot.zq[64 + 4 * l + q], z2 = (int32_t)kZetasDot.zz[64 + 4 * l + q];
+            KOSK_BFLYZ(r[4 * q], r[4 * q + 2], q2, z2);
+            KOSK_BFLYZ(r[4 * q + 1], r[4 * q + 3], q2, z2);
         }
     }
+#undef KOSK_BFLYZ
     const int p = p0 + pl;
     if (p < a.npoly) {
+        // poly_reduce (poly.c:261-265) / encode_to_gf3329: x -> the representative the consumer wants.  One Montgomery step with
+        // 2^16 mod q (the butterfly's first two instructions) leaves x mod q in (-q, q) in the high half of a register; pairs of
+        // those are packed and finished with packed 16-bit arithmetic -- 5 to 6 instructions per coefficient where Barrett
+        // (two 24-bit multiplies) + select + pack took 9.
+        constexpr int32_t CQ = (int32_t)(((uint32_t)(2285 * QINV)) & 0xFFFFu);                       // (2^16 mod q) q^-1 mod 2^16
+        constexpr int32_t CZ = (int32_t)(2285u | ((uint32_t)(uint16_t)(-Q) << 16));
+        constexpr int32_t S15 = 0x000F000F, Q2 = (int32_t)((uint32_t)Q | ((uint32_t)Q << 16)), H2 = (int32_t)((uint32_t)(Q / 2) | ((uint32_t)(Q / 2) << 16));
         uint32_t w[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            int32_t x0 = barrett_reduce((int16_t)r[2 * q]), x1 = barrett_reduce((int16_t)r[2 * q + 1]);
-            if (a.out_canonical) {
-                x0 = (int32_t)gf_encode(x0);
-                x1 = (int32_t)gf_encode(x1);
+            int32_t t0, t1;
+            asm("v_mad_u16 %0, %0, %1, 0 op_sel:[0,0,0,1]" : "+v"(r[2 * q]) : "s"(CQ));
+            asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(t0) : "v"(r[2 * q]), "s"(CZ));
+            asm("v_mad_u16 %0, %0, %1, 0 op_sel:[0,0,0,1]" : "+v"(r[2 * q + 1]) : "s"(CQ));
+            asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(t1) : "v"(r[2 * q + 1]), "s"(CZ));
+            uint32_t c = __builtin_amdgcn_perm((uint32_t)t1, (uint32_t)t0, 0x07060302u), m; // {t0.h16, t1.h16}: both in (-q, q)
+            // c += (c >> 15) & q : [0, q), encode_to_gf3329 -- packed 16-bit, constants in scalar registers
+            asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(m) : "s"(S15), "v"(c));
+            asm("v_and_b32 %0, %1, %0" : "+v"(m) : "s"(Q2));
+            asm("v_pk_add_u16 %0, %0, %1" : "+v"(c) : "v"(m));
+            if (!a.out_canonical) { // c -= ((q/2 - c) >> 15) & q : the centred representative [-(q-1)/2, (q-1)/2] of poly_reduce
+                asm("v_pk_sub_i16 %0, %1, %2" : "=v"(m) : "s"(H2), "v"(c));
+                asm("v_pk_ashrrev_i16 %0, %1, %0" : "+v"(m) : "s"(S15));
+                asm("v_and_b32 %0, %1, %0" : "+v"(m) : "s"(Q2));
+                asm("v_pk_sub_i16 %0, %0, %1" : "+v"(c) : "v"(m));
             }
-            w[q] = ((uint32_t)x0 & 0xFFFFu) | ((uint32_t)x1 << 16);
+            w[q] = c;
         }
-        const int g = p / a.npg, i = p - g * a.npg;
+        int g, i;
+        ntt_split(a, p, g, i);
         const size_t off = (size_t)g * a.out_gstride + (a.dst_off ? (size_t)a.dst_off[i] : (size_t)i * 256);
         uint4 *o = reinterpret_cast<uint4 *>(a.out + off + 16 * l);
         if (a.cmp_fail) {
@@ -653,10 +757,17 @@ __device__ __forceinline__ void ntt256_tile(const NttArgs &a, const int p0, int1
     }
 }
 
+// One tile per workgroup.  (Measured in round 4, tools/ntt_time.py: a workgroup that walks several tiles with the next tile's
+// loads in flight during the transform is no faster -- 22.5 against 21.9 us at 65 536 polynomials -- because the kernel is bound by
+// instruction issue, not by exposed memory latency: without its butterflies it takes 14.4 us, a plain copy of the same bytes 10.4 us.)
 __global__ __launch_bounds__(256) void k_ntt256(NttArgs a)
 {
     __shared__ __attribute__((aligned(16))) int16_t lds[NTT_PPB * NTT_LSTRIDE];
-    ntt256_tile(a, blockIdx.x * NTT_PPB, lds);
+    uint4 x[2];
+    ntt256_fetch(a, blockIdx.x * NTT_PPB, x);
+    ntt256_stage(x, lds);
+    lds_barrier();
+    ntt256_transform(a, blockIdx.x * NTT_PPB, lds);
 }
 
 // ---- K5, packed-fp32 variant (opt-in: KOSK_NTT_FP32=1) ---------------------------------------------------------
@@ -1742,6 +1853,7 @@ hipError_t launch_prover_pre(const uint8_t *tape, size_t tape_stride, uint16_t *
     if (kg) {
         // the witness secrets (role C) read s and e, which role N of this launch produces: they follow in a launch of their own
         a.kg_seeds = kg->seeds; a.kg_seed_stride = kg->seed_stride; a.kg_A = kg->A; a.kg_A_stride = kg->A_stride; a.kg_se = kg->se; a.kg_se_stride = kg->se_stride;
+        a.xof = kg->xof;
         a.nbG = (nproofs * rm.K * rm.K + 63) / 64;
         a.nbN = (nproofs * 2 * rm.K + 63) / 64;
         hipLaunchKernelGGL(k_prover_pre, dim3(a.nbA + a.nbB + a.nbG + a.nbN), dim3(64), 0, st, a);
@@ -1759,9 +1871,10 @@ hipError_t launch_prover_pre(const uint8_t *tape, size_t tape_stride, uint16_t *
 
 // key generation alone (kosk_stage_prover_inputs): roles G and N of the same kernel
 hipError_t launch_keygen(const uint8_t *tape, size_t tape_stride, uint8_t *seeds, size_t seed_stride, int16_t *A, size_t A_stride,
-                         int16_t *se, size_t se_stride, int K, int eta1, int n, hipStream_t st)
+                         int16_t *se, size_t se_stride, int K, int eta1, int n, hipStream_t st, XofGuard xof)
 {
     PreArgs a{};
+    a.xof = xof;
     a.tape = tape; a.tape_stride = tape_stride; a.nproofs = n; a.eta1 = eta1; a.K = K;
     a.kg_seeds = seeds; a.kg_seed_stride = seed_stride; a.kg_A = A; a.kg_A_stride = A_stride; a.kg_se = se; a.kg_se_stride = se_stride;
     a.nbG = (n * K * K + 63) / 64;
@@ -1770,9 +1883,11 @@ hipError_t launch_keygen(const uint8_t *tape, size_t tape_stride, uint8_t *seeds
     return hipGetLastError();
 }
 
-hipError_t launch_ntt(const NttArgs &a, hipStream_t st)
+hipError_t launch_ntt(const NttArgs &args, hipStream_t st)
 {
-    if (a.npoly <= 0) return hipSuccess;
+    if (args.npoly <= 0) return hipSuccess;
+    NttArgs a = args;
+    a.npg_magic = ntt_npg_magic(a.npg);
     if (a.fp32) hipLaunchKernelGGL(k_ntt256_fp32, dim3((a.npoly + NTT_PPB - 1) / NTT_PPB), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_ntt256, dim3((a.npoly + NTT_PPB - 1) / NTT_PPB), dim3(256), 0, st, a);
     return hipGetLastError();
@@ -1782,7 +1897,9 @@ hipError_t launch_relation_ntt(const NttArgs &na, const int16_t *A, size_t A_str
                                int nproofs, hipStream_t st)
 {
     if (na.npg > NTT_PPB) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_relation_ntt, dim3(nproofs), dim3(256), 0, st, na, A, A_stride, P, proof_stride, rm);
+    NttArgs nb = na;
+    nb.npg_magic = ntt_npg_magic(nb.npg);
+    hipLaunchKernelGGL(k_relation_ntt, dim3(nproofs), dim3(256), 0, st, nb, A, A_stride, P, proof_stride, rm);
     return hipGetLastError();
 }
 

@@ -67,13 +67,13 @@ __device__ __forceinline__ uint32_t kg_triple(const KState &s)
 }
 
 // A[i][j] (canonical, 256 coefficients at r) from the public seed; XOF input seed || j || i (gen_matrix, transposed == 0)
-__device__ __forceinline__ void kg_gen_matrix(const uint32_t (&pub)[8], int i, int j, int16_t *__restrict__ r)
+__device__ __forceinline__ void kg_gen_matrix(const uint32_t (&pub)[8], int i, int j, int16_t *__restrict__ r, const XofGuard &xof)
 {
     KState s;
     kg_absorb(s, pub, (uint32_t)j | ((uint32_t)i << 8), 2, 168, 0x1F);
     int ctr = 0;
 #pragma unroll 1
-    for (int blk = 0; blk < 32 && ctr < 256; blk++) { // 3 blocks suffice with probability 1 - 2^-40; bounded anyway
+    for (int blk = 0; blk < xof.max_blocks && ctr < 256; blk++) { // 3 blocks suffice with probability 1 - 2^-40; bounded anyway
         keccak_f1600_dev(s);
         auto parse = [&]<int... Ts>(std::integer_sequence<int, Ts...>) {
             (([&] {
@@ -85,6 +85,10 @@ __device__ __forceinline__ void kg_gen_matrix(const uint32_t (&pub)[8], int i, i
              ...);
         };
         parse(std::make_integer_sequence<int, 56>{}); // 168 bytes = 56 triples
+    }
+    if (ctr < 256) { // block limit reached (XofGuard): never a partly written polynomial, and the host hears about it
+        for (; ctr < 256; ctr++) r[ctr] = 0;
+        if (xof.err) *reinterpret_cast<volatile uint32_t *>(xof.err) = DEVERR_XOF_BLOCKS;
     }
 }
 

@@ -22,14 +22,14 @@ __constant__ static const ZetaTable kZetasKg = ZetaTable();
 // A[b][i][j][256] canonical from the 32-byte public seed found at seeds + b * seed_stride (the verifier's gen_matrix,
 // kosk.cpp:98-99; the prover's runs as a role of k_prover_pre, kosk_kernels.hip)
 __global__ __launch_bounds__(64) void k_gen_matrix(const uint8_t *__restrict__ seeds, size_t seed_stride, int16_t *__restrict__ A,
-                                                   size_t A_stride, int K, int n)
+                                                   size_t A_stride, int K, int n, XofGuard xof)
 {
     const int t = blockIdx.x * 64 + threadIdx.x;
     if (t >= n * K * K) return;
     const int b = t / (K * K), ij = t - b * K * K, i = ij / K, j = ij - i * K;
     uint32_t pub[8];
     kg_load_seed(pub, seeds + (size_t)b * seed_stride);
-    kg_gen_matrix(pub, i, j, A + (size_t)b * A_stride + (size_t)ij * 256);
+    kg_gen_matrix(pub, i, j, A + (size_t)b * A_stride + (size_t)ij * 256, xof);
 }
 
 // poly.c:124-139 on a pair of centred coefficients
@@ -87,11 +87,12 @@ hipError_t launch_keygen_pack(const int16_t *A, size_t A_stride, const int16_t *
                        shat_bytes, sb_stride, K);
     return hipGetLastError();
 }
-hipError_t launch_decode_pk(const uint8_t *pk, size_t pk_stride, uint16_t *t_out, int16_t *A, size_t A_stride, int K, int n, hipStream_t st)
+hipError_t launch_decode_pk(const uint8_t *pk, size_t pk_stride, uint16_t *t_out, int16_t *A, size_t A_stride, int K, int n, hipStream_t st,
+                            XofGuard xof)
 {
     hipLaunchKernelGGL(k_decode_pk, dim3(K, n), dim3(128), 0, st, pk, pk_stride, t_out, K);
     // gen_matrix from the seed stored behind the packed t (kosk.cpp:96-99)
-    hipLaunchKernelGGL(k_gen_matrix, dim3((n * K * K + 63) / 64), dim3(64), 0, st, pk + 384 * K, pk_stride, A, A_stride, K, n);
+    hipLaunchKernelGGL(k_gen_matrix, dim3((n * K * K + 63) / 64), dim3(64), 0, st, pk + 384 * K, pk_stride, A, A_stride, K, n, xof);
     return hipGetLastError();
 }
 

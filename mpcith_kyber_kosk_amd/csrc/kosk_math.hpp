@@ -56,6 +56,21 @@ struct ZetaTable {
 };
 static constexpr ZetaTable kZetas{};
 
+// The same zetas as the two operands of the NTT kernel's four-instruction butterfly (kosk_kernels.hip, ntt_bfly):
+//   zq[k] = z[k] * q^-1 mod 2^16 -- m = lo16(a * zq) is the Montgomery factor (int16)(a z QINV) of reduce.c:19 --
+//   zz[k] = { lo16: z[k], hi16: -q } -- one v_dot2_i32_i16 of {a, m} with it is a z - m q, whose high half is fqmul(a, z).
+struct ZetaTableDot {
+    uint32_t zq[128], zz[128];
+    constexpr ZetaTableDot() : zq(), zz()
+    {
+        const ZetaTable t{};
+        for (int i = 0; i < 128; i++) {
+            zq[i] = (uint32_t)((int32_t)t.z[i] * QINV) & 0xFFFFu;
+            zz[i] = ((uint32_t)(uint16_t)t.z[i]) | ((uint32_t)(uint16_t)(-Q) << 16);
+        }
+    }
+};
+
 // plain (non-Montgomery) roots 17^bitrev7(k) mod q, centred, as floats: the packed-fp32 NTT variant
 struct ZetaTableF {
     float z[128];

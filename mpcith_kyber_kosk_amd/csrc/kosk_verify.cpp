@@ -219,8 +219,9 @@ int stage_verifier_inputs(Ctx &c, int n, const uint8_t *pi, const uint8_t *pk, b
     else
         HIPCHK(hipMemcpyAsync(c.d_proof, c.h_proof, (size_t)n * c.image_stride, hipMemcpyHostToDevice, c.stream));
     // polyvec_frombytes(t) and gen_matrix(A, seed) on the device   kosk.cpp:94-99
-    HIPCHK(launch_decode_pk(c.d_pk, c.pk_stride, c.d_t, c.d_A, c.key_stride, P.K, n, c.stream));
+    HIPCHK(launch_decode_pk(c.d_pk, c.pk_stride, c.d_t, c.d_A, c.key_stride, P.K, n, c.stream, c.xof_guard()));
     HIPCHK(stream_sync(c));
+    if (device_error_check(c)) return -1;
     return 0;
 }
 
@@ -355,7 +356,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     // ---- alpha-independent GPU work, issued before the host hashes so that it runs meanwhile: interpolation of
     // the unopened shares
     if (run_segment(c, Ctx::SEG_V1B, n, [&]() -> int {
-    if (pk_mode) HIPCHK(launch_decode_pk(c.d_pk, c.pk_stride, c.d_t, c.d_A, c.key_stride, K, n, st)); // kosk.cpp:94-99
+    if (pk_mode) HIPCHK(launch_decode_pk(c.d_pk, c.pk_stride, c.d_t, c.d_A, c.key_stride, K, n, st, c.xof_guard())); // kosk.cpp:94-99
     InterpArgs ia{};
     ia.rest = c.d_rest;
     ia.isort = c.d_isort;
@@ -494,6 +495,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     }
     HIPCHK(stream_sync(c)); // fail masks of V2B
     c.prof_collect();
+    if (device_error_check(c)) return -1; // gen_matrix of a public key hit its block limit: no verdict on these proofs
     {
         int b = 0;
         for (const VerifySeg *s = segs; s; s = s->next)

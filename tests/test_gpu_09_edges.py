@@ -212,3 +212,28 @@ def test_graphs_with_alternating_device_tape_buffers(oracle, torch_cuda, monkeyp
             assert pis[b] == oracle.verifiable_keygen(k, sets[s][b])[2], (s, b)
     assert ctx.path_counts()["graph_replay"] > 0
     ctx.close()
+
+
+def test_xof_block_limit_is_an_error_code_not_an_abort_or_a_wrong_matrix(oracle, torch_cuda, monkeypatch):
+    """gen_matrix on the GPU squeezes at most 32 SHAKE128 blocks per matrix entry (indcpa.c:124-145 loops without a bound; the GPU
+    loop needs an exit).  Reaching the limit must be rc -1 with text -- never a partly written matrix, never an abort -- for the
+    prover's key generation and for the verifier's pk decoding.  KOSK_DEBUG_XOF_BLOCKS=1 forces it (one block holds at most 112
+    candidates for 256 coefficients)."""
+    from mpcith_kyber_kosk_amd import api
+    k = 3
+    tapes = [oracle.tape_bytes_for(k, 700 + b) for b in range(2)]
+    good = api.Kosk(kyber_k=k, max_batch=2)
+    pks, sks, pis = good.verifiable_keygen(tapes)
+    monkeypatch.setenv("KOSK_DEBUG_XOF_BLOCKS", "1")
+    ctx = api.Kosk(kyber_k=k, max_batch=2)
+    monkeypatch.delenv("KOSK_DEBUG_XOF_BLOCKS")
+    with pytest.raises(api.KoskError, match="block limit"):
+        ctx.verifiable_keygen(tapes)
+    with pytest.raises(api.KoskError, match="block limit"):
+        ctx.verifiable_keygen_resident(tapes)
+    with pytest.raises(api.KoskError, match="block limit"):
+        ctx.verify(pis, pks)
+    # the knob is per handle and the error does not stick to the process: the other handle is unaffected
+    assert good.verifiable_keygen(tapes) == (pks, sks, pis)
+    assert good.verify(pis, pks) == [True, True]
+    ctx.close(); good.close()
