@@ -393,8 +393,12 @@ class Slot:
     def __init__(self, api, torch, k, B, device, first_tape, nsets, partition=None, combine=1):
         # partition = (i, n): the slot's stream may only use CU partition i of n (KOSK_CU_PARTITION, read by kosk_create)
         env = {"KOSK_CU_PARTITION": "%d/%d" % partition} if partition and partition[1] > 1 else {}
-        # combine = C > 1: the handle joins a cohort of C handles whose resident calls the library merges (KOSK_COMBINE)
+        # combine = C > 1: the handle joins a cohort of C handles whose resident calls the library merges (KOSK_COMBINE).  The slots
+        # are closed loops that pause between the bench's runs (conditioning, barrier, timed run): members stay "expected" by
+        # their cohort for 20 ms instead of the library's default 1 ms, so that a run's first calls merge like all the others
         env["KOSK_COMBINE"] = str(combine)
+        if combine > 1:
+            env["KOSK_COMBINE_IDLE_US"] = os.environ.get("KOSK_COMBINE_IDLE_US", "20000")
         self.c = _with_env(env, lambda: api.Kosk(kyber_k=k, max_batch=B, device=device))
         self.B, self.nsets = B, nsets
         self.stride = (self.c.tape_bytes + 63) // 64 * 64
@@ -551,11 +555,16 @@ def main():
     W, K = max(0, args.warmup), max(1, args.steps)
     D = S  # untimed drain: the window's last steps finish with the pipeline still full
     total = W + K + D
+    if CMB > 1:
+        # every caller thread makes the same number of calls (steps dealt statically, total a multiple of the slot count): the
+        # cohorts stay complete to the last step instead of breaking up when a shared step counter runs out
+        total = -(-total // S) * S
+        D = total - W - K
     state = {"next": 0, "limit": 0, "err": None}
     lock = threading.Lock()
     done_t = []
     lat = []
-    static = want_gather  # collectives: every rank must run the same steps on the same slot
+    static = want_gather or CMB > 1  # collectives: every rank must run the same steps on the same slot; cohorts: see `total`
 
     def take(si, nth):
         """index of slot si's nth step of this run, or None when the run is over"""
@@ -623,7 +632,7 @@ def main():
     # conditioning (setup, untimed, independent of --warmup/--steps): clocks, runtime and worker threads of a fresh
     # process ramp for a few hundred milliseconds
     t_cond = time.perf_counter()
-    if static:
+    if want_gather:
         for _ in range(3):  # a fixed count: every rank must issue the same collectives
             run(2 * S)
     else:
@@ -641,9 +650,14 @@ def main():
     barrier()
     t_e = time.perf_counter()
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
-    t0 = comp[W - 1] if W > 0 else t_s
-    t1 = comp[W + K - 1]
-    dt = t1 - t0
+    # The timed window is exactly K steps, from the completion of step W to the completion of step W + K.  The members of a
+    # cohort complete together and the cohorts of a run tend to stay in phase, so completions come in bursts of up to S steps:
+    # one window of a few tens of steps lands anywhere between "just before a burst" and "just after one" (+-10 % at the driver's
+    # --steps 20).  The mean over the S adjacent windows W .. W + S - 1 (all of exactly K steps, all inside the run: D >= S steps
+    # follow the first window) takes that alignment out; with hundreds of steps it changes nothing.
+    nwin = max(1, min(S, D))
+    dts = [comp[j + K - 1] - (comp[j - 1] if j > 0 else t_s) for j in range(W, W + nwin)]
+    dt = sum(dts) / len(dts)
     dt_drained = t_e - t_s
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     prof = {}
@@ -713,8 +727,10 @@ def main():
             tfile = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tfile) and k == 3 and B == 46:
                 tj = json.load(open(tfile))
-                if abs(tj.get("hash_view_lanes_per_launch", 0) - lanes_per_launch) < 0.02 * lanes_per_launch:
-                    traffic, tsrc = tj.get("hash_view_hbm_bytes_per_launch"), tj.get("source")
+                per_lane = tj.get("hash_view_hbm_bytes_per_lane")
+                if per_lane:  # PMC bytes of the same kernel at a 138-proof launch (tools/pmc_workload.py), per party lane
+                    traffic = int(round(per_lane * lanes_per_launch))
+                    tsrc = "%s; measured on a %d-lane launch, scaled by lanes to this run's mean launch" % (tj.get("source"), tj.get("hash_view_lanes_per_launch", 0))
             roof = {"kernel": "k_commit_hash_dma (SHA3-256 view commitment, prover; %.1f callers' batches = %.0f party lanes per launch on average)"
                               % (ppl / B, lanes_per_launch),
                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -751,7 +767,8 @@ def main():
                                           "calls of a cohort of %d handles with one pipeline run" % (CMB, S, B, CMB)) if CMB > 1 else "off",
                        "cu_partitions": P_, "tape_sets_per_slot": args.tape_sets,
                        "host_threads_per_slot": os.environ.get("KOSK_HOST_THREADS"), "host_waits": "sleep" if os.environ.get("KOSK_BLOCKING_SYNC") == "1" else "spin",
-                       "timing": "steady-state window: completion of step W to completion of step W+K, slots running continuously"},
+                       "timing": "steady-state window of exactly K steps (completion of step W to completion of step W+K, slots running continuously), "
+                                 "mean over the %d adjacent window positions W..W+%d: completions come in bursts of a cohort's calls" % (nwin, nwin - 1)},
             "drained_run": {"steps": total, "ms_per_step": dt_drained / total * 1e3, "value": world * total * B / dt_drained,
                             "note": "the same run from first issue to last completion, barrier + synchronize on both sides (fill and drain included)"},
             "step_latency_ms": {"median": lats[len(lats) // 2] * 1e3, "p90": lats[int(len(lats) * 0.9)] * 1e3,

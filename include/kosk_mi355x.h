@@ -50,6 +50,10 @@ int kosk_set_randombytes(kosk_ctx *ctx, kosk_randombytes_fn fn, void *user); /* 
  * Error containment (all entry points): no C++ exception and no abort leaves the library -- a failed allocation, thread or
  * HIP call is rc -1 + kosk_last_error(); the only abort is the reference's own, an OS entropy failure
  * (kyber/randombytes.c:49-52).  A batch call creates no threads (kosk_create made them).
+ * HIP error state: the library's launchers read hipGetLastError(), so every entry point first RESETS the calling thread's HIP
+ * last-error state; an application that launches kernels of its own must check them before it calls in here.
+ * Proof buffers in host memory must not be shared between concurrent calls unless the caller page-locked them itself (a
+ * multi-chunk call page-locks the whole pages inside a pageable buffer for its own duration only).
  * gen_matrix's rejection sampling (indcpa.c:124-145) loops without a bound in the reference; on the host this library does the
  * same, on the GPU it squeezes at most 32 SHAKE128 blocks per matrix entry (three suffice with probability 1 - 2^-40) and a
  * call that ever reached that limit returns -1 ("block limit") without results -- for key generation and for the verifier's
@@ -184,7 +188,9 @@ int kosk_stream_timer_stop(kosk_ctx *ctx, double *ms);
 
 /* ---- kernel-level entry points on DEVICE pointers (stream 0 of the ctx) ----
  * Used by the parity tests and by bench.py's roofline leg.  Every stream of the library is a NON-BLOCKING HIP stream: it is not
- * ordered against the legacy null stream (nor against any other stream of the caller).  Device buffers handed to these entry
+ * ordered against the legacy null stream (nor against any other stream of the caller) -- with ONE exception: a handle created
+ * with KOSK_CU_PARTITION=i/n runs on a CU-masked stream, which HIP can only create as a blocking stream (null-stream work of
+ * the application then waits for that handle's kernels and vice versa).  Device buffers handed to these entry
  * points -- and device tapes / keys handed to the resident calls -- must be complete before the call (synchronise the stream
  * that produced them), and kosk_device_synchronize() must have returned before another stream reads the outputs. */
 

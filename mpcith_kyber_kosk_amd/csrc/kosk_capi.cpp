@@ -85,6 +85,11 @@ struct kosk_ctx {
         std::vector<int> rc;
         std::vector<std::string> what;
         lanes.run(jobs, rc, what);
+        if (rc.size() < sub.size() || what.size() < sub.size()) { // no memory even for the bookkeeping: nothing was started
+            err = "out of memory while dealing a batch call to the handle's lanes";
+            c->err = err;
+            return -1;
+        }
         for (int i = 0; i < (int)sub.size(); i++)
             if (rc[i]) {
                 if (rc[i] == -2) sub[i]->err = "exception in a batch job: " + what[i];
@@ -113,7 +118,9 @@ static int guard(kosk_ctx *ctx, const char *fn, F &&body) noexcept
 {
     try {
         // a stale per-thread HIP error (an earlier failed call of ours, or of the host application) must not be taken for
-        // the result of this call's first kernel launch
+        // the result of this call's first kernel launch: the launchers report hipGetLastError().  Documented in the header:
+        // every entry point RESETS the calling thread's HIP last-error state, so the application has to look at the outcome of
+        // its own launches before it calls in here
         (void)hipGetLastError();
         return body();
     } catch (const std::exception &e) {
@@ -213,7 +220,11 @@ static bool span_is_pinned(const void *p, size_t bytes)
         (void)hipGetLastError(); // plain pageable memory: not an error
         return false;
     }
-    return a0.type == hipMemoryTypeHost && a1.type == hipMemoryTypeHost;
+    if (a0.type != hipMemoryTypeHost || a1.type != hipMemoryTypeHost) return false;
+    // both ends page-locked is not enough: they must belong to ONE mapping (two registrations with a pageable gap between them,
+    // or a neighbour's registration that ends inside the buffer, give unrelated device addresses)
+    if (!a0.devicePointer || !a1.devicePointer) return false;
+    return static_cast<const uint8_t *>(a1.devicePointer) - static_cast<const uint8_t *>(a0.devicePointer) == (ptrdiff_t)(bytes - 1);
 }
 
 // draw n proofs' worth of randomness through the (stateful) callback / OS entropy, sequentially in proof order and in the

@@ -392,12 +392,14 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
             int mine = 0;
             for (int bit = 0; bit < cus; bit++) {
                 // bit -> (XCD, CU inside it): layout 0 deals consecutive bits round the XCDs (how workgroups are dealt),
-                // layout 1 numbers the CUs XCD after XCD (KOSK_CU_MASK_LAYOUT; which one the driver uses is measured by
-                // tools/cu_mask_probe.py)
+                // layout 1 numbers the CUs XCD after XCD (KOSK_CU_MASK_LAYOUT; round 3 measured the round-robin one to be the
+                // one that maps to whole XCDs on this driver: profiles/r03_partition_sweep.txt)
                 const int xcd = c.cu_mask_layout ? bit / per_xcd : bit % nx, idx = c.cu_mask_layout ? bit % per_xcd : bit / nx;
                 const int ordered = xcd * per_xcd + idx;
                 if ((long)ordered * c.cu_part_n / cus == c.cu_part_i) { mask[(size_t)bit >> 5] |= 1u << (bit & 31); mine++; }
             }
+            // NOTE: hipExtStreamCreateWithCUMask takes no flags: this stream is a BLOCKING stream (ordered against the legacy null
+            // stream), unlike every other stream of the library -- documented with the knob
             HIPCHK(hipExtStreamCreateWithCUMask(&c.stream, (uint32_t)mask.size(), mask.data()));
             c.n_simd = 4 * mine;
         } else {

@@ -282,7 +282,16 @@ int run_segment(Ctx &c, int seg, int n, F &&body, const void *key_ptr = nullptr,
         hipError_t e = hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal);
         if (e != hipSuccess) { c.err = std::string("hipStreamBeginCapture: ") + hipGetErrorString(e); return -1; }
         c.capturing = true;
-        const int rc = body();
+        int rc;
+        try {
+            rc = body();
+        } catch (...) { // never leave the stream in capture mode (the handle would be unusable afterwards)
+            c.capturing = false;
+            hipGraph_t dead = nullptr;
+            (void)hipStreamEndCapture(c.stream, &dead);
+            if (dead) (void)hipGraphDestroy(dead);
+            throw;
+        }
         c.capturing = false;
         hipGraph_t graph = nullptr;
         e = hipStreamEndCapture(c.stream, &graph);

@@ -610,8 +610,20 @@ __device__ __forceinline__ void ntt_split(const NttArgs &a, int p, int &g, int &
 // A tile = up to 16 polynomials p0 .. p0+15, one 256-thread workgroup.  Its input as two 16-byte pieces per thread: loaded into
 // registers (ntt256_fetch), later written to the LDS staging image (ntt256_stage) -- apart, so that a workgroup that walks
 // several tiles has the NEXT tile's loads in flight while it transforms the current one.
+// PLAIN: the polynomials lie back to back in both buffers (no groups, no offset tables, no compare mode): polynomial p at p * 256
+template <bool PLAIN>
 __device__ __forceinline__ void ntt256_fetch(const NttArgs &a, const int p0, uint4 (&x)[2])
 {
+    if constexpr (PLAIN) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.in) + (size_t)p0 * 32 + threadIdx.x;
+        const int left = (a.npoly - p0) * 32; // 16-byte pieces of this tile that exist
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            x[q] = make_uint4(0, 0, 0, 0);
+            if ((int)threadIdx.x + q * 256 < left) x[q] = src[q * 256];
+        }
+        return;
+    }
     int g0, i0;
     ntt_split(a, p0 + ((int)threadIdx.x >> 5), g0, i0);
 #pragma unroll
@@ -639,19 +651,21 @@ __device__ __forceinline__ void ntt256_stage(const uint4 (&x)[2], int16_t *__res
         *reinterpret_cast<uint4 *>(lds + (c >> 5) * NTT_LSTRIDE + (c & 31) * 8) = x[q];
     }
 }
+template <bool PLAIN>
 __device__ __forceinline__ void ntt256_transform(const NttArgs &a, const int p0, int16_t *__restrict__ lds);
 
 // one tile by a 256-thread workgroup (all threads must call it)
 __device__ __forceinline__ void ntt256_tile(const NttArgs &a, const int p0, int16_t *__restrict__ lds)
 {
     uint4 x[2];
-    ntt256_fetch(a, p0, x);
+    ntt256_fetch<false>(a, p0, x);
     ntt256_stage(x, lds);
     __syncthreads();
-    ntt256_transform(a, p0, lds);
+    ntt256_transform<false>(a, p0, lds);
 }
 
 // the staged tile (every thread's ntt256_stage done, barrier passed) -> transformed polynomials in global memory
+template <bool PLAIN>
 __device__ __forceinline__ void ntt256_transform(const NttArgs &a, const int p0, int16_t *__restrict__ lds)
 {
     const int tid = threadIdx.x;
@@ -661,7 +675,7 @@ __device__ __forceinline__ void ntt256_transform(const NttArgs &a, const int p0,
 #pragma unroll
     for (int i = 0; i < 16; i++) r[i] = mine[l + 16 * i];
 
-#define KOSK_BFLYZ(lo, hi, k) ntt_bfly_s((lo), (hi), (int32_t)kZetasDot.zq[(k)], (int32_t)kZetasDot.zz[(k)])
+#define KOSK_BFLYZ(lo, hi, k) ntt_bfly_s((lo), (hi), (int32_t)kZetasDot.e[(k)].zq, (int32_t)kZetasDot.e[(k)].zz)
     // coefficient index j = l + 16 i : len = 128, 64, 32, 16 <-> register distance 8, 4, 2, 1
 #pragma unroll
     for (int i = 0; i < 8; i++) KOSK_BFLYZ(r[i], r[i + 8], 1);
@@ -694,11 +708,12 @@ __device__ __forceinline__ void ntt256_transform(const NttArgs &a, const int p0,
 #undef KOSK_BFLYZ
 #define KOSK_BFLYZ(lo, hi, zq_, zz_) ntt_bfly((lo), (hi), (zq_), (zz_))
     {
-        const int32_t q8 = (int32_t)kZetasDot.zq[16 + l], z8 = (int32_t)kZetasDot.zz[16 + l];
+        const ZetaTableDot::Pair e8 = kZetasDot.e[16 + l];
+        const int32_t q8 = (int32_t)e8.zq, z8 = (int32_t)e8.zz;
 #pragma unroll
         for (int c = 0; c < 8; c++) KOSK_BFLYZ(r[c], r[c + 8], q8, z8);
-        const int32_t q4a = (int32_t)kZetasDot.zq[32 + 2 * l], z4a = (int32_t)kZetasDot.zz[32 + 2 * l];
-        const int32_t q4b = (int32_t)kZetasDot.zq[33 + 2 * l], z4b = (int32_t)kZetasDot.zz[33 + 2 * l];
+        const ZetaTableDot::Pair e4a = kZetasDot.e[32 + 2 * l], e4b = kZetasDot.e[33 + 2 * l]; // neighbours: one 16-byte load
+        const int32_t q4a = (int32_t)e4a.zq, z4a = (int32_t)e4a.zz, q4b = (int32_t)e4b.zq, z4b = (int32_t)e4b.zz;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             KOSK_BFLYZ(r[c], r[c + 4], q4a, z4a);
@@ -706,7 +721,8 @@ __device__ __forceinline__ void ntt256_transform(const NttArgs &a, const int p0,
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int32_t q2 = (int32_t)kZetasDot.zq[64 + 4 * l + q], z2 = (int32_t)kZetasDot.zz[64 + 4 * l + q];
+            const ZetaTableDot::Pair e2 = kZetasDot.e[64 + 4 * l + q];
+            const int32_t q2 = (int32_t)e2.zq, z2 = (int32_t)e2.zz;
             KOSK_BFLYZ(r[4 * q], r[4 * q + 2], q2, z2);
             KOSK_BFLYZ(r[4 * q + 1], r[4 * q + 3], q2, z2);
         }
@@ -742,6 +758,12 @@ __device__ __forceinline__ void ntt256_transform(const NttArgs &a, const int p0,
             }
             w[q] = c;
         }
+        if constexpr (PLAIN) {
+            uint4 *o = reinterpret_cast<uint4 *>(a.out) + (size_t)p * 32 + 2 * l;
+            o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+            return;
+        }
         int g, i;
         ntt_split(a, p, g, i);
         const size_t off = (size_t)g * a.out_gstride + (a.dst_off ? (size_t)a.dst_off[i] : (size_t)i * 256);
@@ -760,14 +782,15 @@ __device__ __forceinline__ void ntt256_transform(const NttArgs &a, const int p0,
 // One tile per workgroup.  (Measured in round 4, tools/ntt_time.py: a workgroup that walks several tiles with the next tile's
 // loads in flight during the transform is no faster -- 22.5 against 21.9 us at 65 536 polynomials -- because the kernel is bound by
 // instruction issue, not by exposed memory latency: without its butterflies it takes 14.4 us, a plain copy of the same bytes 10.4 us.)
+template <bool PLAIN>
 __global__ __launch_bounds__(256) void k_ntt256(NttArgs a)
 {
     __shared__ __attribute__((aligned(16))) int16_t lds[NTT_PPB * NTT_LSTRIDE];
     uint4 x[2];
-    ntt256_fetch(a, blockIdx.x * NTT_PPB, x);
+    ntt256_fetch<PLAIN>(a, blockIdx.x * NTT_PPB, x);
     ntt256_stage(x, lds);
     lds_barrier();
-    ntt256_transform(a, blockIdx.x * NTT_PPB, lds);
+    ntt256_transform<PLAIN>(a, blockIdx.x * NTT_PPB, lds);
 }
 
 // ---- K5, packed-fp32 variant (opt-in: KOSK_NTT_FP32=1) ---------------------------------------------------------
@@ -1182,14 +1205,17 @@ __global__ __launch_bounds__(256) void k_gemm_modq(GemmArgs a)
 // prologue only; with the table split over several workgroups per row block (msplit) another workgroup may already be
 // writing points 384..447 of the same rows -- points < 407 are rewritten with their own values (identity rows of the
 // table) and points >= 407 meet zero table columns, so any value read there is harmless.
-constexpr int TG_NB = 48, TG_WAVES = 8;
+constexpr int TG_WAVES = 8;
+// NBT = data row tiles (of 16) per workgroup: 3 (48 rows, 42 KiB of LDS at 7 k-steps) or 4 (64 rows, 56 KiB).  One workgroup is
+// resident per CU (172+ VGPRs x 8 waves), so a launch takes ceil(row blocks / CUs) rounds of NBT units each: the launcher picks
+// the NBT with the smaller product -- 29 946 rows (138 proofs): 624 blocks of 48 = 3 rounds x 3, 468 blocks of 64 = 2 rounds x 4.
 
 // TG_RT = table row tiles (of 16) per chunk
-template <int KS, int TG_RT>
-__global__ __launch_bounds__(512, KS <= 7 ? 2 : 1) void k_table_gemm(GemmArgs a, int nchunks, int chunks_per_block, int nblk, int msplit)
+template <int KS, int TG_RT, int NBT>
+__global__ __launch_bounds__(512, (KS <= 7 && NBT == 3) ? 2 : 1) void k_table_gemm(GemmArgs a, int nchunks, int chunks_per_block, int nblk, int msplit)
 {
-    constexpr int TG_CHUNK = 16 * TG_RT;
-    __shared__ __attribute__((aligned(16))) uint8_t ldsB[KS * 3 * 2048]; // [k-step][row tile][limb][1 KiB]
+    constexpr int TG_CHUNK = 16 * TG_RT, TG_NB = 16 * NBT;
+    __shared__ __attribute__((aligned(16))) uint8_t ldsB[KS * NBT * 2048]; // [k-step][row tile][limb][1 KiB]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ntot = a.npg * a.ngroups;
     // one-dimensional grid in XCD-aware order: the msplit workgroups that share a row block (each converts the same 48 rows) get
@@ -1225,7 +1251,7 @@ __global__ __launch_bounds__(512, KS <= 7 ? 2 : 1) void k_table_gemm(GemmArgs a,
             const int row_l = item / (KS * 4), kc16 = item - row_l * (KS * 4);
             uint4 lo, hi;
             gm_split16(x0[q], x1[q], lo, hi);
-            uint8_t *d = ldsB + ((kc16 >> 2) * 3 + (row_l >> 4)) * 2048 + (row_l & 15) * 64 + (((kc16 & 3) ^ limb_swz(row_l & 15)) << 4);
+            uint8_t *d = ldsB + ((kc16 >> 2) * NBT + (row_l >> 4)) * 2048 + (row_l & 15) * 64 + (((kc16 & 3) ^ limb_swz(row_l & 15)) << 4);
             *reinterpret_cast<uint4 *>(d) = lo;
             *reinterpret_cast<uint4 *>(d + 1024) = hi;
         }
@@ -1253,10 +1279,10 @@ __global__ __launch_bounds__(512, KS <= 7 ? 2 : 1) void k_table_gemm(GemmArgs a,
     __syncthreads(); // the only workgroup barrier: from here on the waves run independently
     if (nmy == 0) return;
 
-    // output rows of this lane's three columns (n = n0 + 16 j + (lane & 15))
-    uint16_t *crow[3];
+    // output rows of this lane's NBT columns (n = n0 + 16 j + (lane & 15))
+    uint16_t *crow[NBT];
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
+    for (int j = 0; j < NBT; j++) {
         const int n = n0 + j * 16 + (lane & 15);
         crow[j] = nullptr;
         if (n < ntot) {
@@ -1265,16 +1291,16 @@ __global__ __launch_bounds__(512, KS <= 7 ? 2 : 1) void k_table_gemm(GemmArgs a,
         }
     }
 
-    v4i s0[TG_RT][3], s1[TG_RT][3], s2[TG_RT][3];
+    v4i s0[TG_RT][NBT], s1[TG_RT][NBT], s2[TG_RT][NBT];
     const v4i zero4 = {0, 0, 0, 0};
 
     // the data fragments of the next k-step are read from LDS while the current k-step multiplies; the rows are the same
     // for every chunk, so the last k-step prefetches k-step 0 again (into a buffer of its own: KS is odd)
-    v4i fb[2][6], fb0[6];
-    auto load_b = [&](int ks, v4i (&dst)[6]) {
-        const uint8_t *lb = ldsB + ks * 3 * 2048 + frag;
+    v4i fb[2][2 * NBT], fb0[2 * NBT];
+    auto load_b = [&](int ks, v4i (&dst)[2 * NBT]) {
+        const uint8_t *lb = ldsB + ks * NBT * 2048 + frag;
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
+        for (int j = 0; j < NBT; j++) {
             dst[2 * j] = *reinterpret_cast<const v4i *>(lb + j * 2048);
             dst[2 * j + 1] = *reinterpret_cast<const v4i *>(lb + j * 2048 + 1024);
         }
@@ -1285,8 +1311,8 @@ __global__ __launch_bounds__(512, KS <= 7 ? 2 : 1) void k_table_gemm(GemmArgs a,
         const int cn = ci + 1 < nmy ? c + TG_WAVES : c; // the chunk to prefetch (the last one re-loads itself: harmless)
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
-            v4i(&bc)[6] = ks == 0 ? fb0 : fb[ks & 1];
-            v4i(&bn)[6] = ks + 1 == KS ? fb0 : fb[(ks & 1) ^ 1];
+            v4i(&bc)[2 * NBT] = ks == 0 ? fb0 : fb[ks & 1];
+            v4i(&bn)[2 * NBT] = ks + 1 == KS ? fb0 : fb[(ks & 1) ^ 1];
             load_b(ks + 1 < KS ? ks + 1 : 0, bn);
             __builtin_amdgcn_sched_barrier(0); // the reads for the NEXT k-step go out before this k-step's MFMAs, not after them
             // four limb products per 16 x 16 x 64 block, ordered so that no accumulator is used twice in a row; the first
@@ -1294,13 +1320,13 @@ __global__ __launch_bounds__(512, KS <= 7 ? 2 : 1) void k_table_gemm(GemmArgs a,
 #pragma unroll
             for (int i = 0; i < TG_RT; i++) {
 #pragma unroll
-                for (int j = 0; j < 3; j++) s0[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i], bc[2 * j], ks == 0 ? zero4 : s0[i][j], 0, 0, 0);
+                for (int j = 0; j < NBT; j++) s0[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i], bc[2 * j], ks == 0 ? zero4 : s0[i][j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 3; j++) s1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i], bc[2 * j + 1], ks == 0 ? zero4 : s1[i][j], 0, 0, 0);
+                for (int j = 0; j < NBT; j++) s1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i], bc[2 * j + 1], ks == 0 ? zero4 : s1[i][j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 3; j++) s1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i + 1], bc[2 * j], s1[i][j], 0, 0, 0);
+                for (int j = 0; j < NBT; j++) s1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i + 1], bc[2 * j], s1[i][j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 3; j++) s2[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i + 1], bc[2 * j + 1], ks == 0 ? zero4 : s2[i][j], 0, 0, 0);
+                for (int j = 0; j < NBT; j++) s2[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][2 * i + 1], bc[2 * j + 1], ks == 0 ? zero4 : s2[i][j], 0, 0, 0);
             }
             load_chunk_ks(cn, ks, fa[ks]); // in flight for a whole chunk of arithmetic before it is used
             __builtin_amdgcn_sched_barrier(0); // keep the k-steps apart: hoisting every LDS read of the chunk costs 150 VGPRs
@@ -1309,7 +1335,7 @@ __global__ __launch_bounds__(512, KS <= 7 ? 2 : 1) void k_table_gemm(GemmArgs a,
         // store per block.  |S0 + 64 S1 + 767 S2| < 2^29 for k <= 448, so adding 90 000 q makes it a positive u32.
         // (Few VALU instructions on purpose: an MFMA leaves the SIMD's vector issue free only half of the time.)
 #pragma unroll
-        for (int j = 0; j < 3; j++)
+        for (int j = 0; j < NBT; j++)
 #pragma unroll
             for (int i = 0; i < TG_RT; i++) {
                 uint32_t v[4];
@@ -1889,7 +1915,14 @@ hipError_t launch_ntt(const NttArgs &args, hipStream_t st)
     NttArgs a = args;
     a.npg_magic = ntt_npg_magic(a.npg);
     if (a.fp32) hipLaunchKernelGGL(k_ntt256_fp32, dim3((a.npoly + NTT_PPB - 1) / NTT_PPB), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_ntt256, dim3((a.npoly + NTT_PPB - 1) / NTT_PPB), dim3(256), 0, st, a);
+    else {
+        // polynomials back to back in both buffers (kosk_ntt256_batch; the verifier's 140 x n secrets): no group / offset arithmetic
+        const bool plain = !a.src_off && !a.dst_off && !a.cmp_fail && (a.npg >= a.npoly || (a.in_gstride == (size_t)a.npg * 256 && a.out_gstride == (size_t)a.npg * 256)) &&
+                           (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
+        const dim3 grid((a.npoly + NTT_PPB - 1) / NTT_PPB);
+        if (plain) hipLaunchKernelGGL(k_ntt256<true>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_ntt256<false>, grid, dim3(256), 0, st, a);
+    }
     return hipGetLastError();
 }
 
@@ -1931,7 +1964,20 @@ hipError_t launch_table_gemm(const GemmArgs &a, uint16_t *sink, hipStream_t st)
 {
     const int ntot = a.npg * a.ngroups;
     if (ntot <= 0) return hipSuccess;
-    const int nchunks = a.M / 16, nblk = (ntot + TG_NB - 1) / TG_NB;
+    // rows per workgroup: 48, or 64 where that needs fewer round-units on the chip's CUs (see k_table_gemm); 13 k-steps: 48 only
+    // (64 rows of 13 k-steps are 104 KiB of LDS and too many registers)
+    static const int ncu = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+        return cus;
+    }();
+    const int nblk3 = (ntot + 47) / 48, nblk4 = (ntot + 63) / 64;
+    // KOSK_TG_WIDE=1 (process-wide experiment knob) turns the 64-row variant on.  Alone it should take 8 instead of 9 round-units at
+    // 29 946 rows; inside the three-cohort pipeline it changes nothing measurable (gemm_expand1 128-133 us with, 130-138 us
+    // without; 132-135 k against 133-137 k proofs/s, profiles/r04_sweeps.txt): default off
+    static const bool wide_ok = getenv("KOSK_TG_WIDE") && atoi(getenv("KOSK_TG_WIDE")) != 0;
+    const bool wide = wide_ok && a.KS == 7 && nblk3 >= 160 && ((nblk4 + ncu - 1) / ncu) * 4 < ((nblk3 + ncu - 1) / ncu) * 3;
+    const int nchunks = a.M / 16, nblk = wide ? nblk4 : nblk3;
     // few data rows: split the table over several workgroups per row block so that the launch still covers the chip
     int msplit = nblk >= 160 ? 1 : (256 + nblk - 1) / nblk;
     if (msplit > nchunks) msplit = nchunks;
@@ -1939,8 +1985,9 @@ hipError_t launch_table_gemm(const GemmArgs &a, uint16_t *sink, hipStream_t st)
     msplit = (nchunks + cpb - 1) / cpb;
     (void)sink;
     const dim3 grid((unsigned)((nblk * msplit + 7) / 8 * 8));
-    if (a.KS == 7) hipLaunchKernelGGL((k_table_gemm<7, 1>), grid, dim3(512), 0, st, a, nchunks, cpb, nblk, msplit);
-    else hipLaunchKernelGGL((k_table_gemm<13, 1>), grid, dim3(512), 0, st, a, nchunks, cpb, nblk, msplit);
+    if (a.KS == 7 && wide) hipLaunchKernelGGL((k_table_gemm<7, 1, 4>), grid, dim3(512), 0, st, a, nchunks, cpb, nblk, msplit);
+    else if (a.KS == 7) hipLaunchKernelGGL((k_table_gemm<7, 1, 3>), grid, dim3(512), 0, st, a, nchunks, cpb, nblk, msplit);
+    else hipLaunchKernelGGL((k_table_gemm<13, 1, 3>), grid, dim3(512), 0, st, a, nchunks, cpb, nblk, msplit);
     return hipGetLastError();
 }
 

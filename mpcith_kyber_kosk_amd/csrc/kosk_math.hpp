@@ -60,13 +60,14 @@ static constexpr ZetaTable kZetas{};
 //   zq[k] = z[k] * q^-1 mod 2^16 -- m = lo16(a * zq) is the Montgomery factor (int16)(a z QINV) of reduce.c:19 --
 //   zz[k] = { lo16: z[k], hi16: -q } -- one v_dot2_i32_i16 of {a, m} with it is a z - m q, whose high half is fqmul(a, z).
 struct ZetaTableDot {
-    uint32_t zq[128], zz[128];
-    constexpr ZetaTableDot() : zq(), zz()
+    struct alignas(8) Pair { uint32_t zq, zz; }; // one 8-byte load per zeta
+    Pair e[128];
+    constexpr ZetaTableDot() : e()
     {
         const ZetaTable t{};
         for (int i = 0; i < 128; i++) {
-            zq[i] = (uint32_t)((int32_t)t.z[i] * QINV) & 0xFFFFu;
-            zz[i] = ((uint32_t)(uint16_t)t.z[i]) | ((uint32_t)(uint16_t)(-Q) << 16);
+            e[i].zq = (uint32_t)((int32_t)t.z[i] * QINV) & 0xFFFFu;
+            e[i].zz = ((uint32_t)(uint16_t)t.z[i]) | ((uint32_t)(uint16_t)(-Q) << 16);
         }
     }
 };
