@@ -504,7 +504,9 @@ def main():
         usable_cores = os.cpu_count() or 1
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
     threads, blocking = host_budget(usable_cores, local_world, -(-S // CMB), cfg["threads"] * CMB)
-    threads = max(3, threads // CMB)  # per handle; a merged run uses the threads of all its members
+    threads = max(3, threads // CMB)  # per handle; a merged run led by a cohort's first member uses CMB times as many
+    if blocking and CMB > 1:
+        threads = min(threads, 4)  # few cores per rank (an 8-GPU node): 12 + 4 + 4 host workers per cohort of three
     if blocking:
         os.environ.setdefault("KOSK_BLOCKING_SYNC", "1")
     os.environ.setdefault("KOSK_HOST_THREADS", str(threads))

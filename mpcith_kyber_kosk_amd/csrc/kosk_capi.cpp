@@ -311,8 +311,10 @@ int kosk_create(kosk_ctx **ctx, int device, int kyber_k, int max_batch)
                 g_cohorts.push_back(co);
             }
             Ctx *v = nullptr;
-            // a run led by member idx serves at most the members idx .. W - 1: that many callers' worth of host workers
-            if (ctx_make_view(*co->arena, idx * max_batch, max_batch, co->arena->base_threads * (W - idx), &v, g_create_err)) {
+            // Host workers: a full run is led by member 0 and hashes W callers' tables, so member 0 gets W callers' worth; the
+            // other members only ever lead partial runs (start-up, stragglers) and make do with one caller's worth -- a
+            // process with many cohorts (one per rank on an 8-GPU node) stays far below any thread limit
+            if (ctx_make_view(*co->arena, idx * max_batch, max_batch, co->arena->base_threads * (idx == 0 ? W : 1), &v, g_create_err)) {
                 if (co->comb->leave(idx) == 0) {
                     delete co->arena;
                     g_cohorts.erase(std::remove(g_cohorts.begin(), g_cohorts.end(), co), g_cohorts.end());
@@ -471,7 +473,7 @@ static int combined_keygen(kosk_ctx *h, int n, const KeygenCall &call)
             segs[k] = KeygenIn{a->tapes, a->tape_stride, a->pk, a->sk, reqs[k]->n, k + 1 < count ? &segs[k + 1] : nullptr};
             total += reqs[k]->n;
         }
-        c.nthreads = c.base_threads * count; // reserved when the view was made
+        c.nthreads = std::min(c.base_threads * count, c.reserved_threads); // a call never creates threads
         const int rc = prove_resident(c, total, false, &segs[0]);
         c.nthreads = c.base_threads;
         for (int k = 0; k < count; k++) {
@@ -517,7 +519,7 @@ static int combined_verify(kosk_ctx *h, int n, const VerifyCall &call)
         }
         const int keep = c.resident_pk_n;
         if (!given) c.resident_pk_n = total; // every member checked its own keys before it posted
-        c.nthreads = c.base_threads * count;
+        c.nthreads = std::min(c.base_threads * count, c.reserved_threads);
         const int rc = verify_resident(c, total, nullptr, given ? 1 : 2, nullptr, &segs[0]);
         c.nthreads = c.base_threads;
         if (!given) c.resident_pk_n = keep;

@@ -164,6 +164,15 @@ int device_error_check(Ctx &c)
     return -1;
 }
 
+hipError_t copy_table_to_host(Ctx &c, void *h_dst, const void *d_src, size_t bytes)
+{
+    if (c.copy_waves > 0 && bytes >= ((size_t)1 << 16) && bytes % 16 == 0) {
+        if (!c.capturing) c.path_n[PATH_COPY_KERNEL]++;
+        return launch_copy_to_host(d_src, h_dst, bytes, c.copy_waves, c.stream);
+    }
+    return hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c.stream);
+}
+
 hipError_t stream_sync(Ctx &c)
 {
     if (!c.blocking_sync) return hipStreamSynchronize(c.stream);
@@ -352,6 +361,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     c.pool = pool_create();
     c.nthreads = pool_reserve(c.pool, c.nthreads);
     c.base_threads = c.nthreads;
+    c.reserved_threads = c.nthreads;
     c.own_batch = max_batch;
     if (const char *e = getenv("KOSK_GRAPHS")) c.use_graphs = atoi(e) != 0;
     if (const char *e = getenv("KOSK_LINCOMB_FUSED")) c.lincomb_fused = atoi(e) != 0;
@@ -363,6 +373,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     if (const char *e = getenv("KOSK_TABLE_GEMM")) c.table_gemm = atoi(e) != 0;
     if (const char *e = getenv("KOSK_REGISTER")) c.host_register = atoi(e) != 0;
     if (const char *e = getenv("KOSK_DIGEST_DIRECT")) c.digest_direct = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_COPY_WAVES")) c.copy_waves = atoi(e) >= 0 ? (atoi(e) > 65535 ? 65535 : atoi(e)) : c.copy_waves;
     if (const char *e = getenv("KOSK_DEBUG_XOF_BLOCKS")) c.xof_max_blocks = atoi(e) > 0 ? atoi(e) : c.xof_max_blocks;
     if (const char *e = getenv("KOSK_CU_PARTITION")) {
         int i = 0, n = 0;
@@ -531,6 +542,7 @@ int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx
     c.pool = pool_create();
     c.base_threads = arena.base_threads;
     const int got = pool_reserve(c.pool, reserve_threads > c.base_threads ? reserve_threads : c.base_threads);
+    c.reserved_threads = got;
     c.nthreads = got < c.base_threads ? got : c.base_threads;
     *out = vp;
     return 0;
@@ -770,7 +782,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         // the host's table: written by the hash launch itself (HashArgs::out_host), or copied behind it
         h1.out_host = c.digest_direct ? c.h_dig : nullptr;
         HIPCHK(commit_hash_batch(c, h1, n, K, false, st));
-        if (!c.digest_direct) HIPCHK(hipMemcpyAsync(c.h_dig, c.d_dig1, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
+        if (!c.digest_direct) HIPCHK(copy_table_to_host(c, c.h_dig, c.d_dig1, (size_t)n * NPARTY * 32));
         if (!c.capturing) c.path_n[c.digest_direct ? PATH_DIGEST_DIRECT : PATH_DIGEST_COPY]++;
         return 0;
     }, c.tape_cur, c.tape_cur_stride)) return -1; // the tape pointer is baked into the captured launch: part of the graph's key
@@ -820,7 +832,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     ha.out = c.d_dig2;
     ha.out_host = c.digest_direct ? c.h_dig2 : nullptr;
     HIPCHK(commit_hash_batch(c, ha, n, K, true, st));
-    if (!c.digest_direct) HIPCHK(hipMemcpyAsync(c.h_dig2, c.d_dig2, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, st));
+    if (!c.digest_direct) HIPCHK(copy_table_to_host(c, c.h_dig2, c.d_dig2, (size_t)n * NPARTY * 32));
     c.path_n[c.digest_direct ? PATH_DIGEST_DIRECT : PATH_DIGEST_COPY]++;
     HIPCHK(hipEventRecord(c.ev, st));
     c.phase_sec[PH_P2_ISSUE] = now_sec() - t0;

@@ -61,7 +61,7 @@ enum ProfId { PR_HASH_TCOMM = 0, PR_HASH_VIEW, PR_GEMM_EXPAND1, PR_GEMM_EXPAND2,
               PR_V_LINCOMB, PR_HASH_TCOMM_TAIL, PR_HASH_VIEW_TAIL, PR_COUNT };
 
 enum PathId { PATH_HASH_DMA = 0, PATH_HASH_PLAIN, PATH_HASH_PRIMER, PATH_TABLE_GEMM, PATH_LIMB_GEMM, PATH_COPY_DIRECT, PATH_COPY_STAGED,
-              PATH_GRAPH_REPLAY, PATH_NTT_FP32, PATH_NTT_INT, PATH_DIGEST_DIRECT, PATH_DIGEST_COPY, PATH_COUNT };
+              PATH_GRAPH_REPLAY, PATH_NTT_FP32, PATH_NTT_INT, PATH_DIGEST_DIRECT, PATH_DIGEST_COPY, PATH_COPY_KERNEL, PATH_COUNT };
 
 struct GemmTable {
     uint8_t *d = nullptr; // limb matrix (kosk_device.hpp)
@@ -116,6 +116,7 @@ struct Ctx {
     int view_first = 0;
     int own_batch = 0;   // proofs of this context's own callers (a view: its member's kosk_create size; else max_batch)
     int base_threads = 1; // host threads of a call of own_batch proofs (a merged run uses base_threads x members)
+    int reserved_threads = 1; // workers the pool was created with (a call never creates threads: nthreads <= this)
     int nthreads = 1;
     Pool *pool = nullptr; // this context's host worker threads
     hipStream_t stream = nullptr;
@@ -245,6 +246,9 @@ struct Ctx {
     // KOSK_DIGEST_DIRECT=1: the prover's commitment launches also store every digest into the host's page-locked table (no copy
     // behind the launch).  Measured slower with merged runs, neutral without (profiles/r04_digest_direct.txt): default off
     bool digest_direct = false;
+    // KOSK_COPY_WAVES=n (default 512; 0 = the runtime's hipMemcpyAsync): the digest tables go to the host through k_copy_to_host
+    // with n one-wave workgroups instead of the runtime's one-element-per-thread blit kernel
+    int copy_waves = 512;
     bool host_register = true; // KOSK_REGISTER=0: multi-chunk host-buffer calls never page-lock caller memory (staging copies only)
     int cu_part_i = 0, cu_part_n = 1; // KOSK_CU_PARTITION=i/n: the stream is restricted to partition i of n CU partitions
     int cu_mask_layout = 0;           // KOSK_CU_MASK_LAYOUT: how CU-mask bits map to XCDs (0 round-robin, 1 XCD-major)
@@ -322,6 +326,8 @@ int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx
 // C[g][rows_d[i]][off + m] = sum_k A[m][k] * src[g][rows_s[i]][koff + k] mod q  (conversion to limbs + MFMA GEMM)
 // host wait for everything queued on the context's stream (spinning, or sleeping with KOSK_BLOCKING_SYNC=1)
 hipError_t stream_sync(Ctx &c);
+// a digest table (or any 16-byte aligned block) from HBM into the context's page-locked host memory, on the context's stream
+hipError_t copy_table_to_host(Ctx &c, void *h_dst, const void *d_src, size_t bytes);
 // after the stream has been synchronised: -1 (with c.err set, the word cleared) if a kernel of this context raised an error
 int device_error_check(Ctx &c);
 // proofs of an n-proof batch that the FIRST of the two commitment-hash launches takes (n: a single launch)

@@ -265,6 +265,8 @@ hipError_t launch_sha3_msgs(const uint8_t *in, size_t in_stride, int len, uint8_
 // the same on the lane-pair sponge (32 messages per wave; kosk_keccak_split_dev.hpp)
 hipError_t launch_sha3_msgs_pair(const uint8_t *in, size_t in_stride, int len, uint8_t *out, size_t out_stride, int outlen, int n,
                                  int domain, hipStream_t st);
+// HBM -> page-locked host memory with nwg one-wave workgroups (k_copy_to_host); bytes, both pointers: multiples of 16
+hipError_t launch_copy_to_host(const void *d_src, void *h_dst, size_t bytes, int nwg, hipStream_t st);
 hipError_t launch_rows_copy(const uint16_t *src, size_t src_stride, uint16_t *dst, size_t dst_stride, int count,
                             int nrows, hipStream_t st);
 // expand_f + tape randoms + witness secrets (the kernels that only read the tape / the key) in one launch

@@ -1781,6 +1781,25 @@ __global__ __launch_bounds__(64) void k_assemble_fields(AssembleArgs a, uint32_t
     if (lane == 1 && head + 2 * body < n16) out[n16 - 1] = tile[n16 - 1];
 }
 
+// Device-to-host copy of a digest table with FEW waves.  The runtime's own copy (hipMemcpyAsync into page-locked memory) is a
+// blit kernel with one 16-byte element per thread on this pool (no SDMA, profiles/r04_sdma_probe.txt): 6 144 waves for the 6.4 MB
+// of a 138-proof round, parked on PCIe stores for 112 us -- three quarters of the chip's wave slots, while the kernels of the other
+// cohorts want them.  Here one wave per workgroup walks the table in 1 KiB pieces with eight pieces in flight: the link needs
+// ~120 KB in flight (57 GB/s x 2 us), 512 waves x 8 KiB have it 30 times over, and 7 of 8 wave slots stay free.
+__global__ __launch_bounds__(64) void k_copy_to_host(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * 64;
+    size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    for (; i + 7 * stride < n16; i += 8 * stride) {
+        uint4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = src[i + q * stride];
+#pragma unroll
+        for (int q = 0; q < 8; q++) dst[i + q * stride] = v[q];
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+
 // plain strided row copy (kernel-level ABI helpers): dst[r][0..count) = src[r][0..count)
 __global__ __launch_bounds__(256) void k_rows_copy(const uint16_t *__restrict__ src, size_t src_stride,
                                                   uint16_t *__restrict__ dst, size_t dst_stride, int count)
@@ -1849,6 +1868,14 @@ hipError_t launch_sha3_msgs_pair(const uint8_t *in, size_t in_stride, int len, u
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_sha3_msgs_pair, dim3((n + 31) / 32), dim3(64), 0, st, in, in_stride, len, out, out_stride, outlen, n, domain);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_to_host(const void *d_src, void *h_dst, size_t bytes, int nwg, hipStream_t st)
+{
+    if (!bytes) return hipSuccess;
+    if (bytes % 16 || (reinterpret_cast<uintptr_t>(d_src) & 15) || (reinterpret_cast<uintptr_t>(h_dst) & 15)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_copy_to_host, dim3(nwg), dim3(64), 0, st, reinterpret_cast<const uint4 *>(d_src), reinterpret_cast<uint4 *>(h_dst), bytes / 16);
     return hipGetLastError();
 }
 

@@ -347,7 +347,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     c.prof_begin(PR_V_HASH_TCOMM, n);
     HIPCHK(launch_opened_hash(oh, K, false, n, st)); // Tcomm of the opened parties, read from the image   :22-35
     c.prof_end(PR_V_HASH_TCOMM);
-    HIPCHK(hipMemcpyAsync(split_tables ? c.h_odig : c.h_dig, split_tables ? c.d_odig : c.d_dig1, dig_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(copy_table_to_host(c, split_tables ? c.h_odig : c.h_dig, split_tables ? c.d_odig : c.d_dig1, dig_bytes));
     return 0;
     }, split_tables ? c.h_odig : c.h_dig)) return -1; // which table copy the captured segment holds is part of its graph's key
     HIPCHK(hipEventRecord(c.ev, st)); // the opened parties' Tcomm digests are on the host once this event has passed
@@ -450,7 +450,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     c.prof_begin(PR_V_HASH_VIEW, n);
     HIPCHK(launch_opened_hash(oh, K, true, n, st));
     c.prof_end(PR_V_HASH_VIEW);
-    HIPCHK(hipMemcpyAsync(split_tables ? c.h_odig : c.h_dig, split_tables ? c.d_odig : c.d_dig2, dig_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(copy_table_to_host(c, split_tables ? c.h_odig : c.h_dig, split_tables ? c.d_odig : c.d_dig2, dig_bytes));
     HIPCHK(hipEventRecord(c.ev, st));
     t1 = now_sec(); c.phase_sec[PH_V2_ISSUE] = t1 - t0; t0 = t1;
 
