@@ -141,8 +141,8 @@ int kosk_stage_verifier_inputs_compact(kosk_ctx *ctx, int n, const uint8_t *in, 
  * page-locked caller memory, 6 through the pinned staging buffer (KOSK_REGISTER=0, head / tail chunks, single-chunk calls),
  * 7 hipGraph segment replays (KOSK_GRAPHS=1), 8 / 9 NTT launches of the packed-fp32 / integer kernel, 10 prover commitment rounds
  * whose digest table was written to the host's table by the hash launch itself (KOSK_DIGEST_DIRECT=1), 11 rounds that copied it
- * behind the launch (default), 12 digest tables copied to the host by the library's own few-wave copy kernel (default;
- * KOSK_COPY_WAVES=0: the runtime's hipMemcpyAsync). */
+ * behind the launch (default), 12 digest tables copied to the host by the library's own few-wave copy kernel (KOSK_COPY_WAVES=n;
+ * default 0: the runtime's hipMemcpyAsync, which measured faster for the pipeline as a whole). */
 int kosk_path_count(const kosk_ctx *ctx, int id, long *count);
 /* host worker threads per sub-context (<= 8, <= CPUs of the process / KOSK_STREAMS; all created by kosk_create) */
 int kosk_host_threads(const kosk_ctx *ctx);

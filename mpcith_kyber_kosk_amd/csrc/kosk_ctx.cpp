@@ -166,7 +166,7 @@ int device_error_check(Ctx &c)
 
 hipError_t copy_table_to_host(Ctx &c, void *h_dst, const void *d_src, size_t bytes)
 {
-    if (c.copy_waves > 0 && bytes >= ((size_t)1 << 16) && bytes % 16 == 0) {
+    if (c.copy_waves > 0 && bytes >= ((size_t)1 << 15) && bytes % 16 == 0) {
         if (!c.capturing) c.path_n[PATH_COPY_KERNEL]++;
         return launch_copy_to_host(d_src, h_dst, bytes, c.copy_waves, c.stream);
     }

@@ -246,9 +246,11 @@ struct Ctx {
     // KOSK_DIGEST_DIRECT=1: the prover's commitment launches also store every digest into the host's page-locked table (no copy
     // behind the launch).  Measured slower with merged runs, neutral without (profiles/r04_digest_direct.txt): default off
     bool digest_direct = false;
-    // KOSK_COPY_WAVES=n (default 512; 0 = the runtime's hipMemcpyAsync): the digest tables go to the host through k_copy_to_host
-    // with n one-wave workgroups instead of the runtime's one-element-per-thread blit kernel
-    int copy_waves = 512;
+    // KOSK_COPY_WAVES=n (default 0 = the runtime's hipMemcpyAsync): the digest tables go to the host through k_copy_to_host with n
+    // one-wave workgroups instead of the runtime's one-element-per-thread blit kernel.  Measured WORSE at every n from 128 to 2 048
+    // (105 k against 133-137 k proofs/s: the copy takes the same 117 us, but the kernels running beside it stretch by 1.5-1.9 x;
+    // profiles/r04_copy_kernel.txt), so it is an experiment knob only
+    int copy_waves = 0;
     bool host_register = true; // KOSK_REGISTER=0: multi-chunk host-buffer calls never page-lock caller memory (staging copies only)
     int cu_part_i = 0, cu_part_n = 1; // KOSK_CU_PARTITION=i/n: the stream is restricted to partition i of n CU partitions
     int cu_mask_layout = 0;           // KOSK_CU_MASK_LAYOUT: how CU-mask bits map to XCDs (0 round-robin, 1 XCD-major)

@@ -1781,11 +1781,12 @@ __global__ __launch_bounds__(64) void k_assemble_fields(AssembleArgs a, uint32_t
     if (lane == 1 && head + 2 * body < n16) out[n16 - 1] = tile[n16 - 1];
 }
 
-// Device-to-host copy of a digest table with FEW waves.  The runtime's own copy (hipMemcpyAsync into page-locked memory) is a
-// blit kernel with one 16-byte element per thread on this pool (no SDMA, profiles/r04_sdma_probe.txt): 6 144 waves for the 6.4 MB
-// of a 138-proof round, parked on PCIe stores for 112 us -- three quarters of the chip's wave slots, while the kernels of the other
-// cohorts want them.  Here one wave per workgroup walks the table in 1 KiB pieces with eight pieces in flight: the link needs
-// ~120 KB in flight (57 GB/s x 2 us), 512 waves x 8 KiB have it 30 times over, and 7 of 8 wave slots stay free.
+// Device-to-host copy of a digest table with FEW waves (experiment, KOSK_COPY_WAVES).  The runtime's own copy (hipMemcpyAsync into
+// page-locked memory) is a blit kernel with one 16-byte element per thread on this pool (no SDMA, profiles/r04_sdma_probe.txt):
+// 6 144 waves for the 6.4 MB of a 138-proof round, parked on PCIe stores for 112 us.  The idea here: one wave per workgroup walks
+// the table in 1 KiB pieces with eight pieces in flight (the link needs ~120 KB in flight) and leaves the wave slots to the other
+// cohorts' kernels.  Measured: the copy takes the same time and the kernels beside it get SLOWER (table product 230 against 137 us,
+// fused lincomb 295 against 160 us), 105 k against 133-137 k proofs/s at 128 .. 2 048 waves alike -- default off.
 __global__ __launch_bounds__(64) void k_copy_to_host(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
 {
     const size_t stride = (size_t)gridDim.x * 64;

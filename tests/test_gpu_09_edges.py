@@ -138,6 +138,7 @@ KNOBS = {  # knob -> (path counter that must be > 0 on the knob's handle, counte
     "KOSK_BLOCKING_SYNC=1": (None, None),
     "KOSK_GRAPHS=1": ("graph_replay", None),
     "KOSK_DIGEST_DIRECT=1": ("digest_direct", "digest_copy"),
+    "KOSK_COPY_WAVES=256": ("copy_kernel", None),
 }
 
 
