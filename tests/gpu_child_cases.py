@@ -302,3 +302,54 @@ def combined_calls(k, threads=6, rounds=4, min_merge=0.5):
     for h in hs + [plain, fresh]:
         h.close()
     print("combined_calls ok", k, "mean callers per run %.2f" % (members / calls))
+
+
+def combined_members_come_and_go(k):
+    """A cohort whose members are destroyed and re-created while the others keep calling: the freed block is reused by the next
+    handle, members that are no neighbours any more run on their own, the workspace lives until the last member is gone, a
+    second cohort opens when the first is full -- and every caller still gets the uncombined handle's bytes."""
+    import threading
+    from mpcith_kyber_kosk_amd import api
+    per = 2
+    plain = api.Kosk(kyber_k=k, max_batch=per)
+    mk = lambda: _kosk(k, per, KOSK_COMBINE=3, KOSK_COMBINE_WAIT_US=100000, KOSK_COMBINE_IDLE_US=50000)
+    tapes = [[oracle.tape_bytes_for(k, 9000 + t * per + b) for b in range(per)] for t in range(5)]
+    want = []
+    for tp in tapes:
+        plain.verifiable_keygen_resident(tp)
+        want.append((plain.keys(per), plain.fetch_proofs(per)))
+
+    def round_of(handles, idx):
+        """every handle of `handles` (list of (handle, tape set)) does keygen + verify concurrently; returns nothing, asserts bytes"""
+        errs = []
+
+        def w(h, t):
+            try:
+                h.verifiable_keygen_resident(tapes[t])
+                assert h.keys(per) == want[t][0]
+                assert h.verify_resident_pk(per) == [True] * per
+                assert h.fetch_proofs(per) == want[t][1]
+            except Exception as e:  # noqa: BLE001
+                errs.append((idx, t, repr(e)))
+        th = [threading.Thread(target=w, args=(h, t)) for h, t in handles]
+        [x.start() for x in th]; [x.join() for x in th]
+        assert not errs, errs
+    a, b, c = mk(), mk(), mk()
+    round_of([(a, 0), (b, 1), (c, 2)], 0)
+    round_of([(a, 0), (b, 1), (c, 2)], 1)
+    b.close()                                   # the middle member goes: a and c are no neighbours any more
+    round_of([(a, 3), (c, 4)], 2)
+    assert a.fetch_proofs(per) == want[3][1] and c.fetch_proofs(per) == want[4][1]
+    d = mk()                                    # takes the freed block between them
+    round_of([(a, 0), (d, 1), (c, 2)], 3)
+    e = mk()                                    # the cohort is full: a second one opens (and is alone in it)
+    round_of([(a, 3), (d, 4), (c, 0), (e, 1)], 4)
+    merged_before = sum(h.combine_stats()[1] - h.combine_stats()[0] for h in (a, c, d))
+    assert merged_before > 0                    # the three-member rounds really merged
+    a.close(); d.close()
+    round_of([(c, 2), (e, 3)], 5)               # the last member of the first cohort still owns a live workspace
+    c.close(); e.close()
+    f = mk()                                    # both cohorts are gone: a fresh one
+    round_of([(f, 4)], 6)
+    f.close(); plain.close()
+    print("combined_members_come_and_go ok", k)

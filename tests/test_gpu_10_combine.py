@@ -26,3 +26,8 @@ def test_combined_calls_under_glibc_heap_checking(torch_cuda, gpu_child):
     out = gpu_child("from tests.gpu_child_cases import combined_calls; combined_calls(3, threads=5, rounds=3, min_merge=0.0)",
                     env={"MALLOC_CHECK_": "3", "MALLOC_PERTURB_": "165", "LIBC_FATAL_STDERR_": "1"})
     assert "combined_calls ok 3" in out
+
+
+def test_cohort_members_come_and_go(torch_cuda, gpu_child):
+    out = gpu_child("from tests.gpu_child_cases import combined_members_come_and_go; combined_members_come_and_go(3)")
+    assert "combined_members_come_and_go ok 3" in out
