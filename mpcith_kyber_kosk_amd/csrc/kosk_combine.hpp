@@ -43,7 +43,9 @@ public:
     // on the calling thread -- member `first`'s thread; the return value is handed to every member of the run
     using Exec = std::function<int(int first, int count, const CombineReq *const *reqs)>;
 
-    Combiner(int width, int wait_us, int idle_us) : C_(width), wait_us_(wait_us), idle_us_(idle_us), m_(width) {}
+    static constexpr int MAX_WIDTH = 8;
+    Combiner(int width, int wait_us, int idle_us)
+        : C_(width < 1 ? 1 : (width > MAX_WIDTH ? MAX_WIDTH : width)), wait_us_(wait_us), idle_us_(idle_us), m_((size_t)C_) {}
     int width() const { return C_; }
 
     // a free member index (-1: the cohort is full); leave() frees it again
@@ -96,7 +98,7 @@ public:
         me.size_hist[me.run_count < 9 ? me.run_count : 8]++;
         if (me.leader == i) {
             const int cnt = me.run_count;
-            std::vector<const CombineReq *> reqs((size_t)cnt);
+            const CombineReq *reqs[MAX_WIDTH]; // no allocation between "assigned" and "running": nothing here can throw
             for (int k = 0; k < cnt; k++) {
                 reqs[k] = &m_[i + k].req;
                 m_[i + k].st = RUNNING;
@@ -105,7 +107,7 @@ public:
             int rc;
             std::string text;
             try {
-                rc = exec(i, cnt, reqs.data());
+                rc = exec(i, cnt, reqs);
             } catch (const std::exception &e) {
                 rc = -2;
                 try { text = e.what(); } catch (...) {}
