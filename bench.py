@@ -831,27 +831,33 @@ def main():
                 line["drop_in"] = drop_in(api, torch, k, B, tapes, local_rank)
             except Exception as e:  # noqa: BLE001
                 line["drop_in"] = {"error": repr(e)[:400]}
-            # the same workload WITHOUT call combining (every handle on its own: the round-3 arrangement, 6 slots), as a
-            # fresh child process with its own host-thread budget; reported NEXT TO the line of record, never as `value`
+            # two side runs as fresh child processes with their own host-thread budget, reported NEXT TO the line of record, never as
+            # `value`: the same workload WITHOUT call combining (every handle on its own: the round-3 arrangement, 6 slots), and the
+            # throughput-leaning arrangement (15 callers in 3 cohorts of 5: more proofs per launch, more latency per call)
             import subprocess
-            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", str(args.config), "--combine", "1", "--slots", "6",
-                   "--steps", str(max(20, K // 2)), "--warmup", str(max(4, W // 2)), "--no-kernels", "--no-cpu-baseline"]
             env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("KOSK_HOST_THREADS", "KOSK_BLOCKING_SYNC", "KOSK_COMBINE", "KOSK_BENCH_COMBINE", "KOSK_BENCH_SLOTS")}
-            try:
-                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
-                sub = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                if r.returncode != 0 or not sub:
-                    raise RuntimeError("rc %d: %s" % (r.returncode, (r.stderr or "")[-300:]))
-                j = json.loads(sub[-1])
-                line["uncombined"] = {
-                    "proofs_per_s": j["value"], "ms_per_step": j["ms_per_step"], "slots": 6, "steps": j["steps"],
-                    "roofline_frac": (j.get("roofline") or {}).get("frac"),
-                    "hash_view_avg_us": (j.get("kernels_in_pipeline", {}).get("hash_view") or {}).get("avg_us"),
-                    "step_latency_ms_median": (j.get("step_latency_ms") or {}).get("median"),
-                    "note": "python bench.py --combine 1 --slots 6: six independent handles, every launch serves one 46-proof call (round 3's "
-                            "line of record); not the line of record"}
-            except Exception as e:  # noqa: BLE001  (TimeoutExpired, a missing key, bad JSON ...)
-                line["uncombined"] = {"error": repr(e)[:400]}
+
+            def side_run(slots_, combine_, note):
+                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", str(args.config), "--combine", str(combine_), "--slots", str(slots_),
+                       "--steps", str(max(20, K // 2) // slots_ * slots_ + slots_), "--warmup", str(max(4, W // 2)), "--no-kernels", "--no-cpu-baseline"]
+                try:
+                    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+                    sub = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                    if r.returncode != 0 or not sub:
+                        raise RuntimeError("rc %d: %s" % (r.returncode, (r.stderr or "")[-300:]))
+                    j = json.loads(sub[-1])
+                    return {"proofs_per_s": j["value"], "ms_per_step": j["ms_per_step"], "slots": slots_, "handles_per_cohort": combine_, "steps": j["steps"],
+                            "roofline_frac": (j.get("roofline") or {}).get("frac"),
+                            "hash_view_avg_us": (j.get("kernels_in_pipeline", {}).get("hash_view") or {}).get("avg_us"),
+                            "hash_view_proofs_per_launch": (j.get("kernels_in_pipeline", {}).get("hash_view") or {}).get("proofs_per_launch"),
+                            "step_latency_ms_median": (j.get("step_latency_ms") or {}).get("median"),
+                            "host_cpu_cores_busy": j.get("host_cpu_cores_busy"), "note": note}
+                except Exception as e:  # noqa: BLE001  (TimeoutExpired, a missing key, bad JSON ...)
+                    return {"error": repr(e)[:400]}
+            line["uncombined"] = side_run(6, 1, "python bench.py --combine 1 --slots 6: six independent handles, every launch serves one 46-proof call "
+                                                "(round 3's line of record); not the line of record")
+            line["cohorts_of_five"] = side_run(15, 5, "python bench.py --combine 5 --slots 15: fifteen callers, five per merged run (more proofs per launch at "
+                                                      "more latency per call); not the line of record")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(k, tapes, min(args.cpu_proofs, B))

@@ -173,6 +173,17 @@ hipError_t copy_table_to_host(Ctx &c, void *h_dst, const void *d_src, size_t byt
     return hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c.stream);
 }
 
+hipError_t copy_small(Ctx &c, void *dst, size_t dst_stride, const void *src, size_t src_stride, size_t row_bytes, size_t nrows, hipMemcpyKind kind, hipStream_t st)
+{
+    if (!row_bytes || !nrows) return hipSuccess;
+    if (c.small_copy_kernel && copy_small_ok(src, src_stride, dst, dst_stride, row_bytes)) {
+        if (!c.capturing) c.path_n[PATH_SMALL_COPY_KERNEL]++;
+        return launch_copy_small(src, src_stride, dst, dst_stride, row_bytes, nrows, st);
+    }
+    if (nrows == 1 || (src_stride == row_bytes && dst_stride == row_bytes)) return hipMemcpyAsync(dst, src, row_bytes * nrows, kind, st);
+    return hipMemcpy2DAsync(dst, dst_stride, src, src_stride, row_bytes, nrows, kind, st);
+}
+
 hipError_t stream_sync(Ctx &c)
 {
     if (!c.blocking_sync) return hipStreamSynchronize(c.stream);
@@ -373,6 +384,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     if (const char *e = getenv("KOSK_TABLE_GEMM")) c.table_gemm = atoi(e) != 0;
     if (const char *e = getenv("KOSK_REGISTER")) c.host_register = atoi(e) != 0;
     if (const char *e = getenv("KOSK_DIGEST_DIRECT")) c.digest_direct = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_SMALL_COPY_KERNEL")) c.small_copy_kernel = atoi(e) != 0;
     if (const char *e = getenv("KOSK_COPY_WAVES")) c.copy_waves = atoi(e) >= 0 ? (atoi(e) > 65535 ? 65535 : atoi(e)) : c.copy_waves;
     if (const char *e = getenv("KOSK_DEBUG_XOF_BLOCKS")) c.xof_max_blocks = atoi(e) > 0 ? atoi(e) : c.xof_max_blocks;
     if (const char *e = getenv("KOSK_CU_PARTITION")) {
@@ -655,7 +667,7 @@ int issue_keygen(Ctx &c, int n, bool sampled)
     HIPCHK(launch_ntt(na, c.stream)); // polyvec_ntt(s), polyvec_ntt(e)   kosk.cpp:39-40
     HIPCHK(launch_keygen_pack(c.d_A, c.key_stride, c.d_sehat, c.se_stride, c.d_seeds, c.kg_rec, c.d_t, c.d_pk, c.pk_stride, c.d_sb,
                               c.sb_stride, K, n, c.stream));
-    HIPCHK(hipMemcpyAsync(c.h_kg, c.d_kg, (size_t)n * c.kg_rec, hipMemcpyDeviceToHost, c.stream)); // pk, NTT(s) bytes, seeds: one copy
+    HIPCHK(copy_small(c, c.h_kg, 0, c.d_kg, 0, (size_t)n * c.kg_rec, 1, hipMemcpyDeviceToHost, c.stream)); // pk, NTT(s) bytes, seeds: one copy
     c.resident_pk_n = n;
     return 0;
 }
@@ -809,7 +821,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     // ---- P2: beta, gamma, r, NTT_r on every evaluation point (per proof a [J x M] x [M x 1710] product mod q, :159-203),
     // s + r / e + r (:222-245), then the view commitments, which read nothing else of the relation phase
     if (run_segment(c, Ctx::SEG_P2, n, [&]() -> int {
-        HIPCHK(hipMemcpyAsync(c.d_alpha, c.h_alpha, (size_t)n * 80 * 2, hipMemcpyHostToDevice, st));
+        HIPCHK(copy_small(c, c.d_alpha, 0, c.h_alpha, 0, (size_t)n * 80 * 2, 1, hipMemcpyHostToDevice, st));
         c.prof_begin(PR_LINCOMB, n);
         HIPCHK(launch_coef_limbs(c.d_alpha, P.J, P.M, c.d_coef, n, st));
         if (c.lincomb_fused) {
@@ -873,10 +885,10 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     // ---- P3: wire image
     if (run_segment(c, Ctx::SEG_P3, n, [&]() -> int {
         if (!c.is_view) {
-            HIPCHK(hipMemcpyAsync(c.d_I, c.h_I, ((size_t)c.max_batch + n) * c.sel_stride * 2, hipMemcpyHostToDevice, st)); // I and its complement
+            HIPCHK(copy_small(c, c.d_I, 0, c.h_I, 0, ((size_t)c.max_batch + n) * c.sel_stride * 2, 1, hipMemcpyHostToDevice, st)); // I and its complement
         } else { // a view's lists sit inside the arena's two blocks: other views' lists lie between them
-            HIPCHK(hipMemcpyAsync(c.d_I, c.h_I, (size_t)n * c.sel_stride * 2, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(c.d_rest, c.h_rest, (size_t)n * c.sel_stride * 2, hipMemcpyHostToDevice, st));
+            HIPCHK(copy_small(c, c.d_I, 0, c.h_I, 0, (size_t)n * c.sel_stride * 2, 1, hipMemcpyHostToDevice, st));
+            HIPCHK(copy_small(c, c.d_rest, 0, c.h_rest, 0, (size_t)n * c.sel_stride * 2, 1, hipMemcpyHostToDevice, st));
         }
         AssembleArgs aa{};
         aa.P = c.d_P;

@@ -61,7 +61,7 @@ enum ProfId { PR_HASH_TCOMM = 0, PR_HASH_VIEW, PR_GEMM_EXPAND1, PR_GEMM_EXPAND2,
               PR_V_LINCOMB, PR_HASH_TCOMM_TAIL, PR_HASH_VIEW_TAIL, PR_COUNT };
 
 enum PathId { PATH_HASH_DMA = 0, PATH_HASH_PLAIN, PATH_HASH_PRIMER, PATH_TABLE_GEMM, PATH_LIMB_GEMM, PATH_COPY_DIRECT, PATH_COPY_STAGED,
-              PATH_GRAPH_REPLAY, PATH_NTT_FP32, PATH_NTT_INT, PATH_DIGEST_DIRECT, PATH_DIGEST_COPY, PATH_COPY_KERNEL, PATH_COUNT };
+              PATH_GRAPH_REPLAY, PATH_NTT_FP32, PATH_NTT_INT, PATH_DIGEST_DIRECT, PATH_DIGEST_COPY, PATH_COPY_KERNEL, PATH_SMALL_COPY_KERNEL, PATH_COUNT };
 
 struct GemmTable {
     uint8_t *d = nullptr; // limb matrix (kosk_device.hpp)
@@ -251,6 +251,7 @@ struct Ctx {
     // (105 k against 133-137 k proofs/s: the copy takes the same 117 us, but the kernels running beside it stretch by 1.5-1.9 x;
     // profiles/r04_copy_kernel.txt), so it is an experiment knob only
     int copy_waves = 0;
+    bool small_copy_kernel = true; // KOSK_SMALL_COPY_KERNEL=0: hipMemcpyAsync for the small copies too (copy_small)
     bool host_register = true; // KOSK_REGISTER=0: multi-chunk host-buffer calls never page-lock caller memory (staging copies only)
     int cu_part_i = 0, cu_part_n = 1; // KOSK_CU_PARTITION=i/n: the stream is restricted to partition i of n CU partitions
     int cu_mask_layout = 0;           // KOSK_CU_MASK_LAYOUT: how CU-mask bits map to XCDs (0 round-robin, 1 XCD-major)
@@ -330,6 +331,8 @@ int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx
 hipError_t stream_sync(Ctx &c);
 // a digest table (or any 16-byte aligned block) from HBM into the context's page-locked host memory, on the context's stream
 hipError_t copy_table_to_host(Ctx &c, void *h_dst, const void *d_src, size_t bytes);
+// a small copy between HBM and one of the library's OWN page-locked host buffers, rows x row_bytes (kernel or hipMemcpy[2D]Async)
+hipError_t copy_small(Ctx &c, void *dst, size_t dst_stride, const void *src, size_t src_stride, size_t row_bytes, size_t nrows, hipMemcpyKind kind, hipStream_t st);
 // after the stream has been synchronised: -1 (with c.err set, the word cleared) if a kernel of this context raised an error
 int device_error_check(Ctx &c);
 // proofs of an n-proof batch that the FIRST of the two commitment-hash launches takes (n: a single launch)

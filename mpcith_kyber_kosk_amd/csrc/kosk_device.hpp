@@ -267,6 +267,8 @@ hipError_t launch_sha3_msgs_pair(const uint8_t *in, size_t in_stride, int len, u
                                  int domain, hipStream_t st);
 // HBM -> page-locked host memory with nwg one-wave workgroups (k_copy_to_host); bytes, both pointers: multiples of 16
 hipError_t launch_copy_to_host(const void *d_src, void *h_dst, size_t bytes, int nwg, hipStream_t st);
+bool copy_small_ok(const void *src, size_t src_stride, const void *dst, size_t dst_stride, size_t row_bytes);
+hipError_t launch_copy_small(const void *src, size_t src_stride, void *dst, size_t dst_stride, size_t row_bytes, size_t nrows, hipStream_t st);
 hipError_t launch_rows_copy(const uint16_t *src, size_t src_stride, uint16_t *dst, size_t dst_stride, int count,
                             int nrows, hipStream_t st);
 // expand_f + tape randoms + witness secrets (the kernels that only read the tape / the key) in one launch

@@ -1,14 +1,15 @@
 // Host-side crypto and helpers of the product path (see kosk_host.hpp).
 #include "kosk_host.hpp"
 
+#include <linux/futex.h>
 #include <sched.h>
 #include <sys/random.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
-#include <condition_variable>
 #include <mutex>
 #include <stdexcept>
 #include <cstdio>
@@ -544,18 +545,21 @@ void pack_frag_table(const std::vector<uint16_t> &A, int M, int Kdim, int Mpad, 
 // (cur_ = nullptr) and then waits until no worker is inside the pick-up window (inside_ == 0).  inside_++ / load cur_
 // on the worker and store cur_ / load inside_ in run() are sequentially consistent (Dekker pattern): either the worker
 // sees the job retired or run() sees the worker inside.
+//
+// Sleeping workers wait on the generation word itself (futex), not on a condition variable: waking 17 workers for a Fiat-Shamir
+// round through notify_all made each of them take the pool's mutex in turn before it could look at the job (a queue of 17
+// futex hand-offs in front of a 67 us hash chain); FUTEX_WAKE releases them in one system call and they share nothing on the
+// way to the job but its index counter.  Only as many sleepers are woken as the job wants; who works is decided by a ticket
+// (Job::joined), not by a worker's number, because the kernel chooses which sleepers wake.
 class Pool {
 public:
     static Pool &get() { static Pool p; return p; }
     Pool() = default;
     ~Pool()
     {
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            stop_.store(true);
-            gen_.fetch_add(1);
-        }
-        cv_.notify_all();
+        stop_.store(true);
+        gen_.fetch_add(1);
+        wake(INT32_MAX);
         for (auto &t : th_) t.join();
     }
     void run(int n, int nthreads, const std::function<void(int)> &fn)
@@ -564,11 +568,8 @@ public:
         grow(nthreads - 1);
         Job job{&fn, n, std::min<int>((int)th_.size(), nthreads - 1)};
         cur_.store(&job);
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            gen_.fetch_add(1);
-        }
-        cv_.notify_all();
+        gen_.fetch_add(1); // seq_cst: ordered against the sleepers' count (a worker counts itself, THEN the kernel compares gen_)
+        if (sleepers_.load() > 0) wake(job.want);
         work(job);
         while (job.done.load(std::memory_order_acquire) < n) __builtin_ia32_pause();
         cur_.store(nullptr);
@@ -581,7 +582,7 @@ private:
     struct Job {
         const std::function<void(int)> *fn;
         int n, want;
-        std::atomic<int> next{0}, done{0};
+        std::atomic<int> next{0}, done{0}, joined{0};
         std::atomic<bool> failed{false};
         Job(const std::function<void(int)> *f, int n_, int w) : fn(f), n(n_), want(w) {}
     };
@@ -591,10 +592,9 @@ private:
     void grow(int want) noexcept
     {
         while ((int)th_.size() < want && th_.size() < 255 && !grow_failed_) {
-            const int id = (int)th_.size();
-            const uint64_t g = gen_.load(); // never pick up a job published before we existed
+            const uint32_t g = gen_.load(); // never pick up a job published before we existed
             try {
-                th_.emplace_back([this, id, g] { loop(id, g); });
+                th_.emplace_back([this, g] { loop(g); });
             } catch (...) {
                 grow_failed_ = true;
             }
@@ -618,18 +618,26 @@ private:
         static const int v = getenv("KOSK_POOL_SPIN_US") ? atoi(getenv("KOSK_POOL_SPIN_US")) : 20;
         return v;
     }
-    void loop(int id, uint64_t seen0)
+    static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "the generation word is handed to futex(2)");
+    void wake(int count) noexcept { syscall(SYS_futex, reinterpret_cast<uint32_t *>(&gen_), FUTEX_WAKE_PRIVATE, count, nullptr, nullptr, 0); }
+    void sleep_while(uint32_t seen) noexcept
     {
-        uint64_t seen = seen0;
+        sleepers_.fetch_add(1);
+        // returns at once (EAGAIN) when gen_ has moved on already; spurious returns are fine, the caller re-checks
+        syscall(SYS_futex, reinterpret_cast<uint32_t *>(&gen_), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
+        sleepers_.fetch_sub(1);
+    }
+    void loop(uint32_t seen0)
+    {
+        uint32_t seen = seen0;
         for (;;) {
             // spin briefly for the next job (pause, not yield: a yield can cost milliseconds in sandboxed
-            // runtimes), then block: CPU time is usually under a cgroup quota shared with the other slots
-            const auto t0 = std::chrono::steady_clock::now();
+            // runtimes), then sleep: CPU time is usually under a cgroup quota shared with the other slots
+            auto t0 = std::chrono::steady_clock::now();
             while (gen_.load(std::memory_order_acquire) == seen) {
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us())) {
-                    std::unique_lock<std::mutex> lk(mu_);
-                    cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
-                    break;
+                    sleep_while(seen);
+                    continue; // (a sleeper that was not chosen for one job sleeps on; it compares with the newest generation)
                 }
                 __builtin_ia32_pause();
             }
@@ -637,15 +645,14 @@ private:
             if (stop_.load()) return;
             inside_.fetch_add(1);
             if (Job *j = cur_.load())
-                if (id < j->want) work(*j);
+                if (j->joined.fetch_add(1, std::memory_order_relaxed) < j->want) work(*j);
             inside_.fetch_sub(1);
         }
     }
     std::vector<std::thread> th_;
-    std::mutex job_mu_, mu_;
-    std::condition_variable cv_;
-    std::atomic<uint64_t> gen_{0};
-    std::atomic<int> inside_{0};
+    std::mutex job_mu_;
+    std::atomic<uint32_t> gen_{0};
+    std::atomic<int> inside_{0}, sleepers_{0};
     std::atomic<Job *> cur_{nullptr};
     std::atomic<bool> stop_{false};
     bool grow_failed_ = false;

@@ -1168,7 +1168,7 @@ __device__ __forceinline__ void gemm_modq_block(const GemmArgs &a, const int bx,
             if (m0 >= a.M) continue;
             uint32_t v[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) v[r] = gf_from_i32(s0[ib][j][r] + 64 * s1[ib][j][r] + 767 * s2[ib][j][r]); // < 2^31 for k <= 832
+            for (int r = 0; r < 4; r++) v[r] = gf_reduce_limbs(s0[ib][j][r], s1[ib][j][r], s2[ib][j][r]); // k <= 832
             if (m0 + 4 <= a.M) {
                 *reinterpret_cast<uint2 *>(crow + m0) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
             } else { // M % 4 != 0 (the 407-point interpolation operator): never write past the logical output
@@ -1212,7 +1212,7 @@ constexpr int TG_WAVES = 8;
 
 // TG_RT = table row tiles (of 16) per chunk
 template <int KS, int TG_RT, int NBT>
-__global__ __launch_bounds__(512, (KS <= 7 && NBT == 3) ? 2 : 1) void k_table_gemm(GemmArgs a, int nchunks, int chunks_per_block, int nblk, int msplit)
+__global__ __launch_bounds__(512, (KS <= 7 && NBT == 3) ? 2 : 1) void k_table_gemm(GemmArgs a, int nchunks, int chunks_per_block, int nblk, int msplit, int wide_stores)
 {
     constexpr int TG_CHUNK = 16 * TG_RT, TG_NB = 16 * NBT;
     __shared__ __attribute__((aligned(16))) uint8_t ldsB[KS * NBT * 2048]; // [k-step][row tile][limb][1 KiB]
@@ -1278,7 +1278,6 @@ __global__ __launch_bounds__(512, (KS <= 7 && NBT == 3) ? 2 : 1) void k_table_ge
     }
     __syncthreads(); // the only workgroup barrier: from here on the waves run independently
     if (nmy == 0) return;
-
     // output rows of this lane's NBT columns (n = n0 + 16 j + (lane & 15))
     uint16_t *crow[NBT];
 #pragma unroll
@@ -1305,6 +1304,30 @@ __global__ __launch_bounds__(512, (KS <= 7 && NBT == 3) ? 2 : 1) void k_table_ge
             dst[2 * j + 1] = *reinterpret_cast<const v4i *>(lb + j * 2048 + 1024);
         }
     };
+    // ---- epilogue pieces.  D[row = m: 4 (lane >> 4) + r][col = n: lane & 15]: four consecutive m per lane and block
+    const int grp = lane >> 4;
+    // blocks j, j + 1 of chunk c: with 16-byte aligned rows the odd 16-lane rows of block j's packed values are swapped with the
+    // even rows of block j + 1's (v_permlane16_swap), after which an even-row lane holds EIGHT consecutive m of block j and an
+    // odd-row lane eight of block j + 1: one 16-byte store per lane instead of two 8-byte stores
+    auto store_pair = [&](int j, int c, uint2 pj, uint2 pk) {
+        if (wide_stores) {
+            const auto sx = __builtin_amdgcn_permlane16_swap(pj.x, pk.x, false, false);
+            const auto sy = __builtin_amdgcn_permlane16_swap(pj.y, pk.y, false, false);
+            uint16_t *p = (grp & 1) ? (crow[j + 1] ? crow[j + 1] - 4 : nullptr) : crow[j];
+            if (p) *reinterpret_cast<uint4 *>(p + c * TG_CHUNK) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        } else {
+            if (crow[j]) *reinterpret_cast<uint2 *>(crow[j] + c * TG_CHUNK) = pj;
+            if (crow[j + 1]) *reinterpret_cast<uint2 *>(crow[j + 1] + c * TG_CHUNK) = pk;
+        }
+    };
+    auto store_one = [&](int j, int c, uint2 pj) {
+        if (crow[j]) *reinterpret_cast<uint2 *>(crow[j] + c * TG_CHUNK) = pj;
+    };
+
+    static_assert(TG_RT == 1, "the epilogue is written for one table row tile per chunk");
+    // (Tried and not kept, profiles/r04_gemm_stamps.txt: the reduction and the stores of chunk c issued inside chunk c + 1's k-steps,
+    // two vector instructions behind every MFMA.  The k-steps grew by exactly what the epilogue shrank -- two waves per SIMD leave
+    // no idle issue slots under the MFMAs -- so the epilogue stays where it was, behind the chunk's last k-step.)
     load_b(0, fb0);
     for (int ci = 0; ci < nmy; ci++) {
         const int c = c_first + ci * TG_WAVES;
@@ -1331,19 +1354,17 @@ __global__ __launch_bounds__(512, (KS <= 7 && NBT == 3) ? 2 : 1) void k_table_ge
             load_chunk_ks(cn, ks, fa[ks]); // in flight for a whole chunk of arithmetic before it is used
             __builtin_amdgcn_sched_barrier(0); // keep the k-steps apart: hoisting every LDS read of the chunk costs 150 VGPRs
         }
-        // epilogue of the chunk: D[row = m: 4 (lane >> 4) + r][col = n: lane & 15] -> four consecutive m per lane, one 8-byte
-        // store per block.  |S0 + 64 S1 + 767 S2| < 2^29 for k <= 448, so adding 90 000 q makes it a positive u32.
-        // (Few VALU instructions on purpose: an MFMA leaves the SIMD's vector issue free only half of the time.)
+        // epilogue of the chunk: combine the limb products, reduce mod q, pack four consecutive m per lane and block, store
+        uint2 pk[NBT];
 #pragma unroll
-        for (int j = 0; j < NBT; j++)
+        for (int j = 0; j < NBT; j++) {
+            uint32_t v[4];
 #pragma unroll
-            for (int i = 0; i < TG_RT; i++) {
-                uint32_t v[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    v[r] = gf_reduce_pos((uint32_t)(s0[i][j][r] + 64 * s1[i][j][r] + 767 * s2[i][j][r] + 90000 * Q));
-                if (crow[j]) *reinterpret_cast<uint2 *>(crow[j] + c * TG_CHUNK + i * 16) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
-            }
+            for (int r = 0; r < 4; r++) v[r] = gf_reduce_limbs(s0[0][j][r], s1[0][j][r], s2[0][j][r]);
+            pk[j] = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+            if (j & 1) store_pair(j - 1, c, pk[j - 1], pk[j]);
+            else if (j == NBT - 1) store_one(j, c, pk[j]);
+        }
     }
 }
 
@@ -1491,7 +1512,7 @@ __global__ __launch_bounds__(256) void k_lincomb_fused(const uint16_t *P, size_t
                 for (int h = 0; h < 2; h++)
 #pragma unroll
                     for (int r = 0; r < 4; r++)
-                        v[4 * h + r] = gf_from_i32(s0[2 * ip + h][j][r] + 64 * s1[2 * ip + h][j][r] + 767 * s2[2 * ip + h][j][r]);
+                        v[4 * h + r] = gf_reduce_limbs(s0[2 * ip + h][j][r], s1[2 * ip + h][j][r], s2[2 * ip + h][j][r]);
                 *reinterpret_cast<uint4 *>(crow + m) = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
                 if (which == 0 && jo >= NCHK) { // r rows: s + r_i, e + r_{K+i} on the spot (mlwe_prover.cpp:222-245)
                     const int idx = jo - NCHK;
@@ -1801,6 +1822,21 @@ __global__ __launch_bounds__(64) void k_copy_to_host(const uint4 *__restrict__ s
     for (; i < n16; i += stride) dst[i] = src[i];
 }
 
+// The SMALL copies of a step between HBM and the library's own page-locked (device-mapped) host buffers -- challenge vectors and
+// opened lists in, key records, opened lists of the images and fail masks out; 0.5 .. 700 KB -- as a kernel instead of
+// hipMemcpyAsync: on this runtime every copy is a blit kernel with a ~12 us dependency gap in front of it
+// (profiles/r04_trace_gaps.txt: ten copies per step, six of them these), a kernel behind a kernel starts 0.2 us later.
+// rows x row_bytes (4-byte multiples, 4-byte aligned) with separate strides: the 2-D form serves the image field gather.
+__global__ __launch_bounds__(256) void k_copy_small(const uint8_t *__restrict__ src, size_t src_stride, uint8_t *__restrict__ dst, size_t dst_stride,
+                                                    uint32_t row_words, uint32_t nrows)
+{
+    const size_t total = (size_t)row_words * nrows;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const uint32_t r = (uint32_t)(i / row_words), w = (uint32_t)(i - (size_t)r * row_words);
+        reinterpret_cast<uint32_t *>(dst + (size_t)r * dst_stride)[w] = reinterpret_cast<const uint32_t *>(src + (size_t)r * src_stride)[w];
+    }
+}
+
 // plain strided row copy (kernel-level ABI helpers): dst[r][0..count) = src[r][0..count)
 __global__ __launch_bounds__(256) void k_rows_copy(const uint16_t *__restrict__ src, size_t src_stride,
                                                   uint16_t *__restrict__ dst, size_t dst_stride, int count)
@@ -1877,6 +1913,23 @@ hipError_t launch_copy_to_host(const void *d_src, void *h_dst, size_t bytes, int
     if (!bytes) return hipSuccess;
     if (bytes % 16 || (reinterpret_cast<uintptr_t>(d_src) & 15) || (reinterpret_cast<uintptr_t>(h_dst) & 15)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_copy_to_host, dim3(nwg), dim3(64), 0, st, reinterpret_cast<const uint4 *>(d_src), reinterpret_cast<uint4 *>(h_dst), bytes / 16);
+    return hipGetLastError();
+}
+
+bool copy_small_ok(const void *src, size_t src_stride, const void *dst, size_t dst_stride, size_t row_bytes)
+{
+    return row_bytes % 4 == 0 && src_stride % 4 == 0 && dst_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0 &&
+           (reinterpret_cast<uintptr_t>(dst) & 3) == 0 && row_bytes / 4 < 0xFFFFFFFFull;
+}
+hipError_t launch_copy_small(const void *src, size_t src_stride, void *dst, size_t dst_stride, size_t row_bytes, size_t nrows, hipStream_t st)
+{
+    if (!row_bytes || !nrows) return hipSuccess;
+    if (!copy_small_ok(src, src_stride, dst, dst_stride, row_bytes) || nrows > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    if (nrows > 1 && src_stride == row_bytes && dst_stride == row_bytes && row_bytes * nrows / 4 < 0xFFFFFFFFull) { row_bytes *= nrows; nrows = 1; } // contiguous
+    const size_t words = row_bytes / 4 * nrows;
+    const unsigned nwg = (unsigned)std::min<size_t>((words + 255) / 256, 256);
+    hipLaunchKernelGGL(k_copy_small, dim3(nwg), dim3(256), 0, st, reinterpret_cast<const uint8_t *>(src), src_stride, reinterpret_cast<uint8_t *>(dst),
+                       dst_stride, (uint32_t)(row_bytes / 4), (uint32_t)nrows);
     return hipGetLastError();
 }
 
@@ -2012,10 +2065,13 @@ hipError_t launch_table_gemm(const GemmArgs &a, uint16_t *sink, hipStream_t st)
     const int cpb = (nchunks + msplit - 1) / msplit;
     msplit = (nchunks + cpb - 1) / cpb;
     (void)sink;
+    // eight consecutive outputs per lane and 16-byte stores where the output rows allow it (KOSK_TG_STORE16=0: 8-byte stores only)
+    static const bool store16 = !(getenv("KOSK_TG_STORE16") && atoi(getenv("KOSK_TG_STORE16")) == 0);
+    const int ws = store16 && a.c_off % 8 == 0 && a.c_rstride % 8 == 0 && a.c_gstride % 8 == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0;
     const dim3 grid((unsigned)((nblk * msplit + 7) / 8 * 8));
-    if (a.KS == 7 && wide) hipLaunchKernelGGL((k_table_gemm<7, 1, 4>), grid, dim3(512), 0, st, a, nchunks, cpb, nblk, msplit);
-    else if (a.KS == 7) hipLaunchKernelGGL((k_table_gemm<7, 1, 3>), grid, dim3(512), 0, st, a, nchunks, cpb, nblk, msplit);
-    else hipLaunchKernelGGL((k_table_gemm<13, 1, 3>), grid, dim3(512), 0, st, a, nchunks, cpb, nblk, msplit);
+    if (a.KS == 7 && wide) hipLaunchKernelGGL((k_table_gemm<7, 1, 4>), grid, dim3(512), 0, st, a, nchunks, cpb, nblk, msplit, ws);
+    else if (a.KS == 7) hipLaunchKernelGGL((k_table_gemm<7, 1, 3>), grid, dim3(512), 0, st, a, nchunks, cpb, nblk, msplit, ws);
+    else hipLaunchKernelGGL((k_table_gemm<13, 1, 3>), grid, dim3(512), 0, st, a, nchunks, cpb, nblk, msplit, ws);
     return hipGetLastError();
 }
 

@@ -38,13 +38,26 @@ __device__ __forceinline__ void gm_split16(const uint4 &x0, const uint4 &x1, uin
     hi = make_uint4(h[0], h[1], h[2], h[3]);
 }
 
-__device__ __forceinline__ uint32_t gf_reduce_pos(uint32_t x) // x < 2^32 - q
+// x mod q for ANY 32-bit x.  t = trunc(float(x) * c), c = (1 - 2^-22) / q rounded to fp32, is floor(x / q) or one less for every
+// x < 2^32 (checked exhaustively on the host: tools/float_reduce_check.c, largest x - t q = 4 185 < 2 q), so one unsigned minimum
+// finishes (r - q wraps above r when r < q).  Six full-rate vector instructions (convert, multiply, convert, 24-bit multiply-add,
+// add, minimum); the integer form (multiply-high + multiply-low, both quarter rate) costs the issue slots of eleven.
+__device__ __forceinline__ uint32_t gf_reduce_u32(uint32_t x)
 {
-    // t = floor(x * floor(2^32 / q) / 2^32) is floor(x / q) or one less, so x - t q < 2 q: one conditional subtraction,
-    // done as an unsigned minimum (r - q wraps above r when r < q)
-    const uint32_t t = __umulhi(x, 1290167u);
-    const uint32_t r = x - t * (uint32_t)Q;
+    const uint32_t t = (uint32_t)((float)x * 0x1.3afb72p-12f);
+    const uint32_t r = (uint32_t)(__mul24((int)t, -Q) + (int)x); // t < 2^21: v_mad_i32_i24, low 32 bits
     return min(r, r - (uint32_t)Q);
+}
+
+// Recombination of the three limb products of an int8-limb MFMA accumulation (value = c0 + 64 c1, c0 in [-32, 31], c1 in
+// [-26, 26]; 4096 = 767 mod q):  S0 + 64 S1 + 767 S2 mod q.  |S0 + 64 S1 + 767 S2| <= k (1 024 + 64 * 1 664 + 767 * 676) =
+// 626 012 k <= 5.21e8 for k <= 832 whatever the operands are (the verifier multiplies values a prover chose), so a bias of
+// 200 000 q = 6.66e8 makes the sum a positive number below 2^31; |S2| <= 562 432 fits the 24-bit multiplier.
+constexpr int32_t LIMB_BIAS = 200000 * Q;
+static_assert(832LL * 626012 < LIMB_BIAS && 832LL * 626012 + LIMB_BIAS < (1LL << 31), "bias covers 13 k-steps of 64");
+__device__ __forceinline__ uint32_t gf_reduce_limbs(int32_t s0, int32_t s1, int32_t s2)
+{
+    return gf_reduce_u32((uint32_t)(__mul24(s2, 767) + s1 * 64 + s0 + LIMB_BIAS));
 }
 
 } // namespace kosk

@@ -337,7 +337,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     // ---- V0: opened list from the image, validated and expanded on the GPU (no host round trip); the host
     // only needs the list itself for the final Fiat-Shamir comparison and receives it with the first digests
     HIPCHK(launch_opened_setup(c.d_proof, c.image_stride, P.off[F_I], c.d_I, c.d_rest, c.d_isort, c.d_hrange, c.sel_stride, c.d_fail, n, st));
-    HIPCHK(hipMemcpy2DAsync(c.h_Iimg, 2 * NOPEN, c.d_proof + P.off[F_I], c.image_stride, 2 * NOPEN, n, hipMemcpyDeviceToHost, st));
+    HIPCHK(copy_small(c, c.h_Iimg, 2 * NOPEN, c.d_proof + P.off[F_I], c.image_stride, 2 * NOPEN, n, hipMemcpyDeviceToHost, st));
 
 
     // ---- V1: scatter, gate outputs on opened columns, Tcomm of the opened parties
@@ -423,7 +423,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     }
     t1 = now_sec(); c.phase_sec[PH_V_FS_ALPHA] = t1 - t0; t0 = t1;
     if (run_segment(c, Ctx::SEG_V2, n, [&]() -> int {
-    HIPCHK(hipMemcpyAsync(c.d_alpha, c.h_alpha, (size_t)n * 80 * 2, hipMemcpyHostToDevice, st));
+    HIPCHK(copy_small(c, c.d_alpha, 0, c.h_alpha, 0, (size_t)n * 80 * 2, 1, hipMemcpyHostToDevice, st));
 
     // ---- V2/V3: beta, gamma, r, NTT_r on the opened columns; reconstruction and NTT check
     HIPCHK(launch_pow_table(c.d_alpha, P.J, P.M, c.d_pwT, n, st));
@@ -480,7 +480,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     na.cmp_bit = FB_BETA_GAMMA;
     HIPCHK(launch_ntt(na, st));
     HIPCHK(launch_check_opened(va, n, st));
-    HIPCHK(hipMemcpyAsync(c.h_fail, c.d_fail, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(copy_small(c, c.h_fail, 0, c.d_fail, 0, sizeof(uint32_t) * n, 1, hipMemcpyDeviceToHost, st));
     return 0;
     })) return -1;
 

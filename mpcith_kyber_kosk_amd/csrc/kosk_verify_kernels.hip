@@ -475,7 +475,7 @@ __device__ __forceinline__ void interp_apply_block(const InterpApplyArgs &g, con
         if (col >= ncol) continue;
         uint32_t v[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) v[r] = gf_reduce_pos((uint32_t)(s0[j][r] + 64 * s1[j][r] + 767 * s2[j][r] + 90000 * Q));
+        for (int r = 0; r < 4; r++) v[r] = gf_reduce_limbs(s0[j][r], s1[j][r], s2[j][r]);
         if constexpr (SET) {
             *reinterpret_cast<uint2 *>(g.out2 + ((size_t)b * ncol + col) * NSEC + kb) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
         } else {

@@ -139,6 +139,7 @@ KNOBS = {  # knob -> (path counter that must be > 0 on the knob's handle, counte
     "KOSK_GRAPHS=1": ("graph_replay", None),
     "KOSK_DIGEST_DIRECT=1": ("digest_direct", "digest_copy"),
     "KOSK_COPY_WAVES=256": ("copy_kernel", None),
+    "KOSK_SMALL_COPY_KERNEL=0": (None, "small_copy_kernel"),
 }
 
 
@@ -156,6 +157,7 @@ def test_documented_knobs_do_not_change_results(knob, oracle, torch_cuda, monkey
         ref = base.verifiable_keygen(tapes)
         pc0 = base.path_counts()
         assert pc0["table_gemm"] > 0 and pc0["hash_dma"] > 0 and pc0["ntt_int"] > 0 and pc0["graph_replay"] == 0 and pc0["hash_plain"] == 0
+        assert pc0["small_copy_kernel"] > 0  # the default: challenge vectors, opened lists, key records and fail masks move by kernel
         monkeypatch.setenv(name, val)
         ctx = api.Kosk(kyber_k=k, max_batch=n)
         monkeypatch.delenv(name)

@@ -4,6 +4,7 @@ import ctypes as C
 import hashlib
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -179,3 +180,17 @@ def test_compact_codec_roundtrip_on_oracle_proof(oracle):
     assert back.raw == pi
     bad = bytearray(pi); bad[1] = 0x10
     assert api.lib.kosk_proof_compress(k, bytes(bad), out) == -1
+
+
+def test_float_reciprocal_reduction_is_exact_for_every_u32(tmp_path):
+    """The device's mod-q reduction of the MFMA epilogues (gf_reduce_u32, csrc/kosk_limb_dev.hpp) converts to fp32, multiplies by a
+    rounded (1 - 2^-22) / q and truncates: tools/float_reduce_check.c runs the same IEEE operations over all 2^32 inputs."""
+    import re
+    src = os.path.join(ROOT, "tools", "float_reduce_check.c")
+    hdr = open(os.path.join(ROOT, "mpcith_kyber_kosk_amd", "csrc", "kosk_limb_dev.hpp")).read()
+    const = re.search(r"\(float\)x \* (0x[0-9a-f.]+p-12f)", hdr).group(1)
+    assert const in open(src).read(), "the checked constant is not the kernel's"
+    exe = str(tmp_path / "frc")
+    subprocess.check_call(["gcc", "-O2", "-o", exe, src])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, text=True, timeout=300).stdout
+    assert "bad=0" in out and int(re.search(r"maxr=(\d+)", out).group(1)) < 2 * 3329, out
