@@ -1,15 +1,14 @@
 #!/usr/bin/env python3
 """Where ONE stream's time goes between its kernels (rocprofv3 kernel trace of a one-cohort run, e.g. tools/gpu_busy.sh with
 BUSY_ARGS="--slots 3 --combine 3"): for every kernel, the idle time on the stream BEFORE it (previous kernel's end -> its start),
-averaged over the steady-state steps and listed in launch order of one step.  A 'step' starts at k_prover_pre's first launch after a
-k_check_opened.  Not product code.   usage: trace_gaps.py <kernel_trace.csv>"""
+averaged over the steady-state steps and listed in launch order of one step.  A 'step' starts at the first k_prover_pre after a
+k_check_opened; the idle time between two steps (the caller's turn-around) is reported on its own.  Not product code.   usage: trace_gaps.py <kernel_trace.csv>"""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("kosk::", "")) for r in rows)
-# split into steps at the first kernel after every k_check_opened (the verifier's last kernel but the fail-mask copy)
 steps, cur, closing = [], [], False
 for s, e, n in ev:
-    if closing and not n.startswith("__amd_rocclr"):
+    if closing and n.startswith("k_prover_pre"):
         steps.append(cur); cur = []; closing = False
     cur.append((s, e, n))
     if n.startswith("k_check_opened"): closing = True
@@ -26,4 +25,5 @@ for i in range(L):
     gap = sum((st[i][0] - st[i - 1][1]) if i else 0 for st in steps) / len(steps) / 1e3
     tot_gap += gap
     print("%3d %-36s gap before %7.1f us   kernel %7.1f us%s" % (i, name[:36], gap, dur, "   <<" if gap > 30 else ""))
-print("sum of gaps inside a step: %.0f us" % tot_gap)
+print("sum of gaps inside a step: %.0f us; between a step's last kernel and the next step's first: %.0f us" % (tot_gap,
+      sum(b[0][0] - a[-1][1] for a, b in zip(steps, steps[1:]) if b[0][0] - a[-1][1] < 5e6) / max(1, len(steps) - 1) / 1e3))
