@@ -2,11 +2,11 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r4
 O=gpurun_out/r4/sweep26.txt; rm -f $O
 run() { echo "== $1" >> $O; shift
-  /usr/bin/time -f "%e s wall" -o gpurun_out/r4/t26.time timeout -k 10 300 python bench.py --gpus 1 --no-kernels --no-cpu-baseline "$@" 2>>gpurun_out/r4/sweep26.err | python -c "
+  t0=$(date +%s.%N); timeout -k 10 300 python bench.py --gpus 1 --no-kernels --no-cpu-baseline "$@" 2>>gpurun_out/r4/sweep26.err | python -c "
 import sys,json
 j=json.loads(sys.stdin.readline())
 print(json.dumps({'value':round(j['value']),'steps':j['steps'],'ms_per_step':round(j['ms_per_step'],4),'lat':round(j['step_latency_ms']['median'],2),'p90':round(j['step_latency_ms']['p90'],2),'frac':round((j['roofline'] or {}).get('frac'),4),'cores':j['host_cpu_cores_busy'],'drained':round(j['drained_run']['value'])}))
-" >> $O; cat gpurun_out/r4/t26.time >> $O
+" >> $O; python3 -c "import time,sys; print(\"%.1f s wall\" % (time.time() - float(sys.argv[1])))" $t0 >> $O
 }
 for i in 1 2 3 4 5; do
 run "9/3 driver flags #$i" --steps 20 --warmup 5
