@@ -196,6 +196,25 @@ def big_batches():
     print("big_batches ok")
 
 
+def process_wide_knobs(n):
+    """The per-PROCESS kernel knobs (read once by the first launch, so they need a process of their own; the caller sets them in
+    this child's environment): KOSK_TG_WIDE=1 -- 64 data rows per workgroup in the expansion product where that takes fewer rounds,
+    which is the case at 138 proofs = 29 946 rows per launch -- and KOSK_TG_STORE16=0 -- 8-byte stores only.  Same bytes as the
+    oracle, every proof verifies."""
+    from mpcith_kyber_kosk_amd import api
+    k = 3
+    ctx = api.Kosk(kyber_k=k, max_batch=n)
+    tapes = [oracle.tape_bytes_for(k, 7000 + b) for b in range(n)]
+    pks, sks, pis = ctx.verifiable_keygen(tapes)
+    for b in sorted({0, n // 2, n - 1}):
+        opk, osk, opi, _, _ = oracle.verifiable_keygen(k, tapes[b])
+        assert (pks[b], sks[b], pis[b]) == (opk, osk, opi), b
+    assert ctx.verify(pis, pks) == [True] * n
+    assert ctx.path_counts()["table_gemm"] > 0
+    ctx.close()
+    print("process_wide_knobs ok", n, os.environ.get("KOSK_TG_WIDE"), os.environ.get("KOSK_TG_STORE16"))
+
+
 def combined_calls(k, threads=6, rounds=4, min_merge=0.5):
     """KOSK_COMBINE=3: six caller threads, each with its own handle and its own small resident calls.  The calls of a cohort's
     members are served by merged pipeline runs; every caller must get exactly what an uncombined handle gives it -- pk, sk, proof

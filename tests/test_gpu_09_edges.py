@@ -63,6 +63,13 @@ def test_host_paths_under_glibc_heap_checking(torch_cuda, gpu_child):
     assert "heap-checked ok" in out
 
 
+@pytest.mark.parametrize("env,n", [({"KOSK_TG_WIDE": "1"}, 138), ({"KOSK_TG_STORE16": "0"}, 5)])
+def test_per_process_table_product_knobs_do_not_change_results(env, n, torch_cuda, gpu_child):
+    """tests/gpu_child_cases.py: process_wide_knobs -- the two table-product knobs that are read once per process."""
+    out = gpu_child("from tests.gpu_child_cases import process_wide_knobs; process_wide_knobs(%d)" % n, env=env)
+    assert "process_wide_knobs ok %d" % n in out
+
+
 def test_abi_errors_are_return_codes(torch_cuda, gpu_child):
     out = gpu_child("from tests.gpu_child_cases import errors_do_not_kill; errors_do_not_kill(2)")
     assert "errors_do_not_kill ok" in out

@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r4f
-timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/r4f/r04_gputest.log 2>&1; echo "pytest exit $?" >> gpurun_out/r4f/r04_gputest.log; tail -3 gpurun_out/r4f/r04_gputest.log; rm -f gpurun_out/r4f/r04_b* gpurun_out/r4f/r04_gpu* gpurun_out/r4f/r04_pmc* gpurun_out/r4f/traffic.json
+rm -rf gpurun_out/r4f; mkdir -p gpurun_out/r4f
+timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/r4f/r04_gputest.log 2>&1; echo "pytest exit $?" >> gpurun_out/r4f/r04_gputest.log; tail -3 gpurun_out/r4f/r04_gputest.log
 timeout -k 10 900 python bench.py > gpurun_out/r4f/r04_bench_default.json 2> gpurun_out/r4f/bench_default.err; echo "bench exit $?"
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 > gpurun_out/r4f/r04_bench_driver_flags.json 2>/dev/null; echo "bench (driver flags) exit $?"
 bash tools/make_profiles.sh r04 > gpurun_out/r4f/make_profiles.log 2>&1; tail -8 gpurun_out/r4f/make_profiles.log
