@@ -326,7 +326,79 @@ __attribute__((always_inline)) static inline void sha3_256_xw(uint8_t *const *ou
         }
 }
 
-__attribute__((target("avx512f"))) void sha3_256_x8_avx512(uint8_t *const *out, const uint8_t *const *in, size_t len) { sha3_256_xw<8>(out, in, len); }
+// Eight messages of equal length, SHA3-256, AVX-512: the state's 25 lanes stay in 25 vector variables for the whole message and the
+// 24 rounds are an IN-PLACE schedule (kosk_keccak_x8_rounds.inc, generated by tools/gen_keccak_x8.py): chi writes a row of the new
+// state into the registers whose old lanes it has just consumed, so there is no second copy of the state to spill (the generic
+// template above needs 50 vectors plus temporaries for the 32 registers: a third of its instructions were moves to and from the
+// stack).  Three-way XOR and chi are one vpternlogq each.  The Fiat-Shamir rounds of a step hash 186 KB per proof on the host: this
+// function is the largest single consumer of the host's CPU share.
+#include <immintrin.h>
+__attribute__((target("avx512f"))) void sha3_256_x8_avx512(uint8_t *const *out, const uint8_t *const *in, size_t len)
+{
+    const __m512i zero = _mm512_setzero_si512();
+    __m512i s0 = zero, s1 = zero, s2 = zero, s3 = zero, s4 = zero, s5 = zero, s6 = zero, s7 = zero, s8 = zero, s9 = zero, s10 = zero, s11 = zero,
+            s12 = zero, s13 = zero, s14 = zero, s15 = zero, s16 = zero, s17 = zero, s18 = zero, s19 = zero, s20 = zero, s21 = zero, s22 = zero,
+            s23 = zero, s24 = zero;
+    __m512i C0, C1, C2, C3, C4, D0, D1, D2, D3, D4;
+#define KTHETA(x, a, b, c, d, e) C##x = _mm512_ternarylogic_epi64(_mm512_ternarylogic_epi64(a, b, c, 0x96), d, e, 0x96);
+#define KD()                                            \
+    D0 = _mm512_xor_si512(C4, _mm512_rol_epi64(C1, 1)); \
+    D1 = _mm512_xor_si512(C0, _mm512_rol_epi64(C2, 1)); \
+    D2 = _mm512_xor_si512(C1, _mm512_rol_epi64(C3, 1)); \
+    D3 = _mm512_xor_si512(C2, _mm512_rol_epi64(C4, 1)); \
+    D4 = _mm512_xor_si512(C3, _mm512_rol_epi64(C0, 1));
+#define KROW(a0, d0, r0, a1, d1, r1, a2, d2, r2, a3, d3, r3, a4, d4, r4)        \
+    {                                                                           \
+        const __m512i t0 = _mm512_rol_epi64(_mm512_xor_si512(a0, D##d0), r0);    \
+        const __m512i t1 = _mm512_rol_epi64(_mm512_xor_si512(a1, D##d1), r1);    \
+        const __m512i t2 = _mm512_rol_epi64(_mm512_xor_si512(a2, D##d2), r2);    \
+        const __m512i t3 = _mm512_rol_epi64(_mm512_xor_si512(a3, D##d3), r3);    \
+        const __m512i t4 = _mm512_rol_epi64(_mm512_xor_si512(a4, D##d4), r4);    \
+        a0 = _mm512_ternarylogic_epi64(t0, t1, t2, 0xD2); /* t0 ^ (~t1 & t2) */  \
+        a1 = _mm512_ternarylogic_epi64(t1, t2, t3, 0xD2);                        \
+        a2 = _mm512_ternarylogic_epi64(t2, t3, t4, 0xD2);                        \
+        a3 = _mm512_ternarylogic_epi64(t3, t4, t0, 0xD2);                        \
+        a4 = _mm512_ternarylogic_epi64(t4, t0, t1, 0xD2);                        \
+    }
+#define KIOTA(a, r) a = _mm512_xor_si512(a, _mm512_set1_epi64((long long)kKeccak.rc[r]));
+#define KABSORB(w, src, off) s##w = _mm512_xor_si512(s##w, _mm512_set_epi64((long long)load64(src[7] + (off) + 8 * w), (long long)load64(src[6] + (off) + 8 * w), \
+        (long long)load64(src[5] + (off) + 8 * w), (long long)load64(src[4] + (off) + 8 * w), (long long)load64(src[3] + (off) + 8 * w),                          \
+        (long long)load64(src[2] + (off) + 8 * w), (long long)load64(src[1] + (off) + 8 * w), (long long)load64(src[0] + (off) + 8 * w)));
+#define KABSORB_BLOCK(src, off)                                                                                                     \
+    KABSORB(0, src, off) KABSORB(1, src, off) KABSORB(2, src, off) KABSORB(3, src, off) KABSORB(4, src, off) KABSORB(5, src, off)   \
+    KABSORB(6, src, off) KABSORB(7, src, off) KABSORB(8, src, off) KABSORB(9, src, off) KABSORB(10, src, off) KABSORB(11, src, off) \
+    KABSORB(12, src, off) KABSORB(13, src, off) KABSORB(14, src, off) KABSORB(15, src, off) KABSORB(16, src, off)
+    size_t off = 0;
+    while (len - off >= 136) {
+        KABSORB_BLOCK(in, off)
+#include "kosk_keccak_x8_rounds.inc"
+        off += 136;
+    }
+    uint8_t last[8][136];
+    const uint8_t *lp[8];
+    for (int i = 0; i < 8; i++) {
+        memset(last[i], 0, 136);
+        memcpy(last[i], in[i] + off, len - off);
+        last[i][len - off] = 0x06;
+        last[i][135] |= 0x80;
+        lp[i] = last[i];
+    }
+    KABSORB_BLOCK(lp, 0)
+#include "kosk_keccak_x8_rounds.inc"
+    alignas(64) uint64_t w[4][8];
+    _mm512_store_si512(w[0], s0);
+    _mm512_store_si512(w[1], s1);
+    _mm512_store_si512(w[2], s2);
+    _mm512_store_si512(w[3], s3);
+    for (int i = 0; i < 8; i++)
+        for (int q = 0; q < 4; q++) memcpy(out[i] + 8 * q, &w[q][i], 8);
+#undef KTHETA
+#undef KD
+#undef KROW
+#undef KIOTA
+#undef KABSORB
+#undef KABSORB_BLOCK
+}
 __attribute__((target("avx2"))) void sha3_256_x4_avx2(uint8_t *const *out, const uint8_t *const *in, size_t len) { sha3_256_xw<4>(out, in, len); }
 __attribute__((target("avx512f,avx512vl"))) void sha3_256_x4_avx512vl(uint8_t *const *out, const uint8_t *const *in, size_t len) { sha3_256_xw<4>(out, in, len); }
 
