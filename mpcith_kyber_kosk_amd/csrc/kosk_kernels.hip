@@ -531,15 +531,19 @@ __device__ __forceinline__ void pre_noise(const PreArgs &a, int t)
 
 __global__ __launch_bounds__(64) void k_prover_pre(PreArgs a)
 {
+    // Workgroups are dispatched in index order, so the roles come longest chain first: G (a matrix entry: six or more dependent
+    // Keccak permutations and a rejection parse per lane, ~60 us for a lone wave), N, A (four permutations per lane) start at once
+    // and the thousands of short role-B workgroups stream through beside them.  With B in front of G (rounds 1-3) the launch took
+    // B's streaming time PLUS G's chain: 100 us at 138 proofs, 73 us at 46.
     int blk = blockIdx.x;
-    if (blk < a.nbA) return pre_expand_f(a, blk * 64 + threadIdx.x);
-    blk -= a.nbA;
-    if (blk < a.nbB) return pre_tape_randoms(a, blk, threadIdx.x);
-    blk -= a.nbB;
     if (blk < a.nbG) return pre_gen_matrix(a, blk * 64 + threadIdx.x);
     blk -= a.nbG;
     if (blk < a.nbN) return pre_noise(a, blk * 64 + threadIdx.x);
-    pre_witness_secrets(a, blk - a.nbN, threadIdx.x);
+    blk -= a.nbN;
+    if (blk < a.nbA) return pre_expand_f(a, blk * 64 + threadIdx.x);
+    blk -= a.nbA;
+    if (blk < a.nbB) return pre_tape_randoms(a, blk, threadIdx.x);
+    pre_witness_secrets(a, blk - a.nbB, threadIdx.x);
 }
 
 // =========================================================================
