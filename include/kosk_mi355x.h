@@ -52,8 +52,8 @@ int kosk_set_randombytes(kosk_ctx *ctx, kosk_randombytes_fn fn, void *user); /* 
  * (kyber/randombytes.c:49-52).  A batch call creates no threads (kosk_create made them).
  * HIP error state: the library's launchers read hipGetLastError(), so every entry point first RESETS the calling thread's HIP
  * last-error state; an application that launches kernels of its own must check them before it calls in here.
- * Proof buffers in host memory must not be shared between concurrent calls unless the caller page-locked them itself (a
- * multi-chunk call page-locks the whole pages inside a pageable buffer for its own duration only).
+ * With KOSK_REGISTER=2 proof buffers in pageable host memory must not be shared between concurrent calls (a multi-chunk call then
+ * page-locks the whole pages inside the buffer for its own duration; by default nothing of the caller's is page-locked).
  * gen_matrix's rejection sampling (indcpa.c:124-145) loops without a bound in the reference; on the host this library does the
  * same, on the GPU it squeezes at most 32 SHAKE128 blocks per matrix entry (three suffice with probability 1 - 2^-40) and a
  * call that ever reached that limit returns -1 ("block limit") without results -- for key generation and for the verifier's
@@ -64,8 +64,8 @@ int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, siz
 /* Page-locked host memory for the proof buffers of the two host-buffer calls (no reference counterpart: the reference's
  * caller owns plain arrays, main.cpp:71).  Proof images in such a buffer (or in any memory the caller page-locked itself with
  * hipHostMalloc / hipHostRegister) cross PCIe straight from / to it: no staging copy on the host and no per-call locking.
- * Plain (pageable) buffers keep working: a multi-chunk call page-locks the whole pages inside the buffer for its duration,
- * everything else goes through the library's pinned staging buffers.  NULL on failure. */
+ * Plain (pageable) buffers keep working through the library's pinned staging buffers (KOSK_REGISTER=2: a multi-chunk call
+ * page-locks the whole pages inside the buffer for its duration and copies to them directly).  NULL on failure. */
 void *kosk_host_alloc(size_t bytes);
 void kosk_host_free(void *p);
 

@@ -182,7 +182,7 @@ struct HostSpan {
 static HostSpan lock_span(const kosk_ctx *h, const uint8_t *p, size_t bytes)
 {
     HostSpan s;
-    if (!h->c->host_register || !p) return s;
+    if (!h->c->host_register || !h->c->host_lock_pageable || !p) return s;
     const long pg = sysconf(_SC_PAGESIZE);
     const uintptr_t page = pg > 0 ? (uintptr_t)pg : 4096;
     const uintptr_t a = (reinterpret_cast<uintptr_t>(p) + page - 1) & ~(page - 1), b = (reinterpret_cast<uintptr_t>(p) + bytes) & ~(page - 1);

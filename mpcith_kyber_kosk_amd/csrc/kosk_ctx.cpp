@@ -382,7 +382,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     if (const char *e = getenv("KOSK_HASH_DMA")) c.hash_dma = atoi(e) != 0;
     if (const char *e = getenv("KOSK_HASH_PRIMER")) c.hash_primer = atoi(e) != 0;
     if (const char *e = getenv("KOSK_TABLE_GEMM")) c.table_gemm = atoi(e) != 0;
-    if (const char *e = getenv("KOSK_REGISTER")) c.host_register = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_REGISTER")) { c.host_register = atoi(e) != 0; c.host_lock_pageable = atoi(e) >= 2; }
     if (const char *e = getenv("KOSK_DIGEST_DIRECT")) c.digest_direct = atoi(e) != 0;
     if (const char *e = getenv("KOSK_SMALL_COPY_KERNEL")) c.small_copy_kernel = atoi(e) != 0;
     if (const char *e = getenv("KOSK_COPY_WAVES")) c.copy_waves = atoi(e) >= 0 ? (atoi(e) > 65535 ? 65535 : atoi(e)) : c.copy_waves;

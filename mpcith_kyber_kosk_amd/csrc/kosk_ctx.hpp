@@ -252,7 +252,11 @@ struct Ctx {
     // profiles/r04_copy_kernel.txt), so it is an experiment knob only
     int copy_waves = 0;
     bool small_copy_kernel = true; // KOSK_SMALL_COPY_KERNEL=0: hipMemcpyAsync for the small copies too (copy_small)
-    bool host_register = true; // KOSK_REGISTER=0: multi-chunk host-buffer calls never page-lock caller memory (staging copies only)
+    bool host_register = true;       // KOSK_REGISTER=0: staging copies only, even for buffers the caller page-locked itself
+    bool host_lock_pageable = false; // KOSK_REGISTER=2: a multi-chunk host-buffer call page-locks the whole pages inside a PAGEABLE caller
+                                     // buffer for its duration (hipHostRegister).  Off by default since round 4: both process aborts on
+                                     // record (round 2's GPU test run, one of nine suite runs of round 4) happened inside calls that had
+                                     // just page-locked Python heap memory; neither left a message and neither was reproduced
     int cu_part_i = 0, cu_part_n = 1; // KOSK_CU_PARTITION=i/n: the stream is restricted to partition i of n CU partitions
     int cu_mask_layout = 0;           // KOSK_CU_MASK_LAYOUT: how CU-mask bits map to XCDs (0 round-robin, 1 XCD-major)
     unsigned hash_opts() const { return (hash_dma ? HASH_OPT_DMA : 0u) | (hash_primer ? HASH_OPT_PRIMER : 0u); }

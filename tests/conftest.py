@@ -11,6 +11,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    os.environ.setdefault("LIBC_FATAL_STDERR_", "1")  # glibc's fatal messages (heap checks, stack protector) to stderr, not to /dev/tty
     # where the reference tree is mounted (the build container) the pins against the reference compiled in place are REQUIRED:
     # tests/test_oracle_vs_ref.py fails instead of skipping when oracle/_ref is missing.  Elsewhere (the GPU box has no
     # /root/reference; the prebuilt oracle/_ref travels with the tree) set KOSK_REQUIRE_REF=1 by hand to get the same.

@@ -26,15 +26,15 @@ def _kosk(k, max_batch, **env):
 
 def streamed_chunks(k):
     """KOSK_STREAMS=3: a call longer than one sub-context is cut into chunks that run on three sub-contexts concurrently
-    (whole pages of the caller's buffer page-locked for the call); n = 7 over sub-batches of 2 leaves a ragged last chunk.
-    Same bytes as the single-context path and the oracle, with and without page-locking (KOSK_REGISTER=0)."""
+    (KOSK_REGISTER=2: whole pages of the caller's buffer page-locked for the call); n = 7 over sub-batches of 2 leaves a ragged last
+    chunk.  Same bytes as the single-context path and the oracle, with page-locking and without (the default)."""
     from mpcith_kyber_kosk_amd import api
     n = 7
     tapes = [oracle.tape_bytes_for(k, 40 + b) for b in range(n)]
     plain = api.Kosk(kyber_k=k, max_batch=n)
     pks0, sks0, pis0 = plain.verifiable_keygen(tapes)
     assert plain.path_counts()["copy_direct"] == 0          # single chunk: always staged
-    st = _kosk(k, 6, KOSK_STREAMS=3)
+    st = _kosk(k, 6, KOSK_STREAMS=3, KOSK_REGISTER=2)  # page-lock the caller's pageable buffer (the default of rounds 2-3)
     assert st.streams == 3 and st.host_threads >= 1
     pks, sks, pis = st.verifiable_keygen(tapes)
     assert pks == pks0 and sks == sks0 and pis == pis0
@@ -58,14 +58,14 @@ def streamed_chunks(k):
     assert plain.verify(bad, keys) == want
     assert plain.fail_masks(n) == m_st
     assert all((m != 0) == (not w) for m, w in zip(m_st, want))
-    # the opt-out of page-locking: per handle, gives the same bytes, and really never locks
-    st2 = _kosk(k, 6, KOSK_STREAMS=3, KOSK_REGISTER=0)
+    # the default (and KOSK_REGISTER=0): per handle, gives the same bytes, and never locks pageable caller memory
+    st2 = _kosk(k, 6, KOSK_STREAMS=3)
     pks2, sks2, pis2 = st2.verifiable_keygen(tapes)
     assert pks2 == pks0 and sks2 == sks0 and pis2 == pis0
     assert st2.verify(bad, keys) == want
     pc2 = st2.path_counts()
     assert pc2["copy_direct"] == 0 and pc2["copy_staged"] == 8, pc2
-    # the handle created BEFORE that knob was set still page-locks (the knob is per handle, not per process)
+    # the handle created with KOSK_REGISTER=2 still page-locks (the knob is per handle, not per process)
     before = st.path_counts()["copy_direct"]
     assert st.verifiable_keygen(tapes)[2] == pis0
     assert st.path_counts()["copy_direct"] > before
@@ -82,7 +82,7 @@ def streamed_loop(k, iters):
     tapes = [oracle.tape_bytes_for(k, 40 + b) for b in range(n)]
     plain = api.Kosk(kyber_k=k, max_batch=n)
     ref = plain.verifiable_keygen(tapes)
-    hs = [_kosk(k, 6, KOSK_STREAMS=3), _kosk(k, 4, KOSK_STREAMS=2), _kosk(k, 6, KOSK_STREAMS=3, KOSK_REGISTER=0), _kosk(k, 3)]
+    hs = [_kosk(k, 6, KOSK_STREAMS=3, KOSK_REGISTER=2), _kosk(k, 4, KOSK_STREAMS=2), _kosk(k, 6, KOSK_STREAMS=3, KOSK_REGISTER=0), _kosk(k, 3)]
     for it in range(iters):
         h = hs[it % len(hs)]
         got = h.verifiable_keygen(tapes)
