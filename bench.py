@@ -484,6 +484,7 @@ def main():
     ap.add_argument("--cpu-proofs", type=int, default=12, help="bounded CPU baseline sample (about 13 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the 65 536-lane kernel leg and the PCIe-inclusive drop-in leg")
+    ap.add_argument("--leg", default="", choices=["", "drop_in"], help="(internal) run ONE auxiliary leg in this process and print its JSON object")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     if args.kyber_k:
@@ -492,6 +493,11 @@ def main():
         cfg["batch"] = args.batch
     custom = bool(args.kyber_k or args.batch)
     k, B = cfg["k"], cfg["batch"]
+    if args.leg == "drop_in":  # a child of the measuring process (below): handles, threads and page-locked buffers of its own
+        import torch
+        from mpcith_kyber_kosk_amd import api
+        print(json.dumps(drop_in(api, torch, k, B, tapes_for(0, B, api.tape_bytes(k)), 0)))
+        return
     S = args.slots if args.slots > 0 else cfg["slots"]
     CMB = args.combine if args.combine > 0 else (cfg.get("combine", 1) if not args.batch else 1)
     if args.partitions > 1:
@@ -827,8 +833,17 @@ def main():
             sl.c.close()
     if rank == 0:
         if aux:
+            # the host-buffer leg runs in a child process as well: it drives KOSK_STREAMS=3 handles from two threads over caller
+            # memory, and nothing that could go wrong there may take the measured line with it
             try:
-                line["drop_in"] = drop_in(api, torch, k, B, tapes, local_rank)
+                import subprocess
+                env_ = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("KOSK_HOST_THREADS", "KOSK_BLOCKING_SYNC", "KOSK_COMBINE", "KOSK_BENCH_COMBINE", "KOSK_BENCH_SLOTS")}
+                r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", "drop_in", "--config", str(args.config)], stdout=subprocess.PIPE,
+                                    stderr=subprocess.PIPE, text=True, timeout=600, env=env_)
+                sub_ = [ln for ln in r_.stdout.splitlines() if ln.startswith("{")]
+                if r_.returncode != 0 or not sub_:
+                    raise RuntimeError("rc %d: %s" % (r_.returncode, (r_.stderr or "")[-300:]))
+                line["drop_in"] = json.loads(sub_[-1])
             except Exception as e:  # noqa: BLE001
                 line["drop_in"] = {"error": repr(e)[:400]}
             # two side runs as fresh child processes with their own host-thread budget, reported NEXT TO the line of record, never as
