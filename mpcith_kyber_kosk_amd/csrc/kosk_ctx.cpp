@@ -68,6 +68,7 @@ Ctx::~Ctx()
         if (h_compact_bad) (void)hipHostFree(h_compact_bad);
         if (pool) pool_destroy(pool);
         if (ev) (void)hipEventDestroy(ev);
+        if (ev_kg) (void)hipEventDestroy(ev_kg);
         for (auto e : timer_ev)
             if (e) (void)hipEventDestroy(e);
         return; // the stream is the arena's
@@ -87,6 +88,7 @@ Ctx::~Ctx()
     if (h_compact_bad) (void)hipHostFree(h_compact_bad);
     if (pool) pool_destroy(pool);
     if (ev) (void)hipEventDestroy(ev);
+    if (ev_kg) (void)hipEventDestroy(ev_kg);
     for (auto e : timer_ev)
         if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
@@ -429,6 +431,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
             HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
         }
         HIPCHK(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
+        HIPCHK(hipEventCreateWithFlags(&c.ev_kg, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
         if (c.blocking_sync) HIPCHK(hipEventCreateWithFlags(&c.ev_sync, hipEventDisableTiming | hipEventBlockingSync));
         for (auto &pe : c.prof_ev)
             for (auto &e : pe) HIPCHK(hipEventCreate(&e));
@@ -520,7 +523,7 @@ int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx
     // streams of the run leaders of three cohorts of three all landed on the SAME hardware queue (measured: 138-proof runs
     // took 2.8 ms instead of 1.6).  Calls end with a stream synchronisation, so members never leave work behind for each other.
     c.use_graphs = false; // stream capture is per stream: not with several callers on one
-    c.ev = nullptr; c.ev_sync = nullptr; c.pool = nullptr;
+    c.ev = nullptr; c.ev_kg = nullptr; c.ev_sync = nullptr; c.pool = nullptr;
     for (auto &e : c.ev_img) e = nullptr;
     c.host_img = nullptr;
     c.h_err = nullptr;
@@ -542,6 +545,7 @@ int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx
     auto body = [&]() -> int {
         HIPCHK(hipSetDevice(c.device));
         HIPCHK(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
+        HIPCHK(hipEventCreateWithFlags(&c.ev_kg, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
         if (c.blocking_sync) HIPCHK(hipEventCreateWithFlags(&c.ev_sync, hipEventDisableTiming | hipEventBlockingSync));
         for (auto &pe : c.prof_ev)
             for (auto &e : pe) HIPCHK(hipEventCreate(&e));
@@ -668,6 +672,8 @@ int issue_keygen(Ctx &c, int n, bool sampled)
     HIPCHK(launch_keygen_pack(c.d_A, c.key_stride, c.d_sehat, c.se_stride, c.d_seeds, c.kg_rec, c.d_t, c.d_pk, c.pk_stride, c.d_sb,
                               c.sb_stride, K, n, c.stream));
     HIPCHK(copy_small(c, c.h_kg, 0, c.d_kg, 0, (size_t)n * c.kg_rec, 1, hipMemcpyDeviceToHost, c.stream)); // pk, NTT(s) bytes, seeds: one copy
+    c.kg_on_host_pending = false;
+    if (!c.capturing) { HIPCHK(hipEventRecord(c.ev_kg, c.stream)); c.kg_on_host_pending = true; } // (a keygen-in-front call is never captured)
     c.resident_pk_n = n;
     return 0;
 }
@@ -809,12 +815,22 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         if (!c.lincomb_fused) HIPCHK(launch_cols_to_limbs(c.d_P, c.proof_stride, rm.f, rm.tf, P.M, c.d_linA, a_gstride, n, st));
         return 0;
     })) return -1;
+    // the host half of the key generation (sk = NTT(s) bytes || pk || H(pk) || z per proof) needs only the key records, which left
+    // the GPU behind the first launches: done HERE, under the expansion product, the Tcomm hash and the digest copy, not after them
+    // in front of the host's first round (where it was 30-40 us of a step's critical path with the GPU idle)
+    bool keys_done = false;
+    if (keygen && c.kg_on_host_pending) {
+        HIPCHK(hipEventSynchronize(c.ev_kg));
+        finish_keygen_segs(c, n, *keygen);
+        keys_done = true;
+    }
+    c.kg_on_host_pending = false;
     HIPCHK(hipEventSynchronize(c.ev));
     t1 = now_sec(); c.phase_sec[PH_GPU_COMMIT] = t1 - t0; t0 = t1;
     if (c.round_hook) c.round_hook(c.round_user, 0, 0, c.d_dig1, (size_t)n * NPARTY * 32);
 
-    // ---- Fiat-Shamir round 1 on the host (and the host half of the key generation)
-    if (keygen) finish_keygen_segs(c, n, *keygen);
+    // ---- Fiat-Shamir round 1 on the host
+    if (keygen && !keys_done) finish_keygen_segs(c, n, *keygen);
     fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool);
     t1 = now_sec(); c.phase_sec[PH_FS_ALPHA] = t1 - t0; t0 = t1;
 

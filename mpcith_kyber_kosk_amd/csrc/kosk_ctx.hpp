@@ -202,6 +202,10 @@ struct Ctx {
     const uint8_t *host_img = nullptr;            // the caller's host copy of the proof images of THIS call (kosk_verify_batch)
     size_t host_img_stride = 0;
     hipEvent_t ev = nullptr;
+    std::vector<uint16_t> v_I2, v_rest2; // the verifier's recomputed opened lists (kept across calls: two fresh 0.4 MB vectors per call were
+                                         // an mmap, a page fault per page and a munmap on the tail of every verify call)
+    bool kg_on_host_pending = false; // ev_kg was recorded by this call's key generation
+    hipEvent_t ev_kg = nullptr; // the key records (pk, NTT(s) bytes, seeds) of a keygen-in-front call are on the host once it has passed
     hipEvent_t ev_sync = nullptr; // KOSK_BLOCKING_SYNC=1: every host wait sleeps on an event instead of spinning (few host cores per GPU)
     bool blocking_sync = false;
     int n_simd = 1024;      // SIMDs of the device (4 per CU)
