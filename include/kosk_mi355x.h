@@ -178,7 +178,8 @@ int kosk_profile_read_units(const kosk_ctx *ctx, int id, double *total_ms, long 
  * waits at most KOSK_COMBINE_WAIT_US (default 5000) for the other members, and only for those that are inside a call or left
  * one less than KOSK_COMBINE_IDLE_US (default 1000) ago: a lone caller is never delayed, callers that loop fall into step after
  * one or two calls (a request whose kind is in the minority of its window is held back once, so that callers alternating
- * keygen / verify in opposite phase meet).  Calls that draw randomness through
+ * keygen / verify in opposite phase meet).  The callers of a merged run sleep while it executes and are woken shortly before its
+ * end (they then spin at most KOSK_COMBINE_PREWAKE_US, default 400, for the return).  Calls that draw randomness through
  * the callback (tapes == NULL), handles with a round hook, and every other entry point run unmerged on the member's own
  * block.  All handles of a cohort must be destroyed before the process ends (the last one frees the workspace).
  * kosk_combine_stats: resident calls of THIS handle that went through the combiner, and the sum over those calls of the

@@ -296,7 +296,9 @@ int kosk_create(kosk_ctx **ctx, int device, int kyber_k, int max_batch)
                 int wait_us = 5000, idle_us = 1000;
                 if (const char *e = getenv("KOSK_COMBINE_WAIT_US")) wait_us = atoi(e) >= 0 ? atoi(e) : wait_us;
                 if (const char *e = getenv("KOSK_COMBINE_IDLE_US")) idle_us = atoi(e) >= 0 ? atoi(e) : idle_us;
-                fresh->comb.reset(new Combiner(W, wait_us, idle_us));
+                int prewake_us = 400; // how long a member whose run has announced its end may spin for it (0: members sleep to the end)
+                if (const char *e = getenv("KOSK_COMBINE_PREWAKE_US")) prewake_us = atoi(e) >= 0 ? atoi(e) : prewake_us;
+                fresh->comb.reset(new Combiner(W, wait_us, idle_us, prewake_us));
                 fresh->member.assign((size_t)W, nullptr);
                 if ((long)W * max_batch > 1 << 20) { g_create_err = "KOSK_COMBINE x max_batch too large"; delete h; return -1; }
                 if (ctx_create(&fresh->arena, device, kyber_k, W * max_batch, g_create_err, 1)) { delete h; return -1; }
@@ -454,6 +456,22 @@ static void run_epilogue(Cohort &co, int first, int count, int rc, const Ctx &le
     }
 }
 
+// Scope of a merged run on its leader's view: while it lives, prove_resident / verify_resident tell the combiner when only their tail
+// is left, and the run's other callers wake up for the return instead of sleeping through it (kosk_combine.hpp: near_end).
+struct NearEnd {
+    Ctx &c;
+    NearEnd(Ctx &c_, Cohort &co, int first, int count) : c(c_)
+    {
+        if (count > 1) {
+            Combiner *comb = co.comb.get();
+            try { c.near_end_hook = [comb, first] { comb->near_end(first); }; } catch (...) { c.near_end_hook = nullptr; }
+        }
+    }
+    ~NearEnd() { c.near_end_hook = nullptr; }
+    NearEnd(const NearEnd &) = delete;
+    NearEnd &operator=(const NearEnd &) = delete;
+};
+
 static int combined_keygen(kosk_ctx *h, int n, const KeygenCall &call)
 {
     Cohort &co = *h->cohort;
@@ -474,6 +492,7 @@ static int combined_keygen(kosk_ctx *h, int n, const KeygenCall &call)
             total += reqs[k]->n;
         }
         c.nthreads = std::min(c.base_threads * count, c.reserved_threads); // a call never creates threads
+        NearEnd ne(c, co, first, count);
         const int rc = prove_resident(c, total, false, &segs[0]);
         c.nthreads = c.base_threads;
         for (int k = 0; k < count; k++) {
@@ -520,6 +539,7 @@ static int combined_verify(kosk_ctx *h, int n, const VerifyCall &call)
         const int keep = c.resident_pk_n;
         if (!given) c.resident_pk_n = total; // every member checked its own keys before it posted
         c.nthreads = std::min(c.base_threads * count, c.reserved_threads);
+        NearEnd ne(c, co, first, count);
         const int rc = verify_resident(c, total, nullptr, given ? 1 : 2, nullptr, &segs[0]);
         c.nthreads = c.base_threads;
         if (!given) c.resident_pk_n = keep;

@@ -19,6 +19,7 @@
 // Callers that loop (the bench's slots, a service under load) fall into step after one iteration: members of a run return
 // together, call again together, and the window closes as soon as the last of them has posted.
 #pragma once
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <condition_variable>
@@ -44,8 +45,8 @@ public:
     using Exec = std::function<int(int first, int count, const CombineReq *const *reqs)>;
 
     static constexpr int MAX_WIDTH = 8;
-    Combiner(int width, int wait_us, int idle_us)
-        : C_(width < 1 ? 1 : (width > MAX_WIDTH ? MAX_WIDTH : width)), wait_us_(wait_us), idle_us_(idle_us), m_((size_t)C_) {}
+    Combiner(int width, int wait_us, int idle_us, int prewake_us = 0)
+        : C_(width < 1 ? 1 : (width > MAX_WIDTH ? MAX_WIDTH : width)), wait_us_(wait_us), idle_us_(idle_us), prewake_us_(prewake_us), m_((size_t)C_) {}
     int width() const { return C_; }
 
     // a free member index (-1: the cohort is full); leave() frees it again
@@ -85,6 +86,8 @@ public:
         me.req = r;
         me.st = POSTED;
         me.deferred = false;
+        me.prewake = false;
+        __atomic_store_n(&me.done_flag, 0, __ATOMIC_RELAXED);
         me.posted_at = clock::now();
         if (leader_ < 0) leader_ = i; // nobody is collecting requests: this member opens a window
         cv_.notify_all();
@@ -120,12 +123,24 @@ public:
                 m_[i + k].rc = rc;
                 try { m_[i + k].what = text; } catch (...) {}
                 m_[i + k].st = DONE;
+                __atomic_store_n(&m_[i + k].done_flag, 1, __ATOMIC_RELEASE); // a pre-woken member spins on this outside the lock
             }
             runs_++;
             served_ += cnt;
             cv_.notify_all();
         } else {
-            cv_.wait(lk, [&] { return me.st == DONE; });
+            for (;;) {
+                cv_.wait(lk, [&] { return me.st == DONE || me.prewake; });
+                if (me.st == DONE) break;
+                // the run's executor has announced its end (near_end): stay awake for it -- a sleeping thread needs 30-50 us to get
+                // back on a core, and the members' next calls can only merge once the LAST of them is back
+                me.prewake = false;
+                lk.unlock();
+                const auto t0 = clock::now();
+                while (!__atomic_load_n(&me.done_flag, __ATOMIC_ACQUIRE) && clock::now() - t0 < std::chrono::microseconds(prewake_us_)) cpu_relax();
+                lk.lock();
+                if (me.st == DONE) break; // (otherwise: the end took longer than announced; back to sleep)
+            }
         }
         const int rc = me.rc;
         if (what && rc == -2) { try { *what = me.what; } catch (...) {} }
@@ -134,6 +149,19 @@ public:
         me.last_exit = clock::now();
         me.t_run += std::chrono::duration<double>(me.last_exit - assigned_at).count();
         return rc;
+    }
+
+    // Called by the executor of member `leader`'s run when only a short tail of the run is left (the last kernel has been queued, or
+    // the last host round begins): the run's sleeping members wake up now and spin until the run is over.  No-op with prewake_us 0.
+    void near_end(int leader)
+    {
+        if (prewake_us_ <= 0) return;
+        std::lock_guard<std::mutex> lk(mu_);
+        if (leader < 0 || leader >= C_ || m_[leader].st != RUNNING) return;
+        bool any = false;
+        for (int k = 1; k < m_[leader].run_count && leader + k < C_; k++)
+            if (m_[leader + k].st == RUNNING) { m_[leader + k].prewake = true; any = true; }
+        if (any) cv_.notify_all();
     }
 
     // diagnostic (KOSK_COMBINE_TRACE=1 prints it when a member leaves): calls, seconds between posting and being assigned to a
@@ -164,7 +192,8 @@ private:
         State st = ABSENT;
         CombineReq req;
         int leader = -1, run_count = 0, rc = 0;
-        bool deferred = false;
+        bool deferred = false, prewake = false;
+        int done_flag = 0; // written under the lock, read by a pre-woken member outside it: __atomic accesses (keeps Member assignable)
         std::string what;
         clock::time_point last_exit, posted_at;
         double t_window = 0, t_run = 0;
@@ -249,7 +278,13 @@ private:
         }
     }
 
-    const int C_, wait_us_, idle_us_;
+    static void cpu_relax()
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
+    const int C_, wait_us_, idle_us_, prewake_us_;
     mutable std::mutex mu_;
     std::condition_variable cv_;
     std::vector<Member> m_;

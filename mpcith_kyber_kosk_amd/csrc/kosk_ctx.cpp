@@ -922,6 +922,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         c.prof_begin(PR_ASSEMBLE, n);
         HIPCHK(launch_assemble(aa, c.nfields, P.off[F_TCOMM], P.off[F_COMM], P.off[F_I], n, st));
         c.prof_end(PR_ASSEMBLE);
+        if (c.near_end_hook) c.near_end_hook(); // the last kernel is queued: a merged run's sleeping callers get ready for the return
         return 0;
     })) return -1;
     c.phase_sec[PH_P3_ISSUE] = now_sec() - t0;

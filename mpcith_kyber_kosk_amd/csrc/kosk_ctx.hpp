@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "kosk_device.hpp"
@@ -204,6 +205,7 @@ struct Ctx {
     hipEvent_t ev = nullptr;
     std::vector<uint16_t> v_I2, v_rest2; // the verifier's recomputed opened lists (kept across calls: two fresh 0.4 MB vectors per call were
                                          // an mmap, a page fault per page and a munmap on the tail of every verify call)
+    std::function<void()> near_end_hook; // set by a merged run's executor: called once when only the call's tail is left (kosk_combine.hpp: near_end)
     bool kg_on_host_pending = false; // ev_kg was recorded by this call's key generation
     hipEvent_t ev_kg = nullptr; // the key records (pk, NTT(s) bytes, seeds) of a keygen-in-front call are on the host once it has passed
     hipEvent_t ev_sync = nullptr; // KOSK_BLOCKING_SYNC=1: every host wait sleeps on an event instead of spinning (few host cores per GPU)

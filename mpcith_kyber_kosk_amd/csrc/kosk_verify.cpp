@@ -488,6 +488,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     if (split_tables && !himg) HIPCHK(hipEventSynchronize(c.ev_img[1]));
     t1 = now_sec(); c.phase_sec[PH_V2_WAIT] = t1 - t0; t0 = t1;
     if (c.round_hook) c.round_hook(c.round_user, 1, 1, c.d_dig2, (size_t)n * NPARTY * 32);
+    if (c.near_end_hook) c.near_end_hook(); // only the host's last round is left: a merged run's sleeping callers get ready for the return
     if (c.v_I2.size() < (size_t)n * c.sel_stride) { c.v_I2.resize((size_t)n * c.sel_stride); c.v_rest2.resize((size_t)n * c.sel_stride); }
     std::vector<uint16_t> &I2 = c.v_I2, &rest2 = c.v_rest2; // every entry that is read below is written by fs_opened_batch first
     {

@@ -239,7 +239,7 @@ static void combine_hammer(int rounds)
     const int C = 3, per = 4;
     // (1) closed loops in opposite phase: members 0,1 start with kind 0, member 2 with kind 1; each alternates 0,1,0,1...
     {
-        Combiner comb(C, 200000, 100000);
+        Combiner comb(C, 200000, 100000, 300); // members pre-woken by near_end spin up to 300 us for the end of their run
         for (int i = 0; i < C; i++) CHECK(comb.join() == i, "join order");
         CHECK(comb.join() == -1, "a full cohort must refuse a fourth member");
         std::vector<std::vector<FakeCall>> calls(C);
@@ -260,7 +260,9 @@ static void combine_hammer(int rounds)
                         CHECK(f->served_by < 0, "a call served twice");
                         f->served_by = first; f->run_first = first; f->run_count = count;
                     }
-                    std::this_thread::sleep_for(std::chrono::microseconds(200));
+                    std::this_thread::sleep_for(std::chrono::microseconds(100));
+                    comb.near_end(first); // the run announces its end: its other members wake up and wait awake
+                    std::this_thread::sleep_for(std::chrono::microseconds(100));
                     return 0;
                 }, nullptr, &rc_count);
                 CHECK(rc == 0 && fc.served_by >= 0 && fc.run_count == rc_count, "call %d/%d not served (rc %d)", i, r, rc);
@@ -282,7 +284,7 @@ static void combine_hammer(int rounds)
     }
     // (2) ragged batches, unmergeable kinds, a throwing run, members that leave and join
     {
-        Combiner comb(C, 20000, 5000);
+        Combiner comb(C, 20000, 5000, 40); // a pre-wake window SHORTER than the tails below: pre-woken members go back to sleep
         for (int i = 0; i < C; i++) comb.join();
         std::atomic<int> bad{0};
         auto worker = [&](int i) {
@@ -299,6 +301,9 @@ static void combine_hammer(int rounds)
                         if (count > 1 && reqs[k]->kind < 0) bad++;        // an unmergeable request merged
                         f->served_by = first;
                     }
+                    if (static_cast<FakeCall *>(reqs[0]->args)->seq % 3 != 0) comb.near_end(first); // some runs announce their end, twice even
+                    if (static_cast<FakeCall *>(reqs[0]->args)->seq % 6 == 1) comb.near_end(first);
+                    if (static_cast<FakeCall *>(reqs[0]->args)->seq % 4 == 2) std::this_thread::sleep_for(std::chrono::microseconds(120)); // longer than the window
                     if (static_cast<FakeCall *>(reqs[0]->args)->seq % 11 == 6) throw std::runtime_error("boom");
                     return 0;
                 }, &what);
