@@ -466,8 +466,8 @@ class Slot:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=1200)
+    ap.add_argument("--warmup", type=int, default=120)
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS), help="BASELINE.json workload, 1-based (see the module docstring)")
     ap.add_argument("--kyber-k", type=int, default=0, help="override the configuration's KYBER_K")
     ap.add_argument("--batch", type=int, default=0, help="override the configuration's proofs per GPU per step")

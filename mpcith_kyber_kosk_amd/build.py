@@ -20,7 +20,7 @@ COMMON = ["-O3", "-std=c++20", "-fPIC"]
 
 
 def _headers():
-    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(HERE, "..", "include", "kosk_mi355x.h")]
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))] + [os.path.join(HERE, "..", "include", "kosk_mi355x.h")]
 
 
 def _compile(src, hip, force):
