@@ -399,6 +399,8 @@ class Slot:
         env["KOSK_COMBINE"] = str(combine)
         if combine > 1:
             env["KOSK_COMBINE_IDLE_US"] = os.environ.get("KOSK_COMBINE_IDLE_US", "20000")
+            if os.environ.get("KOSK_BLOCKING_SYNC") == "1":  # few host cores per rank (host_budget): nobody spins, a run's callers sleep to its end
+                env["KOSK_COMBINE_PREWAKE_US"] = os.environ.get("KOSK_COMBINE_PREWAKE_US", "0")
         self.c = _with_env(env, lambda: api.Kosk(kyber_k=k, max_batch=B, device=device))
         self.B, self.nsets = B, nsets
         self.stride = (self.c.tape_bytes + 63) // 64 * 64
