@@ -1739,6 +1739,33 @@ __global__ __launch_bounds__(256) void k_post_relation(uint16_t *__restrict__ P,
 // =========================================================================
 constexpr int ASM_TILE = 64 * 80; // u16 per tile: 64 parties x the widest field (79)
 
+// width (<= MAXW) elements of one party's record: element e = row rt[e] at this lane's column (byte offset voff inside the row).
+// The row indices past the record's width are clamped to its last row (a few redundant loads instead of a branch per element).
+template <int MAXW>
+__device__ __forceinline__ void asm_gather(const uint16_t *Pb, uint32_t voff, const int16_t *rt, int width, uint16_t *t, bool live)
+{
+    // the record's row indices first (the compiler reads the 16-bit table with vector loads and waits for them with vmcnt(0): that
+    // wait must not sit between the gather loads)
+    int rr[MAXW];
+#pragma unroll
+    for (int e = 0; e < MAXW; e++) rr[e] = rt[e < width ? e : width - 1];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t v[MAXW];
+#pragma unroll
+    for (int e = 0; e < MAXW; e++) {
+        const int r = __builtin_amdgcn_readfirstlane(rr[e]); // the same for every lane: a scalar
+        const uint16_t *rowp = Pb + (size_t)r * RS;
+        asm volatile("global_load_ushort %0, %1, %2" : "=v"(v[e]) : "v"(voff), "s"(rowp));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (loads issued by inline assembly are not counted by the compiler)
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < MAXW; e++)
+            if (e < width) t[e] = (uint16_t)v[e];
+    }
+}
+
 // One wave per (field, 64 parties): for the fields of unopened parties the 64 parties are those of one ALIGNED window of
 // 64 party columns (a single 128-byte line per row read, PMC: 125 -> 35 MB fetched), for opened fields 64 entries of I.
 // No workgroup barrier: the wave gathers its whole tile (independent loads), then streams it out.
@@ -1786,12 +1813,19 @@ __global__ __launch_bounds__(64) void k_assemble_fields(AssembleArgs a, uint32_t
     if (cnt <= 0) return;
     const FieldDesc fd = a.fields[f];
     const uint16_t *sel = kind ? a.rest + (size_t)b * a.sel_stride : orow;
-    if (lane < cnt) {
-        const uint16_t *src = a.P + (size_t)b * a.proof_stride + NSEC + sel[i0 + lane];
+    {
+        // Every load of the record is issued before the first LDS write: the launch is latency-bound -- its waves sit in s_waitcnt 76 %
+        // of their lifetime (profiles/r04_wire_pmc.txt) with 32 loads in flight each.  Written as scalar row base + one 32-bit lane
+        // offset (global_load ... saddr), so that 80 loads in flight cost 80 data registers and ONE address register.  Lanes past the
+        // block's last party load their neighbour's column (same cache line) and write nothing: no divergence around the loads.
+        const uint16_t *Pb = a.P + (size_t)b * a.proof_stride; // uniform
+        const uint32_t voff = 2u * (uint32_t)(NSEC + sel[i0 + min(lane, cnt - 1)]);
         const int16_t *rt = a.rowtab + fd.rowtab_off;
         uint16_t *t = tile + lane * fd.width;
-#pragma unroll 8
-        for (int e = 0; e < fd.width; e++) t[e] = src[(size_t)rt[e] * RS];
+        const bool live = lane < cnt;
+        if (fd.width <= 4) asm_gather<4>(Pb, voff, rt, fd.width, t, live);
+        else if (fd.width <= 16) asm_gather<16>(Pb, voff, rt, fd.width, t, live);
+        else asm_gather<80>(Pb, voff, rt, fd.width, t, live);
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
