@@ -52,8 +52,9 @@ int kosk_set_randombytes(kosk_ctx *ctx, kosk_randombytes_fn fn, void *user); /* 
  * (kyber/randombytes.c:49-52).  A batch call creates no threads (kosk_create made them).
  * HIP error state: the library's launchers read hipGetLastError(), so every entry point first RESETS the calling thread's HIP
  * last-error state; an application that launches kernels of its own must check them before it calls in here.
- * With KOSK_REGISTER=2 proof buffers in pageable host memory must not be shared between concurrent calls (a multi-chunk call then
- * page-locks the whole pages inside the buffer for its own duration; by default nothing of the caller's is page-locked).
+ * The library never page-locks caller memory (KOSK_REGISTER=2 of rounds 2-4, which did so for the duration of a multi-chunk call,
+ * was removed in round 5: the two process aborts on record both happened inside calls that had just page-locked Python heap
+ * memory and were never explained; the value is now read as 1).
  * gen_matrix's rejection sampling (indcpa.c:124-145) loops without a bound in the reference; on the host this library does the
  * same, on the GPU it squeezes at most 32 SHAKE128 blocks per matrix entry (three suffice with probability 1 - 2^-40) and a
  * call that ever reached that limit returns -1 ("block limit") without results -- for key generation and for the verifier's
@@ -64,8 +65,7 @@ int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, siz
 /* Page-locked host memory for the proof buffers of the two host-buffer calls (no reference counterpart: the reference's
  * caller owns plain arrays, main.cpp:71).  Proof images in such a buffer (or in any memory the caller page-locked itself with
  * hipHostMalloc / hipHostRegister) cross PCIe straight from / to it: no staging copy on the host and no per-call locking.
- * Plain (pageable) buffers keep working through the library's pinned staging buffers (KOSK_REGISTER=2: a multi-chunk call
- * page-locks the whole pages inside the buffer for its duration and copies to them directly).  NULL on failure. */
+ * Plain (pageable) buffers keep working through the library's pinned staging buffers.  NULL on failure. */
 void *kosk_host_alloc(size_t bytes);
 void kosk_host_free(void *p);
 
@@ -138,7 +138,7 @@ int kosk_stage_verifier_inputs_compact(kosk_ctx *ctx, int n, const uint8_t *in, 
  * read from the environment by kosk_create, per handle).  ids: 0 commitment hash with LDS-DMA staging, 1 without (KOSK_HASH_DMA=0
  * or a layout it cannot take), 2 placement primer launches (KOSK_HASH_PRIMER=1), 3 shared-table products on k_table_gemm,
  * 4 products on the generic limb GEMM (KOSK_TABLE_GEMM=0, grouped products), 5 proof images copied straight between HBM and
- * page-locked caller memory, 6 through the pinned staging buffer (KOSK_REGISTER=0, head / tail chunks, single-chunk calls),
+ * page-locked caller memory (kosk_host_alloc or locked by the caller), 6 through the pinned staging buffer (pageable caller memory, KOSK_REGISTER=0),
  * 7 hipGraph segment replays (KOSK_GRAPHS=1), 8 / 9 NTT launches of the packed-fp32 / integer kernel, 10 prover commitment rounds
  * whose digest table was written to the host's table by the hash launch itself (KOSK_DIGEST_DIRECT=1), 11 rounds that copied it
  * behind the launch (default), 12 digest tables copied to the host by the library's own few-wave copy kernel (KOSK_COPY_WAVES=n;

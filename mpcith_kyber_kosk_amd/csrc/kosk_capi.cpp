@@ -6,8 +6,10 @@
 //     anything else into rc -1 + kosk_last_error() text;
 //   * no thread is created inside a batch call: the S - 1 lane threads of a handle (KOSK_STREAMS = S) and every
 //     sub-context's host workers are created by kosk_create(), whose failure is an ordinary -1;
-//   * caller memory is page-locked only over whole pages the caller's buffer fully covers, every HIP result of that is
-//     checked, and any failure falls back to the pinned staging buffers.
+//   * the library never page-locks caller memory (round 5: KOSK_REGISTER=2, which did for the duration of a multi-chunk call, is
+//     gone -- both process aborts on record happened inside calls that had just done so and neither was ever explained);
+//     buffers the caller page-locked itself (kosk_host_alloc, hipHostMalloc, hipHostRegister) are copied to / from directly,
+//     everything else goes through the library's own pinned staging buffers.
 #include "../../include/kosk_mi355x.h"
 
 #include <unistd.h>
@@ -168,45 +170,8 @@ static int run_chunks(kosk_ctx *h, int n, F &&fn)
     h->clear_err();
     auto on_lane = [&](int i, int first, int count) { return fn(*h->sub[i], first, count); };
     std::vector<std::function<int()>> jobs;
-    deal_chunks((int)h->sub.size(), h->sub[0]->max_batch, n, on_lane, jobs);
+    deal_chunks((int)h->sub.size(), h->sub[0]->own_batch, n, on_lane, jobs); // own_batch: a cohort member's max_batch spans its neighbours' blocks
     return h->run_lanes(jobs);
-}
-
-// Caller memory page-locked for the duration of one multi-chunk call, so that proof images cross PCIe straight from / to
-// it.  Only the whole pages INSIDE the buffer are locked (never a page shared with a neighbouring allocation); records
-// that touch the unlocked head or tail go through the pinned staging buffer like everything does with KOSK_REGISTER=0.
-struct HostSpan {
-    uint8_t *lo = nullptr, *hi = nullptr;
-    bool covers(const uint8_t *p, size_t len) const { return lo && p >= lo && p + len <= hi; }
-};
-static HostSpan lock_span(const kosk_ctx *h, const uint8_t *p, size_t bytes)
-{
-    HostSpan s;
-    if (!h->c->host_register || !h->c->host_lock_pageable || !p) return s;
-    const long pg = sysconf(_SC_PAGESIZE);
-    const uintptr_t page = pg > 0 ? (uintptr_t)pg : 4096;
-    const uintptr_t a = (reinterpret_cast<uintptr_t>(p) + page - 1) & ~(page - 1), b = (reinterpret_cast<uintptr_t>(p) + bytes) & ~(page - 1);
-    if (b <= a || b - a < ((size_t)1 << 20)) return s; // under 1 MiB the two driver calls cost more than the staging copy
-    if (hipSetDevice(h->c->device) != hipSuccess ||
-        hipHostRegister(reinterpret_cast<void *>(a), b - a, hipHostRegisterDefault) != hipSuccess) {
-        (void)hipGetLastError(); // e.g. a read-only mapping, memory that is already registered, a locked-memory limit: stage instead
-        return s;
-    }
-    s.lo = reinterpret_cast<uint8_t *>(a);
-    s.hi = reinterpret_cast<uint8_t *>(b);
-    return s;
-}
-// after every lane has synchronised its stream (run_lanes has returned): nothing is in flight on the span any more
-static int unlock_span(kosk_ctx *h, HostSpan &s)
-{
-    if (!s.lo) return 0;
-    const hipError_t e = hipHostUnregister(s.lo);
-    s = HostSpan{};
-    if (e == hipSuccess) return 0;
-    (void)hipGetLastError();
-    h->err = std::string("hipHostUnregister of the caller's buffer failed (the results are complete; the pages stay locked): ") + hipGetErrorString(e);
-    h->c->err = h->err;
-    return -1;
 }
 
 // [p, p + bytes) is page-locked host memory already (kosk_host_alloc, hipHostMalloc, hipHostRegister by the caller): the
@@ -472,10 +437,30 @@ struct NearEnd {
     NearEnd &operator=(const NearEnd &) = delete;
 };
 
+// Scope of a run on its leader's view: the view may run `total` proofs (its own block and the blocks of the run's other members
+// behind it) with the host workers of `count` callers; both go back to one caller's worth however the run ends.
+struct RunScope {
+    Ctx &c;
+    RunScope(Ctx &c_, int count, int total) : c(c_)
+    {
+        c.call_cap = std::min(std::max(total, c.own_batch), c.max_batch);
+        c.nthreads = std::min(c.base_threads * count, c.reserved_threads); // a call never creates threads
+    }
+    ~RunScope() { c.call_cap = c.own_batch; c.nthreads = c.base_threads; }
+    RunScope(const RunScope &) = delete;
+    RunScope &operator=(const RunScope &) = delete;
+};
+
 static int combined_keygen(kosk_ctx *h, int n, const KeygenCall &call)
 {
     Cohort &co = *h->cohort;
     h->clear_err();
+    // a caller's bad arguments fail THAT caller, here, not the run it would have joined (and every innocent member of it)
+    if (call.tapes && call.tape_stride < h->c->P.tape_bytes) {
+        h->err = "tape_stride is smaller than one proof's tape (kosk_tape_bytes)";
+        h->c->err = h->err;
+        return -1;
+    }
     CombineReq r;
     r.kind = (call.tapes && !h->c->round_hook) ? CK_KEYGEN : CK_ALONE; // the stateful randombytes callback and round hooks are per handle
     r.n = n;
@@ -491,10 +476,12 @@ static int combined_keygen(kosk_ctx *h, int n, const KeygenCall &call)
             segs[k] = KeygenIn{a->tapes, a->tape_stride, a->pk, a->sk, reqs[k]->n, k + 1 < count ? &segs[k + 1] : nullptr};
             total += reqs[k]->n;
         }
-        c.nthreads = std::min(c.base_threads * count, c.reserved_threads); // a call never creates threads
         NearEnd ne(c, co, first, count);
-        const int rc = prove_resident(c, total, false, &segs[0]);
-        c.nthreads = c.base_threads;
+        int rc;
+        {
+            RunScope scope(c, count, total);
+            rc = prove_resident(c, total, false, &segs[0]);
+        }
         for (int k = 0; k < count; k++) {
             Ctx &v = *co.member[first + k]->c;
             v.resident_pk_n = rc ? 0 : reqs[k]->n;
@@ -538,11 +525,13 @@ static int combined_verify(kosk_ctx *h, int n, const VerifyCall &call)
         }
         const int keep = c.resident_pk_n;
         if (!given) c.resident_pk_n = total; // every member checked its own keys before it posted
-        c.nthreads = std::min(c.base_threads * count, c.reserved_threads);
         NearEnd ne(c, co, first, count);
-        const int rc = verify_resident(c, total, nullptr, given ? 1 : 2, nullptr, &segs[0]);
-        c.nthreads = c.base_threads;
-        if (!given) c.resident_pk_n = keep;
+        int rc;
+        {
+            struct KeepPk { Ctx &c; int keep; bool on; ~KeepPk() { if (on) c.resident_pk_n = keep; } } keep_pk{c, keep, !given};
+            RunScope scope(c, count, total);
+            rc = verify_resident(c, total, nullptr, given ? 1 : 2, nullptr, &segs[0]);
+        }
         int off = 0;
         for (int k = 0; k < count; k++) {
             kosk_ctx *m = co.member[first + k];
@@ -627,25 +616,13 @@ int kosk_verifiable_keygen_batch(kosk_ctx *ctx, int n, const uint8_t *tapes, siz
         tapes = drawn.data();
         tape_stride = P.tape_bytes;
     }
-    // several chunks: the whole pages of the caller's proof buffer are page-locked for the call and the images of the
-    // chunks inside them are copied straight there (KOSK_REGISTER=0, or any failure: pinned staging buffer + host memcpy)
-    HostSpan span;
-    const bool pinned = ctx->c->host_register && span_is_pinned(pi, (size_t)n * P.proof_bytes); // the caller's own page-locked buffer
-    if (!pinned && n > ctx->sub[0]->max_batch) span = lock_span(ctx, pi, (size_t)n * P.proof_bytes);
-    int rc = -1;
-    try {
-        rc = run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
-            const KeygenIn kg{tapes + (size_t)first * tape_stride, tape_stride, pk + (size_t)first * P.pk_bytes, sk + (size_t)first * P.sk_bytes};
-            if (prove_resident(c, count, false, &kg)) return -1;
-            uint8_t *dst = pi + (size_t)first * P.proof_bytes;
-            return fetch_proofs(c, count, dst, pinned || span.covers(dst, (size_t)count * P.proof_bytes));
-        });
-    } catch (...) {
-        (void)unlock_span(ctx, span);
-        throw;
-    }
-    if (unlock_span(ctx, span) && !rc) rc = -1;
-    return rc;
+    // images go straight into a buffer the CALLER page-locked (KOSK_REGISTER=0: never), else through the pinned staging buffer
+    const bool pinned = ctx->c->host_register && span_is_pinned(pi, (size_t)n * P.proof_bytes);
+    return run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
+        const KeygenIn kg{tapes + (size_t)first * tape_stride, tape_stride, pk + (size_t)first * P.pk_bytes, sk + (size_t)first * P.sk_bytes};
+        if (prove_resident(c, count, false, &kg)) return -1;
+        return fetch_proofs(c, count, pi + (size_t)first * P.proof_bytes, pinned);
+    });
     GUARD_END
 }
 
@@ -656,31 +633,24 @@ int kosk_verify_batch(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *pk
     GUARD(ctx)
     const Params &P = ctx->c->P;
     reset_masks(ctx, n);
-    HostSpan span;
     const bool pinned = ctx->c->host_register && span_is_pinned(pi, (size_t)n * P.proof_bytes);
-    if (!pinned && n > ctx->sub[0]->max_batch) span = lock_span(ctx, pi, (size_t)n * P.proof_bytes);
-    int rc = -1;
-    try {
-        rc = run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
-            const uint8_t *src = pi + (size_t)first * P.proof_bytes;
-            if (stage_verifier_inputs(c, count, src, pk + (size_t)first * P.pk_bytes, pinned || span.covers(src, (size_t)count * P.proof_bytes))) return -1;
-            // the verifier's host reads the unopened parties' digests straight from the caller's images: nothing to copy back for them
-            c.host_img = src;
-            c.host_img_stride = P.proof_bytes;
-            return verify_into(ctx, c, first, count, ok, 0, nullptr);
-        });
-    } catch (...) {
-        (void)unlock_span(ctx, span);
-        throw;
-    }
-    if (unlock_span(ctx, span) && !rc) rc = -1;
+    const int rc = run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
+        const uint8_t *src = pi + (size_t)first * P.proof_bytes;
+        c.host_img = nullptr;
+        if (stage_verifier_inputs(c, count, src, pk + (size_t)first * P.pk_bytes, pinned)) return -1;
+        // the verifier's host reads the unopened parties' digests straight from the caller's images: nothing to copy back for them
+        // (verify_resident takes the pointer and clears it first thing)
+        c.host_img = src;
+        c.host_img_stride = P.proof_bytes;
+        return verify_into(ctx, c, first, count, ok, 0, nullptr);
+    });
     if (!rc) ctx->masks_n = n;
     return rc;
     GUARD_END
 }
 
 // The two host-buffer calls with the proofs in the compact wire format: packed / unpacked on the GPU, so PCIe
-// carries 78 % of the image bytes in each direction.  Same chunking, lanes and page-locking as the calls above.
+// carries 78 % of the image bytes in each direction.  Same chunking and lanes as the calls above.
 int kosk_verifiable_keygen_batch_compact(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t tape_stride,
                                          uint8_t *pk, uint8_t *sk, uint8_t *out)
 {
@@ -695,23 +665,12 @@ int kosk_verifiable_keygen_batch_compact(kosk_ctx *ctx, int n, const uint8_t *ta
         tapes = drawn.data();
         tape_stride = P.tape_bytes;
     }
-    HostSpan span;
     const bool pinned = ctx->c->host_register && span_is_pinned(out, (size_t)n * cb);
-    if (!pinned && n > ctx->sub[0]->max_batch) span = lock_span(ctx, out, (size_t)n * cb);
-    int rc = -1;
-    try {
-        rc = run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
-            const KeygenIn kg{tapes + (size_t)first * tape_stride, tape_stride, pk + (size_t)first * P.pk_bytes, sk + (size_t)first * P.sk_bytes};
-            if (prove_resident(c, count, false, &kg)) return -1;
-            uint8_t *dst = out + (size_t)first * cb;
-            return fetch_proofs_compact(c, count, dst, pinned || span.covers(dst, (size_t)count * cb));
-        });
-    } catch (...) {
-        (void)unlock_span(ctx, span);
-        throw;
-    }
-    if (unlock_span(ctx, span) && !rc) rc = -1;
-    return rc;
+    return run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
+        const KeygenIn kg{tapes + (size_t)first * tape_stride, tape_stride, pk + (size_t)first * P.pk_bytes, sk + (size_t)first * P.sk_bytes};
+        if (prove_resident(c, count, false, &kg)) return -1;
+        return fetch_proofs_compact(c, count, out + (size_t)first * cb, pinned);
+    });
     GUARD_END
 }
 int kosk_verify_batch_compact(kosk_ctx *ctx, int n, const uint8_t *in, const uint8_t *pk, uint8_t *ok)
@@ -722,21 +681,11 @@ int kosk_verify_batch_compact(kosk_ctx *ctx, int n, const uint8_t *in, const uin
     const Params &P = ctx->c->P;
     const size_t cb = make_compact_plan(P).bytes;
     reset_masks(ctx, n);
-    HostSpan span;
     const bool pinned = ctx->c->host_register && span_is_pinned(in, (size_t)n * cb);
-    if (!pinned && n > ctx->sub[0]->max_batch) span = lock_span(ctx, in, (size_t)n * cb);
-    int rc = -1;
-    try {
-        rc = run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
-            const uint8_t *src = in + (size_t)first * cb;
-            if (stage_verifier_inputs_compact(c, count, src, pk + (size_t)first * P.pk_bytes, pinned || span.covers(src, (size_t)count * cb))) return -1;
-            return verify_into(ctx, c, first, count, ok, 0, nullptr);
-        });
-    } catch (...) {
-        (void)unlock_span(ctx, span);
-        throw;
-    }
-    if (unlock_span(ctx, span) && !rc) rc = -1;
+    const int rc = run_chunks(ctx, n, [&](Ctx &c, int first, int count) {
+        if (stage_verifier_inputs_compact(c, count, in + (size_t)first * cb, pk + (size_t)first * P.pk_bytes, pinned)) return -1;
+        return verify_into(ctx, c, first, count, ok, 0, nullptr);
+    });
     if (!rc) ctx->masks_n = n;
     return rc;
     GUARD_END
@@ -754,7 +703,7 @@ int kosk_prepare_randomness(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t t
     Ctx &c = *ctx->c;
     ctx->clear_err();
     for (int done = 0; done < n;) {
-        const int m = (n - done) < c.max_batch ? (n - done) : c.max_batch;
+        const int m = (n - done) < c.own_batch ? (n - done) : c.own_batch;
         if (prepare_randomness(c, m, tapes ? tapes + (size_t)done * tape_stride : nullptr, tape_stride,
                                rand_out + (size_t)done * randomness_bytes(c.P))) return -1;
         done += m;
@@ -769,7 +718,7 @@ int kosk_prepare_range_proof(kosk_ctx *ctx, int n, const uint8_t *tapes, size_t 
     Ctx &c = *ctx->c;
     ctx->clear_err();
     for (int done = 0; done < n;) {
-        const int m = (n - done) < c.max_batch ? (n - done) : c.max_batch;
+        const int m = (n - done) < c.own_batch ? (n - done) : c.own_batch;
         if (prepare_range_proof(c, m, tapes ? tapes + (size_t)done * tape_stride : nullptr, tape_stride,
                                 range_out + (size_t)done * range_proof_bytes(c.P))) return -1;
         done += m;
@@ -785,7 +734,7 @@ int kosk_prove_prepared(kosk_ctx *ctx, int n, const uint8_t *inst, const uint8_t
     Ctx &c = *ctx->c;
     ctx->clear_err();
     for (int done = 0; done < n;) {
-        const int m = (n - done) < c.max_batch ? (n - done) : c.max_batch;
+        const int m = (n - done) < c.own_batch ? (n - done) : c.own_batch;
         if (prove_prepared(c, m, inst + (size_t)done * mlwe_inst_bytes(c.P), rand_in + (size_t)done * randomness_bytes(c.P),
                            range_in + (size_t)done * range_proof_bytes(c.P), tapes ? tapes + (size_t)done * tape_stride : nullptr,
                            tape_stride, pi + (size_t)done * c.P.proof_bytes)) return -1;
@@ -802,7 +751,7 @@ int kosk_verify_inst(kosk_ctx *ctx, int n, const uint8_t *pi, const uint8_t *ins
     ctx->clear_err();
     reset_masks(ctx, n);
     for (int done = 0; done < n;) {
-        const int m = (n - done) < c.max_batch ? (n - done) : c.max_batch;
+        const int m = (n - done) < c.own_batch ? (n - done) : c.own_batch;
         if (stage_verifier_inst(c, m, pi + (size_t)done * c.P.proof_bytes, inst + (size_t)done * mlwe_inst_bytes(c.P))) return -1;
         if (verify_into(ctx, c, done, m, ok, 0, nullptr)) return -1;
         done += m;
@@ -1081,7 +1030,7 @@ int kosk_lagrange_expand(kosk_ctx *ctx, const uint16_t *d_y407, uint16_t *d_shar
     Ctx &c = *ctx->c;
     ctx->clear_err();
     HIPCHK_C(hipSetDevice(c.device));
-    const int cap_rows = c.max_batch * c.rm.nrows; // the row matrix doubles as scratch
+    const int cap_rows = c.own_batch * c.rm.nrows; // the row matrix doubles as scratch (this handle's own block of it)
     const int cap = std::min<long>(cap_rows, (long)(c.limb_cap / (7 * 128)) - 64);
     for (int done = 0; done < n;) {
         const int m = (n - done) < cap ? (n - done) : cap;
@@ -1104,7 +1053,7 @@ int kosk_recon_secrets(kosk_ctx *ctx, const uint16_t *d_shares, uint16_t *d_secr
     ctx->clear_err();
     HIPCHK_C(hipSetDevice(c.device));
     const GemmTable &t = two_d ? c.t_recon_2d : c.t_recon_d;
-    const int cap_rows = c.max_batch * c.rm.nrows;
+    const int cap_rows = c.own_batch * c.rm.nrows;
     const int cap = std::min<long>(cap_rows, (long)(c.limb_cap / ((size_t)t.KS * 128)) - 64);
     for (int done = 0; done < n;) {
         const int m = (n - done) < cap ? (n - done) : cap;

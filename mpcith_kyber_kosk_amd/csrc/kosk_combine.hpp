@@ -225,12 +225,17 @@ private:
         while (present_ > 1 && !all_expected_posted(clock::now())) {
             const auto now = clock::now();
             if (now >= deadline) { timed_out = true; m_[i].n_timeouts++; break; }
-            // idle members stop being expected as time passes: poll, nobody notifies for that.  A short timed wait on the
-            // SYSTEM clock: pthread_cond_timedwait, which ThreadSanitizer intercepts (a steady-clock wait is
+            // idle members stop being expected as time passes: poll, nobody notifies for that.  Under ThreadSanitizer the nap is
+            // on the SYSTEM clock: pthread_cond_timedwait, which the sanitizer intercepts (a steady-clock wait is
             // pthread_cond_clockwait, which gcc 11's libtsan does not see: it then reports the mutex as locked twice);
             // the deadline itself is kept on the steady clock above
             const auto left = std::chrono::duration_cast<std::chrono::microseconds>(deadline - now);
-            cv_.wait_until(lk, std::chrono::system_clock::now() + (left < std::chrono::microseconds(50) ? left : std::chrono::microseconds(50)));
+            const auto nap = left < std::chrono::microseconds(50) ? left : std::chrono::microseconds(50);
+#if defined(__SANITIZE_THREAD__)
+            cv_.wait_until(lk, std::chrono::system_clock::now() + nap);
+#else
+            cv_.wait_for(lk, nap); // steady clock: a wall-clock step (NTP, a manual set) must not stretch a 50 us nap into the size of the step
+#endif
         }
         form_runs(!timed_out);
         leader_ = -1;

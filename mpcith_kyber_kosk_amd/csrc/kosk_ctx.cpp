@@ -376,6 +376,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     c.base_threads = c.nthreads;
     c.reserved_threads = c.nthreads;
     c.own_batch = max_batch;
+    c.call_cap = max_batch;
     if (const char *e = getenv("KOSK_GRAPHS")) c.use_graphs = atoi(e) != 0;
     if (const char *e = getenv("KOSK_LINCOMB_FUSED")) c.lincomb_fused = atoi(e) != 0;
     if (const char *e = getenv("KOSK_NTT_FP32")) c.ntt_fp32 = atoi(e) != 0;
@@ -384,8 +385,9 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     if (const char *e = getenv("KOSK_HASH_DMA")) c.hash_dma = atoi(e) != 0;
     if (const char *e = getenv("KOSK_HASH_PRIMER")) c.hash_primer = atoi(e) != 0;
     if (const char *e = getenv("KOSK_TABLE_GEMM")) c.table_gemm = atoi(e) != 0;
-    if (const char *e = getenv("KOSK_REGISTER")) { c.host_register = atoi(e) != 0; c.host_lock_pageable = atoi(e) >= 2; }
+    if (const char *e = getenv("KOSK_REGISTER")) c.host_register = atoi(e) != 0;
     if (const char *e = getenv("KOSK_DIGEST_DIRECT")) c.digest_direct = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_STRICT_ENCODING")) c.strict_encoding = atoi(e) != 0;
     if (const char *e = getenv("KOSK_SMALL_COPY_KERNEL")) c.small_copy_kernel = atoi(e) != 0;
     if (const char *e = getenv("KOSK_COPY_WAVES")) c.copy_waves = atoi(e) >= 0 ? (atoi(e) > 65535 ? 65535 : atoi(e)) : c.copy_waves;
     if (const char *e = getenv("KOSK_DEBUG_XOF_BLOCKS")) c.xof_max_blocks = atoi(e) > 0 ? atoi(e) : c.xof_max_blocks;
@@ -516,6 +518,7 @@ int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx
     c.view_first = first;
     c.max_batch = arena.max_batch - first;
     c.own_batch = own_batch;
+    c.call_cap = own_batch;
     c.err.clear();
     // what the copy must not share with the arena.  The STREAM is shared on purpose: one HIP stream per cohort.  In steady state
     // a cohort has one merged run in flight, so nothing is lost -- and the number of streams that carry work stays at the
@@ -709,7 +712,7 @@ static void finish_keygen_segs(Ctx &c, int n, const KeygenIn &kg)
 
 int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk)
 {
-    if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
+    if (n < 1 || n > c.call_cap) { c.err = "batch size out of range"; return -1; }
     if (!pk || !sk) { c.err = "pk / sk output buffers are required"; return -1; }
     HIPCHK(hipSetDevice(c.device));
     const double t0 = now_sec();
@@ -767,7 +770,7 @@ int issue_sharing_front(Ctx &c, int n, FrontPart part, bool with_keygen)
 
 int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
 {
-    if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
+    if (n < 1 || n > c.call_cap) { c.err = "batch size out of range"; return -1; }
     for (const KeygenIn *s = keygen; s; s = s->next)
         if (!s->pk || !s->sk) { c.err = "pk / sk output buffers are required"; return -1; }
     if (!keygen && !c.tape_cur) { c.err = "no resident prover inputs: call kosk_stage_prover_inputs first"; return -1; }
@@ -936,7 +939,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
 
 int fetch_proofs(Ctx &c, int n, uint8_t *pi, bool registered)
 {
-    if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
+    if (n < 1 || n > c.call_cap) { c.err = "batch size out of range"; return -1; }
     HIPCHK(hipSetDevice(c.device));
     const double t0 = now_sec();
     if (registered) {

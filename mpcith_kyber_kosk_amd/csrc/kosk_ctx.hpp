@@ -116,6 +116,10 @@ struct Ctx {
     bool is_view = false;
     int view_first = 0;
     int own_batch = 0;   // proofs of this context's own callers (a view: its member's kosk_create size; else max_batch)
+    // the largest batch ONE call may run on this context: own_batch, except while this view leads a merged run of its cohort
+    // (kosk_capi.cpp: RunScope raises it to the run's total).  A view's max_batch is everything behind its first proof in the
+    // arena -- its neighbours' blocks included -- so no entry point may size a chunk by max_batch
+    int call_cap = 0;
     int base_threads = 1; // host threads of a call of own_batch proofs (a merged run uses base_threads x members)
     int reserved_threads = 1; // workers the pool was created with (a call never creates threads: nthreads <= this)
     int nthreads = 1;
@@ -257,12 +261,14 @@ struct Ctx {
     // (105 k against 133-137 k proofs/s: the copy takes the same 117 us, but the kernels running beside it stretch by 1.5-1.9 x;
     // profiles/r04_copy_kernel.txt), so it is an experiment knob only
     int copy_waves = 0;
+    // KOSK_STRICT_ENCODING=1: the verifier marks a proof malformed (fail bit 0) when ANY u16 element of a record the reference reads
+    // is >= q (rounds 1-4).  Default 0: such elements are treated exactly as the reference treats them, record by record
+    // (INTEGRATION.md 6): folded where it only multiplies / converts to ZZ_p, raw in its non-reducing add / sub and comparisons
+    bool strict_encoding = false;
     bool small_copy_kernel = true; // KOSK_SMALL_COPY_KERNEL=0: hipMemcpyAsync for the small copies too (copy_small)
-    bool host_register = true;       // KOSK_REGISTER=0: staging copies only, even for buffers the caller page-locked itself
-    bool host_lock_pageable = false; // KOSK_REGISTER=2: a multi-chunk host-buffer call page-locks the whole pages inside a PAGEABLE caller
-                                     // buffer for its duration (hipHostRegister).  Off by default since round 4: both process aborts on
-                                     // record (round 2's GPU test run, one of nine suite runs of round 4) happened inside calls that had
-                                     // just page-locked Python heap memory; neither left a message and neither was reproduced
+    bool host_register = true;       // KOSK_REGISTER=0: staging copies only, even for buffers the caller page-locked itself.  (KOSK_REGISTER=2 of
+                                     // rounds 2-4 -- the library page-locking PAGEABLE caller memory for a call -- is gone: both process aborts on
+                                     // record happened inside calls that had just done that, and neither was ever reproduced or explained)
     int cu_part_i = 0, cu_part_n = 1; // KOSK_CU_PARTITION=i/n: the stream is restricted to partition i of n CU partitions
     int cu_mask_layout = 0;           // KOSK_CU_MASK_LAYOUT: how CU-mask bits map to XCDs (0 round-robin, 1 XCD-major)
     unsigned hash_opts() const { return (hash_dma ? HASH_OPT_DMA : 0u) | (hash_primer ? HASH_OPT_PRIMER : 0u); }

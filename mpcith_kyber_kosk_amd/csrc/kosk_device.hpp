@@ -133,6 +133,11 @@ struct FieldDesc {
     // read iff (limit_by_party ? p : i) < limit.  What it never reads is not range-checked either (any bytes there are accepted
     // by the reference, mlwe_verifier.cpp:106-107, :321-323, :390-394, :503-507).  0 = every record.
     int limit, limit_by_party;
+    // verifier, default (reference-following) mode: what a u16 element >= q in a READ record of this field does.  -1: nothing --
+    // the reference only ever reduces it (gf3329_mul's `% 3329`, gf3329.c:282-284; NTL's conversion to ZZ_p) or emulating its
+    // arithmetic on the raw value is the consumer's job (opened-party fields, kept raw in the opened matrix); otherwise the fail
+    // bit of the raw comparison the reference makes against a canonical value (s + r / e + r shares, mlwe_verifier.cpp:232-246).
+    int noncanon_bit;
 };
 
 // which (field, chunk) a block of the assemble / disassemble kernels works on: blocks [0, nrest * NWIN) walk the
@@ -185,7 +190,17 @@ struct VerifyArgs {
     const uint16_t *opened, *rest; // [proof][sel_stride]
     int sel_stride;
     uint32_t *fail; // [proof]
+    int strict;     // KOSK_STRICT_ENCODING=1: a u16 element >= q in any record the reference reads is FB_MALFORMED (rounds 1-4)
 };
+
+// The reference's field operations on RAW u16 operands (utils/gf3329.c:274-280): the sum / difference is formed in int and
+// truncated to uint16_t on return, with ONE conditional correction by q -- for canonical operands the canonical result, for an
+// operand >= q (only a crafted proof holds one) whatever that arithmetic gives.  The verifier's comparisons on opened-party
+// records (mlwe_verifier.cpp:275, :279, :306, :370, :451, :459, :487, :491) are made on these values, so they are reproduced
+// bit for bit; everything that goes through gf3329_mul (`% 3329`) is simply folded.
+KOSK_HD inline uint32_t ref_add_u16(uint32_t a, uint32_t b) { const int32_t s = (int32_t)a + (int32_t)b; return (uint32_t)(s < Q ? s : s - Q) & 0xFFFFu; }
+KOSK_HD inline uint32_t ref_sub_u16(uint32_t a, uint32_t b) { return (uint32_t)(a < b ? (int32_t)a + Q - (int32_t)b : (int32_t)a - (int32_t)b) & 0xFFFFu; }
+KOSK_HD inline uint32_t gf_fold(uint32_t x) { return x >= (uint32_t)Q ? x % (uint32_t)Q : x; }
 
 // Interpolation through the nodes x_j = 256 + rest[j] (j < 407 resp. 813), barycentric form
 //   p(k) = l(k) * sum_j (w_j y_j) / (k - x_j):

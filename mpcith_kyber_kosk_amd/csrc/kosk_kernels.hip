@@ -1612,14 +1612,16 @@ __global__ __launch_bounds__(256) void k_lincomb(LincombArgs a)
     int32_t acc[LC_JC];
 #pragma unroll
     for (int j = 0; j < LC_JC; j++) acc[j] = 0;
+    // The verifier's inputs are the image's RAW u16 (a crafted proof may hold elements >= q): every term k >= 1 goes through
+    // gf3329_mul in the reference (mlwe_verifier.cpp:76, :85, :157, :166) and is folded here; the k == 0 term does not, see below.
 #pragma unroll 8
     for (int k = 1; k < a.rm.M; k++) { // independent loads: unrolled so that eight are in flight
-        const int32_t v = gf_center(in0[(size_t)k * istride]);
+        const int32_t v = gf_center(gf_fold(in0[(size_t)k * istride]));
         const int32_t *pk = pw + (size_t)k * LC_JPAD;
 #pragma unroll
         for (int j = 0; j < LC_JC; j++) acc[j] += pk[j] * v;
     }
-    const int32_t base_chk = in0[0], base_r = in0[(size_t)(NCHK + 1) * istride];
+    const uint32_t raw_chk = in0[0], raw_r = in0[(size_t)(NCHK + 1) * istride];
 #pragma unroll
     for (int jj = 0; jj < LC_JC; jj++) {
         const int j = jc * LC_JC + jj;
@@ -1627,14 +1629,31 @@ __global__ __launch_bounds__(256) void k_lincomb(LincombArgs a)
         int row;
         if (j < NCHK) row = which ? a.rm.gamma(j) : a.rm.beta(j);
         else row = (which ? a.rm.nttr : a.rm.r) + (j - NCHK);
-        const int32_t base = j < NCHK ? base_chk : base_r;
-        const uint16_t out = (uint16_t)gf_from_i32(acc[jj] + base);
+        const uint32_t raw = j < NCHK ? raw_chk : raw_r;
+        const uint32_t base = gf_fold(raw);
+        uint32_t out = gf_from_i32(acc[jj] + (int32_t)base);
+        if (raw >= (uint32_t)Q) {
+            // The reference starts its chain from the RAW share (:73, :82, :154, :163) and adds the M - 1 reduced products with
+            // gf3329_add, which subtracts q at most once per step: a value u + e q (u < q, e >= 1 multiples of q in excess) becomes
+            // u + b - q + e q when u + b wraps and u + b + (e - 1) q when it does not -- every non-wrapping step sheds one
+            // excess q until none is left.  The number of wrapping steps is floor((u0 + sum of the canonical products) / q)
+            // whatever their order, so the chain's result is the canonical sum plus max(0, e0 - non-wrapping steps) q.
+            // Only a crafted proof comes here; the sum is recomputed with canonical operands.
+            uint32_t sum = base;
+            for (int k = 1; k < a.rm.M; k++) {
+                const int32_t pc = pw[(size_t)k * LC_JPAD + jj];
+                sum += gf_mul((uint32_t)(pc < 0 ? pc + Q : pc), gf_fold(in0[(size_t)k * istride]));
+            }
+            const int nonwrap = (a.rm.M - 1) - (int)(sum / (uint32_t)Q), e0 = (int)(raw / (uint32_t)Q);
+            if (e0 > nonwrap) out += (uint32_t)(e0 - nonwrap) * Q;
+        }
         if (Ob) {
-            Ob[(size_t)row * OS] = out;
+            Ob[(size_t)row * OS] = (uint16_t)out;
             // recon_secrets_ddeg (mlwe_verifier.cpp:106-107) reads the beta / gamma shares of parties 0..406 from the merged row
-            if (j < NCHK && col < NSEC + XLEN) Pb[(size_t)row * RS + col] = out;
+            // (through gf3329_mul: the product's limb conversion folds a raw value)
+            if (j < NCHK && col < NSEC + XLEN) Pb[(size_t)row * RS + col] = (uint16_t)out;
         } else {
-            Pb[(size_t)row * RS + col] = out;
+            Pb[(size_t)row * RS + col] = (uint16_t)out;
         }
     }
 }

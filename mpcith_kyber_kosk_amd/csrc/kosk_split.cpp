@@ -67,7 +67,7 @@ static void put_share_vec(uint8_t *dst, const uint16_t *row)
 
 int prepare_randomness(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *out)
 {
-    if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
+    if (n < 1 || n > c.call_cap) { c.err = "batch size out of range"; return -1; }
     HIPCHK(hipSetDevice(c.device));
     const Params &P = c.P;
     const RowMap &rm = c.rm;
@@ -94,7 +94,7 @@ int prepare_randomness(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride, 
 
 int prepare_range_proof(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *out)
 {
-    if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
+    if (n < 1 || n > c.call_cap) { c.err = "batch size out of range"; return -1; }
     HIPCHK(hipSetDevice(c.device));
     const Params &P = c.P;
     const RowMap &rm = c.rm;
@@ -145,7 +145,7 @@ static int upload_inst(Ctx &c, int n, const uint8_t *inst, bool with_se, bool wi
 int prove_prepared(Ctx &c, int n, const uint8_t *inst, const uint8_t *rand_in, const uint8_t *range_in, const uint8_t *tapes,
                    size_t tape_stride, uint8_t *pi)
 {
-    if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
+    if (n < 1 || n > c.call_cap) { c.err = "batch size out of range"; return -1; }
     HIPCHK(hipSetDevice(c.device));
     const Params &P = c.P;
     const RowMap &rm = c.rm;
@@ -187,7 +187,7 @@ int prove_prepared(Ctx &c, int n, const uint8_t *inst, const uint8_t *rand_in, c
 
 int stage_verifier_inst(Ctx &c, int n, const uint8_t *pi, const uint8_t *inst)
 {
-    if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
+    if (n < 1 || n > c.call_cap) { c.err = "batch size out of range"; return -1; }
     HIPCHK(hipSetDevice(c.device));
     if (ensure_verify_workspace(c)) return -1;
     const Params &P = c.P;

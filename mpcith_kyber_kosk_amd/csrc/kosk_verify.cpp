@@ -99,8 +99,9 @@ int ensure_verify_workspace(Ctx &c)
     // where each proof field lands in the verifier's row matrix
     std::vector<FieldDesc> vf;
     std::vector<int16_t> rt;
-    auto add = [&](int fid, int sel, int width, auto rowfn, int limit = 0, int by_party = 0) {
+    auto add = [&](int fid, int sel, int width, auto rowfn, int limit = 0, int by_party = 0, int noncanon_bit = -1) {
         FieldDesc fd{};
+        fd.noncanon_bit = noncanon_bit;
         fd.off = (uint32_t)P.off[fid];
         fd.sel = sel;
         fd.width = width;
@@ -121,8 +122,9 @@ int ensure_verify_workspace(Ctx &c)
     add(F_NTTE, 0, K, [&](int e) { return rm.ntte + e; });
     add(F_NTTAR, 0, K, [&](int e) { return rm.nttar + e; });
     add(F_NTTAS, 0, K, [&](int e) { return rm.nttas + e; });
-    add(F_SR, 1, K, [&](int e) { return rm.sr_in + e; });
-    add(F_ER, 1, K, [&](int e) { return rm.er_in + e; });
+    // s + r / e + r shares of EVERY unopened party are compared raw with the recomputed (canonical) ones: an element >= q fails that check  :232-246
+    add(F_SR, 1, K, [&](int e) { return rm.sr_in + e; }, 0, 0, FB_SR_ER_SHARES);
+    add(F_ER, 1, K, [&](int e) { return rm.er_in + e; }, 0, 0, FB_SR_ER_SHARES);
     add(F_SETA, 1, K * E, [&](int e) { return rm.seta_in + e; }, DEG + 1); // :390-394
     add(F_EETA, 1, K * E, [&](int e) { return rm.eeta_in + e; }, DEG + 1);
     add(F_SSUB, 0, K * E, [&](int e) { return rm.ssub + e; });
@@ -204,7 +206,7 @@ int ensure_verify_workspace(Ctx &c)
 
 int stage_verifier_inputs(Ctx &c, int n, const uint8_t *pi, const uint8_t *pk, bool registered)
 {
-    if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
+    if (n < 1 || n > c.call_cap) { c.err = "batch size out of range"; return -1; }
     HIPCHK(hipSetDevice(c.device));
     const Params &P = c.P;
     parallel_for(c.pool, n, c.nthreads, [&](int b) {
@@ -237,7 +239,12 @@ static bool is_device_pointer(const void *p)
 
 int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, const VerifySeg *segs)
 {
-    if (n < 1 || n > c.max_batch) { c.err = "batch size out of range"; return -1; }
+    // the caller's host copy of the images is valid for THIS call only, whichever way the call ends (an early error return must
+    // not leave the pointer behind for the next resident call on this context)
+    const uint8_t *himg = c.host_img;
+    const size_t himg_stride = c.host_img_stride;
+    c.host_img = nullptr;
+    if (n < 1 || n > c.call_cap) { c.err = "batch size out of range"; return -1; }
     // a merged call (kosk_combine.hpp): `segs` lists the callers' parts, each with its own keys and result bytes
     const VerifySeg whole{n, pk, ok, nullptr};
     if (!segs) segs = &whole;
@@ -295,6 +302,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     va.rest = c.d_rest;
     va.sel_stride = c.sel_stride;
     va.fail = c.d_fail;
+    va.strict = c.strict_encoding ? 1 : 0;
     oh.proof = c.d_proof;
     oh.image_stride = c.image_stride;
     oh.off_s = (uint32_t)P.off[F_S]; oh.off_e = (uint32_t)P.off[F_E]; oh.off_f = (uint32_t)P.off[F_F];
@@ -311,10 +319,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     // how the host gets its two digest tables (see Ctx::h_imgdig): the 1304 digests per proof and table that the proof itself
     // carries come from the caller's host copy of the images when there is one, else over the side stream, starting now; only the
     // 150 recomputed ones per proof follow each round's hash on the context's own stream
-    const uint8_t *himg = c.host_img;
     const bool split_tables = !c.verify_tables || himg != nullptr;
-    const size_t himg_stride = c.host_img_stride;
-    c.host_img = nullptr; // valid for this call only
     if (split_tables && !himg) {
         const size_t w = (size_t)NREST * 32;
         for (int r = 0; r < 2; r++) {

@@ -18,8 +18,16 @@ namespace kosk {
 constexpr int DIS_TILE = 64 * 80;
 
 // inverse of k_assemble_fields: proof image -> rows at the listed party columns.
-// Non-canonical values (>= q) can never be produced by an honest prover; they are
-// folded mod q to keep arithmetic bounded and the proof is marked malformed.
+// u16 elements >= q never come out of an honest prover; what happens to one follows the reference record by record
+// (INTEGRATION.md 6 has the table):
+//  * records of UNOPENED parties go to the row matrix folded mod q -- the reference only ever multiplies them (gf3329_mul's
+//    `% 3329`, ss.cpp:47, :66) or converts them to ZZ_p (mlwe_verifier.cpp:193-198, :329-332, :402-408, :515-521), both of which
+//    reduce -- except the s + r / e + r shares, which it also compares RAW with the recomputed canonical shares (:232-246): an
+//    element >= q there sets that check's fail bit (FieldDesc::noncanon_bit);
+//  * records of OPENED parties go to the opened matrix RAW: the reference hashes them raw and compares / adds / subtracts them
+//    with its non-reducing gf3329_add / gf3329_sub (k_lincomb, k_check_opened and the gate block below reproduce that).
+// VerifyArgs::strict (KOSK_STRICT_ENCODING=1) is the behaviour of rounds 1-4: any element >= q in a record the reference reads
+// marks the proof malformed (fail bit 0).
 __global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const FieldDesc *__restrict__ fields, FieldPlan plan,
                                                           const int16_t *__restrict__ rowtab,
                                                           const uint8_t *__restrict__ proof, size_t image_stride, uint32_t off_tcomm,
@@ -36,22 +44,23 @@ __global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const F
             const uint8_t *img = proof + (size_t)b * image_stride;
             uint16_t *Pc = v.P + (size_t)b * v.proof_stride + NSEC + v.opened[(size_t)b * v.sel_stride + t];
             uint16_t *Oc = v.O + (size_t)b * v.o_stride + t; // the same values for the view hash (coalesced over t)
-            bool bad = false;
-            auto rd = [&](uint32_t off, int idx) { uint32_t x_ = reinterpret_cast<const uint16_t *>(img + off)[idx]; if (x_ >= (uint32_t)Q) { bad = true; x_ %= Q; } return x_; };
+            // raw operands: gf3329_mul reduces the product of any two u16 (:475-483), gf3329_sub does not (:487-492) -- the raw
+            // difference enters the view hash (:624-629) and, through gf3329_mul again, recon_secrets_2ddeg (the GEMM's limb
+            // conversion folds it)
+            auto rd = [&](uint32_t off, int idx) { return (uint32_t)reinterpret_cast<const uint16_t *>(img + off)[idx]; };
             for (int who = 0; who < 2; who++)
                 for (int i = 0; i < rm.K; i++) {
                     const uint32_t osub = who ? go.esub : go.ssub, oz = who ? go.ze : go.zs;
                     uint32_t prev = rd(osub, (t * rm.K + i) * rm.E);
                     for (int j = 0; j < rm.Z; j++) {
-                        const uint32_t z2 = gf_mul(prev, rd(osub, (t * rm.K + i) * rm.E + j + 1));
+                        const uint32_t z2 = gf_mul(prev, rd(osub, (t * rm.K + i) * rm.E + j + 1)); // < 2^32 for any two u16
                         const uint32_t zd = rd(oz, (t * rm.K + i) * rm.Z + j);
-                        const uint16_t uv = (uint16_t)gf_sub(z2, zd);
+                        const uint16_t uv = (uint16_t)ref_sub_u16(z2, zd);
                         Pc[(size_t)(who ? rm.ue(i, j) : rm.us(i, j)) * RS] = uv; // recon_secrets_2ddeg reads the merged row
                         Oc[(size_t)(who ? rm.ue(i, j) : rm.us(i, j)) * OS] = uv;
                         prev = zd;
                     }
                 }
-            (void)bad; // the same values are range-checked by the scatter blocks
             return;
         }
     }
@@ -91,9 +100,8 @@ __global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const F
     const int head = (int)((reinterpret_cast<uintptr_t>(in) >> 1) & 1);
     const int body = (n16 - head) >> 1;
     bool bad = false;
-    // folded mod q, with bit 15 marking a non-canonical element: whether that makes the proof malformed is decided per record
-    // below (records the reference never reads are not range-checked)
-    auto canon = [&](uint32_t x_) { return (uint16_t)(x_ >= (uint32_t)Q ? (x_ % Q) | 0x8000u : x_); };
+    // the tile holds the image's u16 as they are; what an element >= q means is decided per record below
+    auto canon = [&](uint32_t x_) { return (uint16_t)x_; };
     if (lane == 0 && head) tile[0] = canon(in[0]);
     const uint32_t *in32 = reinterpret_cast<const uint32_t *>(in + head);
     for (int q0 = 0; q0 < body; q0 += 64 * 8) { // eight independent loads in flight per lane
@@ -119,22 +127,25 @@ __global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const F
     if (lane < cnt) {
         const int16_t *rt = rowtab + fd.rowtab_off;
         const uint16_t *t = tile + lane * fd.width;
-        uint32_t marks = 0;
+        bool big = false; // an element >= q in this record
         if (kind) {
             const int party = sel[i0 + lane];
             uint16_t *dst = v.P + (size_t)b * v.proof_stride + NSEC + party;
 #pragma unroll 8
-            for (int e = 0; e < fd.width; e++) { marks |= t[e]; dst[(size_t)rt[e] * RS] = t[e] & 0x7FFFu; }
-            if (fd.limit && (fd.limit_by_party ? party : i0 + lane) >= fd.limit) marks = 0; // never read by the reference
+            for (int e = 0; e < fd.width; e++) { const uint32_t x_ = t[e]; big |= x_ >= (uint32_t)Q; dst[(size_t)rt[e] * RS] = (uint16_t)gf_fold(x_); }
+            if (fd.limit && (fd.limit_by_party ? party : i0 + lane) >= fd.limit) big = false; // never read by the reference
         } else {
             // records of the opened parties: into the opened matrix, consecutive lanes = consecutive entries of a row
             uint16_t *dst = v.O + (size_t)b * v.o_stride + i0 + lane;
 #pragma unroll 8
-            for (int e = 0; e < fd.width; e++) { marks |= t[e]; dst[(size_t)rt[e] * OS] = t[e] & 0x7FFFu; }
+            for (int e = 0; e < fd.width; e++) { const uint32_t x_ = t[e]; big |= x_ >= (uint32_t)Q; dst[(size_t)rt[e] * OS] = (uint16_t)x_; }
         }
-        bad = (marks & 0x8000u) != 0;
+        bad = big;
     }
-    if (bad) atomicOr(&v.fail[b], 1u << FB_MALFORMED);
+    if (bad) {
+        if (v.strict) atomicOr(&v.fail[b], 1u << FB_MALFORMED);
+        else if (fd.noncanon_bit >= 0) atomicOr(&v.fail[b], 1u << fd.noncanon_bit);
+    }
 }
 
 
@@ -517,15 +528,17 @@ __global__ __launch_bounds__(192) void k_check_opened(VerifyArgs v)
     const uint16_t *Ob = v.O + (size_t)b * v.o_stride + t;
     auto at = [&](int row) { return (uint32_t)Pb[(size_t)row * RS]; };
     auto op = [&](int row) { return (uint32_t)Ob[(size_t)row * OS]; };
+    // op() values are the image's RAW u16 (and the raw NTT_r of k_lincomb): the reference compares and combines them with its
+    // non-reducing gf3329_add / gf3329_sub, reproduced by ref_add_u16 / ref_sub_u16 (identical to gf_add / gf_sub on canonical values)
     uint32_t bits = 0;
     for (int i = 0; i < rm.K; i++) {
-        if (op(rm.ntts + i) != gf_sub(at(rm.nttsr + i), op(rm.nttr + i))) bits |= 1u << FB_NTT_S_E;
-        if (op(rm.ntte + i) != gf_sub(at(rm.ntter + i), op(rm.nttr + rm.K + i))) bits |= 1u << FB_NTT_S_E;
-        if (at(rm.nttasr + i) != gf_add(op(rm.nttas + i), op(rm.nttar + i))) bits |= 1u << FB_A_SR;
-        if (at(rm.t + i) != gf_add(op(rm.nttas + i), op(rm.ntte + i))) bits |= 1u << FB_T_RELATION;
+        if (op(rm.ntts + i) != ref_sub_u16(at(rm.nttsr + i), op(rm.nttr + i))) bits |= 1u << FB_NTT_S_E;          // :275
+        if (op(rm.ntte + i) != ref_sub_u16(at(rm.ntter + i), op(rm.nttr + rm.K + i))) bits |= 1u << FB_NTT_S_E;   // :279
+        if (at(rm.nttasr + i) != ref_add_u16(op(rm.nttas + i), op(rm.nttar + i))) bits |= 1u << FB_A_SR;          // :306
+        if (at(rm.t + i) != ref_add_u16(op(rm.nttas + i), op(rm.ntte + i))) bits |= 1u << FB_T_RELATION;          // :370
         for (int m = 0; m < rm.E; m++) {
-            if (op(rm.ssub + i * rm.E + m) != gf_sub(op(rm.s + i), at(rm.seta + i * rm.E + m))) bits |= 1u << FB_SUB_ETA;
-            if (op(rm.esub + i * rm.E + m) != gf_sub(op(rm.e + i), at(rm.eeta + i * rm.E + m))) bits |= 1u << FB_SUB_ETA;
+            if (op(rm.ssub + i * rm.E + m) != ref_sub_u16(op(rm.s + i), at(rm.seta + i * rm.E + m))) bits |= 1u << FB_SUB_ETA; // :451
+            if (op(rm.esub + i * rm.E + m) != ref_sub_u16(op(rm.e + i), at(rm.eeta + i * rm.E + m))) bits |= 1u << FB_SUB_ETA; // :459
         }
     }
     if (bits) atomicOr(&v.fail[b], bits);

@@ -760,6 +760,26 @@ static inline uint16_t lincomb(const uint16_t *pwj, const uint16_t *v, uint16_t 
 
 typedef uint16_t sharerow[KO_PARTIES];
 
+/* ---- test hook: a CRAFTING prover ---------------------------------------
+ * No counterpart in the reference.  The verifier's behaviour on u16 values
+ * >= q (gf3329_add / gf3329_sub do not reduce, gf3329.c:274-280) can only be
+ * exercised end to end by proofs whose Fiat-Shamir hashes were computed OVER
+ * such values -- substituting them into a finished proof changes a hash and
+ * is rejected for that reason alone.  ko_craft_add() queues "add mult * q to
+ * share `idx` of party `party`" (kind 0: s_sh, 1: e_sh, 2: f_sh, 3:
+ * ntt_f_sh); ko_prove applies the queue right after the witness sharing and
+ * otherwise runs the reference's steps unchanged on what it finds.        */
+typedef struct { int kind, idx, party, mult; } craft_item;
+static craft_item g_craft[512];
+static int g_ncraft;
+void ko_craft_clear(void) { g_ncraft = 0; }
+int ko_craft_add(int kind, int idx, int party, int mult)
+{
+    if (g_ncraft >= (int)(sizeof g_craft / sizeof g_craft[0]) || kind < 0 || kind > 3 || party < 0 || party >= KO_PARTIES || idx < 0) return -1;
+    g_craft[g_ncraft++] = (craft_item){kind, idx, party, mult};
+    return 0;
+}
+
 void ko_prove(int K, ko_tape *tp, uint8_t *pi, const ko_mlwe *mlwe, const ko_pre *pre, ko_trace *trace)
 {
     ko_params P;
@@ -789,6 +809,17 @@ void ko_prove(int K, ko_tape *tp, uint8_t *pi, const ko_mlwe *mlwe, const ko_pre
         ko_share_secrets_ddeg(s_sh[i], sec, tp);
         for (int j = 0; j < 256; j++) sec[j] = ko_gf_encode(mlwe->e[i][j]);
         ko_share_secrets_ddeg(e_sh[i], sec, tp);
+    }
+
+    for (int c = 0; c < g_ncraft; c++) { /* test hook, see ko_craft_add */
+        const craft_item *ci = &g_craft[c];
+        ko_pre *wpre = (ko_pre *)pre;
+        uint16_t *v = NULL;
+        if (ci->kind == 0 && ci->idx < K) v = &s_sh[ci->idx][ci->party];
+        else if (ci->kind == 1 && ci->idx < K) v = &e_sh[ci->idx][ci->party];
+        else if (ci->kind == 2 && ci->idx < M) v = &wpre->f_sh[ci->idx][ci->party];
+        else if (ci->kind == 3 && ci->idx < M) v = &wpre->ntt_f_sh[ci->idx][ci->party];
+        if (v && (long)*v + (long)ci->mult * KO_Q <= 65535 && ci->mult >= 0) *v = (uint16_t)(*v + ci->mult * KO_Q);
     }
 
     /* P2+P3 :103-127 per-party commitment of (s, e, f, NTT f) shares */

@@ -155,6 +155,11 @@ int ko_kosk_verify(int K, const uint8_t *pi, const uint8_t *pk, char *why, size_
 int ko_bench(int K, int nproofs, const uint8_t *tapes, size_t tape_stride,
              double *sec_keygen_prove, double *sec_verify);
 
+/* test hook (no reference counterpart): a crafting prover that plants u16 values >= q into its own shares before it
+ * commits to them, so that the verifier's non-reducing arithmetic meets hash-consistent inputs (see kosk_oracle.c) */
+void ko_craft_clear(void);
+int ko_craft_add(int kind, int idx, int party, int mult);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,23 +25,21 @@ def _kosk(k, max_batch, **env):
 
 
 def streamed_chunks(k):
-    """KOSK_STREAMS=3: a call longer than one sub-context is cut into chunks that run on three sub-contexts concurrently
-    (KOSK_REGISTER=2: whole pages of the caller's buffer page-locked for the call); n = 7 over sub-batches of 2 leaves a ragged last
-    chunk.  Same bytes as the single-context path and the oracle, with page-locking and without (the default)."""
+    """KOSK_STREAMS=3: a call longer than one sub-context is cut into chunks that run on three sub-contexts concurrently; n = 7
+    over sub-batches of 2 leaves a ragged last chunk.  Same bytes as the single-context path and the oracle.  The library never
+    page-locks the caller's (pageable) buffers -- KOSK_REGISTER=2 of rounds 2-4 is gone and is read as 1 -- so every chunk is staged."""
     from mpcith_kyber_kosk_amd import api
     n = 7
     tapes = [oracle.tape_bytes_for(k, 40 + b) for b in range(n)]
     plain = api.Kosk(kyber_k=k, max_batch=n)
     pks0, sks0, pis0 = plain.verifiable_keygen(tapes)
-    assert plain.path_counts()["copy_direct"] == 0          # single chunk: always staged
-    st = _kosk(k, 6, KOSK_STREAMS=3, KOSK_REGISTER=2)  # page-lock the caller's pageable buffer (the default of rounds 2-3)
+    assert plain.path_counts()["copy_direct"] == 0
+    st = _kosk(k, 6, KOSK_STREAMS=3, KOSK_REGISTER=2)  # the retired value: behaves like the default
     assert st.streams == 3 and st.host_threads >= 1
     pks, sks, pis = st.verifiable_keygen(tapes)
     assert pks == pks0 and sks == sks0 and pis == pis0
     pc = st.path_counts()
-    # 4 chunks of <= 2 proofs: the two inner ones lie inside the page-locked span, the first and last touch its unlocked
-    # head / tail pages (unless the buffer happens to be page aligned) and are staged
-    assert pc["copy_direct"] >= 2 and pc["copy_direct"] + pc["copy_staged"] == 4, pc
+    assert pc["copy_direct"] == 0 and pc["copy_staged"] == 4, pc  # 4 chunks of <= 2 proofs
     for b in (0, n - 1):
         opk, osk, opi, _, _ = oracle.verifiable_keygen(k, tapes[b])
         assert pks[b] == opk and sks[b] == osk and pis[b] == opi
@@ -58,17 +56,12 @@ def streamed_chunks(k):
     assert plain.verify(bad, keys) == want
     assert plain.fail_masks(n) == m_st
     assert all((m != 0) == (not w) for m, w in zip(m_st, want))
-    # the default (and KOSK_REGISTER=0): per handle, gives the same bytes, and never locks pageable caller memory
     st2 = _kosk(k, 6, KOSK_STREAMS=3)
     pks2, sks2, pis2 = st2.verifiable_keygen(tapes)
     assert pks2 == pks0 and sks2 == sks0 and pis2 == pis0
     assert st2.verify(bad, keys) == want
     pc2 = st2.path_counts()
     assert pc2["copy_direct"] == 0 and pc2["copy_staged"] == 8, pc2
-    # the handle created with KOSK_REGISTER=2 still page-locks (the knob is per handle, not per process)
-    before = st.path_counts()["copy_direct"]
-    assert st.verifiable_keygen(tapes)[2] == pis0
-    assert st.path_counts()["copy_direct"] > before
     for c in (plain, st, st2):
         c.close()
     print("streamed_chunks ok", k)
@@ -76,13 +69,13 @@ def streamed_chunks(k):
 
 def streamed_loop(k, iters):
     """The round-2 abort's territory, many times over: several live handles (1, 2 and 3 lanes), streamed keygen + verify in
-    a loop, caller buffers allocated and freed every iteration (so page-locked spans come and go at recycled addresses)."""
+    a loop, caller buffers allocated and freed every iteration (rounds 2-4 page-locked spans of them per call; that is gone)."""
     from mpcith_kyber_kosk_amd import api
     n = 7
     tapes = [oracle.tape_bytes_for(k, 40 + b) for b in range(n)]
     plain = api.Kosk(kyber_k=k, max_batch=n)
     ref = plain.verifiable_keygen(tapes)
-    hs = [_kosk(k, 6, KOSK_STREAMS=3, KOSK_REGISTER=2), _kosk(k, 4, KOSK_STREAMS=2), _kosk(k, 6, KOSK_STREAMS=3, KOSK_REGISTER=0), _kosk(k, 3)]
+    hs = [_kosk(k, 6, KOSK_STREAMS=3), _kosk(k, 4, KOSK_STREAMS=2), _kosk(k, 6, KOSK_STREAMS=3, KOSK_REGISTER=0), _kosk(k, 3)]
     for it in range(iters):
         h = hs[it % len(hs)]
         got = h.verifiable_keygen(tapes)
@@ -321,6 +314,157 @@ def combined_calls(k, threads=6, rounds=4, min_merge=0.5):
     for h in hs + [plain, fresh]:
         h.close()
     print("combined_calls ok", k, "mean callers per run %.2f" % (members / calls))
+
+
+def line_of_record_shape(k=3, per=46, callers=3, rounds=3):
+    """The shape bench.py's line of record runs (bench.py: Slot.step), checked byte for byte: `callers` caller threads of ONE cohort
+    (KOSK_COMBINE=3), each with 46 Kyber-768 proofs per call on DEVICE tapes with a 64-byte-aligned stride that a merged run reads in
+    place (the tape pointer table of the first kernel), the raw resident entry points with the key generation's pk / sk staying
+    resident for the verifier (pk == NULL) -- so every launch covers 138 proofs: the single-buffer instantiation of the commitment
+    hash (3 174 waves), three rounds of row blocks in the expansion product.  Every caller's pk / sk / proof images / both digest
+    tables equal an uncombined handle's, the first and last proof of every caller equal the oracle's, and the digest tables of
+    those proofs equal the oracle's Tcomm / view commitments."""
+    import ctypes as C
+    import threading
+    import numpy as np
+    import torch
+    from mpcith_kyber_kosk_amd import api
+    lib = api.lib
+    plain = api.Kosk(kyber_k=k, max_batch=per)
+    hs = [_kosk(k, per, KOSK_COMBINE=callers, KOSK_COMBINE_WAIT_US=5000000, KOSK_COMBINE_IDLE_US=2000000) for _ in range(callers)]
+    stride = (plain.tape_bytes + 63) // 64 * 64
+    nsets = rounds
+    tapes = {(t, r): [oracle.tape_bytes_for(k, 20000 + ((t * nsets) + r) * per + b) for b in range(per)] for t in range(callers) for r in range(nsets)}
+    banks = []
+    for t in range(callers):
+        host = np.zeros((nsets, per, stride), np.uint8)
+        for r in range(nsets):
+            for b, x in enumerate(tapes[t, r]):
+                host[r, b, :len(x)] = np.frombuffer(x, np.uint8)
+        banks.append(torch.from_numpy(host).to("cuda"))
+    torch.cuda.synchronize()
+    want = {}
+    for key, tp in tapes.items():
+        plain.verifiable_keygen_resident(tp)
+        pk, sk = plain.keys(per)
+        assert plain.verify_resident_pk(per) == [True] * per
+        want[key] = (pk, sk, plain.fetch_proofs(per),
+                     [torch.as_tensor(plain.resident_digests(i, per), device="cuda").cpu().numpy().tobytes() for i in (0, 1)])
+    # the oracle on the first and the last proof of every caller (last round): images, keys and both digest tables
+    for t in range(callers):
+        for b in (0, per - 1):
+            opk, osk, opi, _, _, tr = oracle.verifiable_keygen(k, tapes[t, nsets - 1][b], trace=True)
+            w = want[t, nsets - 1]
+            assert (w[0][b], w[1][b], w[2][b]) == (opk, osk, opi), ("oracle", t, b)
+            assert w[3][0][b * 1454 * 32:(b + 1) * 1454 * 32] == bytes(tr.tcomm), ("tcomm", t, b)
+            assert w[3][1][b * 1454 * 32:(b + 1) * 1454 * 32] == bytes(tr.view_digest), ("view", t, b)
+    errs, base = [], [None] * callers
+    barrier = threading.Barrier(callers)
+
+    def worker(t):
+        try:
+            h = hs[t]
+            pk = C.create_string_buffer(h.pk_bytes * per); sk = C.create_string_buffer(h.sk_bytes * per); ok = C.create_string_buffer(per)
+            ptrs = [C.c_void_p(banks[t][r].data_ptr()) for r in range(nsets)]
+
+            def step(r):
+                assert lib.kosk_verifiable_keygen_resident(h.handle, per, ptrs[r], stride, pk, sk) == 0, lib.kosk_last_error(h.handle)
+                assert lib.kosk_verify_resident_pk(h.handle, per, None, ok) == 0, lib.kosk_last_error(h.handle)
+                assert ok.raw == b"\x01" * per, ("verify bits", t, r)
+            barrier.wait()
+            for _ in range(2):  # nobody is expected at a cohort's very first call: two unchecked steps bring the callers into step
+                step(0)
+            base[t] = h.combine_stats()
+            for r in range(nsets):
+                step(r)
+                w = want[t, r]
+                assert [pk.raw[i * h.pk_bytes:(i + 1) * h.pk_bytes] for i in range(per)] == w[0], ("pk", t, r)
+                assert [sk.raw[i * h.sk_bytes:(i + 1) * h.sk_bytes] for i in range(per)] == w[1], ("sk", t, r)
+                assert h.fail_masks(per) == [0] * per
+                assert h.fetch_proofs(per) == w[2], ("proofs", t, r)
+                for i in (0, 1):
+                    got = torch.as_tensor(h.resident_digests(i, per), device="cuda").cpu().numpy().tobytes()
+                    assert got == w[3][i], ("digests", t, r, i)
+        except Exception as e:  # noqa: BLE001
+            errs.append((t, repr(e)))
+            try:
+                barrier.abort()
+            except Exception:
+                pass
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(callers)]
+    for x in ths:
+        x.start()
+    for x in ths:
+        x.join()
+    assert not errs, errs
+    calls = sum(h.combine_stats()[0] - base[t][0] for t, h in enumerate(hs))
+    members = sum(h.combine_stats()[1] - base[t][1] for t, h in enumerate(hs))
+    assert calls == callers * 2 * nsets, calls
+    assert members == callers * calls, (calls, members)  # every checked call ran in a merged run of all the cohort's callers
+    pc = hs[0].path_counts()
+    assert sum(h.path_counts()["hash_dma"] for h in hs) > 0 and all(h.path_counts()["hash_plain"] == 0 for h in hs), pc
+    for h in hs + [plain]:
+        h.close()
+    print("line_of_record_shape ok", k, per, callers, "callers per run %.2f" % (members / calls))
+
+
+def member_big_batch_stays_in_its_block(k=3, per=3):
+    """a cohort member's view spans its neighbours' blocks of the shared workspace, so its non-merged entry points must
+    chunk by the member's OWN batch size.  Member 0 makes host-buffer calls of 2 * per + 1 proofs (keygen, verify, the compact pair,
+    the second-level prepare calls) while members 1 and 2 loop resident calls: member 0's results equal a plain handle's, and the
+    neighbours' keys, resident proofs and verify bits never change."""
+    import threading
+    from mpcith_kyber_kosk_amd import api
+    plain = api.Kosk(kyber_k=k, max_batch=per)
+    hs = [_kosk(k, per, KOSK_COMBINE=3, KOSK_COMBINE_WAIT_US=2000, KOSK_COMBINE_IDLE_US=500) for _ in range(3)]
+    n_big = 2 * per + 1
+    big_tapes = [oracle.tape_bytes_for(k, 7000 + b) for b in range(n_big)]
+    want_big = plain.verifiable_keygen(big_tapes)
+    nb_tapes = {t: [oracle.tape_bytes_for(k, 7100 + t * per + b) for b in range(per)] for t in (1, 2)}
+    want_nb = {}
+    for t in (1, 2):
+        plain.verifiable_keygen_resident(nb_tapes[t])
+        want_nb[t] = (plain.keys(per), plain.fetch_proofs(per))
+    errs, stop = [], threading.Event()
+
+    def neighbour(t):
+        try:
+            h = hs[t]
+            it = 0
+            while not stop.is_set() or it < 3:
+                h.verifiable_keygen_resident(nb_tapes[t])
+                assert h.keys(per) == want_nb[t][0], ("neighbour keys", t, it)
+                assert h.verify_resident_pk(per) == [True] * per, ("neighbour verify", t, it)
+                assert h.fail_masks(per) == [0] * per
+                assert h.fetch_proofs(per) == want_nb[t][1], ("neighbour proofs", t, it)
+                it += 1
+        except Exception as e:  # noqa: BLE001
+            errs.append((t, repr(e)))
+    ths = [threading.Thread(target=neighbour, args=(t,)) for t in (1, 2)]
+    for x in ths:
+        x.start()
+    try:
+        h0 = hs[0]
+        for it in range(4):
+            got = h0.verifiable_keygen(big_tapes)
+            assert got == want_big, ("member 0 keygen", it)
+            assert h0.verify(got[2], got[0]) == [True] * n_big, ("member 0 verify", it)
+            bad = list(got[2]); flip = bytearray(bad[n_big - 1]); flip[100] ^= 1; bad[n_big - 1] = bytes(flip)
+            assert h0.verify(bad, got[0]) == [True] * (n_big - 1) + [False]
+        # the second-level entry points chunk the same way
+        mo = [oracle.main_order(k, oracle.tape_bytes_for(k, 7300 + b)) for b in range(n_big)]
+        rands = h0.prepare_randomness([oracle.tape_bytes_for(k, 7300 + b)[:mo[b]["used"][0]] for b in range(n_big)])
+        assert rands == [m["rand"] for m in mo]
+    except Exception as e:  # noqa: BLE001
+        errs.append((0, repr(e)))
+    finally:
+        stop.set()
+        for x in ths:
+            x.join()
+    assert not errs, errs
+    for h in hs + [plain]:
+        h.close()
+    print("member_big_batch_stays_in_its_block ok", k)
 
 
 def combined_members_come_and_go(k):

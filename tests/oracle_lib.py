@@ -61,6 +61,19 @@ def verifiable_keygen(k, tape, trace=False):
     return out + (tr,) if trace else out
 
 
+def crafted_verifiable_keygen(k, tape, items):
+    """ko_verifiable_keygen by the oracle's CRAFTING prover (kosk_oracle.c: ko_craft_add): items = [(kind, idx, party, mult)] adds
+    mult * q to share idx of the party (kind 0 s, 1 e, 2 f, 3 NTT f) before the prover commits to its shares, so the proof's
+    Fiat-Shamir hashes are consistent with the non-canonical u16 it holds.  Returns (pk, sk, pi)."""
+    lib.ko_craft_clear()
+    try:
+        for it in items:
+            assert lib.ko_craft_add(*it) == 0
+        return verifiable_keygen(k, tape)[:3]
+    finally:
+        lib.ko_craft_clear()
+
+
 def kosk_verify(k, pi, pk):
     why = C.create_string_buffer(256)
     ok = lib.ko_kosk_verify(k, C.c_char_p(pi), C.c_char_p(pk), why, 256)

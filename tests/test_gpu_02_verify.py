@@ -125,11 +125,174 @@ def test_verify_random_corruptions_match_oracle(k, oracle, torch_cuda):
     ctx.close()
 
 
+U16_FIELDS = [f for f in range(24) if f not in BYTE_FIELDS and f != 5]
+
+
+def _oracle_verify_many(oracle, k, proofs, pk):
+    """the oracle's verdicts on many proofs, a few at a time (ctypes releases the interpreter lock; the oracle's verifier has no
+    shared mutable state once its tables exist)"""
+    from concurrent.futures import ThreadPoolExecutor
+    oracle.kosk_verify(k, proofs[0], pk)  # tables built by one thread
+    with ThreadPoolExecutor(6) as ex:
+        return list(ex.map(lambda t: oracle.kosk_verify(k, t, pk), proofs))
+
+
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_verify_congruent_encodings_match_oracle(k, oracle, torch_cuda):
+    """orig + 3329 m substituted for a u16 element -- the SAME residue, a non-canonical encoding -- in every one of the 21 u16
+    fields, at a position the reference reads and (where the field has one) at a position it never reads, for m = 1 and the
+    largest m that fits 16 bits everywhere and EVERY m that fits at one position of the fields with a story: beta (reduced by
+    gf3329_mul), t (only ever converted to ZZ_p), NTT(As) / NTT(Ar) (summed by the non-reducing gf3329_add: accepted exactly when
+    that sum happens to come out canonical), u (ZZ_p and gf3329_mul), s + r (compared raw).  The oracle -- the reference's
+    arithmetic on the raw values, line by line -- decides; the verify bit must be the same and the fail mask zero exactly for
+    the accepted.  mlwe_verifier.cpp:97-124, ss.cpp:37-54, gf3329.c:274-284."""
+    from mpcith_kyber_kosk_amd import api
+    p = oracle.params(k)
+    ctx = api.Kosk(kyber_k=k, max_batch=64)
+    assert ctx.path_counts is not None
+    pks, sks, pis = ctx.verifiable_keygen([oracle.tape_bytes_for(k, 130 + k)])
+    pi = pis[0]
+    I = [int.from_bytes(pi[p.off[5] + 2 * i:p.off[5] + 2 * i + 2], "little") for i in range(150)]
+    rest = [q for q in range(1454) if q not in set(I)]
+    width = {f: p.size[f] // 2 // (150 if f in (0, 1, 6, 7, 9, 10, 11, 12, 17, 18, 19, 20) else 1304) for f in U16_FIELDS}
+
+    def elem(f, idx):
+        return int.from_bytes(pi[p.off[f] + 2 * idx:p.off[f] + 2 * idx + 2], "little")
+
+    def put(f, idx, val):
+        t = bytearray(pi)
+        t[p.off[f] + 2 * idx:p.off[f] + 2 * idx + 2] = val.to_bytes(2, "little")
+        return bytes(t)
+    i_lo = next(i for i, q in enumerate(rest) if q < 407)   # an unopened party recon_secrets_ddeg reaches
+    i_hi = next(i for i, q in enumerate(rest) if q >= 813)  # one neither recon_secrets_ddeg nor _2ddeg reaches
+    positions = {}
+    for f in U16_FIELDS:
+        w = width[f]
+        if f in (2, 3):
+            positions[f] = [i_lo * w + 3, i_hi * w + 5]
+        elif f in (8, 15, 16):
+            positions[f] = [406 * w + w - 1, 407 * w]           # last interpolation node, first record behind the nodes
+        elif f in (21, 22):
+            positions[f] = [812 * w + 1, max(813, i_hi) * w + 2]
+        elif f in (13, 14):
+            positions[f] = [5 * w, 1303 * w + w - 1]            # compared raw for every unopened party
+        else:
+            positions[f] = [0, 149 * w + w - 1]                 # opened-party records: all read
+    bad, what = [], []
+    for f in U16_FIELDS:
+        for idx in positions[f]:
+            v = elem(f, idx)
+            mmax = (65535 - v) // 3329
+            ms = range(1, mmax + 1) if (f in (2, 8, 11, 12, 13, 21) and idx == positions[f][0]) else sorted({1, mmax})
+            for m in ms:
+                bad.append(put(f, idx, v + 3329 * m)); what.append((f, idx, m))
+    got, masks = [], []
+    for i in range(0, len(bad), 64):
+        got += ctx.verify(bad[i:i + 64], [pks[0]] * len(bad[i:i + 64]))
+        masks += ctx.fail_masks(len(bad[i:i + 64]))
+    exp = _oracle_verify_many(oracle, k, bad, pks[0])
+    acc = set()
+    for w, g, m, (e, why) in zip(what, got, masks, exp):
+        assert g == e, f"field {w[0]} element {w[1]} + {w[2]} q: gpu={g} (mask {m:#x}) oracle={e} ({why})"
+        assert (m == 0) == g, (w, g, hex(m))
+        if g:
+            acc.add(w[0])
+    # fields whose non-canonical encodings the reference accepts wherever they sit (it only ever reduces them) ...
+    assert acc >= {2, 3, 8, 15, 16, 21, 22}, acc
+    # ... and fields it can only accept when gf3329_add's single correction happens to land on the canonical sum
+    assert acc <= {2, 3, 8, 15, 16, 21, 22, 11, 12}, acc
+    ctx.close()
+
+
+# (tape index, [(kind, share index, party, multiples of q)]): kind 0 s, 1 e, 2 f, 3 NTT f (oracle_lib.crafted_verifiable_keygen).
+# Found by search on the CPU oracle so that the set holds accepted AND rejected proofs with non-canonical u16 in opened records.
+CRAFTS = {
+    2: [(305, [(0, 0, 1200, 1)]),                                   # accepted: raw s share, s - eta shares >= q, gf3329_sub emulated
+        (305, [(0, 0, 11, 1)])],
+    3: [(300, [(1, 1, 11, 2)]),                                     # rejected at NTT(e): the raw chain value meets gf3329_sub
+        (300, [(1, 1, 1200, 2)]),                                   # rejected at I' != I only
+        (301, [(0, 0, 1200, 1)])],
+    4: [(301, [(1, 1, 1200, 2)]),
+        (302, [(0, 0, 1200, 1)])],
+}
+
+
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_verify_crafted_hash_consistent_non_canonical_proofs(k, oracle, torch_cuda):
+    """Proofs by the oracle's CRAFTING prover: u16 values >= q planted into the prover's own shares BEFORE it commits, so every
+    hash of the proof is consistent with them -- the only way the reference's non-reducing gf3329_add / gf3329_sub chains
+    (beta = f_0 + ..., NTT_r = NTT f_71 + ..., s - eta, z_2d - z_d) ever meet such values on an otherwise valid proof.  The
+    reference accepts many of these; the verify bit must be the oracle's on every one, and at least one accepted proof must
+    hold non-canonical u16 in opened-party records (so the emulation, not an early reject, is what ran)."""
+    import numpy as np
+    from mpcith_kyber_kosk_amd import api
+    p = oracle.params(k)
+    crafts = list(CRAFTS[k])
+    crafts += [(310, [(2, 0, q, 1) for q in range(0, 1454, 7)]),         # f_0 of 208 parties + q: the chain sheds the excess
+               (311, [(2, 0, q, 15) for q in range(3, 1454, 11)]),       # + 15 q: it cannot (76 steps shed at most ~40): raw beta, gamma >= q
+               (312, [(3, 71, q, 3) for q in range(0, 1454, 7)]),        # NTT f_71: the base of NTT_r
+               (313, [(3, 0, q, 19) for q in range(5, 1454, 13)]),       # NTT f_0 + 19 q where it fits
+               (314, [(2, 5, q, 2) for q in range(0, 1454, 7)]),         # an inner f share: only ever multiplied
+               (315, [(2, 0, q, 9) for q in range(1, 1454, 9)] + [(3, 71, q, 12) for q in range(1, 1454, 9)]),
+               (316, [(0, 0, q, 1) for q in range(0, 1454, 7)])]         # raw s shares everywhere: s + r shares >= q among the unopened
+    pks, pis = [], []
+    for tidx, items in crafts:
+        pk, sk, pi = oracle.crafted_verifiable_keygen(k, oracle.tape_bytes_for(k, tidx), items)
+        pks.append(pk); pis.append(pi)
+    ctx = api.Kosk(kyber_k=k, max_batch=len(pis))
+    got = ctx.verify(pis, pks)
+    masks = ctx.fail_masks(len(pis))
+    opened_fields = (0, 1, 6, 7, 9, 10, 11, 12, 17, 18, 19, 20)
+    n_acc_noncanon = 0
+    for (tidx, items), pi, pk, g, m in zip(crafts, pis, pks, got, masks):
+        e, why = oracle.kosk_verify(k, pi, pk)
+        assert g == e, f"tape {tidx} {items[:2]}...: gpu={g} (mask {m:#x}) oracle={e} ({why})"
+        assert (m == 0) == g
+        nc = sum(int((np.frombuffer(pi[p.off[f]:p.off[f] + p.size[f]], dtype="<u2") >= 3329).sum()) for f in opened_fields)
+        n_acc_noncanon += bool(g and nc)
+    assert n_acc_noncanon >= 3, n_acc_noncanon
+    assert not all(got), got
+    ctx.close()
+
+
+def test_strict_encoding_knob_rejects_what_the_reference_accepts(oracle, torch_cuda):
+    """KOSK_STRICT_ENCODING=1 (rounds 1-4): a u16 >= q in any record the reference reads marks the proof malformed (fail bit 0),
+    whatever the reference would do with it; records it never reads stay unchecked."""
+    import os
+    from mpcith_kyber_kosk_amd import api
+    k = 3
+    p = oracle.params(k)
+    os.environ["KOSK_STRICT_ENCODING"] = "1"
+    try:
+        ctx = api.Kosk(kyber_k=k, max_batch=8)
+    finally:
+        os.environ.pop("KOSK_STRICT_ENCODING", None)
+    pks, sks, pis = ctx.verifiable_keygen([oracle.tape_bytes_for(k, 133)])
+    pi = pis[0]
+    I = [int.from_bytes(pi[p.off[5] + 2 * i:p.off[5] + 2 * i + 2], "little") for i in range(150)]
+    rest = [q for q in range(1454) if q not in set(I)]
+    i_lo = next(i for i, q in enumerate(rest) if q < 407)
+    i_hi = next(i for i, q in enumerate(rest) if q >= 407)
+
+    def bump(f, idx):
+        t = bytearray(pi)
+        v = int.from_bytes(t[p.off[f] + 2 * idx:p.off[f] + 2 * idx + 2], "little") + 3329
+        t[p.off[f] + 2 * idx:p.off[f] + 2 * idx + 2] = v.to_bytes(2, "little")
+        return bytes(t)
+    cases = [bump(2, i_lo * 70 + 3), bump(8, 406 * k), bump(21, 812 * k * 4), bump(2, i_hi * 70 + 3), pi]
+    got = ctx.verify(cases, [pks[0]] * 5)
+    masks = ctx.fail_masks(5)
+    assert got == [False, False, False, True, True] and all(m & 1 for m in masks[:3]) and masks[3:] == [0, 0], (got, masks)
+    for t in cases:  # the reference (oracle) accepts all five
+        assert oracle.kosk_verify(k, t, pks[0])[0]
+    ctx.close()
+
+
 def test_verify_non_canonical_elements(oracle, torch_cuda):
     """u16 values >= q never come out of an honest prover.  Where the reference never reads a record, any bytes are accepted,
-    by the reference, the oracle and this verifier alike.  Where it does read, this verifier rejects the proof outright (fail
-    bit 0) -- the reference computes on the out-of-range value with gf3329's non-reducing add/sub and rejects or (for some
-    congruent encodings) accepts; the cases below are ones it rejects as well."""
+    by the reference, the oracle and this verifier alike.  Where it does read, this verifier does what the reference does with
+    the raw value (round 5; rounds 1-4 rejected outright, now KOSK_STRICT_ENCODING=1): DIFFERENT residues below are rejected by
+    the check they break, the congruent s + r share by the raw comparison of mlwe_verifier.cpp:234."""
     from mpcith_kyber_kosk_amd import api
     k = 3
     p = oracle.params(k)
@@ -152,15 +315,15 @@ def test_verify_non_canonical_elements(oracle, torch_cuda):
               put(15, (1000 * K + 1) * E + 2, 65535),            # eta share beyond the 407 nodes
               put(21, (813 * K) * Z, 40000),                     # u share of the 814th unopened party
               put(22, ((len(rest) - 1) * K + 2) * Z + 3, 3329)]
-    read = [put(2, i_lo * NCHK + 3, 3329 + 5),                   # beta share of an unopened party below 407
+    read = [put(2, i_lo * NCHK + 3, 3329 + 5),                   # beta share of an unopened party below 407: another residue
             put(13, 5 * K, int.from_bytes(pi[p.off[13] + 10 * K:p.off[13] + 10 * K + 2], "little") + 3329),  # s + r share, compared raw
-            put(8, 406 * K, 5000),                               # t share of the last node
-            put(21, (812 * K) * Z, 3329)]                        # u share of the last node
+            put(8, 406 * K, 5000),                               # t share of the last node: another residue
+            put(21, (812 * K) * Z, 3329 + 1)]                    # u share of the last node: another residue
     got = ctx.verify(unread + read, [pks[0]] * 10)
     masks = ctx.fail_masks(10)
-    assert got == [True] * 6 + [False] * 4, got
-    assert all(m == 0 for m in masks[:6]) and all(m & 1 for m in masks[6:]), [hex(m) for m in masks]
-    for t in unread:
-        assert oracle.kosk_verify(k, t, pks[0])[0]
-    assert not oracle.kosk_verify(k, read[1], pks[0])[0]
+    exp = [oracle.kosk_verify(k, t, pks[0])[0] for t in unread + read]
+    assert got == exp, (got, exp)
+    assert got[:6] == [True] * 6 and got[7] is False, got
+    assert all((m == 0) == g for m, g in zip(masks, got)), [hex(m) for m in masks]
+    assert masks[7] == 1 << 2, hex(masks[7])                      # the s + r share comparison, not "malformed"
     ctx.close()

@@ -31,3 +31,18 @@ def test_combined_calls_under_glibc_heap_checking(torch_cuda, gpu_child):
 def test_cohort_members_come_and_go(torch_cuda, gpu_child):
     out = gpu_child("from tests.gpu_child_cases import combined_members_come_and_go; combined_members_come_and_go(3)")
     assert "combined_members_come_and_go ok 3" in out
+
+
+def test_line_of_record_shape(torch_cuda, gpu_child):
+    """tests/gpu_child_cases.py: line_of_record_shape -- bench.py's default arrangement (KOSK_COMBINE=3, three caller threads x 46
+    Kyber-768 proofs on device tapes read in place by merged 138-proof runs, raw resident entry points, resident public keys)
+    against an uncombined handle byte for byte and against the oracle (proof images, keys, both digest tables)."""
+    out = gpu_child("from tests.gpu_child_cases import line_of_record_shape; line_of_record_shape()")
+    assert "line_of_record_shape ok 3 46 3 callers per run 3.00" in out
+
+
+def test_member_calls_larger_than_its_block_stay_in_its_block(torch_cuda, gpu_child):
+    """tests/gpu_child_cases.py: member_big_batch_stays_in_its_block -- a cohort member's host-buffer calls of 2 * per + 1 proofs are
+    chunked by its own batch size and never touch the neighbouring members' blocks of the shared workspace."""
+    out = gpu_child("from tests.gpu_child_cases import member_big_batch_stays_in_its_block; member_big_batch_stays_in_its_block(3)")
+    assert "member_big_batch_stays_in_its_block ok 3" in out
