@@ -144,7 +144,8 @@ int kosk_stage_verifier_inputs_compact(kosk_ctx *ctx, int n, const uint8_t *in, 
  * behind the launch (default), 12 digest tables copied to the host by the library's own few-wave copy kernel (KOSK_COPY_WAVES=n;
  * default 0: the runtime's hipMemcpyAsync, which measured faster for the pipeline as a whole), 13 small copies between HBM and the
  * library's own page-locked buffers (challenge vectors, opened lists, key records, fail masks) made by a copy kernel instead of
- * hipMemcpyAsync (default; KOSK_SMALL_COPY_KERNEL=0 turns it off). */
+ * hipMemcpyAsync (default; KOSK_SMALL_COPY_KERNEL=0 turns it off), 14 / 15 prover beta / gamma / r launches of the one-shot kernel of rounds
+ * 2-4 (KOSK_LINCOMB_FUSED=2) / of the streaming kernel (default). */
 int kosk_path_count(const kosk_ctx *ctx, int id, long *count);
 /* host worker threads per sub-context (<= 8, <= CPUs of the process / KOSK_STREAMS; all created by kosk_create) */
 int kosk_host_threads(const kosk_ctx *ctx);

@@ -1035,7 +1035,7 @@ int kosk_lagrange_expand(kosk_ctx *ctx, const uint16_t *d_y407, uint16_t *d_shar
     for (int done = 0; done < n;) {
         const int m = (n - done) < cap ? (n - done) : cap;
         HIPCHK_C(launch_rows_copy(d_y407 + (size_t)done * XLEN, XLEN, c.d_P, RS, XLEN, m, c.stream));
-        const GemmSrc gs{c.d_P, 0, nullptr, RS, 0, XLEN};
+        const GemmSrc gs{c.d_P, 0, nullptr, RS, 0, XLEN, 0}; // caller data: folded while converted
         const GemmDst gd{c.d_P, 0, nullptr, RS, EXP_OFF};
         if (gemm_modq(c, c.t_expand, gs, gd, m, 1)) return -1;
         HIPCHK_C(launch_rows_copy(c.d_P + NSEC, RS, d_shares + (size_t)done * NPARTY, NPARTY, NPARTY, m, c.stream));
@@ -1058,7 +1058,7 @@ int kosk_recon_secrets(kosk_ctx *ctx, const uint16_t *d_shares, uint16_t *d_secr
     for (int done = 0; done < n;) {
         const int m = (n - done) < cap ? (n - done) : cap;
         HIPCHK_C(launch_rows_copy(d_shares + (size_t)done * NPARTY, NPARTY, c.d_P + NSEC, RS, NPARTY, m, c.stream));
-        const GemmSrc gs{c.d_P, 0, nullptr, RS, NSEC, t.Kdim};
+        const GemmSrc gs{c.d_P, 0, nullptr, RS, NSEC, t.Kdim, 0};
         const GemmDst gd{c.d_P, 0, nullptr, RS, 0};
         if (gemm_modq(c, t, gs, gd, m, 1)) return -1;
         HIPCHK_C(launch_rows_copy(c.d_P, RS, d_secrets + (size_t)done * NSEC, NSEC, NSEC, m, c.stream));

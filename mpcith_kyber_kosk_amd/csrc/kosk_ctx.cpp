@@ -207,6 +207,7 @@ int gemm_modq(Ctx &c, const uint8_t *A, size_t a_gstride, int Mpad, int M, int K
         GemmArgs ta = ga;
         ta.B = nullptr; ta.BRT = 0;
         ta.src = s.src; ta.src_gstride = s.gstride; ta.src_rows = s.rows; ta.src_rstride = s.rstride; ta.src_koff = s.koff;
+        ta.src_canonical = s.canonical;
         if (c.table_gemm && table_gemm_usable(ta)) {
             HIPCHK(launch_table_gemm(ta, reinterpret_cast<uint16_t *>(c.d_limbs), c.stream));
             if (!c.capturing) c.path_n[PATH_TABLE_GEMM]++;
@@ -378,7 +379,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     c.own_batch = max_batch;
     c.call_cap = max_batch;
     if (const char *e = getenv("KOSK_GRAPHS")) c.use_graphs = atoi(e) != 0;
-    if (const char *e = getenv("KOSK_LINCOMB_FUSED")) c.lincomb_fused = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_LINCOMB_FUSED")) c.lincomb_fused = atoi(e) < 0 ? 1 : (atoi(e) > 2 ? 1 : atoi(e));
     if (const char *e = getenv("KOSK_NTT_FP32")) c.ntt_fp32 = atoi(e) != 0;
     if (const char *e = getenv("KOSK_BLOCKING_SYNC")) c.blocking_sync = atoi(e) != 0;
     if (const char *e = getenv("KOSK_HASH_SPLIT")) c.hash_split = atoi(e) != 0;
@@ -844,7 +845,8 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         c.prof_begin(PR_LINCOMB, n);
         HIPCHK(launch_coef_limbs(c.d_alpha, P.J, P.M, c.d_coef, n, st));
         if (c.lincomb_fused) {
-            HIPCHK(launch_lincomb_fused(c.d_P, c.proof_stride, rm, c.d_coef, c.d_P, c.d_lin_rows, P.J, n, st)); // includes s + r, e + r
+            HIPCHK(launch_lincomb_fused(c.d_P, c.proof_stride, rm, c.d_coef, c.d_P, c.d_lin_rows, P.J, n, st, c.lincomb_fused)); // includes s + r, e + r
+            if (!c.capturing) c.path_n[c.lincomb_fused == 2 ? PATH_LINCOMB_ONESHOT : PATH_LINCOMB_STREAM]++;
         } else {
             GemmArgs ga{};
             ga.A = c.d_linA; ga.a_gstride = a_gstride; ga.Mpad = 1792; ga.M = NPTS; ga.KS = 2;

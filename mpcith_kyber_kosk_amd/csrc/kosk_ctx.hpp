@@ -62,7 +62,8 @@ enum ProfId { PR_HASH_TCOMM = 0, PR_HASH_VIEW, PR_GEMM_EXPAND1, PR_GEMM_EXPAND2,
               PR_V_LINCOMB, PR_HASH_TCOMM_TAIL, PR_HASH_VIEW_TAIL, PR_COUNT };
 
 enum PathId { PATH_HASH_DMA = 0, PATH_HASH_PLAIN, PATH_HASH_PRIMER, PATH_TABLE_GEMM, PATH_LIMB_GEMM, PATH_COPY_DIRECT, PATH_COPY_STAGED,
-              PATH_GRAPH_REPLAY, PATH_NTT_FP32, PATH_NTT_INT, PATH_DIGEST_DIRECT, PATH_DIGEST_COPY, PATH_COPY_KERNEL, PATH_SMALL_COPY_KERNEL, PATH_COUNT };
+              PATH_GRAPH_REPLAY, PATH_NTT_FP32, PATH_NTT_INT, PATH_DIGEST_DIRECT, PATH_DIGEST_COPY, PATH_COPY_KERNEL, PATH_SMALL_COPY_KERNEL,
+              PATH_LINCOMB_ONESHOT, PATH_LINCOMB_STREAM, PATH_COUNT };
 
 struct GemmTable {
     uint8_t *d = nullptr; // limb matrix (kosk_device.hpp)
@@ -76,6 +77,10 @@ struct GemmSrc {
     size_t gstride;
     const int16_t *rows;
     int rstride, koff, ncols;
+    // every u16 of the rows is a canonical field element (< q): true for everything the pipelines produce (the verifier folds what it
+    // takes from a proof image before it reaches the row matrix); 0 for caller data of the kernel-level entry points, which is
+    // folded while it is converted (the slower conversion)
+    int canonical = 1;
 };
 struct GemmDst {
     uint16_t *C;
@@ -248,7 +253,8 @@ struct Ctx {
     bool use_graphs = false; // KOSK_GRAPHS=1 turns them on (measured on ROCm 7.2: no gain over plain launches)
     bool capturing = false;
     int ntt_fp32 = 0; // KOSK_NTT_FP32=1: packed-fp32 NTT kernel (see its HAZARD note in kosk_kernels.hip); default integer
-    bool lincomb_fused = true; // KOSK_LINCOMB_FUSED=0: separate transposition pass + generic GEMM
+    int lincomb_fused = 1; // KOSK_LINCOMB_FUSED: 1 the streaming kernel k_lincomb_stream (default, round 5), 2 the one-shot kernel of rounds 2-4
+                           // (k_lincomb_fused), 0 a separate transposition pass + the generic GEMM
     // kernel / copy path choices, read from the environment when the context is created (per handle, never per process)
     bool hash_dma = true;      // KOSK_HASH_DMA=0: commitment hashes without the LDS-DMA staging (k_commit_hash)
     bool hash_primer = false;  // KOSK_HASH_PRIMER=1: placement primer in front of a commitment launch (k_hash_primer)

@@ -99,6 +99,7 @@ struct GemmArgs {
     size_t src_gstride;
     const int16_t *src_rows; // null: i
     int src_rstride, src_koff;
+    int src_canonical; // 1: every source value is < q (no folding while converting to limbs)
     uint16_t *C;
     size_t c_gstride;
     const int16_t *c_rows; // output row per i (null: i)
@@ -322,8 +323,10 @@ hipError_t launch_table_gemm(const GemmArgs &a, uint16_t *sink, hipStream_t st);
 hipError_t launch_cols_to_limbs(const uint16_t *P, size_t proof_stride, int row_f, int row_tf, int M, uint8_t *A, size_t a_gstride,
                                 int nproofs, hipStream_t st);
 // beta/gamma/r/NTT_r rows of every proof from its f / NTT f rows, plus s + r and e + r (the k_post_open step) in the epilogue
+// variant 1: the streaming kernel (k_lincomb_stream, persistent workgroups, prefetched inputs; default), 2: the one-shot kernel of
+// rounds 2-4 (k_lincomb_fused)
 hipError_t launch_lincomb_fused(const uint16_t *P, size_t proof_stride, const RowMap &rm, const uint8_t *coef, uint16_t *C,
-                                const int16_t *lin_rows, int J, int nproofs, hipStream_t st);
+                                const int16_t *lin_rows, int J, int nproofs, hipStream_t st, int variant = 1);
 hipError_t launch_coef_limbs(const uint16_t *alpha, int J, int M, uint8_t *B, int nproofs, hipStream_t st);
 hipError_t launch_pow_table(const uint16_t *alpha, int J, int M, int32_t *pwT, int nproofs, hipStream_t st);
 hipError_t launch_lincomb(const LincombArgs &a, int nproofs, hipStream_t st);

@@ -1372,6 +1372,191 @@ __global__ __launch_bounds__(512, (KS <= 7 && NBT == 3) ? 2 : 1) void k_table_ge
     }
 }
 
+// ---- the same product with PERSISTENT workgroups (round 5; default for KS = 7) ----------------------------------------------------
+// k_table_gemm gives every 48-row block a workgroup of its own, one workgroup per CU at a time: a launch takes ceil(blocks / CUs) rounds
+// (29 946 rows = 624 blocks = 2.44 rounds of work in 3 rounds of time; the verifier's and the re-sharing products of a 138-proof step
+// are 1.03 .. 1.6 rounds of work in 2), and every block starts with a prologue -- 43 KB of rows from HBM, their conversion, the first
+// chunk's table fragments -- during which the matrix pipe idles (9-12 k of a block's 55 k cycles, profiles/r04_gemm_stamps.txt).
+// Here the launch is ONE workgroup per CU and the flattened list of (row block, 16-row table chunk) units is dealt evenly over them:
+// a workgroup walks its share block by block (the first and the last may be partial: another workgroup has the block's other
+// chunks and converts the same rows), its eight waves taking the block's chunks round-robin as before.  The NEXT block's rows are
+// fetched and converted inside this block's chunk loop, one 32-byte item per thread and chunk iteration -- loaded at the top of
+// the iteration, converted and written to the OTHER half of the LDS buffer behind its epilogue -- so the only thing between two
+// blocks is a barrier.  Same fragments, same arithmetic, same stores: bit-identical to k_table_gemm (KOSK_TG_PERSIST=0 runs that).
+// CANON: the source rows hold canonical values (everything the pipelines produce): packed conversion; otherwise gm_split16 (folds).
+template <int KS, int NBT, bool CANON>
+__global__ __launch_bounds__(512, 1) void k_table_gemm_p(GemmArgs a, int nchunks, int nblk, int wide_stores, uint32_t npg_magic)
+{
+    // row n -> (group, index inside the group) by multiply-high with floor(2^32 / npg) and one correction step (as ntt_split)
+    auto split = [&](int n, int &g, int &i) {
+        uint32_t gg = __umulhi((uint32_t)n, npg_magic);
+        int r = n - (int)gg * a.npg;
+        if (r >= a.npg) { gg++; r -= a.npg; }
+        g = (int)gg;
+        i = r;
+    };
+    constexpr int TG_RT = 1, TG_CHUNK = 16, TG_NB = 16 * NBT, BUF = KS * NBT * 2048;
+    __shared__ __attribute__((aligned(16))) uint8_t ldsB[2 * BUF]; // two row blocks: [buffer][k-step][row tile][limb][1 KiB]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ntot = a.npg * a.ngroups;
+    const long total = (long)nblk * nchunks;
+    const long u0 = (long)blockIdx.x * total / gridDim.x, u1 = (long)(blockIdx.x + 1) * total / gridDim.x;
+    if (u0 >= u1) return;
+    int rb = (int)(u0 / nchunks), ca = (int)(u0 - (long)rb * nchunks);
+    long u = u0;
+
+    constexpr int ITEMS = TG_NB * KS * 4, PER = (ITEMS + 511) / 512;
+    auto item_src = [&](int blk, int item) -> const uint16_t * { // nullptr: behind the last row (zero limbs)
+        const int row_l = item / (KS * 4), kc16 = item - row_l * (KS * 4);
+        const int n = blk * TG_NB + row_l;
+        if (item >= ITEMS || n >= ntot) return nullptr;
+        int g, i;
+        split(n, g, i);
+        return a.src + (size_t)g * a.src_gstride + (size_t)(a.src_rows ? (int)a.src_rows[i] : i) * a.src_rstride + a.src_koff + kc16 * 16;
+    };
+    auto item_put = [&](int buf, int item, const uint4 &x0, const uint4 &x1) {
+        if (item >= ITEMS) return;
+        const int row_l = item / (KS * 4), kc16 = item - row_l * (KS * 4);
+        uint4 lo, hi;
+        if constexpr (CANON) gm_split16_pk(x0, x1, lo, hi);
+        else gm_split16(x0, x1, lo, hi);
+        uint8_t *d = ldsB + buf * BUF + ((kc16 >> 2) * NBT + (row_l >> 4)) * 2048 + (row_l & 15) * 64 + (((kc16 & 3) ^ limb_swz(row_l & 15)) << 4);
+        *reinterpret_cast<uint4 *>(d) = lo;
+        *reinterpret_cast<uint4 *>(d + 1024) = hi;
+    };
+    { // the first block's rows: every load of a thread in flight before the first conversion
+        uint4 x0[PER], x1[PER];
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const uint16_t *src = item_src(rb, tid + q * 512);
+            x0[q] = make_uint4(0, 0, 0, 0);
+            x1[q] = x0[q];
+            if (src) { x0[q] = *reinterpret_cast<const uint4 *>(src); x1[q] = *reinterpret_cast<const uint4 *>(src + 8); }
+        }
+#pragma unroll
+        for (int q = 0; q < PER; q++) item_put(0, tid + q * 512, x0[q], x1[q]);
+    }
+    const int ART = a.Mpad / 16;
+    const int frag = (lane & 15) * 64 + (((lane >> 4) ^ limb_swz(lane & 15)) << 4);
+    v4i fa[KS][2 * TG_RT];
+    auto load_chunk_ks = [&](int c, int ks, v4i (&dst)[2 * TG_RT]) {
+        const uint8_t *src = a.Afrag + ((size_t)(ks * ART + TG_RT * c) * 2) * 1024 + lane * 16;
+#pragma unroll
+        for (int q = 0; q < 2 * TG_RT; q++) dst[q] = *reinterpret_cast<const v4i *>(src + q * 1024);
+    };
+    {
+        const int c_first = ca + w < nchunks ? ca + w : 0; // (a wave without a chunk in the first block loads a harmless one)
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) load_chunk_ks(c_first, ks, fa[ks]);
+    }
+    __syncthreads();
+    const v4i zero4 = {0, 0, 0, 0};
+    const int grp = lane >> 4;
+    int buf = 0;
+    while (u < u1) {
+        const int cb = (long)(nchunks - ca) <= u1 - u ? nchunks : ca + (int)(u1 - u); // this block's chunks [ca, cb)
+        const bool have_next = u + (cb - ca) < u1;
+        const uint8_t *lds_cur = ldsB + buf * BUF;
+        // output rows of this lane's NBT columns (n = n0 + 16 j + (lane & 15))
+        uint16_t *crow[NBT];
+#pragma unroll
+        for (int j = 0; j < NBT; j++) {
+            const int n = rb * TG_NB + j * 16 + (lane & 15);
+            crow[j] = nullptr;
+            if (n < ntot) {
+                int g, i;
+                split(n, g, i);
+                crow[j] = a.C + (size_t)g * a.c_gstride + (size_t)(a.c_rows ? (int)a.c_rows[i] : i) * a.c_rstride + a.c_off + (lane >> 4) * 4;
+            }
+        }
+        auto store_pair = [&](int j, int c, uint2 pj, uint2 pk) {
+            if (wide_stores) {
+                const auto sx = __builtin_amdgcn_permlane16_swap(pj.x, pk.x, false, false);
+                const auto sy = __builtin_amdgcn_permlane16_swap(pj.y, pk.y, false, false);
+                uint16_t *p = (grp & 1) ? (crow[j + 1] ? crow[j + 1] - 4 : nullptr) : crow[j];
+                if (p) *reinterpret_cast<uint4 *>(p + c * TG_CHUNK) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            } else {
+                if (crow[j]) *reinterpret_cast<uint2 *>(crow[j] + c * TG_CHUNK) = pj;
+                if (crow[j + 1]) *reinterpret_cast<uint2 *>(crow[j + 1] + c * TG_CHUNK) = pk;
+            }
+        };
+        auto store_one = [&](int j, int c, uint2 pj) {
+            if (crow[j]) *reinterpret_cast<uint2 *>(crow[j] + c * TG_CHUNK) = pj;
+        };
+        v4i fb[2][2 * NBT], fb0[2 * NBT];
+        auto load_b = [&](int ks, v4i (&dst)[2 * NBT]) {
+            const uint8_t *lb = lds_cur + ks * NBT * 2048 + frag;
+#pragma unroll
+            for (int j = 0; j < NBT; j++) {
+                dst[2 * j] = *reinterpret_cast<const v4i *>(lb + j * 2048);
+                dst[2 * j + 1] = *reinterpret_cast<const v4i *>(lb + j * 2048 + 1024);
+            }
+        };
+        int it = 0; // items of the NEXT block's rows this thread has fetched, converted and written so far
+        const int c_first = ca + w;
+        const int nmy = c_first < cb ? (cb - c_first + TG_WAVES - 1) / TG_WAVES : 0;
+        if (nmy > 0) load_b(0, fb0);
+        for (int ci = 0; ci < nmy; ci++) {
+            const int c = c_first + ci * TG_WAVES;
+            // the chunk to prefetch: this wave's next one in this block, else its first one of the next block (which starts at chunk
+            // 0), else the current one again (harmless)
+            const int cn = ci + 1 < nmy ? c + TG_WAVES : (have_next && w < nchunks ? w : c);
+            uint4 nx0 = make_uint4(0, 0, 0, 0), nx1 = nx0;
+            const bool fetch = have_next && it < PER;
+            if (fetch) {
+                const uint16_t *src = item_src(rb + 1, tid + it * 512);
+                if (src) { nx0 = *reinterpret_cast<const uint4 *>(src); nx1 = *reinterpret_cast<const uint4 *>(src + 8); }
+            }
+            v4i s0[NBT], s1[NBT], s2[NBT];
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                v4i(&bc)[2 * NBT] = ks == 0 ? fb0 : fb[ks & 1];
+                v4i(&bn)[2 * NBT] = ks + 1 == KS ? fb0 : fb[(ks & 1) ^ 1];
+                load_b(ks + 1 < KS ? ks + 1 : 0, bn);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NBT; j++) s0[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][0], bc[2 * j], ks == 0 ? zero4 : s0[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NBT; j++) s1[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][0], bc[2 * j + 1], ks == 0 ? zero4 : s1[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NBT; j++) s1[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][1], bc[2 * j], s1[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NBT; j++) s2[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][1], bc[2 * j + 1], ks == 0 ? zero4 : s2[j], 0, 0, 0);
+                load_chunk_ks(cn, ks, fa[ks]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            uint2 pk[NBT];
+#pragma unroll
+            for (int j = 0; j < NBT; j++) {
+                uint32_t v[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = gf_reduce_limbs(s0[j][r], s1[j][r], s2[j][r]);
+                pk[j] = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+                if (j & 1) store_pair(j - 1, c, pk[j - 1], pk[j]);
+                else if (j == NBT - 1) store_one(j, c, pk[j]);
+            }
+            if (fetch) { item_put(buf ^ 1, tid + it * 512, nx0, nx1); it++; }
+        }
+        if (have_next) {
+            for (; it < PER; it++) { // a wave with fewer chunk iterations than items (a short first block): the rest here
+                const uint16_t *src = item_src(rb + 1, tid + it * 512);
+                uint4 nx0 = make_uint4(0, 0, 0, 0), nx1 = nx0;
+                if (src) { nx0 = *reinterpret_cast<const uint4 *>(src); nx1 = *reinterpret_cast<const uint4 *>(src + 8); }
+                item_put(buf ^ 1, tid + it * 512, nx0, nx1);
+            }
+            if (nmy == 0 && w < nchunks) { // this wave sat the block out: its table fragments are those of the clamped chunk, load the next block's
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) load_chunk_ks(w, ks, fa[ks]);
+            }
+        }
+        u += cb - ca;
+        rb++;
+        ca = 0;
+        buf ^= 1;
+        lds_barrier(); // everybody has written the next block's rows and finished reading this block's
+    }
+}
+
 // ---- K3 (prover) on the matrix cores: out_j[x] = sum_k Coef[j][k] * in_k[x] as the same GEMM -----
 // "A" operand: the 77 f (or NTT f) rows of one proof transposed: limb-matrix row = evaluation point x,
 // k = row index (padded to 128).  Loads are coalesced along x.
@@ -1533,6 +1718,169 @@ __global__ __launch_bounds__(256) void k_lincomb_fused(const uint16_t *P, size_t
     }
 }
 
+// ---- K3 (prover), streaming form (round 5; default).  Same product, same operand tiles, same epilogue as k_lincomb_fused, but a
+// workgroup is PERSISTENT over a run of consecutive (group, 128-point block) units of the launch (the flattened list is dealt evenly
+// over two workgroups per CU: 7 or 8 blocks each at 138 proofs):
+//   * the coefficient tiles of a group are copied to LDS once per run of that group's blocks, not once per block (k_lincomb_fused:
+//     every one of a group's 14 blocks re-read 32 KiB from L2: 124 MB of L2 -> LDS per launch for 62 MB of input), and only the five
+//     16-column tiles that J <= 80 needs (20 KiB);
+//   * the NEXT block's 77 x 128 input values are already in flight (20 dwords per thread, issued right after the barrier that
+//     publishes this block's operand tiles) while the matrix cores and the epilogue work on this block, so a workgroup never
+//     sits out a load latency with nothing else to do; the barriers order LDS traffic only (lds_barrier: __syncthreads would wait
+//     for the prefetch and for the epilogue's stores);
+//   * the u16 -> int8-limb conversion works on BOTH halves of a loaded dword at once with packed 16-bit arithmetic (seven packed
+//     instructions and a byte-permute per value pair and limb instead of ~12 scalar ones per value): u = v + 1664 mod q by one
+//     unsigned minimum, w = u - 1632 = centred value + 32, low limb = (w & 63) - 32, high limb = w >> 6;
+//   * a wave owns 32 points (one MFMA row-tile pair) x all five column tiles: 80 MFMAs per block on every wave (the one-shot kernel's
+//     second 64-column half kept two of the four waves idle and computed a column tile nobody stores).
+// The k-step 1 tiles hold rows 64 .. M-1 in their first 16-byte chunk only; the other three chunks are zeroed once.
+constexpr int LS_JT = 5;                       // 16-column tiles of the coefficient operand that hold j < J <= 80
+constexpr int LS_A_BYTES = 2 * 8 * 2048;       // 2 k-steps x 8 point tiles x (2 limbs x 1 KiB)
+constexpr int LS_B_BYTES = 2 * LS_JT * 2048;   // 2 k-steps x 5 column tiles
+__global__ __launch_bounds__(256, 2) void k_lincomb_stream(const uint16_t *P, size_t proof_stride, int row_f, int row_tf, int M,
+                                                           const uint8_t *__restrict__ coef, int BRT, uint16_t *C,
+                                                           const int16_t *__restrict__ lin_rows, int J, int K, int row_s, int row_e,
+                                                           int row_sr, int row_er, int ngroups)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LS_A_BYTES + LS_B_BYTES];
+    uint8_t *ldsB = lds + LS_A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int MB = (NPTS + 127) / 128;
+    const int total = ngroups * MB;
+    const int fb0 = (int)(((long)blockIdx.x * total) / gridDim.x), fb1 = (int)(((long)(blockIdx.x + 1) * total) / gridDim.x);
+    if (fb0 >= fb1) return;
+    // this thread's part of a block: dwords (two points) of rows 16 c4 .. 16 c4 + 15 at point pair pp (k-step 0), and of rows
+    // 64 + 4 c4 .. + 3 (k-step 1: the M - 64 <= 15 rows of chunk 4, a quarter of the chunk per thread)
+    const int pp = tid & 63, c4 = tid >> 6, xl = pp * 2;
+    uint32_t raw[20];
+    auto gload = [&](int fb) {
+        const int g = fb / MB, m0 = (fb - g * MB) * 128;
+        // No predicates: a point pair behind the row's last point (only in a group's last block) reads the row's first pair instead,
+        // and rows M .. 79 of chunk 4 are whatever rows follow the f rows in the row matrix (always inside the proof's block: f and
+        // NTT f sit in its first quarter).  Neither reaches an output: MFMA rows are independent and those points are never
+        // stored; the coefficient columns k >= M are zero (k_coef_limbs).
+        const uint16_t *src = P + (size_t)(g >> 1) * proof_stride + (size_t)((g & 1) ? row_tf : row_f) * RS + (m0 + xl < NPTS ? m0 + xl : 0);
+#pragma unroll
+        for (int q = 0; q < 16; q++) raw[q] = *reinterpret_cast<const uint32_t *>(src + (size_t)(c4 * 16 + q) * RS);
+#pragma unroll
+        for (int q = 0; q < 4; q++) raw[16 + q] = *reinterpret_cast<const uint32_t *>(src + (size_t)(64 + c4 * 4 + q) * RS);
+    };
+    // LDS position of point x of the block: MFMA row tile 2 (x >> 5) + ((x >> 2) & 1), row 4 ((x >> 3) & 3) + (x & 3) -- an output lane
+    // (row group lane >> 4) then holds eight CONSECUTIVE points across the two tiles of a pair: one 16-byte store per output row
+    int a_off[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; pt++) {
+        const int x = xl + pt, xt = (x >> 5) * 2 + ((x >> 2) & 1), xr = ((x >> 3) & 3) * 4 + (x & 3);
+        a_off[pt] = xt * 2048 + xr * 64;
+    }
+    auto stage = [&]() { // raw -> limb tiles of the A operand
+        uint32_t lo[20], hi[20];
+#pragma unroll
+        for (int q = 0; q < 20; q++) limb_split_pk(raw[q], lo[q], hi[q]);
+        uint32_t l0[4], l1[4], h0[4], h1[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t rl[4] = {lo[4 * d], lo[4 * d + 1], lo[4 * d + 2], lo[4 * d + 3]}, rh[4] = {hi[4 * d], hi[4 * d + 1], hi[4 * d + 2], hi[4 * d + 3]};
+            limb_pack4(rl, l0[d], l1[d]);
+            limb_pack4(rh, h0[d], h1[d]);
+        }
+        uint32_t e0, e1, f0, f1;
+        {
+            const uint32_t rl[4] = {lo[16], lo[17], lo[18], lo[19]}, rh[4] = {hi[16], hi[17], hi[18], hi[19]};
+            limb_pack4(rl, e0, e1);
+            limb_pack4(rh, f0, f1);
+        }
+#pragma unroll
+        for (int pt = 0; pt < 2; pt++) {
+            const int xr = (a_off[pt] >> 6) & 15;
+            uint8_t *d0 = lds + a_off[pt] + ((c4 ^ limb_swz(xr)) << 4);                          // k-step 0, chunk c4
+            *reinterpret_cast<uint4 *>(d0) = pt ? make_uint4(l1[0], l1[1], l1[2], l1[3]) : make_uint4(l0[0], l0[1], l0[2], l0[3]);
+            *reinterpret_cast<uint4 *>(d0 + 1024) = pt ? make_uint4(h1[0], h1[1], h1[2], h1[3]) : make_uint4(h0[0], h0[1], h0[2], h0[3]);
+            uint8_t *d1 = lds + 8 * 2048 + a_off[pt] + ((0 ^ limb_swz(xr)) << 4) + c4 * 4;      // k-step 1, chunk 0, bytes 4 c4 ..
+            *reinterpret_cast<uint32_t *>(d1) = pt ? e1 : e0;
+            *reinterpret_cast<uint32_t *>(d1 + 1024) = pt ? f1 : f0;
+        }
+    };
+    gload(fb0);
+    // k-step 1, chunks 1..3 (rows 80 .. 127 of the padded k dimension): zero, once
+    for (int i = tid; i < 8 * 2 * 16 * 3; i += 256) { // (tile, limb, row, chunk 1..3)
+        const int ch = 1 + i % 3, r = (i / 3) & 15, tl = i / 48; // tl = tile * 2 + limb
+        *reinterpret_cast<uint4 *>(lds + 8 * 2048 + tl * 1024 + r * 64 + ((ch ^ limb_swz(r)) << 4)) = make_uint4(0, 0, 0, 0);
+    }
+    const int frag = (lane & 15) * 64 + (((lane >> 4) ^ limb_swz(lane & 15)) << 4);
+    int g_cur = -1;
+    int lrow[LS_JT]; // output rows of this lane's five columns (looked up once per group: a lookup inside the epilogue would make it wait for the prefetch)
+    for (int fb = fb0; fb < fb1; fb++) {
+        const int g = fb / MB, m0 = (fb - g * MB) * 128, b = g >> 1, which = g & 1;
+        if (g != g_cur) { // this group's coefficient tiles (the previous group's readers passed the barrier at the end of its last block)
+            g_cur = g;
+#pragma unroll
+            for (int j = 0; j < LS_JT; j++) lrow[j] = j * 16 + (lane & 15) < J ? (int)lin_rows[which * 128 + j * 16 + (lane & 15)] : 0;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(coef + ((size_t)ks * BRT + (size_t)g * 8) * 2048);
+                uint4 *dst = reinterpret_cast<uint4 *>(ldsB + ks * LS_JT * 2048);
+                for (int i = tid; i < LS_JT * 128; i += 256) dst[i] = src[i];
+            }
+        }
+        stage();
+        lds_barrier();
+        if (fb + 1 < fb1) gload(fb + 1);
+        __builtin_amdgcn_sched_barrier(0); // the prefetch goes out before the arithmetic below, not behind it
+        v4i s0[2][LS_JT], s1[2][LS_JT], s2[2][LS_JT];
+        const v4i zero4 = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const uint8_t *la = lds + (ks * 8 + w * 2) * 2048 + frag;
+            const uint8_t *lb = ldsB + (ks * LS_JT) * 2048 + frag;
+            v4i a0[2], a1[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                a0[i] = *reinterpret_cast<const v4i *>(la + i * 2048);
+                a1[i] = *reinterpret_cast<const v4i *>(la + i * 2048 + 1024);
+            }
+#pragma unroll
+            for (int j = 0; j < LS_JT; j++) {
+                const v4i b0 = *reinterpret_cast<const v4i *>(lb + j * 2048), b1 = *reinterpret_cast<const v4i *>(lb + j * 2048 + 1024);
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    s0[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[i], b0, ks == 0 ? zero4 : s0[i][j], 0, 0, 0);
+                    s1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[i], b1, ks == 0 ? zero4 : s1[i][j], 0, 0, 0);
+                    s2[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[i], b1, ks == 0 ? zero4 : s2[i][j], 0, 0, 0);
+                    s1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[i], b0, s1[i][j], 0, 0, 0);
+                }
+            }
+        }
+        uint16_t *Cb = C + (size_t)b * proof_stride;
+        const int m = m0 + w * 32 + (lane >> 4) * 8; // eight consecutive points per lane (see a_off)
+        if (m < NPTS) { // the last live group (1704..1711) ends two points inside the row padding (RS = 1728)
+#pragma unroll
+            for (int j = 0; j < LS_JT; j++) {
+                const int jo = j * 16 + (lane & 15);
+                if (jo >= J) continue;
+                uint16_t *crow = Cb + (size_t)lrow[j] * RS;
+                uint32_t v[8];
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[4 * h + r] = gf_reduce_limbs(s0[h][j][r], s1[h][j][r], s2[h][j][r]);
+                *reinterpret_cast<uint4 *>(crow + m) = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+                if (j == LS_JT - 1 && which == 0 && jo >= NCHK) { // r rows (columns 70 .. 69 + 2K, all in the last tile): s + r_i, e + r_{K+i} on the spot (mlwe_prover.cpp:222-245)
+                    const int idx = jo - NCHK;
+                    const int src_row = idx < K ? row_s + idx : row_e + (idx - K), dst_row = idx < K ? row_sr + idx : row_er + (idx - K);
+                    const uint4 sv = *reinterpret_cast<const uint4 *>(Cb + (size_t)src_row * RS + m);
+                    const uint32_t sw[4] = {sv.x, sv.y, sv.z, sv.w};
+                    uint32_t ow[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) ow[q] = gf_add(sw[q] & 0xFFFFu, v[2 * q]) | (gf_add(sw[q] >> 16, v[2 * q + 1]) << 16);
+                    *reinterpret_cast<uint4 *>(Cb + (size_t)dst_row * RS + m) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                }
+            }
+        }
+        lds_barrier(); // every wave has read this block's tiles (and this group's coefficients) before the next block overwrites them
+    }
+}
+
 // "B" operand: Coef[j][k] = alpha_j^k for the 70 check rows; for the r rows (j >= 70) the constant term is
 // f_71 instead of f_0 (mlwe_prover.cpp:187,196): Coef[j][0] = 0 and Coef[j][71] = alpha_j^71 + 1.
 // Written for both groups (f and NTT f) of the proof.  One thread per (j, 16-k chunk).
@@ -1650,8 +1998,8 @@ __global__ __launch_bounds__(256) void k_lincomb(LincombArgs a)
         if (Ob) {
             Ob[(size_t)row * OS] = (uint16_t)out;
             // recon_secrets_ddeg (mlwe_verifier.cpp:106-107) reads the beta / gamma shares of parties 0..406 from the merged row
-            // (through gf3329_mul: the product's limb conversion folds a raw value)
-            if (j < NCHK && col < NSEC + XLEN) Pb[(size_t)row * RS + col] = (uint16_t)out;
+            // (through gf3329_mul, which reduces: the row matrix gets the folded value, the opened matrix keeps the raw one)
+            if (j < NCHK && col < NSEC + XLEN) Pb[(size_t)row * RS + col] = (uint16_t)gf_fold(out);
         } else {
             Pb[(size_t)row * RS + col] = (uint16_t)out;
         }
@@ -2125,6 +2473,19 @@ hipError_t launch_table_gemm(const GemmArgs &a, uint16_t *sink, hipStream_t st)
     // eight consecutive outputs per lane and 16-byte stores where the output rows allow it (KOSK_TG_STORE16=0: 8-byte stores only)
     static const bool store16 = !(getenv("KOSK_TG_STORE16") && atoi(getenv("KOSK_TG_STORE16")) == 0);
     const int ws = store16 && a.c_off % 8 == 0 && a.c_rstride % 8 == 0 && a.c_gstride % 8 == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0;
+    // persistent workgroups (k_table_gemm_p): one per CU, the (row block, table chunk) units dealt evenly; KOSK_TG_PERSIST=0 (per process): the
+    // one-block-per-workgroup kernel of rounds 2-4
+    static const bool persist = !(getenv("KOSK_TG_PERSIST") && atoi(getenv("KOSK_TG_PERSIST")) == 0);
+    if (persist && a.KS == 7 && !wide) {
+        const long total = (long)(nblk3) * nchunks;
+        // at least eight chunks per workgroup where the product is that large (a chunk per wave), never more workgroups than CUs
+        long nwg = total / 8 < ncu ? total / 8 : ncu;
+        if (nwg < 1) nwg = 1;
+        const uint32_t magic = ntt_npg_magic(a.npg);
+        if (a.src_canonical) hipLaunchKernelGGL((k_table_gemm_p<7, 3, true>), dim3((unsigned)nwg), dim3(512), 0, st, a, nchunks, nblk3, ws, magic);
+        else hipLaunchKernelGGL((k_table_gemm_p<7, 3, false>), dim3((unsigned)nwg), dim3(512), 0, st, a, nchunks, nblk3, ws, magic);
+        return hipGetLastError();
+    }
     const dim3 grid((unsigned)((nblk * msplit + 7) / 8 * 8));
     if (a.KS == 7 && wide) hipLaunchKernelGGL((k_table_gemm<7, 1, 4>), grid, dim3(512), 0, st, a, nchunks, cpb, nblk, msplit, ws);
     else if (a.KS == 7) hipLaunchKernelGGL((k_table_gemm<7, 1, 3>), grid, dim3(512), 0, st, a, nchunks, cpb, nblk, msplit, ws);
@@ -2149,8 +2510,21 @@ hipError_t launch_cols_to_limbs(const uint16_t *P, size_t proof_stride, int row_
     return hipGetLastError();
 }
 hipError_t launch_lincomb_fused(const uint16_t *P, size_t proof_stride, const RowMap &rm, const uint8_t *coef, uint16_t *C,
-                                const int16_t *lin_rows, int J, int nproofs, hipStream_t st)
+                                const int16_t *lin_rows, int J, int nproofs, hipStream_t st, int variant)
 {
+    if (variant != 2 && J <= 16 * LS_JT && rm.M > 64 && rm.M <= 80) {
+        // the streaming kernel: the (group, point block) units dealt evenly over two persistent workgroups per CU
+        static const int ncu = [] {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+            return cus;
+        }();
+        const int total = (NPTS + 127) / 128 * 2 * nproofs;
+        const int nwg = total < 2 * ncu ? total : 2 * ncu;
+        hipLaunchKernelGGL(k_lincomb_stream, dim3(nwg), dim3(256), 0, st, P, proof_stride, rm.f, rm.tf, rm.M, coef, 2 * nproofs * 8, C, lin_rows, J,
+                           rm.K, rm.s, rm.e, rm.sr, rm.er, 2 * nproofs);
+        return hipGetLastError();
+    }
     const int nwg = ((NPTS + 127) / 128 * 2 * nproofs + 7) / 8 * 8;
     hipLaunchKernelGGL(k_lincomb_fused, dim3(nwg), dim3(256), 0, st, P, proof_stride, rm.f, rm.tf, rm.M, coef,
                        2 * nproofs * 8, C, lin_rows, J, rm.K, rm.s, rm.e, rm.sr, rm.er, 2 * nproofs);

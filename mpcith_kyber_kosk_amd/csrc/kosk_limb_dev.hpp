@@ -38,6 +38,49 @@ __device__ __forceinline__ void gm_split16(const uint4 &x0, const uint4 &x1, uin
     hi = make_uint4(h[0], h[1], h[2], h[3]);
 }
 
+
+// ---- packed 16-bit conversion of CANONICAL values (< q) to limbs: both halves of a dword at once -------------------------
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef short ss2 __attribute__((ext_vector_type(2)));
+
+// two canonical values (the halves of v) -> their low limbs (bytes 0 and 2 of lo) and high limbs (bytes 0 and 2 of hi)
+__device__ __forceinline__ void limb_split_pk(uint32_t v, uint32_t &lo, uint32_t &hi)
+{
+    const us2 x = __builtin_bit_cast(us2, v);
+    const us2 u = x + (us2){1664, 1664}, t = x - (us2){1665, 1665};          // t = u - q (wraps above u when u < q)
+    const us2 m = __builtin_elementwise_min(u, t);                             // (v + 1664) mod q
+    const ss2 w = __builtin_bit_cast(ss2, m) - (ss2){1632, 1632};              // centred value + 32, in [-1632, 1696]
+    hi = __builtin_bit_cast(uint32_t, w >> (ss2){6, 6});                       // floor(w / 64) = c1
+    lo = __builtin_bit_cast(uint32_t, __builtin_bit_cast(ss2, __builtin_bit_cast(uint32_t, w) & 0x003F003Fu) - (ss2){32, 32}); // c0
+}
+// rows q .. q+3 of one limb, two points: r[i] holds the limb of point 0 in byte 0 and of point 1 in byte 2
+__device__ __forceinline__ void limb_pack4(const uint32_t (&r)[4], uint32_t &p0, uint32_t &p1)
+{
+    const uint32_t t01 = __builtin_amdgcn_perm(r[1], r[0], 0x06020400u), t23 = __builtin_amdgcn_perm(r[3], r[2], 0x06020400u);
+    p0 = __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+    p1 = __builtin_amdgcn_perm(t23, t01, 0x07060302u);
+}
+
+
+// 16 canonical u16 (two uint4, consecutive k of one row) -> 16 low-limb bytes + 16 high-limb bytes, as gm_split16 but without its
+// fold of values >= q (callers guarantee canonical input, or input whose products are discarded): 7 packed instructions per value
+// pair and one byte-permute per output dword and limb, about a third of gm_split16's instruction count
+__device__ __forceinline__ void gm_split16_pk(const uint4 &x0, const uint4 &x1, uint4 &lo, uint4 &hi)
+{
+    const uint32_t w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    uint32_t l[8], h[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) limb_split_pk(w[q], l[q], h[q]); // limbs of values 2q (byte 0) and 2q + 1 (byte 2)
+    uint32_t lo4[4], hi4[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        lo4[d] = __builtin_amdgcn_perm(l[2 * d + 1], l[2 * d], 0x06040200u);
+        hi4[d] = __builtin_amdgcn_perm(h[2 * d + 1], h[2 * d], 0x06040200u);
+    }
+    lo = make_uint4(lo4[0], lo4[1], lo4[2], lo4[3]);
+    hi = make_uint4(hi4[0], hi4[1], hi4[2], hi4[3]);
+}
+
 // x mod q for ANY 32-bit x.  t = trunc(float(x) * c), c = (1 - 2^-22) / q rounded to fp32, is floor(x / q) or one less for every
 // x < 2^32 (checked exhaustively on the host: tools/float_reduce_check.c, largest x - t q = 4 185 < 2 q), so one unsigned minimum
 // finishes (r - q wraps above r when r < q).  Six full-rate vector instructions (convert, multiply, convert, 24-bit multiply-add,

@@ -45,8 +45,7 @@ __global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const F
             uint16_t *Pc = v.P + (size_t)b * v.proof_stride + NSEC + v.opened[(size_t)b * v.sel_stride + t];
             uint16_t *Oc = v.O + (size_t)b * v.o_stride + t; // the same values for the view hash (coalesced over t)
             // raw operands: gf3329_mul reduces the product of any two u16 (:475-483), gf3329_sub does not (:487-492) -- the raw
-            // difference enters the view hash (:624-629) and, through gf3329_mul again, recon_secrets_2ddeg (the GEMM's limb
-            // conversion folds it)
+            // difference enters the view hash (:624-629) and, through gf3329_mul again (folded), recon_secrets_2ddeg
             auto rd = [&](uint32_t off, int idx) { return (uint32_t)reinterpret_cast<const uint16_t *>(img + off)[idx]; };
             for (int who = 0; who < 2; who++)
                 for (int i = 0; i < rm.K; i++) {
@@ -56,7 +55,7 @@ __global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const F
                         const uint32_t z2 = gf_mul(prev, rd(osub, (t * rm.K + i) * rm.E + j + 1)); // < 2^32 for any two u16
                         const uint32_t zd = rd(oz, (t * rm.K + i) * rm.Z + j);
                         const uint16_t uv = (uint16_t)ref_sub_u16(z2, zd);
-                        Pc[(size_t)(who ? rm.ue(i, j) : rm.us(i, j)) * RS] = uv; // recon_secrets_2ddeg reads the merged row
+                        Pc[(size_t)(who ? rm.ue(i, j) : rm.us(i, j)) * RS] = (uint16_t)gf_fold(uv); // recon_secrets_2ddeg reads the merged row, through gf3329_mul: folded
                         Oc[(size_t)(who ? rm.ue(i, j) : rm.us(i, j)) * OS] = uv;
                         prev = zd;
                     }

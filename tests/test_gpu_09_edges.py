@@ -140,7 +140,8 @@ def test_split_commitment_launches_give_identical_proofs(oracle, torch_cuda, mon
 KNOBS = {  # knob -> (path counter that must be > 0 on the knob's handle, counter that must stay 0 there)
     "KOSK_TABLE_GEMM=0": ("limb_gemm", "table_gemm"),
     "KOSK_HASH_DMA=0": ("hash_plain", "hash_dma"),
-    "KOSK_LINCOMB_FUSED=0": ("limb_gemm", None),
+    "KOSK_LINCOMB_FUSED=0": ("limb_gemm", "lincomb_stream"),
+    "KOSK_LINCOMB_FUSED=2": ("lincomb_oneshot", "lincomb_stream"),
     "KOSK_NTT_FP32=1": ("ntt_fp32", "ntt_int"),
     "KOSK_BLOCKING_SYNC=1": (None, None),
     "KOSK_GRAPHS=1": ("graph_replay", None),
@@ -164,6 +165,7 @@ def test_documented_knobs_do_not_change_results(knob, oracle, torch_cuda, monkey
         ref = base.verifiable_keygen(tapes)
         pc0 = base.path_counts()
         assert pc0["table_gemm"] > 0 and pc0["hash_dma"] > 0 and pc0["ntt_int"] > 0 and pc0["graph_replay"] == 0 and pc0["hash_plain"] == 0
+        assert pc0["lincomb_stream"] > 0 and pc0["lincomb_oneshot"] == 0  # the default beta / gamma kernel
         assert pc0["small_copy_kernel"] > 0  # the default: challenge vectors, opened lists, key records and fail masks move by kernel
         monkeypatch.setenv(name, val)
         ctx = api.Kosk(kyber_k=k, max_batch=n)
