@@ -52,7 +52,7 @@ CONFIGS = {  # 1-based config number -> (kyber_k, proofs per GPU per step, defau
     # a cohort of three handles with one pipeline run (KOSK_COMBINE=3, include/kosk_mi355x.h), i.e. three merged runs in flight
     2: dict(k=2, batch=46, slots=9, threads=6, combine=3, what="Kyber-512 (KYBER_K=2), 46 proofs = 66 884 party lanes per GPU per step"),
     3: dict(k=3, batch=46, slots=9, threads=6, combine=3, what="Kyber-768 (KYBER_K=3), 46 proofs = 66 884 party lanes per GPU per step"),
-    4: dict(k=4, batch=91, slots=4, threads=6, what="Kyber-1024 (KYBER_K=4), 91 proofs = 132 314 party lanes per GPU per step "
+    4: dict(k=4, batch=91, slots=9, threads=6, combine=3, what="Kyber-1024 (KYBER_K=4), 91 proofs = 132 314 party lanes per GPU per step "
                                                     "(2^20 lanes over 8 GPUs, proof-aligned), digest tables all-gathered after each commitment round"),
     5: dict(k=3, batch=512, slots=4, threads=8, what="Kyber-768 (KYBER_K=3), 512 verifiable keygens per GPU per step (4096 over 8 GPUs, throughput mode)"),
 }

@@ -145,7 +145,8 @@ int kosk_stage_verifier_inputs_compact(kosk_ctx *ctx, int n, const uint8_t *in, 
  * default 0: the runtime's hipMemcpyAsync, which measured faster for the pipeline as a whole), 13 small copies between HBM and the
  * library's own page-locked buffers (challenge vectors, opened lists, key records, fail masks) made by a copy kernel instead of
  * hipMemcpyAsync (default; KOSK_SMALL_COPY_KERNEL=0 turns it off), 14 / 15 prover beta / gamma / r launches of the one-shot kernel of rounds
- * 2-4 (KOSK_LINCOMB_FUSED=2) / of the streaming kernel (default). */
+ * 2-4 (KOSK_LINCOMB_FUSED=2) / of the streaming kernel (default), 16 / 17 proof images put together by the per-field kernel of rounds 1-4
+ * (KOSK_ASSEMBLE_GROUPS=0) / by the grouped kernel (default: opened-party records from dense window gathers). */
 int kosk_path_count(const kosk_ctx *ctx, int id, long *count);
 /* host worker threads per sub-context (<= 8, <= CPUs of the process / KOSK_STREAMS; all created by kosk_create) */
 int kosk_host_threads(const kosk_ctx *ctx);
@@ -181,8 +182,8 @@ int kosk_profile_read_units(const kosk_ctx *ctx, int id, double *total_ms, long 
  * one or two calls (a request whose kind is in the minority of its window is held back once, so that callers alternating
  * keygen / verify in opposite phase meet).  The callers of a merged run sleep while it executes and are woken shortly before its
  * end (they then spin at most KOSK_COMBINE_PREWAKE_US, default 400, for the return).  Calls that draw randomness through
- * the callback (tapes == NULL), handles with a round hook, and every other entry point run unmerged on the member's own
- * block.  All handles of a cohort must be destroyed before the process ends (the last one frees the workspace).
+ * the callback (tapes == NULL) and every other entry point run unmerged on the member's own block.  A member's round hook
+ * (kosk_set_round_hook) fires from a merged run as well, with that member's block of the table, on the thread of the run's leader.  All handles of a cohort must be destroyed before the process ends (the last one frees the workspace).
  * kosk_combine_stats: resident calls of THIS handle that went through the combiner, and the sum over those calls of the
  * members their run served (members / calls = mean callers per launch; both 0 for a handle outside a cohort). */
 int kosk_combine_stats(const kosk_ctx *ctx, long *calls, long *members);
@@ -238,9 +239,10 @@ int kosk_resident_proofs(kosk_ctx *ctx, void **d_proofs, size_t *stride);
  * (:397-444, input of :445-449); `stride` = bytes per proof (1454 * 32).  This is what a multi-GPU job all-gathers
  * (RCCL) after each commitment round (BASELINE.json configs[3]).  Needs KOSK_STREAMS=1. */
 int kosk_resident_digests(kosk_ctx *ctx, int round, void **d_digests, size_t *stride);
-/* Called on the calling thread as soon as a round's table is complete in HBM (role 0 prover / 1 verifier; round as
- * above; bytes = n * 1454 * 32); the context's stream may already be running the kernels of the next segment, none of
- * which writes the tables.  The place to start that all-gather so that it overlaps the host's Fiat-Shamir hashing.
+/* Called on the calling thread -- for a call served by a merged run of a cohort (KOSK_COMBINE): on the thread of the caller that
+ * leads the run, while this handle's own caller sleeps inside its call -- as soon as a round's table is complete in HBM (role 0
+ * prover / 1 verifier; round as above; bytes = n * 1454 * 32; d_digests = this handle's own block); the context's stream may
+ * already be running the kernels of the next segment, none of which writes the tables.  The place to start that all-gather so that it overlaps the host's Fiat-Shamir hashing.
  * fn == NULL removes the hook. */
 typedef void (*kosk_round_fn)(void *user, int role, int round, const void *d_digests, size_t bytes);
 int kosk_set_round_hook(kosk_ctx *ctx, kosk_round_fn fn, void *user);

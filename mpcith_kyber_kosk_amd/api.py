@@ -386,7 +386,7 @@ class Kosk:
         return a.value, b.value
 
     PATH_IDS = ["hash_dma", "hash_plain", "hash_primer", "table_gemm", "limb_gemm", "copy_direct", "copy_staged", "graph_replay",
-                "ntt_fp32", "ntt_int", "digest_direct", "digest_copy", "copy_kernel", "small_copy_kernel", "lincomb_oneshot", "lincomb_stream"]
+                "ntt_fp32", "ntt_int", "digest_direct", "digest_copy", "copy_kernel", "small_copy_kernel", "lincomb_oneshot", "lincomb_stream", "assemble_fields", "assemble_groups"]
 
     def path_counts(self):
         """{name: launches / copies} of the alternative kernel and copy paths on this handle since it was created"""

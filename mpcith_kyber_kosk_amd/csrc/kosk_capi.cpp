@@ -462,7 +462,7 @@ static int combined_keygen(kosk_ctx *h, int n, const KeygenCall &call)
         return -1;
     }
     CombineReq r;
-    r.kind = (call.tapes && !h->c->round_hook) ? CK_KEYGEN : CK_ALONE; // the stateful randombytes callback and round hooks are per handle
+    r.kind = call.tapes ? CK_KEYGEN : CK_ALONE; // the stateful randombytes callback is per handle
     r.n = n;
     r.full = n == co.per;
     r.args = const_cast<KeygenCall *>(&call);
@@ -473,7 +473,8 @@ static int combined_keygen(kosk_ctx *h, int n, const KeygenCall &call)
         int total = 0;
         for (int k = 0; k < count; k++) {
             const KeygenCall *a = static_cast<const KeygenCall *>(reqs[k]->args);
-            segs[k] = KeygenIn{a->tapes, a->tape_stride, a->pk, a->sk, reqs[k]->n, k + 1 < count ? &segs[k + 1] : nullptr};
+            const Ctx &mv = *co.member[first + k]->c; // round hooks are per handle: every member's fires with its own block of the tables
+            segs[k] = KeygenIn{a->tapes, a->tape_stride, a->pk, a->sk, reqs[k]->n, k + 1 < count ? &segs[k + 1] : nullptr, mv.round_hook, mv.round_user};
             total += reqs[k]->n;
         }
         NearEnd ne(c, co, first, count);
@@ -507,7 +508,7 @@ static int combined_verify(kosk_ctx *h, int n, const VerifyCall &call)
         return -1;
     }
     CombineReq r;
-    r.kind = h->c->round_hook ? CK_ALONE : (call.pk ? CK_VERIFY_PK_GIVEN : CK_VERIFY_PK_RESIDENT);
+    r.kind = call.pk ? CK_VERIFY_PK_GIVEN : CK_VERIFY_PK_RESIDENT;
     r.n = n;
     r.full = n == co.per;
     r.args = const_cast<VerifyCall *>(&call);
@@ -519,7 +520,8 @@ static int combined_verify(kosk_ctx *h, int n, const VerifyCall &call)
         bool given = false;
         for (int k = 0; k < count; k++) {
             const VerifyCall *a = static_cast<const VerifyCall *>(reqs[k]->args);
-            segs[k] = VerifySeg{reqs[k]->n, a->pk, a->ok, k + 1 < count ? &segs[k + 1] : nullptr};
+            const Ctx &mv = *co.member[first + k]->c;
+            segs[k] = VerifySeg{reqs[k]->n, a->pk, a->ok, k + 1 < count ? &segs[k + 1] : nullptr, mv.round_hook, mv.round_user};
             total += reqs[k]->n;
             given = a->pk != nullptr;
         }

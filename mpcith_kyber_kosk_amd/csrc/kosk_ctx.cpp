@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <thread>
 
 #include "kosk_math.hpp"
@@ -73,7 +74,7 @@ Ctx::~Ctx()
             if (e) (void)hipEventDestroy(e);
         return; // the stream is the arena's
     }
-    void *dev[] = {t_expand.d, t_recon_d.d, t_recon_2d.d, t_expand.dfrag, t_recon_d.dfrag, t_recon_2d.dfrag, d_fresh_rows, d_gemm1_rows, d_gemm2_rows, d_off, d_fields,
+    void *dev[] = {t_expand.d, t_recon_d.d, t_recon_2d.d, t_expand.dfrag, t_recon_d.dfrag, t_recon_2d.dfrag, d_fresh_rows, d_gemm1_rows, d_gemm2_rows, d_off, d_fields, d_asm_groups, d_asm_elems,
                    d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_kg, d_sehat, d_t, d_alpha, d_I, d_pwT, d_limbs, d_linA, d_coef, d_lin_rows,
                    d_gather, d_gather2, d_O, d_w, d_ell, d_sec, d_sec_u1, d_sec_u2, d_fail, d_inv, d_invlimb, d_vfields,
                    d_vrowtab, d_rows_bg, d_rows_isrc, d_rows_idst, d_rows_u, d_fact, d_invfact, d_node_of, d_isort, d_hrange, d_odig};
@@ -191,6 +192,37 @@ hipError_t stream_sync(Ctx &c)
     if (!c.blocking_sync) return hipStreamSynchronize(c.stream);
     const hipError_t e = hipEventRecord(c.ev_sync, c.stream);
     return e != hipSuccess ? e : hipEventSynchronize(c.ev_sync);
+}
+
+hipError_t wait_event(Ctx &c, hipEvent_t ev, int site, int n)
+{
+    if (c.blocking_sync || !c.wait_nap || site < 0 || site >= Ctx::WAIT_SITES) return hipEventSynchronize(ev);
+    if (c.wait_ema_n[site] != n) { c.wait_ema_n[site] = n; c.wait_ema_us[site] = 0; } // another batch size: learn again
+    const double t0 = now_sec();
+    const double ema = c.wait_ema_us[site];
+    bool overslept = false;
+    if (ema > 250.0) {
+        const double keep = ema * 0.3 > 100.0 ? ema * 0.3 : 100.0; // spin through the last 30 % (at least 100 us: the sleep's own wake-up jitter)
+        const double nap_us = ema - keep;
+        struct timespec ts;
+        ts.tv_sec = 0;
+        ts.tv_nsec = (long)(nap_us * 1e3);
+        nanosleep(&ts, nullptr);
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) overslept = true;
+        else if (q != hipErrorNotReady) return q;
+    }
+    const hipError_t e = overslept ? hipSuccess : hipEventSynchronize(ev);
+    const double took = (now_sec() - t0) * 1e6;
+    // an overslept wait says nothing about the phase's real length except that it was shorter than the nap: halve the estimate
+    c.wait_ema_us[site] = overslept ? ema * 0.5 : (ema == 0 ? took : 0.75 * ema + 0.25 * took);
+    return e;
+}
+hipError_t stream_sync_site(Ctx &c, int site, int n)
+{
+    if (c.blocking_sync || !c.wait_nap) return stream_sync(c);
+    const hipError_t e = hipEventRecord(c.ev_sync, c.stream);
+    return e != hipSuccess ? e : wait_event(c, c.ev_sync, site, n);
 }
 
 int gemm_modq(Ctx &c, const uint8_t *A, size_t a_gstride, int Mpad, int M, int KS, const GemmSrc &s, const GemmDst &d,
@@ -342,6 +374,39 @@ static int build_tables(Ctx &c)
     add(F_UE, 1, K * Z, [&](int e) { return rm.ue(e / Z, e % Z); });
     c.nfields = (int)c.h_fields.size();
     c.pplan = make_field_plan(c.h_fields.data(), c.nfields);
+    // groups of the grouped image kernel: fields of one kind packed greedily, in declaration order, into groups of <= 80 rows
+    // (K = 3: unopened {beta}, {gamma}, {t, s+r, e+r, eta x 2, u x 2}; opened {f}, {NTT f}, {s, e, NTT s, NTT e, NTT Ar, NTT As, s - eta, e - eta, z x 2})
+    {
+        std::vector<AsmGroup> groups;
+        std::vector<AsmElem> elems;
+        for (int sel = 1; sel >= 0; sel--) {
+            AsmGroup g{};
+            auto flush = [&]() {
+                if (g.nsub) groups.push_back(g);
+                g = AsmGroup{};
+            };
+            for (int f = 0; f < c.nfields; f++) {
+                const FieldDesc &fd = c.h_fields[f];
+                if (fd.sel != sel) continue;
+                if (g.nsub && (g.nrows + fd.width > 80 || g.nsub == 12)) flush();
+                if (!g.nsub) { g.sel = sel; g.rowtab_off = (int)c.h_rowtab.size(); g.elem_off = (int)elems.size(); }
+                g.sub_off[g.nsub] = fd.off; g.sub_width[g.nsub] = (int16_t)fd.width; g.sub_col[g.nsub] = (int16_t)g.nrows;
+                for (int k = 0; k < fd.width; k++) {
+                    c.h_rowtab.push_back(c.h_rowtab[fd.rowtab_off + k]);
+                    elems.push_back(AsmElem{(int32_t)(fd.off / 2 + k), (int16_t)fd.width, (int16_t)(64 * g.nrows + k)});
+                }
+                g.nrows += fd.width;
+                g.nsub++;
+            }
+            flush();
+        }
+        // a group's row table is read up to 80 entries deep with clamped indices; the element table per lane up to 128
+        if ((int)groups.size() > ASM_MAX_GROUPS) { c.err = "internal: image field groups"; return -1; }
+        for (int i = 0; i < 128; i++) elems.push_back(AsmElem{0, 1, 0});
+        c.n_asm_groups = (int)groups.size();
+        if (upload_vec(c, &c.d_asm_groups, groups)) return -1;
+        if (upload_vec(c, &c.d_asm_elems, elems)) return -1;
+    }
     if (upload_vec(c, &c.d_fields, c.h_fields)) return -1;
     if (upload_vec(c, &c.d_rowtab, c.h_rowtab)) return -1;
     return 0;
@@ -382,6 +447,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     if (const char *e = getenv("KOSK_LINCOMB_FUSED")) c.lincomb_fused = atoi(e) < 0 ? 1 : (atoi(e) > 2 ? 1 : atoi(e));
     if (const char *e = getenv("KOSK_NTT_FP32")) c.ntt_fp32 = atoi(e) != 0;
     if (const char *e = getenv("KOSK_BLOCKING_SYNC")) c.blocking_sync = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_WAIT_NAP")) c.wait_nap = atoi(e) != 0;
     if (const char *e = getenv("KOSK_HASH_SPLIT")) c.hash_split = atoi(e) != 0;
     if (const char *e = getenv("KOSK_HASH_DMA")) c.hash_dma = atoi(e) != 0;
     if (const char *e = getenv("KOSK_HASH_PRIMER")) c.hash_primer = atoi(e) != 0;
@@ -389,6 +455,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     if (const char *e = getenv("KOSK_REGISTER")) c.host_register = atoi(e) != 0;
     if (const char *e = getenv("KOSK_DIGEST_DIRECT")) c.digest_direct = atoi(e) != 0;
     if (const char *e = getenv("KOSK_STRICT_ENCODING")) c.strict_encoding = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_ASSEMBLE_GROUPS")) c.assemble_groups = atoi(e) != 0;
     if (const char *e = getenv("KOSK_SMALL_COPY_KERNEL")) c.small_copy_kernel = atoi(e) != 0;
     if (const char *e = getenv("KOSK_COPY_WAVES")) c.copy_waves = atoi(e) >= 0 ? (atoi(e) > 65535 ? 65535 : atoi(e)) : c.copy_waves;
     if (const char *e = getenv("KOSK_DEBUG_XOF_BLOCKS")) c.xof_max_blocks = atoi(e) > 0 ? atoi(e) : c.xof_max_blocks;
@@ -436,6 +503,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
         HIPCHK(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
         HIPCHK(hipEventCreateWithFlags(&c.ev_kg, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
         if (c.blocking_sync) HIPCHK(hipEventCreateWithFlags(&c.ev_sync, hipEventDisableTiming | hipEventBlockingSync));
+        else if (c.wait_nap) HIPCHK(hipEventCreateWithFlags(&c.ev_sync, hipEventDisableTiming));
         for (auto &pe : c.prof_ev)
             for (auto &e : pe) HIPCHK(hipEventCreate(&e));
         if (build_tables(c)) return -1;
@@ -551,6 +619,7 @@ int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx
         HIPCHK(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
         HIPCHK(hipEventCreateWithFlags(&c.ev_kg, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
         if (c.blocking_sync) HIPCHK(hipEventCreateWithFlags(&c.ev_sync, hipEventDisableTiming | hipEventBlockingSync));
+        else if (c.wait_nap) HIPCHK(hipEventCreateWithFlags(&c.ev_sync, hipEventDisableTiming));
         for (auto &pe : c.prof_ev)
             for (auto &e : pe) HIPCHK(hipEventCreate(&e));
         for (auto &e : c.ev_img) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
@@ -829,9 +898,25 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         keys_done = true;
     }
     c.kg_on_host_pending = false;
-    HIPCHK(hipEventSynchronize(c.ev));
+    HIPCHK(wait_event(c, c.ev, 0, n));
     t1 = now_sec(); c.phase_sec[PH_GPU_COMMIT] = t1 - t0; t0 = t1;
-    if (c.round_hook) c.round_hook(c.round_user, 0, 0, c.d_dig1, (size_t)n * NPARTY * 32);
+    // a round's table is complete in HBM: the hook of every caller of this run with ITS block of the table (a merged run), else the
+    // context's own hook with the whole batch
+    auto fire_hooks = [&](int rnd, const uint8_t *d_table) {
+        bool seg_hooks = false;
+        for (const KeygenIn *s = keygen; s; s = s->next) seg_hooks |= s->hook != nullptr;
+        if (!seg_hooks) {
+            if (c.round_hook) c.round_hook(c.round_user, 0, rnd, d_table, (size_t)n * NPARTY * 32);
+            return;
+        }
+        int first = 0;
+        for (const KeygenIn *s = keygen; s && first < n; s = s->next) {
+            const int cnt = s->count ? s->count : n - first;
+            if (s->hook) s->hook(s->hook_user, 0, rnd, d_table + (size_t)first * NPARTY * 32, (size_t)cnt * NPARTY * 32);
+            first += cnt;
+        }
+    };
+    fire_hooks(0, c.d_dig1);
 
     // ---- Fiat-Shamir round 1 on the host
     if (keygen && !keys_done) finish_keygen_segs(c, n, *keygen);
@@ -893,9 +978,9 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         return 0;
     })) return -1;
 
-    HIPCHK(hipEventSynchronize(c.ev));
+    HIPCHK(wait_event(c, c.ev, 1, n));
     t1 = now_sec(); c.phase_sec[PH_GPU_RELATION] = t1 - t0; t0 = t1;
-    if (c.round_hook) c.round_hook(c.round_user, 0, 1, c.d_dig2, (size_t)n * NPARTY * 32);
+    fire_hooks(1, c.d_dig2);
 
     // ---- Fiat-Shamir round 2 on the host
     // I, its complement, and the complement entries owned by each aligned 64-party window (k_assemble_fields), all derived by
@@ -924,15 +1009,19 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         aa.proof = c.d_proof;
         aa.image_stride = c.image_stride;
         aa.plan = c.pplan;
+        aa.groups = c.d_asm_groups;
+        aa.elems = c.d_asm_elems;
+        aa.ngroups = c.n_asm_groups;
         c.prof_begin(PR_ASSEMBLE, n);
-        HIPCHK(launch_assemble(aa, c.nfields, P.off[F_TCOMM], P.off[F_COMM], P.off[F_I], n, st));
+        HIPCHK(launch_assemble(aa, c.nfields, P.off[F_TCOMM], P.off[F_COMM], P.off[F_I], n, st, c.assemble_groups));
+        if (!c.capturing) c.path_n[c.assemble_groups ? PATH_ASSEMBLE_GROUPS : PATH_ASSEMBLE_FIELDS]++;
         c.prof_end(PR_ASSEMBLE);
         if (c.near_end_hook) c.near_end_hook(); // the last kernel is queued: a merged run's sleeping callers get ready for the return
         return 0;
     })) return -1;
     c.phase_sec[PH_P3_ISSUE] = now_sec() - t0;
     c.tape_segs.count = 0; // the callers' tape buffers are only promised for this call
-    HIPCHK(stream_sync(c));
+    HIPCHK(stream_sync_site(c, 2, n));
     t1 = now_sec(); c.phase_sec[PH_GPU_ASSEMBLE] = t1 - t0;
     c.prof_collect();
     if (device_error_check(c)) return -1; // e.g. the key generation's gen_matrix hit its block limit: pk / sk / proofs are not valid

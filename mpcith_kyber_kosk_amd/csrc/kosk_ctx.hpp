@@ -42,6 +42,10 @@ struct KeygenIn {
     // next `count` proofs (0: all the remaining ones), `next` the ones behind it
     int count = 0;
     const KeygenIn *next = nullptr;
+    // this caller's own round hook (a merged run fires every member's hook with that member's block of the digest table; an
+    // unmerged call leaves these null and the context's round_hook fires for the whole batch)
+    round_fn hook = nullptr;
+    void *hook_user = nullptr;
 };
 // the verifier's per-caller parts of a merged call: `count` proofs each, own key source and own result bytes
 struct VerifySeg {
@@ -49,6 +53,8 @@ struct VerifySeg {
     const uint8_t *pk; // pk_mode 1: this caller's public keys (host or device memory)
     uint8_t *ok;
     const VerifySeg *next = nullptr;
+    round_fn hook = nullptr; // as KeygenIn::hook
+    void *hook_user = nullptr;
 };
 
 enum Phase { PH_HOST_PRE = 0, PH_GPU_COMMIT, PH_FS_ALPHA, PH_GPU_RELATION, PH_FS_OPEN, PH_GPU_ASSEMBLE, PH_D2H,
@@ -63,7 +69,7 @@ enum ProfId { PR_HASH_TCOMM = 0, PR_HASH_VIEW, PR_GEMM_EXPAND1, PR_GEMM_EXPAND2,
 
 enum PathId { PATH_HASH_DMA = 0, PATH_HASH_PLAIN, PATH_HASH_PRIMER, PATH_TABLE_GEMM, PATH_LIMB_GEMM, PATH_COPY_DIRECT, PATH_COPY_STAGED,
               PATH_GRAPH_REPLAY, PATH_NTT_FP32, PATH_NTT_INT, PATH_DIGEST_DIRECT, PATH_DIGEST_COPY, PATH_COPY_KERNEL, PATH_SMALL_COPY_KERNEL,
-              PATH_LINCOMB_ONESHOT, PATH_LINCOMB_STREAM, PATH_COUNT };
+              PATH_LINCOMB_ONESHOT, PATH_LINCOMB_STREAM, PATH_ASSEMBLE_FIELDS, PATH_ASSEMBLE_GROUPS, PATH_COUNT };
 
 struct GemmTable {
     uint8_t *d = nullptr; // limb matrix (kosk_device.hpp)
@@ -145,6 +151,10 @@ struct Ctx {
     int off_sr_er = 0, off_nttsr_er = 0;
     FieldDesc *d_fields = nullptr;
     int16_t *d_rowtab = nullptr;
+    AsmGroup *d_asm_groups = nullptr; // the grouped image kernel's tables (build_tables)
+    AsmElem *d_asm_elems = nullptr;
+    int n_asm_groups = 0;
+    bool assemble_groups = true; // KOSK_ASSEMBLE_GROUPS=0: the per-field kernel of rounds 1-4
     int nfields = 0;
     std::vector<FieldDesc> h_fields;
     std::vector<int16_t> h_rowtab;
@@ -217,6 +227,15 @@ struct Ctx {
     std::function<void()> near_end_hook; // set by a merged run's executor: called once when only the call's tail is left (kosk_combine.hpp: near_end)
     bool kg_on_host_pending = false; // ev_kg was recorded by this call's key generation
     hipEvent_t ev_kg = nullptr; // the key records (pk, NTT(s) bytes, seeds) of a keygen-in-front call are on the host once it has passed
+    // KOSK_WAIT_NAP (default 1 since round 5; 0: spin throughout): the long host waits of the resident calls (six per step: the GPU
+    // phases between the host's rounds) sleep through most of their expected duration -- a moving average per wait site and batch
+    // size, only phases above 250 us -- and spin only for the last 30 %: a spinning wait keeps a core busy for the whole GPU phase,
+    // and an 8-GPU node has few cores per rank (wait_event, kosk_ctx.cpp).  Measured with nine callers in three cohorts: the same
+    // throughput (148-151 k proofs/s either way) at 3.5 busy cores fewer together with KOSK_POOL_SPIN_US=0 (profiles/r05_sweep_host.txt)
+    bool wait_nap = true;
+    enum { WAIT_SITES = 8 };
+    double wait_ema_us[WAIT_SITES] = {0};
+    int wait_ema_n[WAIT_SITES] = {0};
     hipEvent_t ev_sync = nullptr; // KOSK_BLOCKING_SYNC=1: every host wait sleeps on an event instead of spinning (few host cores per GPU)
     bool blocking_sync = false;
     int n_simd = 1024;      // SIMDs of the device (4 per CU)
@@ -351,6 +370,10 @@ int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx
 // C[g][rows_d[i]][off + m] = sum_k A[m][k] * src[g][rows_s[i]][koff + k] mod q  (conversion to limbs + MFMA GEMM)
 // host wait for everything queued on the context's stream (spinning, or sleeping with KOSK_BLOCKING_SYNC=1)
 hipError_t stream_sync(Ctx &c);
+// wait for `ev` (recorded on the context's stream); site = which of the pipeline's long waits this is (0..WAIT_SITES-1: napped with
+// KOSK_WAIT_NAP=1), n = the batch size the wait belongs to; site < 0: a plain wait
+hipError_t wait_event(Ctx &c, hipEvent_t ev, int site, int n);
+hipError_t stream_sync_site(Ctx &c, int site, int n);
 // a digest table (or any 16-byte aligned block) from HBM into the context's page-locked host memory, on the context's stream
 hipError_t copy_table_to_host(Ctx &c, void *h_dst, const void *d_src, size_t bytes);
 // a small copy between HBM and one of the library's OWN page-locked host buffers, rows x row_bytes (kernel or hipMemcpy[2D]Async)

@@ -157,11 +157,37 @@ inline FieldPlan make_field_plan(const FieldDesc *fields, int nfields)
     return p;
 }
 
+// (round 5) the grouped image kernel: a block = (group of image fields of one kind, aligned window of 64 party columns).  A group's rows
+// are the concatenated rows of its fields (<= 80); element e of the group belongs to one field: AsmElem says where it goes.
+//   fields of UNOPENED parties: the wave gathers at the window's unopened columns (one 128-byte line per row) and keeps every field's
+//     [party][width] block contiguous in its LDS tile (tile = 64 field_col + party width + k), so each field is written out as one run;
+//   fields of OPENED parties: the wave gathers the window's 64 columns DENSELY (the same single line per row; the one-shot kernel
+//     gathered 64 entries of I per wave: 64 scattered columns = about 20 lines per row and instruction), keeps [party][rows] in the
+//     tile, and writes the records of the window's opened parties (6.6 on average) to their positions in the list I.
+struct AsmElem {
+    int32_t dst;    // u16 index inside the proof image of this element of party record 0 (field offset / 2 + k)
+    int16_t width;  // u16 per party of the element's field
+    int16_t tile;   // unopened kind: 64 field_col + k (the tile index of party 0's element)
+};
+struct AsmGroup {
+    int sel;        // 0 opened parties, 1 unopened
+    int nrows;      // rows = elements of the group (<= 80)
+    int rowtab_off; // first entry in the row table
+    int elem_off;   // first entry in the AsmElem table
+    int nsub;
+    uint32_t sub_off[12]; // image byte offset, width and first tile column of the group's fields (unopened kind: the write-out runs)
+    int16_t sub_width[12], sub_col[12];
+};
+constexpr int ASM_MAX_GROUPS = 8;
+
 struct AssembleArgs {
     const uint16_t *P;
     size_t proof_stride;
     const FieldDesc *fields;
     const int16_t *rowtab;
+    const AsmGroup *groups; // grouped kernel
+    const AsmElem *elems;
+    int ngroups;
     const uint16_t *opened, *rest; // [proof][sel_stride]
     int sel_stride;
     const uint8_t *dig1, *dig2; // [proof][NPARTY][32]
@@ -334,7 +360,8 @@ hipError_t launch_post_gates(uint16_t *P, size_t proof_stride, const RowMap &rm,
 hipError_t launch_post_open(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st);
 hipError_t launch_copy_tails(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st);
 hipError_t launch_post_relation(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st);
+// grouped: k_assemble_groups (round 5, default), else the one-shot per-field kernel of rounds 1-4 (KOSK_ASSEMBLE_GROUPS=0)
 hipError_t launch_assemble(const AssembleArgs &a, int nfields, size_t off_tcomm, size_t off_comm, size_t off_I,
-                           int nproofs, hipStream_t st);
+                           int nproofs, hipStream_t st, bool grouped = false);
 
 } // namespace kosk

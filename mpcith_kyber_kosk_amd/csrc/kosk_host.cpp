@@ -524,6 +524,13 @@ void fs_opened_batch(int n, const uint8_t *digs, size_t dig_stride, uint16_t *I,
                 while (j < NREST && rb[j] < 64 * w) j++;
                 win[w] = (uint16_t)j;
             }
+            // the opened parties ascending and where each sits in I (the grouped image kernel writes an opened party's records
+            // from the window its column lies in)
+            uint16_t pos[NPARTY];
+            for (int p = 0; p < NPARTY; p++) pos[p] = 0xFFFF;
+            for (int i = 0; i < NOPEN; i++) pos[Ib[i]] = (uint16_t)i;
+            for (int p = 0, k = 0; p < NPARTY; p++)
+                if (pos[p] != 0xFFFF) { Ib[SEL_OSORT + k] = (uint16_t)p; Ib[SEL_OPOS + k] = pos[p]; k++; }
         }
     };
     sha3_digest_tables(n, digs, dig_stride, h.data(), nthreads, pool, &derive, prep);
@@ -687,7 +694,7 @@ private:
     }
     static int spin_us()
     {
-        static const int v = getenv("KOSK_POOL_SPIN_US") ? atoi(getenv("KOSK_POOL_SPIN_US")) : 20;
+        static const int v = getenv("KOSK_POOL_SPIN_US") ? atoi(getenv("KOSK_POOL_SPIN_US")) : 0; // round 5: 0 (was 20): same throughput, one to two busy cores fewer (profiles/r05_sweep_host.txt)
         return v;
     }
     static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "the generation word is handed to futex(2)");

@@ -2207,6 +2207,137 @@ __global__ __launch_bounds__(64) void k_assemble_fields(AssembleArgs a, uint32_t
     if (lane == 1 && head + 2 * body < n16) out[n16 - 1] = tile[n16 - 1];
 }
 
+// ---- K8, grouped form (round 5; default).  k_assemble_fields gathers the records of the OPENED parties 64 entries of I at a time:
+// 64 scattered columns, i.e. about 20 different 128-byte lines per row and load instruction, where a window of 64 adjacent columns
+// is ONE line -- three quarters of the launch's line requests for a tenth of its bytes (232 rows x 3 chunks x ~20 lines against 203
+// rows x 23 windows x 1 line per proof; tools/probe_wire.hip: a dense window gather of this shape runs at the rate of a linear sweep).
+// Here every block is (group of fields, aligned window of 64 party columns) and every row costs one line:
+//   * fields of unopened parties, as before, but packed into groups of up to 80 rows (the seven small fields of 3 .. 15 rows are
+//     one 63-row block per window instead of seven short ones: as many loads in flight per wave as the big fields have);
+//   * fields of opened parties: the window's 64 columns gathered densely, and the records of the window's opened parties (6.6 on
+//     average; the host's Fiat-Shamir round leaves them sorted with their positions in I, SEL_OSORT / SEL_OPOS) written from the
+//     LDS tile; a window without an opened party does nothing.
+// Same image bytes as k_assemble_fields (KOSK_ASSEMBLE_GROUPS=0 runs that).
+// A block = (group, window).  The window's 64 columns of the group's rows are gathered DENSE with 8-byte loads: lane = (row slot
+// lane >> 4, column quad lane & 15), so one instruction brings four whole 128-byte lines (four rows) where a 2-byte-per-lane gather
+// brings one -- the launch is bound by the number of load instructions, not by bytes (measured: the same dense gather with 2-byte
+// loads made the launch 25 % SLOWER than the scattered gathers it replaced, profiles/r05_wire.txt).  Only the columns this block
+// writes out reach the LDS tile, already compacted: a column's RANK among them (unopened kind: its position among the window's
+// unopened parties; opened kind: among the window's opened ones) comes from a 64-entry table the block builds first, and the tile
+// position of (rank, row) is the image order of the write-out -- per field [party][width] blocks for the unopened kind (each field
+// is then one linear run), [party][rows] for the opened kind (one record set per opened party).
+template <int NQ> // NQ >= ceil(nrows / 4)
+__device__ __forceinline__ void asm_group_block(const AssembleArgs &a, const AsmGroup &g, const int b, const int w, uint16_t *tile, int16_t *rank_s,
+                                                AsmElem *el_s)
+{
+    const int lane = threadIdx.x, slot = lane >> 4, cq = lane & 15;
+    const uint16_t *orow = a.opened + (size_t)b * a.sel_stride;
+    const uint16_t *Pb = a.P + (size_t)b * a.proof_stride;
+    const int16_t *rt = a.rowtab + g.rowtab_off;
+    uint16_t *img16 = reinterpret_cast<uint16_t *>(a.proof + (size_t)b * a.image_stride);
+    const int nrows = g.nrows;
+    const int lo = min(64 * w, NPARTY), hi = min(64 * (w + 1), NPARTY);
+    const int i0 = orow[SEL_WIN + w], cnt = (int)orow[SEL_WIN + w + 1] - i0; // unopened parties of the window: records [i0, i0 + cnt)
+    const int k0 = lo - i0, nk = (hi - lo) - cnt;                               // its opened parties: entries [k0, k0 + nk) of the sorted list
+    const int nsel = g.sel ? cnt : nk;
+    if (nsel <= 0) return;
+    // rank table: rank_s[column] = position among the columns this block writes out, -1 for the others
+    rank_s[lane] = -1;
+    int my_pos = 0;
+    int my_col = 0;
+    if (lane < nsel) {
+        if (g.sel) my_col = (int)a.rest[(size_t)b * a.sel_stride + i0 + lane] - lo;
+        else { my_col = (int)orow[SEL_OSORT + k0 + lane] - lo; my_pos = orow[SEL_OPOS + k0 + lane]; }
+    }
+    const AsmElem *el = a.elems + g.elem_off;
+    el_s[lane] = el[lane]; // the group's element table (padded to 128 entries), for per-lane row indices
+    el_s[lane + 64] = el[lane + 64];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < nsel) rank_s[my_col] = (int16_t)lane;
+    // the gather: all loads first
+    int rr[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) rr[q] = rt[min(4 * q + slot, nrows - 1)];
+    uint2 v[NQ];
+    const uint16_t *src = Pb + NSEC + lo + 4 * cq;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) v[q] = *reinterpret_cast<const uint2 *>(src + (size_t)rr[q] * RS);
+    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the rank table is written
+    __builtin_amdgcn_wave_barrier();
+    int rk[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) rk[m] = rank_s[4 * cq + m];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int r = 4 * q + slot;
+        if (r < nrows) {
+            const uint32_t x[4] = {v[q].x & 0xFFFFu, v[q].x >> 16, v[q].y & 0xFFFFu, v[q].y >> 16};
+            if (g.sel) {
+                const AsmElem e = el_s[r];
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+                    if (rk[m] >= 0) tile[(int)e.tile + rk[m] * (int)e.width] = (uint16_t)x[m];
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+                    if (rk[m] >= 0) tile[rk[m] * nrows + r] = (uint16_t)x[m];
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (g.sel) {
+        for (int s = 0; s < g.nsub; s++) { // one contiguous run per field; its start is only 2-byte aligned in general
+            const int width = g.sub_width[s];
+            uint16_t *out = img16 + g.sub_off[s] / 2 + (size_t)i0 * width;
+            const uint16_t *srct = tile + 64 * (int)g.sub_col[s];
+            const int n16 = cnt * width;
+            const int head = (int)((reinterpret_cast<uintptr_t>(out) >> 1) & 1);
+            const int body = (n16 - head) >> 1;
+            if (lane == 0 && head) out[0] = srct[0];
+            uint32_t *out32 = reinterpret_cast<uint32_t *>(out + head);
+            for (int q = lane; q < body; q += 64) out32[q] = (uint32_t)srct[head + 2 * q] | ((uint32_t)srct[head + 2 * q + 1] << 16);
+            if (lane == 1 && head + 2 * body < n16) out[n16 - 1] = srct[n16 - 1];
+        }
+    } else {
+        const AsmElem e0 = el_s[lane], e1 = el_s[lane + 64];
+        for (int j = 0; j < nk; j++) {
+            const int i = __builtin_amdgcn_readlane(my_pos, j);
+            if (lane < nrows) img16[e0.dst + i * (int)e0.width] = tile[j * nrows + lane];
+            if (NQ > 16 && lane + 64 < nrows) img16[e1.dst + i * (int)e1.width] = tile[j * nrows + lane + 64];
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_assemble_groups(AssembleArgs a, uint32_t off_tcomm, uint32_t off_comm, uint32_t off_I, int blocks_per_proof, int nproofs)
+{
+    const int vid = xcd_virtual_id(); // the windows of a group read adjacent lines of the same rows: one XCD, one L2
+    const int b = vid / blocks_per_proof, bx = vid - b * blocks_per_proof;
+    if (b >= nproofs) return;
+    const int ngb = a.ngroups * NWIN;
+    if (bx >= ngb) { // Tcomm / comm of the unopened parties and the list I itself (64 u16 per block), as in k_assemble_fields
+        const int q = (bx - ngb) * 64 + threadIdx.x;
+        uint8_t *img = a.proof + (size_t)b * a.image_stride;
+        if (q < NREST * 16) {
+            const int i = q >> 4, w = q & 15;
+            const size_t src = ((size_t)b * NPARTY + a.rest[(size_t)b * a.sel_stride + i]) * 32 + 2 * w;
+            reinterpret_cast<uint16_t *>(img + off_tcomm)[q] = *reinterpret_cast<const uint16_t *>(a.dig1 + src);
+            reinterpret_cast<uint16_t *>(img + off_comm)[q] = *reinterpret_cast<const uint16_t *>(a.dig2 + src);
+        }
+        if (q < NOPEN) reinterpret_cast<uint16_t *>(img + off_I)[q] = a.opened[(size_t)b * a.sel_stride + q];
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) uint16_t tile[ASM_TILE];
+    __shared__ int16_t rank_s[64];
+    __shared__ AsmElem el_s[128];
+    const int gi = bx / NWIN, w = bx - gi * NWIN;
+    const AsmGroup &g = a.groups[gi];
+    if (g.nrows <= 16) asm_group_block<4>(a, g, b, w, tile, rank_s, el_s);
+    else if (g.nrows <= 64) asm_group_block<16>(a, g, b, w, tile, rank_s, el_s);
+    else asm_group_block<20>(a, g, b, w, tile, rank_s, el_s);
+}
+
 // Device-to-host copy of a digest table with FEW waves (experiment, KOSK_COPY_WAVES).  The runtime's own copy (hipMemcpyAsync into
 // page-locked memory) is a blit kernel with one 16-byte element per thread on this pool (no SDMA, profiles/r04_sdma_probe.txt):
 // 6 144 waves for the 6.4 MB of a 138-proof round, parked on PCIe stores for 112 us.  The idea here: one wave per workgroup walks
@@ -2576,8 +2707,14 @@ hipError_t launch_post_relation(uint16_t *P, size_t proof_stride, const RowMap &
 }
 
 hipError_t launch_assemble(const AssembleArgs &a, int nfields, size_t off_tcomm, size_t off_comm, size_t off_I,
-                           int nproofs, hipStream_t st)
+                           int nproofs, hipStream_t st, bool grouped)
 {
+    if (grouped && a.groups && a.ngroups > 0) {
+        const int bpp = a.ngroups * NWIN + (NREST * 16 + 63) / 64;
+        const long nwg = ((long)bpp * nproofs + 7) / 8 * 8;
+        hipLaunchKernelGGL(k_assemble_groups, dim3((unsigned)nwg), dim3(64), 0, st, a, (uint32_t)off_tcomm, (uint32_t)off_comm, (uint32_t)off_I, bpp, nproofs);
+        return hipGetLastError();
+    }
     const int bpp = a.plan.nrest * NWIN + a.plan.nopen * ((NOPEN + 63) / 64) + (NREST * 16 + 63) / 64;
     const long nwg = ((long)bpp * nproofs + 7) / 8 * 8;
     hipLaunchKernelGGL(k_assemble_fields, dim3((unsigned)nwg), dim3(64), 0, st, a, (uint32_t)off_tcomm, (uint32_t)off_comm, (uint32_t)off_I, bpp,

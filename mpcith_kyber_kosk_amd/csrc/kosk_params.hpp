@@ -44,6 +44,9 @@ constexpr int OS = 160;
 // an opened-list row [proof][sel_stride] holds I in [0,150) and, from SEL_WIN on, for each aligned window of 64
 // parties w = 0..23 the number of unopened parties below 64w (so window w owns complement entries [win[w], win[w+1]))
 constexpr int SEL_WIN = 160, NWIN = (NPARTY + 63) / 64;
+// (prover, round 5) behind the window boundaries: the OPENED parties in ascending order (SEL_OSORT, 150 entries) and the position of each
+// of them in the list I (SEL_OPOS): window w of the grouped image kernel owns the entries [min(64 w, N) - win[w], min(64 (w + 1), N) - win[w + 1])
+constexpr int SEL_OSORT = 192, SEL_OPOS = 352;
 constexpr int MAXK = 4, MAXM = 79, MAXJ = NCHK + 2 * MAXK;
 
 struct Params {

@@ -246,7 +246,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     c.host_img = nullptr;
     if (n < 1 || n > c.call_cap) { c.err = "batch size out of range"; return -1; }
     // a merged call (kosk_combine.hpp): `segs` lists the callers' parts, each with its own keys and result bytes
-    const VerifySeg whole{n, pk, ok, nullptr};
+    const VerifySeg whole{n, pk, ok, nullptr, nullptr, nullptr};
     if (!segs) segs = &whole;
     {
         int total = 0;
@@ -416,10 +416,23 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     return 0;
     })) return -1;
 
-    HIPCHK(hipEventSynchronize(c.ev));
+    HIPCHK(wait_event(c, c.ev, 3, n));
     if (split_tables && !himg) HIPCHK(hipEventSynchronize(c.ev_img[0])); // the images' Tcomm fields (under way since the call began)
     t1 = now_sec(); c.phase_sec[PH_V1_WAIT] = t1 - t0; t0 = t1;
-    if (c.round_hook) c.round_hook(c.round_user, 1, 0, c.d_dig1, (size_t)n * NPARTY * 32);
+    auto fire_hooks = [&](int rnd, const uint8_t *d_table) { // as in prove_resident: per caller of a merged run, else the context's own
+        bool seg_hooks = false;
+        for (const VerifySeg *s = segs; s; s = s->next) seg_hooks |= s->hook != nullptr;
+        if (!seg_hooks) {
+            if (c.round_hook) c.round_hook(c.round_user, 1, rnd, d_table, (size_t)n * NPARTY * 32);
+            return;
+        }
+        int first = 0;
+        for (const VerifySeg *s = segs; s; s = s->next) {
+            if (s->hook) s->hook(s->hook_user, 1, rnd, d_table + (size_t)first * NPARTY * 32, (size_t)s->count * NPARTY * 32);
+            first += s->count;
+        }
+    };
+    fire_hooks(0, c.d_dig1);
 
     // ---- host: alpha while the GPU works
     {
@@ -489,10 +502,10 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     return 0;
     })) return -1;
 
-    HIPCHK(hipEventSynchronize(c.ev)); // the view digests are on the host; V2B keeps running
+    HIPCHK(wait_event(c, c.ev, 4, n)); // the view digests are on the host; V2B keeps running
     if (split_tables && !himg) HIPCHK(hipEventSynchronize(c.ev_img[1]));
     t1 = now_sec(); c.phase_sec[PH_V2_WAIT] = t1 - t0; t0 = t1;
-    if (c.round_hook) c.round_hook(c.round_user, 1, 1, c.d_dig2, (size_t)n * NPARTY * 32);
+    fire_hooks(1, c.d_dig2);
     if (c.near_end_hook) c.near_end_hook(); // only the host's last round is left: a merged run's sleeping callers get ready for the return
     if (c.v_I2.size() < (size_t)n * c.sel_stride) { c.v_I2.resize((size_t)n * c.sel_stride); c.v_rest2.resize((size_t)n * c.sel_stride); }
     std::vector<uint16_t> &I2 = c.v_I2, &rest2 = c.v_rest2; // every entry that is read below is written by fs_opened_batch first
@@ -500,7 +513,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
         const std::function<void(int)> prep = table_prep(1);
         fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, I2.data(), rest2.data(), c.sel_stride, c.nthreads, c.pool, false, split_tables ? &prep : nullptr);
     }
-    HIPCHK(stream_sync(c)); // fail masks of V2B
+    HIPCHK(stream_sync_site(c, 5, n)); // fail masks of V2B
     c.prof_collect();
     if (device_error_check(c)) return -1; // gen_matrix of a public key hit its block limit: no verdict on these proofs
     {

@@ -103,22 +103,27 @@ __global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const F
     auto canon = [&](uint32_t x_) { return (uint16_t)x_; };
     if (lane == 0 && head) tile[0] = canon(in[0]);
     const uint32_t *in32 = reinterpret_cast<const uint32_t *>(in + head);
-    for (int q0 = 0; q0 < body; q0 += 64 * 8) { // eight independent loads in flight per lane
-        uint32_t xv[8];
+    // every load of the block in flight before the first LDS write (a 64-party block of the widest field is 40 dwords per lane;
+    // rounds 2-4 went eight at a time: five dependent round trips per block)
+    auto fetch_all = [&]<int NX>(std::integral_constant<int, NX>) {
+        uint32_t xv[NX];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int q = q0 + u * 64 + lane;
+        for (int u = 0; u < NX; u++) {
+            const int q = u * 64 + lane;
             xv[u] = q < body ? in32[q] : 0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int q = q0 + u * 64 + lane;
+        for (int u = 0; u < NX; u++) {
+            const int q = u * 64 + lane;
             if (q < body) {
                 tile[head + 2 * q] = canon(xv[u] & 0xFFFFu);
                 tile[head + 2 * q + 1] = canon(xv[u] >> 16);
             }
         }
-    }
+    };
+    if (body <= 64 * 8) fetch_all(std::integral_constant<int, 8>{});
+    else if (body <= 64 * 24) fetch_all(std::integral_constant<int, 24>{});
+    else fetch_all(std::integral_constant<int, 40>{});
     if (lane == 1 && head + 2 * body < n16) tile[n16 - 1] = canon(in[n16 - 1]);
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();

@@ -142,6 +142,8 @@ KNOBS = {  # knob -> (path counter that must be > 0 on the knob's handle, counte
     "KOSK_HASH_DMA=0": ("hash_plain", "hash_dma"),
     "KOSK_LINCOMB_FUSED=0": ("limb_gemm", "lincomb_stream"),
     "KOSK_LINCOMB_FUSED=2": ("lincomb_oneshot", "lincomb_stream"),
+    "KOSK_ASSEMBLE_GROUPS=0": ("assemble_fields", "assemble_groups"),
+    "KOSK_WAIT_NAP=0": (None, None),
     "KOSK_NTT_FP32=1": ("ntt_fp32", "ntt_int"),
     "KOSK_BLOCKING_SYNC=1": (None, None),
     "KOSK_GRAPHS=1": ("graph_replay", None),

@@ -107,7 +107,7 @@ def test_config4_two_ranks_on_one_gpu_rehearsal():
     env = dict(os.environ, KOSK_BENCH_REHEARSE="1", LOCAL_WORLD_SIZE="8")  # 8: also drives the scarce-cores branch of host_budget
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--config", "4", "--steps", "6", "--warmup", "2",
-           "--slots", "2", "--no-cpu-baseline", "--no-kernels"]
+           "--slots", "3", "--no-cpu-baseline", "--no-kernels"]
     r = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -120,6 +120,10 @@ def test_config4_two_ranks_on_one_gpu_rehearsal():
     # two gathers (Tcomm, view) per step on every slot, the same count on every slot (static dealing)
     assert all(n == 2 * s for n, s in zip(g["gathers_issued_per_slot"], g["steps_per_slot"])) and len(set(g["steps_per_slot"])) == 1
     assert line["value"] > 0
+    # round 5: handles with a round hook merge like any other (every member's hook fires from the merged run with its own block of
+    # the tables): the three slots of a rank are one cohort, and their calls really ran merged
+    assert line["config"]["handles_per_cohort"] == 3 and line["combining"]["mean_callers_per_run"] > 1.5, line["combining"]
+    assert line["rccl"]["world"] == 2 and [d["rank"] for d in line["rccl"]["devices"]] == [0, 1], line["rccl"]
 
 
 @pytest.mark.gpu
