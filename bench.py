@@ -919,6 +919,8 @@ def main():
                 line["roofline"]["alone_frac"] = ppl_ * 1454 * (VIEW_MSG[k] + 32) / (oc_["hash_view_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
             line["uncombined"] = side_run(6, 1, "python bench.py --combine 1 --slots 6: six independent handles, every launch serves one 46-proof call "
                                                 "(round 3's line of record); not the line of record")
+            line["cohorts_of_four"] = side_run(12, 4, "python bench.py --combine 4 --slots 12: twelve callers, four per merged run (184 proofs per launch: the arrangement "
+                                                      "where this round's shorter kernels show -- 133 k proofs/s at 4.0 ms in round 4); not the line of record")
             line["cohorts_of_five"] = side_run(15, 5, "python bench.py --combine 5 --slots 15: fifteen callers, five per merged run (more proofs per launch at "
                                                       "more latency per call); not the line of record")
         if world == 1 and not args.no_cpu_baseline:

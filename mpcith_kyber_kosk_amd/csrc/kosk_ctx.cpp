@@ -197,16 +197,22 @@ hipError_t stream_sync(Ctx &c)
 hipError_t wait_event(Ctx &c, hipEvent_t ev, int site, int n)
 {
     if (c.blocking_sync || !c.wait_nap || site < 0 || site >= Ctx::WAIT_SITES) return hipEventSynchronize(ev);
-    if (c.wait_ema_n[site] != n) { c.wait_ema_n[site] = n; c.wait_ema_us[site] = 0; } // another batch size: learn again
+    double *hist = c.wait_hist_us[site];
+    if (c.wait_ema_n[site] != n) { // another batch size: learn again
+        c.wait_ema_n[site] = n;
+        for (int i = 0; i < Ctx::WAIT_HIST; i++) hist[i] = 0;
+    }
+    int filled = 0;
+    double est = 0;
+    for (int i = 0; i < Ctx::WAIT_HIST; i++)
+        if (hist[i] > 0) { est = filled ? (hist[i] < est ? hist[i] : est) : hist[i]; filled++; }
     const double t0 = now_sec();
-    const double ema = c.wait_ema_us[site];
     bool overslept = false;
-    if (ema > 250.0) {
-        const double keep = ema * 0.3 > 100.0 ? ema * 0.3 : 100.0; // spin through the last 30 % (at least 100 us: the sleep's own wake-up jitter)
-        const double nap_us = ema - keep;
+    if (filled >= 4 && est > 250.0) { // (no nap before the site has been seen four times at this batch size)
+        const double keep = est * 0.3 > 100.0 ? est * 0.3 : 100.0; // spin through the last 30 % (at least 100 us: the sleep's own wake-up jitter)
         struct timespec ts;
         ts.tv_sec = 0;
-        ts.tv_nsec = (long)(nap_us * 1e3);
+        ts.tv_nsec = (long)((est - keep) * 1e3);
         nanosleep(&ts, nullptr);
         const hipError_t q = hipEventQuery(ev);
         if (q == hipSuccess) overslept = true;
@@ -214,8 +220,12 @@ hipError_t wait_event(Ctx &c, hipEvent_t ev, int site, int n)
     }
     const hipError_t e = overslept ? hipSuccess : hipEventSynchronize(ev);
     const double took = (now_sec() - t0) * 1e6;
-    // an overslept wait says nothing about the phase's real length except that it was shorter than the nap: halve the estimate
-    c.wait_ema_us[site] = overslept ? ema * 0.5 : (ema == 0 ? took : 0.75 * ema + 0.25 * took);
+    if (overslept) { // the phase was shorter than the nap: everything the site remembers is too long
+        for (int i = 0; i < Ctx::WAIT_HIST; i++) hist[i] = est * 0.5;
+    } else {
+        hist[c.wait_hist_at[site]] = took > 1.0 ? took : 1.0;
+        c.wait_hist_at[site] = (c.wait_hist_at[site] + 1) % Ctx::WAIT_HIST;
+    }
     return e;
 }
 hipError_t stream_sync_site(Ctx &c, int site, int n)

@@ -228,13 +228,16 @@ struct Ctx {
     bool kg_on_host_pending = false; // ev_kg was recorded by this call's key generation
     hipEvent_t ev_kg = nullptr; // the key records (pk, NTT(s) bytes, seeds) of a keygen-in-front call are on the host once it has passed
     // KOSK_WAIT_NAP (default 1 since round 5; 0: spin throughout): the long host waits of the resident calls (six per step: the GPU
-    // phases between the host's rounds) sleep through most of their expected duration -- a moving average per wait site and batch
-    // size, only phases above 250 us -- and spin only for the last 30 %: a spinning wait keeps a core busy for the whole GPU phase,
+    // phases between the host's rounds) sleep through most of their expected duration -- the SHORTEST of the site's last eight waits
+    // at this batch size (a phase has a floor and outliers are always longer: one 10 ms hiccup must not make the next waits
+    // oversleep), only phases above 250 us -- and spin only for the last 30 %: a spinning wait keeps a core busy for the whole GPU phase,
     // and an 8-GPU node has few cores per rank (wait_event, kosk_ctx.cpp).  Measured with nine callers in three cohorts: the same
     // throughput (148-151 k proofs/s either way) at 3.5 busy cores fewer together with KOSK_POOL_SPIN_US=0 (profiles/r05_sweep_host.txt)
     bool wait_nap = true;
     enum { WAIT_SITES = 8 };
-    double wait_ema_us[WAIT_SITES] = {0};
+    enum { WAIT_HIST = 8 };
+    double wait_hist_us[WAIT_SITES][WAIT_HIST] = {{0}}; // the site's last measured waits (0 = empty): the nap is sized by their MINIMUM
+    int wait_hist_at[WAIT_SITES] = {0};
     int wait_ema_n[WAIT_SITES] = {0};
     hipEvent_t ev_sync = nullptr; // KOSK_BLOCKING_SYNC=1: every host wait sleeps on an event instead of spinning (few host cores per GPU)
     bool blocking_sync = false;

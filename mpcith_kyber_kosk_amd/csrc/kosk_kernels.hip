@@ -414,6 +414,7 @@ struct PreArgs {
     int16_t *kg_se;      // [proof][2K][256] s then e
     size_t kg_se_stride;
     XofGuard xof;
+    int pair; // roles G, N, A on the lane-pair sponge (kosk_keygen_dev.hpp: kp_*): 32 sponges per 64-thread block instead of 64
 };
 constexpr int PRE_SLICES = 8; // fresh sharings per role-B block
 __device__ __forceinline__ const uint8_t *pre_tape(const PreArgs &a, int b)
@@ -529,6 +530,63 @@ __device__ __forceinline__ void pre_noise(const PreArgs &a, int t)
     kg_noise(noise, nonce, a.eta1, a.kg_se + (size_t)b * a.kg_se_stride + (size_t)nonce * 256);
 }
 
+// ---- roles A, G, N on the lane-pair sponge: pair pr = thread >> 1 of the role's range, hi = the lane that holds the high halves ----
+__device__ __forceinline__ void pre_expand_f_pair(const PreArgs &a, int pr, bool hi)
+{
+    const int n = a.M * a.nproofs;
+    const bool live = pr < n;
+    const int t = live ? pr : n - 1;
+    const int b = t / a.M, i = t % a.M;
+    const uint32_t *seed = reinterpret_cast<const uint32_t *>(pre_tape(a, b) + 64 + 32 * i) + (hi ? 1 : 0); // my half of each of the four seed words
+    KHalf s;
+#pragma unroll
+    for (int k = 0; k < 25; k++) s.w[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) s.w[k] = seed[2 * k];
+    if (!hi) s.w[4] = (uint32_t)(uint8_t)i | (0x1Fu << 8);
+    if (hi) s.w[16] = 0x80000000u;
+    uint16_t *dst = a.P + (size_t)b * a.proof_stride + (size_t)(a.row_f + i) * RS + (hi ? 2 : 0);
+#pragma unroll 1
+    for (int blk = 0; blk < 4; blk++) {
+        keccak_f1600_split(s, hi);
+        if (live) {
+#pragma unroll
+            for (int w = 0; w < 17; w++) { // my half of word w = elements 4 w (+ 2), 4 w + 1 (+ 2) of the block's 68 (52 in the last)
+                if (blk == 3 && w >= 13) break;
+                const uint32_t v = s.w[w];
+                const uint32_t h0 = v & 0xFFFFu, h1 = v >> 16;
+                const uint32_t be0 = ((h0 & 0xFF) << 8) | (h0 >> 8), be1 = ((h1 & 0xFF) << 8) | (h1 >> 8);
+                *reinterpret_cast<uint32_t *>(dst + blk * 68 + w * 4) = (be0 % (uint32_t)Q) | ((be1 % (uint32_t)Q) << 16);
+            }
+        }
+    }
+}
+__device__ __forceinline__ void pre_gen_matrix_pair(const PreArgs &a, int pr, bool hi)
+{
+    const int KK = a.K * a.K, n = a.nproofs * KK;
+    const bool live = pr < n;
+    const int t = live ? pr : n - 1;
+    const int b = t / KK, ij = t - b * KK, i = ij / a.K, j = ij - i * a.K;
+    uint32_t pub[8], noise[8];
+    kp_seed_hash(pre_tape(a, b), a.K, hi, pub, noise);
+    kp_gen_matrix(pub, i, j, hi, live, a.kg_A + (size_t)b * a.kg_A_stride + (size_t)ij * 256, a.xof);
+}
+__device__ __forceinline__ void pre_noise_pair(const PreArgs &a, int pr, bool hi)
+{
+    const int n = a.nproofs * 2 * a.K;
+    const bool live = pr < n;
+    const int t = live ? pr : n - 1;
+    const int b = t / (2 * a.K), nonce = t - b * 2 * a.K;
+    uint32_t pub[8], noise[8];
+    kp_seed_hash(pre_tape(a, b), a.K, hi, pub, noise);
+    if (nonce == 0 && live && !hi) {
+        uint32_t *o = reinterpret_cast<uint32_t *>(a.kg_seeds + (size_t)b * a.kg_seed_stride);
+#pragma unroll
+        for (int q = 0; q < 8; q++) { o[q] = pub[q]; o[8 + q] = noise[q]; }
+    }
+    kp_noise(noise, nonce, a.eta1, hi, live, a.kg_se + (size_t)b * a.kg_se_stride + (size_t)nonce * 256);
+}
+
 __global__ __launch_bounds__(64) void k_prover_pre(PreArgs a)
 {
     // Workgroups are dispatched in index order, so the roles come longest chain first: G (a matrix entry: six or more dependent
@@ -536,11 +594,13 @@ __global__ __launch_bounds__(64) void k_prover_pre(PreArgs a)
     // and the thousands of short role-B workgroups stream through beside them.  With B in front of G (rounds 1-3) the launch took
     // B's streaming time PLUS G's chain: 100 us at 138 proofs, 73 us at 46.
     int blk = blockIdx.x;
-    if (blk < a.nbG) return pre_gen_matrix(a, blk * 64 + threadIdx.x);
+    const int th = a.pair ? blk * 32 + ((int)threadIdx.x >> 1) : blk * 64 + (int)threadIdx.x; // sponge index inside the role's range
+    const bool hi = threadIdx.x & 1;
+    if (blk < a.nbG) return a.pair ? pre_gen_matrix_pair(a, th, hi) : pre_gen_matrix(a, th);
     blk -= a.nbG;
-    if (blk < a.nbN) return pre_noise(a, blk * 64 + threadIdx.x);
+    if (blk < a.nbN) return a.pair ? pre_noise_pair(a, blk * 32 + ((int)threadIdx.x >> 1), hi) : pre_noise(a, blk * 64 + (int)threadIdx.x);
     blk -= a.nbN;
-    if (blk < a.nbA) return pre_expand_f(a, blk * 64 + threadIdx.x);
+    if (blk < a.nbA) return a.pair ? pre_expand_f_pair(a, blk * 32 + ((int)threadIdx.x >> 1), hi) : pre_expand_f(a, blk * 64 + (int)threadIdx.x);
     blk -= a.nbA;
     if (blk < a.nbB) return pre_tape_randoms(a, blk, threadIdx.x);
     pre_witness_secrets(a, blk - a.nbB, threadIdx.x);
@@ -2490,15 +2550,19 @@ hipError_t launch_prover_pre(const uint8_t *tape, size_t tape_stride, uint16_t *
     a.witness_mode = witness_mode;
     a.se = se; a.se_stride = se_stride; a.rm = rm; a.eta1 = eta1;
     a.K = rm.K;
-    a.nbA = expand_f ? (M * nproofs + 63) / 64 : 0;
+    // KOSK_PRE_PAIR=0 (per process): one sponge per lane in roles G, N, A, as in rounds 1-4
+    static const bool pre_pair = !(getenv("KOSK_PRE_PAIR") && atoi(getenv("KOSK_PRE_PAIR")) == 0);
+    a.pair = pre_pair ? 1 : 0;
+    const int per = a.pair ? 32 : 64; // sponges per block
+    a.nbA = expand_f ? (M * nproofs + per - 1) / per : 0;
     a.nbB = 3 * ((slice_end - slice_begin + PRE_SLICES - 1) / PRE_SLICES) * nproofs;
     const int nbC = witness_mode ? 4 * nproofs : 0;
     if (kg) {
         // the witness secrets (role C) read s and e, which role N of this launch produces: they follow in a launch of their own
         a.kg_seeds = kg->seeds; a.kg_seed_stride = kg->seed_stride; a.kg_A = kg->A; a.kg_A_stride = kg->A_stride; a.kg_se = kg->se; a.kg_se_stride = kg->se_stride;
         a.xof = kg->xof;
-        a.nbG = (nproofs * rm.K * rm.K + 63) / 64;
-        a.nbN = (nproofs * 2 * rm.K + 63) / 64;
+        a.nbG = (nproofs * rm.K * rm.K + per - 1) / per;
+        a.nbN = (nproofs * 2 * rm.K + per - 1) / per;
         hipLaunchKernelGGL(k_prover_pre, dim3(a.nbA + a.nbB + a.nbG + a.nbN), dim3(64), 0, st, a);
         if (nbC) {
             a.nbA = a.nbB = a.nbG = a.nbN = 0;
@@ -2520,8 +2584,11 @@ hipError_t launch_keygen(const uint8_t *tape, size_t tape_stride, uint8_t *seeds
     a.xof = xof;
     a.tape = tape; a.tape_stride = tape_stride; a.nproofs = n; a.eta1 = eta1; a.K = K;
     a.kg_seeds = seeds; a.kg_seed_stride = seed_stride; a.kg_A = A; a.kg_A_stride = A_stride; a.kg_se = se; a.kg_se_stride = se_stride;
-    a.nbG = (n * K * K + 63) / 64;
-    a.nbN = (n * 2 * K + 63) / 64;
+    static const bool pre_pair = !(getenv("KOSK_PRE_PAIR") && atoi(getenv("KOSK_PRE_PAIR")) == 0);
+    a.pair = pre_pair ? 1 : 0;
+    const int per = a.pair ? 32 : 64;
+    a.nbG = (n * K * K + per - 1) / per;
+    a.nbN = (n * 2 * K + per - 1) / per;
     hipLaunchKernelGGL(k_prover_pre, dim3(a.nbG + a.nbN), dim3(64), 0, st, a);
     return hipGetLastError();
 }

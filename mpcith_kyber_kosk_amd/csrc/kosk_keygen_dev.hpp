@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kosk_keccak_dev.hpp"
+#include "kosk_keccak_split_dev.hpp"
 #include "kosk_math.hpp"
 
 namespace kosk {
@@ -151,6 +152,121 @@ __device__ __forceinline__ void kg_noise(const uint32_t (&noise)[8], int nonce, 
         };
         go2(std::make_integer_sequence<int, 18>{});
     }
+}
+
+// ---- the same three samplers on the LANE-PAIR sponge (kosk_keccak_split_dev.hpp; round 5) -----------------------------------------
+// One state on two adjacent lanes (even lane: low halves of the 25 words, odd lane: high halves): 120 instead of 180 vector
+// instructions per lane and round.  These samplers are a few waves per launch, each alone on its SIMD, so their time is the
+// dependent chain of permutations at ONE wave's issue rate; two thirds of the instructions are two thirds of that time.  All 64
+// lanes of a wave must stay active (the DPP exchange reads the partner's registers): callers clamp indices and predicate stores.
+
+// both halves of word l of the state on both lanes of the pair: lo = dword 2 l, hi = dword 2 l + 1 of the squeezed block
+__device__ __forceinline__ void kp_full(const KHalf &s, bool hi, int nwords, KState &f)
+{
+#pragma unroll
+    for (int l = 0; l < 25; l++) {
+        if (l < nwords) {
+            const uint32_t p = kpartner(s.w[l]);
+            f.lo[l] = hi ? p : s.w[l];
+            f.hi[l] = hi ? s.w[l] : p;
+        }
+    }
+}
+// my half of pad(seed32 || extra[0..nextra) || dom) for a sponge of `rate` bytes (kg_absorb)
+__device__ __forceinline__ void kp_absorb(KHalf &s, bool hi, const uint32_t (&seed)[8], uint32_t extra, int nextra, int rate, uint32_t dom)
+{
+#pragma unroll
+    for (int l = 0; l < 25; l++) s.w[l] = 0;
+#pragma unroll
+    for (int l = 0; l < 4; l++) s.w[l] = hi ? seed[2 * l + 1] : seed[2 * l];
+    if (!hi) s.w[4] = (extra & ((1u << (8 * nextra)) - 1u)) | (dom << (8 * nextra));
+    const int last = rate / 8 - 1;
+#pragma unroll
+    for (int l = 0; l < 25; l++)
+        if (l == last && hi) s.w[l] ^= 0x80000000u;
+}
+// sha3_512(d[32] || K) on the pair; both lanes end up with both seeds
+__device__ __forceinline__ void kp_seed_hash(const uint8_t *d32, int K, bool hi, uint32_t (&pub)[8], uint32_t (&noise)[8])
+{
+    uint32_t d[8];
+    kg_load_seed(d, d32);
+    KHalf s;
+    kp_absorb(s, hi, d, (uint32_t)K, 1, 72, 0x06);
+    keccak_f1600_split(s, hi);
+    KState f;
+    kp_full(s, hi, 8, f);
+#pragma unroll
+    for (int l = 0; l < 4; l++) { pub[2 * l] = f.lo[l]; pub[2 * l + 1] = f.hi[l]; noise[2 * l] = f.lo[4 + l]; noise[2 * l + 1] = f.hi[4 + l]; }
+}
+// gen_matrix entry (i, j): both lanes run the rejection parse on the whole squeezed block (the running count is sequential), the
+// even lane stores
+__device__ __forceinline__ void kp_gen_matrix(const uint32_t (&pub)[8], int i, int j, bool hi, bool store, int16_t *__restrict__ r, const XofGuard &xof)
+{
+    KHalf s;
+    kp_absorb(s, hi, pub, (uint32_t)j | ((uint32_t)i << 8), 2, 168, 0x1F);
+    int ctr = 0;
+    const bool st = store && !hi;
+#pragma unroll 1
+    for (int blk = 0; blk < xof.max_blocks && ctr < 256; blk++) { // uniform over the pair: both lanes see the same count
+        keccak_f1600_split(s, hi);
+        KState f;
+        kp_full(s, hi, 21, f);
+        auto parse = [&]<int... Ts>(std::integer_sequence<int, Ts...>) {
+            (([&] {
+                 const uint32_t x = kg_triple<Ts>(f);
+                 const uint32_t v0 = x & 0xFFFu, v1 = x >> 12;
+                 if (v0 < (uint32_t)Q && ctr < 256) { if (st) r[ctr] = (int16_t)v0; ctr++; }
+                 if (v1 < (uint32_t)Q && ctr < 256) { if (st) r[ctr] = (int16_t)v1; ctr++; }
+             }()),
+             ...);
+        };
+        parse(std::make_integer_sequence<int, 56>{});
+    }
+    if (ctr < 256) {
+        if (st) {
+            for (; ctr < 256; ctr++) r[ctr] = 0;
+            if (xof.err) *reinterpret_cast<volatile uint32_t *>(xof.err) = DEVERR_XOF_BLOCKS;
+        }
+    }
+}
+// poly_getnoise_eta1: eta1 == 2: every lane turns its own dwords of the block into coefficients (dword W = 2 l + half -> eight
+// coefficients, no exchange); eta1 == 3: 3-byte groups straddle dwords, so both lanes rebuild the block and the even lane runs the
+// one-lane parse
+__device__ __forceinline__ void kp_noise(const uint32_t (&noise)[8], int nonce, int eta1, bool hi, bool store, int16_t *__restrict__ r)
+{
+    KHalf s;
+    kp_absorb(s, hi, noise, (uint32_t)nonce, 1, 136, 0x1F);
+    keccak_f1600_split(s, hi);
+    if (eta1 == 2) {
+        if (store) {
+#pragma unroll
+            for (int l = 0; l < 16; l++) reinterpret_cast<uint4 *>(r)[2 * l + (hi ? 1 : 0)] = kg_cbd2_word(s.w[l]);
+        }
+        return;
+    }
+    const bool st = store && !hi;
+    KState f;
+    kp_full(s, hi, 17, f);
+    auto go1 = [&]<int... Ts>(std::integer_sequence<int, Ts...>) {
+        ((st ? (void)(reinterpret_cast<uint2 *>(r)[Ts] = kg_cbd3_triple(kg_triple<Ts>(f))) : (void)0), ...);
+    };
+    go1(std::make_integer_sequence<int, 45>{});
+    const uint32_t carry = kdword<33>(f) >> 24; // byte 135
+    keccak_f1600_split(s, hi);
+    kp_full(s, hi, 8, f); // bytes 0 .. 55 of block 2 (triples 45 .. 63 end at byte 56)
+    if (st) reinterpret_cast<uint2 *>(r)[45] = kg_cbd3_triple(carry | ((kdword<0>(f) & 0xFFFFu) << 8));
+    auto go2 = [&]<int... Us>(std::integer_sequence<int, Us...>) {
+        (([&] {
+             constexpr int bit = 16 + 24 * Us, k = bit / 32, sh = bit % 32;
+             uint32_t x;
+             if constexpr (sh == 0) x = kdword<k>(f) & 0xFFFFFFu;
+             else if constexpr (sh == 8) x = kdword<k>(f) >> 8;
+             else x = __builtin_amdgcn_alignbit(kdword<k + 1>(f), kdword<k>(f), sh) & 0xFFFFFFu;
+             if (st) reinterpret_cast<uint2 *>(r)[46 + Us] = kg_cbd3_triple(x);
+         }()),
+         ...);
+    };
+    go2(std::make_integer_sequence<int, 18>{});
 }
 
 } // namespace kosk

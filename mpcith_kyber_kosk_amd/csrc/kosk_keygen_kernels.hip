@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kosk_device.hpp"
+#include <cstdlib>
 #include <utility>
 
 #include "kosk_keccak_dev.hpp"
@@ -30,6 +31,19 @@ __global__ __launch_bounds__(64) void k_gen_matrix(const uint8_t *__restrict__ s
     uint32_t pub[8];
     kg_load_seed(pub, seeds + (size_t)b * seed_stride);
     kg_gen_matrix(pub, i, j, A + (size_t)b * A_stride + (size_t)ij * 256, xof);
+}
+
+// the same on the lane-pair sponge (kp_gen_matrix): 32 entries per 64-thread block
+__global__ __launch_bounds__(64) void k_gen_matrix_pair(const uint8_t *__restrict__ seeds, size_t seed_stride, int16_t *__restrict__ A,
+                                                        size_t A_stride, int K, int n, XofGuard xof)
+{
+    const int pr = (blockIdx.x * 64 + threadIdx.x) >> 1, total = n * K * K;
+    const bool hi = threadIdx.x & 1, live = pr < total;
+    const int t = live ? pr : total - 1;
+    const int b = t / (K * K), ij = t - b * K * K, i = ij / K, j = ij - i * K;
+    uint32_t pub[8];
+    kg_load_seed(pub, seeds + (size_t)b * seed_stride);
+    kp_gen_matrix(pub, i, j, hi, live, A + (size_t)b * A_stride + (size_t)ij * 256, xof);
 }
 
 // poly.c:124-139 on a pair of centred coefficients
@@ -92,7 +106,9 @@ hipError_t launch_decode_pk(const uint8_t *pk, size_t pk_stride, uint16_t *t_out
 {
     hipLaunchKernelGGL(k_decode_pk, dim3(K, n), dim3(128), 0, st, pk, pk_stride, t_out, K);
     // gen_matrix from the seed stored behind the packed t (kosk.cpp:96-99)
-    hipLaunchKernelGGL(k_gen_matrix, dim3((n * K * K + 63) / 64), dim3(64), 0, st, pk + 384 * K, pk_stride, A, A_stride, K, n, xof);
+    static const bool pair = !(getenv("KOSK_PRE_PAIR") && atoi(getenv("KOSK_PRE_PAIR")) == 0);
+    if (pair) hipLaunchKernelGGL(k_gen_matrix_pair, dim3((n * K * K + 31) / 32), dim3(64), 0, st, pk + 384 * K, pk_stride, A, A_stride, K, n, xof);
+    else hipLaunchKernelGGL(k_gen_matrix, dim3((n * K * K + 63) / 64), dim3(64), 0, st, pk + 384 * K, pk_stride, A, A_stride, K, n, xof);
     return hipGetLastError();
 }
 

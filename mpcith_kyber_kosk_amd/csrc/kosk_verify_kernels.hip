@@ -10,7 +10,10 @@
 
 #include "kosk_device.hpp"
 #include "kosk_keccak_dev.hpp"
+#include "kosk_keccak_split_dev.hpp"
 #include "kosk_math.hpp"
+
+#include <cstdlib>
 #include "kosk_limb_dev.hpp"
 
 namespace kosk {
@@ -246,9 +249,87 @@ __global__ __launch_bounds__(64) void k_opened_hash(OpenedHashArgs a)
     }
 }
 
+// The same hashes on the LANE-PAIR sponge (kosk_keccak_split_dev.hpp; round 5, default): one state on two adjacent lanes -- the even
+// lane holds the low halves of the 25 words, the odd lane the high halves -- 120 instead of 180 vector instructions per lane and
+// round.  These launches are 3 (5 with pairs) waves per proof, every wave alone on its SIMD: their time is the dependent chain of
+// three / four permutations at one wave's issue rate (~9 us each), so two thirds of the instructions are two thirds of the time.
+// A lane absorbs only its half of every 64-bit word: the even lane message words 4 L, 4 L + 1, the odd lane 4 L + 2, 4 L + 3.
+template <int K, bool VIEW, int W0, bool HI>
+__device__ __forceinline__ void opened_absorb_half(KHalf &s, const OpenedHashArgs &a, const uint8_t *img, const uint16_t *col,
+                                                   const uint16_t *ocol, int i, const uint8_t *prefix)
+{
+    using Msg = OpenedMsg<K, VIEW>;
+    constexpr int PW = VIEW ? 16 : 0, TOTAL = PW + Msg::WORDS;
+    auto put = [&](auto lc) {
+        constexpr int L = decltype(lc)::value;       // 64-bit word of the rate block
+        constexpr int gw = W0 + 4 * L + (HI ? 2 : 0); // first of this lane's two message words
+        if constexpr (gw < TOTAL) {
+            uint32_t v;
+            if constexpr (gw < PW) v = *reinterpret_cast<const uint32_t *>(prefix + 2 * gw);
+            else {
+                v = Msg::template word<gw - PW>(a, img, col, ocol, i);
+                if constexpr (gw + 1 < TOTAL) v |= Msg::template word<gw + 1 - PW>(a, img, col, ocol, i) << 16;
+            }
+            s.w[L] ^= v;
+        }
+    };
+    [&]<int... Ls>(std::integer_sequence<int, Ls...>) { (put(std::integral_constant<int, Ls>{}), ...); }(std::make_integer_sequence<int, 17>{});
+}
+
+template <int K, bool VIEW>
+__global__ __launch_bounds__(64) void k_opened_hash_pair(OpenedHashArgs a)
+{
+    const int pr = (blockIdx.x * 64 + threadIdx.x) >> 1, b = blockIdx.y;
+    const bool hi = threadIdx.x & 1;
+    const bool live = pr < NOPEN;
+    const int i = live ? pr : NOPEN - 1; // idle pairs hash the last opened party again and store nothing (all 64 lanes stay active: DPP)
+    using Msg = OpenedMsg<K, VIEW>;
+    constexpr int PW = VIEW ? 16 : 0, TOTAL = PW + Msg::WORDS, NBLK = TOTAL / 68 + 1;
+    const int party = a.opened[(size_t)b * a.sel_stride + i];
+    const uint8_t *img = a.proof + (size_t)b * a.image_stride;
+    const uint16_t *col = a.P + (size_t)b * a.proof_stride + NSEC + party;
+    const uint16_t *ocol = a.O + (size_t)b * a.o_stride + i;
+    const size_t dig = ((size_t)b * NPARTY + party) * 32;
+    const uint8_t *prefix = VIEW ? a.prefix + dig : nullptr;
+    KHalf s;
+#pragma unroll
+    for (int k = 0; k < 25; k++) s.w[k] = 0;
+    [&]<int... Bs>(std::integer_sequence<int, Bs...>) {
+        (([&] {
+             if (hi) opened_absorb_half<K, VIEW, Bs * 68, true>(s, a, img, col, ocol, i, prefix);
+             else opened_absorb_half<K, VIEW, Bs * 68, false>(s, a, img, col, ocol, i, prefix);
+             if constexpr (Bs == NBLK - 1) {
+                 constexpr int padbyte = 2 * TOTAL - (NBLK - 1) * 136;
+                 constexpr uint32_t padv = 0x06u << (8 * (padbyte % 4));
+                 if (hi == ((padbyte % 8) >= 4)) s.w[padbyte / 8] ^= padv;
+                 if (hi) s.w[16] ^= 0x80000000u;
+             }
+             keccak_f1600_split(s, hi);
+         }()),
+         ...);
+    }(std::make_integer_sequence<int, NBLK>{});
+    if (!live) return;
+    uint32_t *o = reinterpret_cast<uint32_t *>(a.out + dig) + (hi ? 1 : 0);
+#pragma unroll
+    for (int L = 0; L < 4; L++) o[2 * L] = s.w[L];
+    if (a.out_compact) {
+        uint32_t *oc = reinterpret_cast<uint32_t *>(a.out_compact + ((size_t)b * NOPEN + i) * 32) + (hi ? 1 : 0);
+#pragma unroll
+        for (int L = 0; L < 4; L++) oc[2 * L] = s.w[L];
+    }
+}
+
 template <int K>
 static void launch_opened_hash_k(const OpenedHashArgs &a, bool view, int nproofs, hipStream_t st)
 {
+    // KOSK_OPENED_HASH_PAIR=0 (per process): one state per lane, as in rounds 1-4
+    static const bool pair = !(getenv("KOSK_OPENED_HASH_PAIR") && atoi(getenv("KOSK_OPENED_HASH_PAIR")) == 0);
+    if (pair) {
+        dim3 grid((2 * NOPEN + 63) / 64, nproofs);
+        if (view) hipLaunchKernelGGL((k_opened_hash_pair<K, true>), grid, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_opened_hash_pair<K, false>), grid, dim3(64), 0, st, a);
+        return;
+    }
     dim3 grid((NOPEN + 63) / 64, nproofs);
     if (view) hipLaunchKernelGGL((k_opened_hash<K, true>), grid, dim3(64), 0, st, a);
     else hipLaunchKernelGGL((k_opened_hash<K, false>), grid, dim3(64), 0, st, a);
