@@ -48,10 +48,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 
 CONFIGS = {  # 1-based config number -> (kyber_k, proofs per GPU per step, default slots, host threads per slot, handles per cohort)
-    # configs 2 and 3: nine caller threads, each with its own handle and its own 46-proof calls; the library serves the calls of
-    # a cohort of three handles with one pipeline run (KOSK_COMBINE=3, include/kosk_mi355x.h), i.e. three merged runs in flight
-    2: dict(k=2, batch=46, slots=9, threads=6, combine=3, what="Kyber-512 (KYBER_K=2), 46 proofs = 66 884 party lanes per GPU per step"),
-    3: dict(k=3, batch=46, slots=9, threads=6, combine=3, what="Kyber-768 (KYBER_K=3), 46 proofs = 66 884 party lanes per GPU per step"),
+    # configs 2 and 3: twelve caller threads, each with its own handle and its own 46-proof calls; the library serves the calls of
+    # a cohort of four handles with one pipeline run (KOSK_COMBINE=4, include/kosk_mi355x.h), i.e. three merged runs in flight.
+    # (Round 4: nine callers in cohorts of three.  With round 5's kernels -- persistent table product, streaming beta / gamma kernel --
+    # the four-caller cohort went from 133 k proofs/s at 4.0 ms per call to 157-166 k at 3.3 ms, the three-caller one from 147 k to
+    # 148-150 k at 2.75 ms: `cohorts_of_three` in the line is that arrangement on the same box, for a like-for-like comparison.)
+    2: dict(k=2, batch=46, slots=12, threads=6, combine=4, what="Kyber-512 (KYBER_K=2), 46 proofs = 66 884 party lanes per GPU per step"),
+    3: dict(k=3, batch=46, slots=12, threads=6, combine=4, what="Kyber-768 (KYBER_K=3), 46 proofs = 66 884 party lanes per GPU per step"),
     4: dict(k=4, batch=91, slots=9, threads=6, combine=3, what="Kyber-1024 (KYBER_K=4), 91 proofs = 132 314 party lanes per GPU per step "
                                                     "(2^20 lanes over 8 GPUs, proof-aligned), digest tables all-gathered after each commitment round"),
     5: dict(k=3, batch=512, slots=4, threads=8, what="Kyber-768 (KYBER_K=3), 512 verifiable keygens per GPU per step (4096 over 8 GPUs, throughput mode)"),
@@ -909,8 +912,8 @@ def main():
                 except Exception as e:  # noqa: BLE001  (TimeoutExpired, a missing key, bad JSON ...)
                     return {"error": repr(e)[:400]}
             # one cohort ALONE on the GPU (three callers, one merged run in flight): the graded kernel's launch time without co-running kernels
-            oc_ = side_run(3, 3, "python bench.py --combine 3 --slots 3: ONE cohort alone on the GPU; its view-commitment launches are not stretched by "
-                                 "other cohorts' kernels; not the line of record")
+            oc_ = side_run(CMB, CMB, "python bench.py --combine %d --slots %d: ONE cohort alone on the GPU; its view-commitment launches are not stretched by "
+                                     "other cohorts' kernels; not the line of record" % (CMB, CMB))
             line["one_cohort_alone"] = oc_
             if line.get("roofline") is not None and oc_.get("hash_view_avg_us"):
                 ppl_ = oc_.get("hash_view_proofs_per_launch") or 0
@@ -919,8 +922,8 @@ def main():
                 line["roofline"]["alone_frac"] = ppl_ * 1454 * (VIEW_MSG[k] + 32) / (oc_["hash_view_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
             line["uncombined"] = side_run(6, 1, "python bench.py --combine 1 --slots 6: six independent handles, every launch serves one 46-proof call "
                                                 "(round 3's line of record); not the line of record")
-            line["cohorts_of_four"] = side_run(12, 4, "python bench.py --combine 4 --slots 12: twelve callers, four per merged run (184 proofs per launch: the arrangement "
-                                                      "where this round's shorter kernels show -- 133 k proofs/s at 4.0 ms in round 4); not the line of record")
+            line["cohorts_of_three"] = side_run(9, 3, "python bench.py --combine 3 --slots 9: nine callers, three per merged run (138 proofs per launch): round 4's line of "
+                                                      "record (147.6 k proofs/s at 2.8 ms there), on this box for a like-for-like comparison; not the line of record")
             line["cohorts_of_five"] = side_run(15, 5, "python bench.py --combine 5 --slots 15: fifteen callers, five per merged run (more proofs per launch at "
                                                       "more latency per call); not the line of record")
         if world == 1 and not args.no_cpu_baseline:

@@ -1510,7 +1510,7 @@ __global__ __launch_bounds__(512, 1) void k_table_gemm_p(GemmArgs a, int nchunks
         for (int ks = 0; ks < KS; ks++) load_chunk_ks(c_first, ks, fa[ks]);
     }
     __syncthreads();
-    const v4i zero4 = {0, 0, 0, 0};
+    const v4i zero4 = {0, 0, 0, 0}, bias4 = {LIMB_BIAS, LIMB_BIAS, LIMB_BIAS, LIMB_BIAS};
     const int grp = lane >> 4;
     int buf = 0;
     while (u < u1) {
@@ -1575,7 +1575,7 @@ __global__ __launch_bounds__(512, 1) void k_table_gemm_p(GemmArgs a, int nchunks
                 load_b(ks + 1 < KS ? ks + 1 : 0, bn);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < NBT; j++) s0[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][0], bc[2 * j], ks == 0 ? zero4 : s0[j], 0, 0, 0);
+                for (int j = 0; j < NBT; j++) s0[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][0], bc[2 * j], ks == 0 ? bias4 : s0[j], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < NBT; j++) s1[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][0], bc[2 * j + 1], ks == 0 ? zero4 : s1[j], 0, 0, 0);
 #pragma unroll
@@ -1590,8 +1590,8 @@ __global__ __launch_bounds__(512, 1) void k_table_gemm_p(GemmArgs a, int nchunks
             for (int j = 0; j < NBT; j++) {
                 uint32_t v[4];
 #pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = gf_reduce_limbs(s0[j][r], s1[j][r], s2[j][r]);
-                pk[j] = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+                for (int r = 0; r < 4; r++) v[r] = gf_reduce_limbs_biased_lazy(s0[j][r], s1[j][r], s2[j][r]); // the bias came in with the first MFMA
+                pk[j] = make_uint2(gf_canon_pair(v[0], v[1]), gf_canon_pair(v[2], v[3]));
                 if (j & 1) store_pair(j - 1, c, pk[j - 1], pk[j]);
                 else if (j == NBT - 1) store_one(j, c, pk[j]);
             }
@@ -1762,16 +1762,13 @@ __global__ __launch_bounds__(256) void k_lincomb_fused(const uint16_t *P, size_t
 #pragma unroll
                     for (int r = 0; r < 4; r++)
                         v[4 * h + r] = gf_reduce_limbs(s0[2 * ip + h][j][r], s1[2 * ip + h][j][r], s2[2 * ip + h][j][r]);
-                *reinterpret_cast<uint4 *>(crow + m) = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+                const uint32_t pw[4] = {v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+                *reinterpret_cast<uint4 *>(crow + m) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
                 if (which == 0 && jo >= NCHK) { // r rows: s + r_i, e + r_{K+i} on the spot (mlwe_prover.cpp:222-245)
                     const int idx = jo - NCHK;
                     const int src_row = idx < K ? row_s + idx : row_e + (idx - K), dst_row = idx < K ? row_sr + idx : row_er + (idx - K);
                     const uint4 sv = *reinterpret_cast<const uint4 *>(Cb + (size_t)src_row * RS + m);
-                    const uint32_t sw[4] = {sv.x, sv.y, sv.z, sv.w};
-                    uint32_t ow[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) ow[q] = gf_add(sw[q] & 0xFFFFu, v[2 * q]) | (gf_add(sw[q] >> 16, v[2 * q + 1]) << 16);
-                    *reinterpret_cast<uint4 *>(Cb + (size_t)dst_row * RS + m) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                    *reinterpret_cast<uint4 *>(Cb + (size_t)dst_row * RS + m) = make_uint4(gf_add_pair(sv.x, pw[0]), gf_add_pair(sv.y, pw[1]), gf_add_pair(sv.z, pw[2]), gf_add_pair(sv.w, pw[3]));
                 }
             }
         }
@@ -1869,13 +1866,14 @@ __global__ __launch_bounds__(256, 2) void k_lincomb_stream(const uint16_t *P, si
     }
     const int frag = (lane & 15) * 64 + (((lane >> 4) ^ limb_swz(lane & 15)) << 4);
     int g_cur = -1;
-    int lrow[LS_JT]; // output rows of this lane's five columns (looked up once per group: a lookup inside the epilogue would make it wait for the prefetch)
+    // output rows of the group's columns, in LDS (looked up once per group: a global lookup inside the epilogue would make it wait for
+    // the prefetch, and five more registers per lane do not fit beside 120 accumulators and the prefetch)
+    __shared__ int16_t lrow_s[16 * LS_JT];
     for (int fb = fb0; fb < fb1; fb++) {
         const int g = fb / MB, m0 = (fb - g * MB) * 128, b = g >> 1, which = g & 1;
         if (g != g_cur) { // this group's coefficient tiles (the previous group's readers passed the barrier at the end of its last block)
             g_cur = g;
-#pragma unroll
-            for (int j = 0; j < LS_JT; j++) lrow[j] = j * 16 + (lane & 15) < J ? (int)lin_rows[which * 128 + j * 16 + (lane & 15)] : 0;
+            if (tid < 16 * LS_JT) lrow_s[tid] = tid < J ? lin_rows[which * 128 + tid] : (int16_t)0; // (read behind the barrier that follows stage())
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 const uint4 *src = reinterpret_cast<const uint4 *>(coef + ((size_t)ks * BRT + (size_t)g * 8) * 2048);
@@ -1918,22 +1916,19 @@ __global__ __launch_bounds__(256, 2) void k_lincomb_stream(const uint16_t *P, si
             for (int j = 0; j < LS_JT; j++) {
                 const int jo = j * 16 + (lane & 15);
                 if (jo >= J) continue;
-                uint16_t *crow = Cb + (size_t)lrow[j] * RS;
+                uint16_t *crow = Cb + (size_t)lrow_s[jo] * RS;
                 uint32_t v[8];
 #pragma unroll
                 for (int h = 0; h < 2; h++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) v[4 * h + r] = gf_reduce_limbs(s0[h][j][r], s1[h][j][r], s2[h][j][r]);
-                *reinterpret_cast<uint4 *>(crow + m) = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+                    for (int r = 0; r < 4; r++) v[4 * h + r] = gf_reduce_limbs_lazy(s0[h][j][r], s1[h][j][r], s2[h][j][r]);
+                const uint32_t pw[4] = {gf_canon_pair(v[0], v[1]), gf_canon_pair(v[2], v[3]), gf_canon_pair(v[4], v[5]), gf_canon_pair(v[6], v[7])};
+                *reinterpret_cast<uint4 *>(crow + m) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
                 if (j == LS_JT - 1 && which == 0 && jo >= NCHK) { // r rows (columns 70 .. 69 + 2K, all in the last tile): s + r_i, e + r_{K+i} on the spot (mlwe_prover.cpp:222-245)
                     const int idx = jo - NCHK;
                     const int src_row = idx < K ? row_s + idx : row_e + (idx - K), dst_row = idx < K ? row_sr + idx : row_er + (idx - K);
                     const uint4 sv = *reinterpret_cast<const uint4 *>(Cb + (size_t)src_row * RS + m);
-                    const uint32_t sw[4] = {sv.x, sv.y, sv.z, sv.w};
-                    uint32_t ow[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) ow[q] = gf_add(sw[q] & 0xFFFFu, v[2 * q]) | (gf_add(sw[q] >> 16, v[2 * q + 1]) << 16);
-                    *reinterpret_cast<uint4 *>(Cb + (size_t)dst_row * RS + m) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                    *reinterpret_cast<uint4 *>(Cb + (size_t)dst_row * RS + m) = make_uint4(gf_add_pair(sv.x, pw[0]), gf_add_pair(sv.y, pw[1]), gf_add_pair(sv.z, pw[2]), gf_add_pair(sv.w, pw[3]));
                 }
             }
         }
