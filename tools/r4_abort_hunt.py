@@ -1,3 +1,4 @@
+# (round 5: KOSK_REGISTER=2, the knob this script hunted, has been removed from the library; kept for the record of profiles/r04_abort_hunt.txt)
 """Bounded hunt for the silent SIGABRT of round 4's one aborted suite run (profiles/r04_gputest_aborted.log): the FIRST call on a
 fresh handle, a multi-chunk compact host-buffer call that page-locks the whole pages inside a pageable Python buffer (KOSK_REGISTER=2, the
 default of rounds 2-3), next to another live handle -- `iters` times, every buffer allocated anew.  Run it with AMD_LOG_LEVEL=1 and
