@@ -253,6 +253,10 @@ class Kosk:
         self._chk(lib.kosk_stage_verifier_inputs_compact(self._h, len(blobs), b"".join(blobs), b"".join(pks)), "stage_verifier_inputs_compact")
 
     # second-level entry points (reference structs as bytes; see include/kosk_mi355x.h)
+    def stage_verifier_inputs(self, pis, pks):
+        """proof images and public keys into HBM for verify_resident (kosk_stage_verifier_inputs)"""
+        self._chk(lib.kosk_stage_verifier_inputs(self._h, len(pis), b"".join(pis), b"".join(pks)), "stage_verifier_inputs")
+
     def prepare_randomness(self, tapes=None, n=None):
         n = len(tapes) if tapes is not None else n
         size = lib.kosk_randomness_bytes(self.k)
@@ -386,7 +390,7 @@ class Kosk:
         return a.value, b.value
 
     PATH_IDS = ["hash_dma", "hash_plain", "hash_primer", "table_gemm", "limb_gemm", "copy_direct", "copy_staged", "graph_replay",
-                "ntt_fp32", "ntt_int", "digest_direct", "digest_copy", "copy_kernel", "small_copy_kernel", "lincomb_oneshot", "lincomb_stream", "assemble_fields", "assemble_groups"]
+                "ntt_fp32", "ntt_int", "digest_direct", "digest_copy", "copy_kernel", "small_copy_kernel", "lincomb_oneshot", "lincomb_stream", "assemble_fields", "assemble_groups", "table_chunks"]
 
     def path_counts(self):
         """{name: launches / copies} of the alternative kernel and copy paths on this handle since it was created"""

@@ -60,6 +60,8 @@ Ctx::~Ctx()
     if (ev_sync) (void)hipEventDestroy(ev_sync);
     for (auto e : ev_img)
         if (e) (void)hipEventDestroy(e);
+    for (auto e : ev_chunk)
+        if (e) (void)hipEventDestroy(e);
     if (is_view) {
         if (h_err) (void)hipHostFree(h_err);
         // a view owns its events, host workers and compact staging; tables, workspace and the stream belong to the arena
@@ -174,6 +176,51 @@ hipError_t copy_table_to_host(Ctx &c, void *h_dst, const void *d_src, size_t byt
         return launch_copy_to_host(d_src, h_dst, bytes, c.copy_waves, c.stream);
     }
     return hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c.stream);
+}
+
+hipError_t copy_round_table(Ctx &c, uint8_t *h_dst, const uint8_t *d_src, int n)
+{
+    const size_t per_proof = (size_t)NPARTY * 32;
+    c.chunk_n = 0;
+    int nch = c.table_chunks < Ctx::TABLE_CHUNKS_MAX ? c.table_chunks : Ctx::TABLE_CHUNKS_MAX;
+    if (nch < 2 || n < 48 || c.capturing || c.use_graphs || c.copy_waves > 0 || !c.ev_chunk[0]) return copy_table_to_host(c, h_dst, d_src, (size_t)n * per_proof);
+    const int per = ((n + nch - 1) / nch + 7) & ~7; // whole 8-proof groups of the host's eight-way SHA-3
+    nch = (n + per - 1) / per;
+    if (nch < 2) return copy_table_to_host(c, h_dst, d_src, (size_t)n * per_proof);
+    for (int k = 0; k < nch; k++) {
+        const int first = k * per, cnt = (first + per <= n ? per : n - first);
+        const hipError_t e = hipMemcpyAsync(h_dst + (size_t)first * per_proof, d_src + (size_t)first * per_proof, (size_t)cnt * per_proof, hipMemcpyDeviceToHost, c.stream);
+        if (e != hipSuccess) return e;
+        if (k + 1 < nch) {
+            const hipError_t e2 = hipEventRecord(c.ev_chunk[k], c.stream);
+            if (e2 != hipSuccess) return e2;
+        }
+    }
+    __atomic_store_n(&c.chunk_passed, 0, __ATOMIC_RELEASE);
+    c.chunk_per = per;
+    c.chunk_n = nch;
+    c.path_n[PATH_TABLE_CHUNKS]++;
+    return hipSuccess;
+}
+
+// called by the host's workers in front of a proof's table (fs_*_batch's prep hook): the piece that holds it has landed.  Pieces
+// land in order, so the highest piece seen is all the state there is; several workers may wait for the same event.
+hipError_t table_gate_wait(Ctx &c, int proof)
+{
+    const int k = proof / c.chunk_per;
+    if (k <= 0 || __atomic_load_n(&c.chunk_passed, __ATOMIC_ACQUIRE) >= k) return hipSuccess;
+    const hipError_t e = hipEventSynchronize(k + 1 < c.chunk_n ? c.ev_chunk[k] : c.ev);
+    if (e != hipSuccess) return e;
+    int seen = __atomic_load_n(&c.chunk_passed, __ATOMIC_RELAXED);
+    while (seen < k && !__atomic_compare_exchange_n(&c.chunk_passed, &seen, k, true, __ATOMIC_RELEASE, __ATOMIC_RELAXED)) {}
+    return hipSuccess;
+}
+
+hipError_t table_done(Ctx &c)
+{
+    if (c.chunk_n < 2) return hipSuccess;
+    c.chunk_n = 0;
+    return hipEventSynchronize(c.ev); // behind the last piece: passed already unless no worker reached it
 }
 
 hipError_t copy_small(Ctx &c, void *dst, size_t dst_stride, const void *src, size_t src_stride, size_t row_bytes, size_t nrows, hipMemcpyKind kind, hipStream_t st)
@@ -458,6 +505,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     if (const char *e = getenv("KOSK_NTT_FP32")) c.ntt_fp32 = atoi(e) != 0;
     if (const char *e = getenv("KOSK_BLOCKING_SYNC")) c.blocking_sync = atoi(e) != 0;
     if (const char *e = getenv("KOSK_WAIT_NAP")) c.wait_nap = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_TABLE_CHUNKS")) c.table_chunks = atoi(e);
     if (const char *e = getenv("KOSK_HASH_SPLIT")) c.hash_split = atoi(e) != 0;
     if (const char *e = getenv("KOSK_HASH_DMA")) c.hash_dma = atoi(e) != 0;
     if (const char *e = getenv("KOSK_HASH_PRIMER")) c.hash_primer = atoi(e) != 0;
@@ -467,6 +515,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     if (const char *e = getenv("KOSK_STRICT_ENCODING")) c.strict_encoding = atoi(e) != 0;
     if (const char *e = getenv("KOSK_ASSEMBLE_GROUPS")) c.assemble_groups = atoi(e) != 0;
     if (const char *e = getenv("KOSK_SMALL_COPY_KERNEL")) c.small_copy_kernel = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_ALPHA_DIRECT")) c.alpha_direct = atoi(e) != 0;
     if (const char *e = getenv("KOSK_COPY_WAVES")) c.copy_waves = atoi(e) >= 0 ? (atoi(e) > 65535 ? 65535 : atoi(e)) : c.copy_waves;
     if (const char *e = getenv("KOSK_DEBUG_XOF_BLOCKS")) c.xof_max_blocks = atoi(e) > 0 ? atoi(e) : c.xof_max_blocks;
     if (const char *e = getenv("KOSK_CU_PARTITION")) {
@@ -514,6 +563,8 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
         HIPCHK(hipEventCreateWithFlags(&c.ev_kg, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
         if (c.blocking_sync) HIPCHK(hipEventCreateWithFlags(&c.ev_sync, hipEventDisableTiming | hipEventBlockingSync));
         else if (c.wait_nap) HIPCHK(hipEventCreateWithFlags(&c.ev_sync, hipEventDisableTiming));
+        if (c.table_chunks > 1)
+            for (auto &e : c.ev_chunk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
         for (auto &pe : c.prof_ev)
             for (auto &e : pe) HIPCHK(hipEventCreate(&e));
         if (build_tables(c)) return -1;
@@ -607,6 +658,8 @@ int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx
     c.use_graphs = false; // stream capture is per stream: not with several callers on one
     c.ev = nullptr; c.ev_kg = nullptr; c.ev_sync = nullptr; c.pool = nullptr;
     for (auto &e : c.ev_img) e = nullptr;
+    for (auto &e : c.ev_chunk) e = nullptr;
+    c.chunk_n = 0;
     c.host_img = nullptr;
     c.h_err = nullptr;
     for (auto &e : c.timer_ev) e = nullptr;
@@ -630,6 +683,8 @@ int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx
         HIPCHK(hipEventCreateWithFlags(&c.ev_kg, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
         if (c.blocking_sync) HIPCHK(hipEventCreateWithFlags(&c.ev_sync, hipEventDisableTiming | hipEventBlockingSync));
         else if (c.wait_nap) HIPCHK(hipEventCreateWithFlags(&c.ev_sync, hipEventDisableTiming));
+        if (c.table_chunks > 1)
+            for (auto &e : c.ev_chunk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
         for (auto &pe : c.prof_ev)
             for (auto &e : pe) HIPCHK(hipEventCreate(&e));
         for (auto &e : c.ev_img) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
@@ -883,7 +938,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         // the host's table: written by the hash launch itself (HashArgs::out_host), or copied behind it
         h1.out_host = c.digest_direct ? c.h_dig : nullptr;
         HIPCHK(commit_hash_batch(c, h1, n, K, false, st));
-        if (!c.digest_direct) HIPCHK(copy_table_to_host(c, c.h_dig, c.d_dig1, (size_t)n * NPARTY * 32));
+        if (!c.digest_direct) HIPCHK(copy_round_table(c, c.h_dig, c.d_dig1, n));
         if (!c.capturing) c.path_n[c.digest_direct ? PATH_DIGEST_DIRECT : PATH_DIGEST_COPY]++;
         return 0;
     }, c.tape_cur, c.tape_cur_stride)) return -1; // the tape pointer is baked into the captured launch: part of the graph's key
@@ -908,8 +963,13 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         keys_done = true;
     }
     c.kg_on_host_pending = false;
-    HIPCHK(wait_event(c, c.ev, 0, n));
+    HIPCHK(wait_event(c, first_event(c), 0, n)); // the table, or its first piece (copy_round_table)
     t1 = now_sec(); c.phase_sec[PH_GPU_COMMIT] = t1 - t0; t0 = t1;
+    hipError_t gate_err = hipSuccess;
+    const std::function<void(int)> gate = [&c, &gate_err](int b) {
+        const hipError_t e = table_gate_wait(c, b);
+        if (e != hipSuccess) gate_err = e;
+    };
     // a round's table is complete in HBM: the hook of every caller of this run with ITS block of the table (a merged run), else the
     // context's own hook with the whole batch
     auto fire_hooks = [&](int rnd, const uint8_t *d_table) {
@@ -930,15 +990,23 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
 
     // ---- Fiat-Shamir round 1 on the host
     if (keygen && !keys_done) finish_keygen_segs(c, n, *keygen);
-    fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool);
+    fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool, c.chunk_n > 1 ? &gate : nullptr);
+    HIPCHK(gate_err);
+    HIPCHK(table_done(c));
     t1 = now_sec(); c.phase_sec[PH_FS_ALPHA] = t1 - t0; t0 = t1;
 
     // ---- P2: beta, gamma, r, NTT_r on every evaluation point (per proof a [J x M] x [M x 1710] product mod q, :159-203),
     // s + r / e + r (:222-245), then the view commitments, which read nothing else of the relation phase
     if (run_segment(c, Ctx::SEG_P2, n, [&]() -> int {
-        HIPCHK(copy_small(c, c.d_alpha, 0, c.h_alpha, 0, (size_t)n * 80 * 2, 1, hipMemcpyHostToDevice, st));
+        // (round 5) the challenge vectors are read by k_coef_limbs straight from the page-locked host table (160 bytes per proof): one
+        // launch less between the host's round and the product; KOSK_SMALL_COPY_KERNEL=0 keeps the explicit copy
+        const uint16_t *alpha_src = c.h_alpha;
+        if (!c.small_copy_kernel || !c.alpha_direct) {
+            HIPCHK(copy_small(c, c.d_alpha, 0, c.h_alpha, 0, (size_t)n * 80 * 2, 1, hipMemcpyHostToDevice, st));
+            alpha_src = c.d_alpha;
+        }
         c.prof_begin(PR_LINCOMB, n);
-        HIPCHK(launch_coef_limbs(c.d_alpha, P.J, P.M, c.d_coef, n, st));
+        HIPCHK(launch_coef_limbs(alpha_src, P.J, P.M, c.d_coef, n, st));
         if (c.lincomb_fused) {
             HIPCHK(launch_lincomb_fused(c.d_P, c.proof_stride, rm, c.d_coef, c.d_P, c.d_lin_rows, P.J, n, st, c.lincomb_fused)); // includes s + r, e + r
             if (!c.capturing) c.path_n[c.lincomb_fused == 2 ? PATH_LINCOMB_ONESHOT : PATH_LINCOMB_STREAM]++;
@@ -960,7 +1028,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     ha.out = c.d_dig2;
     ha.out_host = c.digest_direct ? c.h_dig2 : nullptr;
     HIPCHK(commit_hash_batch(c, ha, n, K, true, st));
-    if (!c.digest_direct) HIPCHK(copy_table_to_host(c, c.h_dig2, c.d_dig2, (size_t)n * NPARTY * 32));
+    if (!c.digest_direct) HIPCHK(copy_round_table(c, c.h_dig2, c.d_dig2, n));
     c.path_n[c.digest_direct ? PATH_DIGEST_DIRECT : PATH_DIGEST_COPY]++;
     HIPCHK(hipEventRecord(c.ev, st));
     c.phase_sec[PH_P2_ISSUE] = now_sec() - t0;
@@ -988,14 +1056,16 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         return 0;
     })) return -1;
 
-    HIPCHK(wait_event(c, c.ev, 1, n));
+    HIPCHK(wait_event(c, first_event(c), 1, n));
     t1 = now_sec(); c.phase_sec[PH_GPU_RELATION] = t1 - t0; t0 = t1;
     fire_hooks(1, c.d_dig2);
 
     // ---- Fiat-Shamir round 2 on the host
     // I, its complement, and the complement entries owned by each aligned 64-party window (k_assemble_fields), all derived by
     // the worker that hashed the proof's table
-    fs_opened_batch(n, c.h_dig2, (size_t)NPARTY * 32, c.h_I, c.h_rest, c.sel_stride, c.nthreads, c.pool, true);
+    fs_opened_batch(n, c.h_dig2, (size_t)NPARTY * 32, c.h_I, c.h_rest, c.sel_stride, c.nthreads, c.pool, true, c.chunk_n > 1 ? &gate : nullptr);
+    HIPCHK(gate_err);
+    HIPCHK(table_done(c));
     t1 = now_sec(); c.phase_sec[PH_FS_OPEN] = t1 - t0; t0 = t1;
 
     // ---- P3: wire image

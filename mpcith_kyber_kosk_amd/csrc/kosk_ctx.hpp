@@ -69,7 +69,7 @@ enum ProfId { PR_HASH_TCOMM = 0, PR_HASH_VIEW, PR_GEMM_EXPAND1, PR_GEMM_EXPAND2,
 
 enum PathId { PATH_HASH_DMA = 0, PATH_HASH_PLAIN, PATH_HASH_PRIMER, PATH_TABLE_GEMM, PATH_LIMB_GEMM, PATH_COPY_DIRECT, PATH_COPY_STAGED,
               PATH_GRAPH_REPLAY, PATH_NTT_FP32, PATH_NTT_INT, PATH_DIGEST_DIRECT, PATH_DIGEST_COPY, PATH_COPY_KERNEL, PATH_SMALL_COPY_KERNEL,
-              PATH_LINCOMB_ONESHOT, PATH_LINCOMB_STREAM, PATH_ASSEMBLE_FIELDS, PATH_ASSEMBLE_GROUPS, PATH_COUNT };
+              PATH_LINCOMB_ONESHOT, PATH_LINCOMB_STREAM, PATH_ASSEMBLE_FIELDS, PATH_ASSEMBLE_GROUPS, PATH_TABLE_CHUNKS, PATH_COUNT };
 
 struct GemmTable {
     uint8_t *d = nullptr; // limb matrix (kosk_device.hpp)
@@ -222,6 +222,19 @@ struct Ctx {
     const uint8_t *host_img = nullptr;            // the caller's host copy of the proof images of THIS call (kosk_verify_batch)
     size_t host_img_stride = 0;
     hipEvent_t ev = nullptr;
+    // KOSK_TABLE_CHUNKS=n (default 1: one copy per round; opt-in, measured slower): a round's [n][1454][32] digest table goes to the
+    // host in up to TABLE_CHUNKS_MAX pieces of whole 8-proof groups with an event behind each but the last (which has `ev`); the host
+    // starts its round when the FIRST piece has landed and a worker that reaches a later piece waits for that piece's event
+    // (table_gate_wait).  The copy (57 GB/s) and the host's hashing run at about the same rate, so one run ALONE saves most of the
+    // copy time per round -- but with three cohorts sharing the GPU the gaps it closes were already filled by the other cohorts'
+    // kernels, and the extra copies and the workers' event waits cost 1-4 % (profiles/r05_table_chunks.txt).
+    // Plain launches only (an event inside a captured segment would be a graph node), batches of >= 48.
+    static constexpr int TABLE_CHUNKS_MAX = 4;
+    int table_chunks = 1;
+    hipEvent_t ev_chunk[TABLE_CHUNKS_MAX - 1] = {nullptr, nullptr, nullptr};
+    int chunk_n = 0;          // pieces of the table copy under way (0: one copy, nobody looks at the gate)
+    int chunk_per = 0;        // proofs per piece
+    int chunk_passed = 0;     // highest piece known to have landed (atomic builtins: Ctx is copied for views)
     std::vector<uint16_t> v_I2, v_rest2; // the verifier's recomputed opened lists (kept across calls: two fresh 0.4 MB vectors per call were
                                          // an mmap, a page fault per page and a munmap on the tail of every verify call)
     std::function<void()> near_end_hook; // set by a merged run's executor: called once when only the call's tail is left (kosk_combine.hpp: near_end)
@@ -294,6 +307,8 @@ struct Ctx {
     // (INTEGRATION.md 6): folded where it only multiplies / converts to ZZ_p, raw in its non-reducing add / sub and comparisons
     bool strict_encoding = false;
     bool small_copy_kernel = true; // KOSK_SMALL_COPY_KERNEL=0: hipMemcpyAsync for the small copies too (copy_small)
+    bool alpha_direct = true;      // KOSK_ALPHA_DIRECT=0: the challenge vectors are copied into HBM in front of k_coef_limbs / k_pow_table
+                                   // instead of being read by those kernels from the page-locked host table
     bool host_register = true;       // KOSK_REGISTER=0: staging copies only, even for buffers the caller page-locked itself.  (KOSK_REGISTER=2 of
                                      // rounds 2-4 -- the library page-locking PAGEABLE caller memory for a call -- is gone: both process aborts on
                                      // record happened inside calls that had just done that, and neither was ever reproduced or explained)
@@ -379,6 +394,13 @@ hipError_t wait_event(Ctx &c, hipEvent_t ev, int site, int n);
 hipError_t stream_sync_site(Ctx &c, int site, int n);
 // a digest table (or any 16-byte aligned block) from HBM into the context's page-locked host memory, on the context's stream
 hipError_t copy_table_to_host(Ctx &c, void *h_dst, const void *d_src, size_t bytes);
+// a round's digest table of n proofs, in pieces when the call qualifies (Ctx::table_chunks); the caller records c.ev behind it.
+// first_event(c): what the host's round waits for before it starts; table_gate(c): the per-proof hook of fs_*_batch (nullptr when
+// the table came in one piece); table_done(c): every piece has landed (after the round)
+hipError_t copy_round_table(Ctx &c, uint8_t *h_dst, const uint8_t *d_src, int n);
+inline hipEvent_t first_event(const Ctx &c) { return c.chunk_n > 1 ? c.ev_chunk[0] : c.ev; }
+hipError_t table_gate_wait(Ctx &c, int proof);
+hipError_t table_done(Ctx &c);
 // a small copy between HBM and one of the library's OWN page-locked host buffers, rows x row_bytes (kernel or hipMemcpy[2D]Async)
 hipError_t copy_small(Ctx &c, void *dst, size_t dst_stride, const void *src, size_t src_stride, size_t row_bytes, size_t nrows, hipMemcpyKind kind, hipStream_t st);
 // after the stream has been synchronised: -1 (with c.err set, the word cleared) if a kernel of this context raised an error

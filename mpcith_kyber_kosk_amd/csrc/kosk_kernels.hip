@@ -2399,6 +2399,22 @@ __global__ __launch_bounds__(64) void k_assemble_groups(AssembleArgs a, uint32_t
 // the table in 1 KiB pieces with eight pieces in flight (the link needs ~120 KB in flight) and leaves the wave slots to the other
 // cohorts' kernels.  Measured: the copy takes the same time and the kernels beside it get SLOWER (table product 230 against 137 us,
 // fused lincomb 295 against 160 us), 105 k against 133-137 k proofs/s at 128 .. 2 048 waves alike -- default off.
+// MODE 1 (experiment, KOSK_COPY_MODE=1): the same with non-temporal stores (the write-combining hint of the ISA's `nt` bit)
+template <int MODE>
+__global__ __launch_bounds__(64) void k_copy_to_host_m(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * 64;
+    for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < n16; i += stride) {
+        const uint4 v = src[i];
+        if (MODE == 1) {
+            __builtin_nontemporal_store(v.x, &dst[i].x); __builtin_nontemporal_store(v.y, &dst[i].y);
+            __builtin_nontemporal_store(v.z, &dst[i].z); __builtin_nontemporal_store(v.w, &dst[i].w);
+        } else {
+            dst[i] = v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void k_copy_to_host(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
 {
     const size_t stride = (size_t)gridDim.x * 64;
@@ -2503,7 +2519,11 @@ hipError_t launch_copy_to_host(const void *d_src, void *h_dst, size_t bytes, int
 {
     if (!bytes) return hipSuccess;
     if (bytes % 16 || (reinterpret_cast<uintptr_t>(d_src) & 15) || (reinterpret_cast<uintptr_t>(h_dst) & 15)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_copy_to_host, dim3(nwg), dim3(64), 0, st, reinterpret_cast<const uint4 *>(d_src), reinterpret_cast<uint4 *>(h_dst), bytes / 16);
+    static const int mode = getenv("KOSK_COPY_MODE") ? atoi(getenv("KOSK_COPY_MODE")) : 0; // experiment knob (per process): 0 eight stores in flight per lane,
+    // 1 one non-temporal store at a time, 2 one plain store at a time (with nwg = bytes / 1 KiB this is the shape of the runtime's blit kernel)
+    if (mode == 1) hipLaunchKernelGGL(k_copy_to_host_m<1>, dim3(nwg), dim3(64), 0, st, reinterpret_cast<const uint4 *>(d_src), reinterpret_cast<uint4 *>(h_dst), bytes / 16);
+    else if (mode == 2) hipLaunchKernelGGL(k_copy_to_host_m<0>, dim3(nwg), dim3(64), 0, st, reinterpret_cast<const uint4 *>(d_src), reinterpret_cast<uint4 *>(h_dst), bytes / 16);
+    else hipLaunchKernelGGL(k_copy_to_host, dim3(nwg), dim3(64), 0, st, reinterpret_cast<const uint4 *>(d_src), reinterpret_cast<uint4 *>(h_dst), bytes / 16);
     return hipGetLastError();
 }
 

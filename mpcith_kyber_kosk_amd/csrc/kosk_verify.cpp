@@ -352,7 +352,8 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     c.prof_begin(PR_V_HASH_TCOMM, n);
     HIPCHK(launch_opened_hash(oh, K, false, n, st)); // Tcomm of the opened parties, read from the image   :22-35
     c.prof_end(PR_V_HASH_TCOMM);
-    HIPCHK(copy_table_to_host(c, split_tables ? c.h_odig : c.h_dig, split_tables ? c.d_odig : c.d_dig1, dig_bytes));
+    if (split_tables) HIPCHK(copy_table_to_host(c, c.h_odig, c.d_odig, dig_bytes));
+    else HIPCHK(copy_round_table(c, c.h_dig, c.d_dig1, n)); // in pieces (Ctx::table_chunks), never in a captured segment
     return 0;
     }, split_tables ? c.h_odig : c.h_dig)) return -1; // which table copy the captured segment holds is part of its graph's key
     HIPCHK(hipEventRecord(c.ev, st)); // the opened parties' Tcomm digests are on the host once this event has passed
@@ -416,7 +417,12 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     return 0;
     })) return -1;
 
-    HIPCHK(wait_event(c, c.ev, 3, n));
+    HIPCHK(wait_event(c, first_event(c), 3, n));
+    hipError_t gate_err = hipSuccess;
+    const std::function<void(int)> gate = [&c, &gate_err](int b) { // whole tables in pieces: a worker waits for the piece it reaches
+        const hipError_t e = table_gate_wait(c, b);
+        if (e != hipSuccess) gate_err = e;
+    };
     if (split_tables && !himg) HIPCHK(hipEventSynchronize(c.ev_img[0])); // the images' Tcomm fields (under way since the call began)
     t1 = now_sec(); c.phase_sec[PH_V1_WAIT] = t1 - t0; t0 = t1;
     auto fire_hooks = [&](int rnd, const uint8_t *d_table) { // as in prove_resident: per caller of a merged run, else the context's own
@@ -437,14 +443,20 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     // ---- host: alpha while the GPU works
     {
         const std::function<void(int)> prep = table_prep(0);
-        fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool, split_tables ? &prep : nullptr);
+        fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool, split_tables ? &prep : c.chunk_n > 1 ? &gate : nullptr);
+        HIPCHK(gate_err);
+        HIPCHK(table_done(c));
     }
     t1 = now_sec(); c.phase_sec[PH_V_FS_ALPHA] = t1 - t0; t0 = t1;
     if (run_segment(c, Ctx::SEG_V2, n, [&]() -> int {
-    HIPCHK(copy_small(c, c.d_alpha, 0, c.h_alpha, 0, (size_t)n * 80 * 2, 1, hipMemcpyHostToDevice, st));
+    const uint16_t *alpha_src = c.h_alpha; // read from the page-locked host table by k_pow_table itself (as the prover's k_coef_limbs)
+    if (!c.small_copy_kernel || !c.alpha_direct) {
+        HIPCHK(copy_small(c, c.d_alpha, 0, c.h_alpha, 0, (size_t)n * 80 * 2, 1, hipMemcpyHostToDevice, st));
+        alpha_src = c.d_alpha;
+    }
 
     // ---- V2/V3: beta, gamma, r, NTT_r on the opened columns; reconstruction and NTT check
-    HIPCHK(launch_pow_table(c.d_alpha, P.J, P.M, c.d_pwT, n, st));
+    HIPCHK(launch_pow_table(alpha_src, P.J, P.M, c.d_pwT, n, st));
     LincombArgs la{};
     la.P = c.d_P;
     la.proof_stride = c.proof_stride;
@@ -468,7 +480,8 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     c.prof_begin(PR_V_HASH_VIEW, n);
     HIPCHK(launch_opened_hash(oh, K, true, n, st));
     c.prof_end(PR_V_HASH_VIEW);
-    HIPCHK(copy_table_to_host(c, split_tables ? c.h_odig : c.h_dig, split_tables ? c.d_odig : c.d_dig2, dig_bytes));
+    if (split_tables) HIPCHK(copy_table_to_host(c, c.h_odig, c.d_odig, dig_bytes));
+    else HIPCHK(copy_round_table(c, c.h_dig, c.d_dig2, n));
     HIPCHK(hipEventRecord(c.ev, st));
     t1 = now_sec(); c.phase_sec[PH_V2_ISSUE] = t1 - t0; t0 = t1;
 
@@ -502,7 +515,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     return 0;
     })) return -1;
 
-    HIPCHK(wait_event(c, c.ev, 4, n)); // the view digests are on the host; V2B keeps running
+    HIPCHK(wait_event(c, first_event(c), 4, n)); // the view digests (or their first piece) are on the host; V2B keeps running
     if (split_tables && !himg) HIPCHK(hipEventSynchronize(c.ev_img[1]));
     t1 = now_sec(); c.phase_sec[PH_V2_WAIT] = t1 - t0; t0 = t1;
     fire_hooks(1, c.d_dig2);
@@ -511,7 +524,9 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     std::vector<uint16_t> &I2 = c.v_I2, &rest2 = c.v_rest2; // every entry that is read below is written by fs_opened_batch first
     {
         const std::function<void(int)> prep = table_prep(1);
-        fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, I2.data(), rest2.data(), c.sel_stride, c.nthreads, c.pool, false, split_tables ? &prep : nullptr);
+        fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, I2.data(), rest2.data(), c.sel_stride, c.nthreads, c.pool, false, split_tables ? &prep : c.chunk_n > 1 ? &gate : nullptr);
+        HIPCHK(gate_err);
+        HIPCHK(table_done(c));
     }
     HIPCHK(stream_sync_site(c, 5, n)); // fail masks of V2B
     c.prof_collect();

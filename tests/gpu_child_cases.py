@@ -316,9 +316,9 @@ def combined_calls(k, threads=6, rounds=4, min_merge=0.5):
     print("combined_calls ok", k, "mean callers per run %.2f" % (members / calls))
 
 
-def line_of_record_shape(k=3, per=46, callers=3, rounds=3):
+def line_of_record_shape(k=3, per=46, callers=3, rounds=3, table_chunks=1):
     """The shape bench.py's line of record runs (bench.py: Slot.step), checked byte for byte: `callers` caller threads of ONE cohort
-    (KOSK_COMBINE=3), each with 46 Kyber-768 proofs per call on DEVICE tapes with a 64-byte-aligned stride that a merged run reads in
+    (KOSK_COMBINE=callers: 4 is the bench's default since round 5, 3 was round 4's), each with 46 Kyber-768 proofs per call on DEVICE tapes with a 64-byte-aligned stride that a merged run reads in
     place (the tape pointer table of the first kernel), the raw resident entry points with the key generation's pk / sk staying
     resident for the verifier (pk == NULL) -- so every launch covers 138 proofs: the single-buffer instantiation of the commitment
     hash (3 174 waves), three rounds of row blocks in the expansion product.  Every caller's pk / sk / proof images / both digest
@@ -331,7 +331,8 @@ def line_of_record_shape(k=3, per=46, callers=3, rounds=3):
     from mpcith_kyber_kosk_amd import api
     lib = api.lib
     plain = api.Kosk(kyber_k=k, max_batch=per)
-    hs = [_kosk(k, per, KOSK_COMBINE=callers, KOSK_COMBINE_WAIT_US=5000000, KOSK_COMBINE_IDLE_US=2000000) for _ in range(callers)]
+    hs = [_kosk(k, per, KOSK_COMBINE=callers, KOSK_COMBINE_WAIT_US=5000000, KOSK_COMBINE_IDLE_US=2000000, KOSK_TABLE_CHUNKS=table_chunks)
+          for _ in range(callers)]
     stride = (plain.tape_bytes + 63) // 64 * 64
     nsets = rounds
     tapes = {(t, r): [oracle.tape_bytes_for(k, 20000 + ((t * nsets) + r) * per + b) for b in range(per)] for t in range(callers) for r in range(nsets)}
@@ -403,6 +404,9 @@ def line_of_record_shape(k=3, per=46, callers=3, rounds=3):
     assert members == callers * calls, (calls, members)  # every checked call ran in a merged run of all the cohort's callers
     pc = hs[0].path_counts()
     assert sum(h.path_counts()["hash_dma"] for h in hs) > 0 and all(h.path_counts()["hash_plain"] == 0 for h in hs), pc
+    # one copy per round by default; KOSK_TABLE_CHUNKS=n: every merged run's four tables reached the host in pieces
+    nchunked = sum(h.path_counts()["table_chunks"] for h in hs)
+    assert (nchunked == 0) if table_chunks < 2 else (nchunked >= 4 * nsets), nchunked
     for h in hs + [plain]:
         h.close()
     print("line_of_record_shape ok", k, per, callers, "callers per run %.2f" % (members / calls))

@@ -137,6 +137,47 @@ def test_split_commitment_launches_give_identical_proofs(oracle, torch_cuda, mon
     ctx.close()
 
 
+@pytest.mark.parametrize("n", [49, 64])
+def test_digest_tables_copied_in_pieces_give_identical_results(n, oracle, torch_cuda, monkeypatch):
+    """KOSK_TABLE_CHUNKS=n (opt-in): batches of >= 48 proofs send each round's digest table to the host in n pieces of whole 8-proof
+    groups and the host's workers wait for the piece they reach (csrc/kosk_ctx.cpp: copy_round_table, table_gate_wait).  A ragged
+    batch (49 = 24 + 24 + 1) and an even one, prover and resident verifier: same keys, proof images, digest tables and verify bits
+    as the default's one copy per round, in three and in four pieces; first / last proof of each piece against the oracle; a corrupted
+    proof in the LAST piece is still rejected (its table reached the host)."""
+    import torch
+    from mpcith_kyber_kosk_amd import api
+    k = 2
+    tapes = [oracle.tape_bytes_for(k, 7000 + b) for b in range(n)]
+    one = api.Kosk(kyber_k=k, max_batch=n)
+
+    def run(ctx):
+        ctx.verifiable_keygen_resident(tapes)
+        pk, sk = ctx.keys(n)
+        bits = ctx.verify_resident_pk(n)
+        return pk, sk, ctx.fetch_proofs(n), bits, [torch.as_tensor(ctx.resident_digests(i, n), device="cuda").cpu().numpy().tobytes() for i in (0, 1)]
+    ref = run(one)
+    assert one.path_counts()["table_chunks"] == 0 and ref[3] == [True] * n
+    for b in (0, 23, 24, 47, 48, n - 1):
+        opk, osk, opi, _, _ = oracle.verifiable_keygen(k, tapes[b])
+        assert (ref[0][b], ref[1][b], ref[2][b]) == (opk, osk, opi), b
+    for chunks in ("3", "4"):
+        monkeypatch.setenv("KOSK_TABLE_CHUNKS", chunks)
+        ctx = api.Kosk(kyber_k=k, max_batch=n)
+        monkeypatch.delenv("KOSK_TABLE_CHUNKS")
+        assert run(ctx) == ref, chunks
+        assert ctx.path_counts()["table_chunks"] == 4, ctx.path_counts()  # two rounds of the prover, two of the verifier
+        # host-buffer verify of the same proofs takes the split tables (150 recomputed digests per proof: one small copy)
+        bad = bytearray(ref[2][n - 1]); bad[oracle.params(k).off[0] + 9] ^= 2
+        pis = list(ref[2][:n - 1]) + [bytes(bad)]
+        assert ctx.verify(pis, ref[0]) == [True] * (n - 1) + [False]
+        # ... and the resident verifier with pieces, on a batch whose last proof is corrupted in HBM
+        ctx.stage_verifier_inputs(pis, ref[0])
+        assert ctx.verify_resident(n) == [True] * (n - 1) + [False]
+        assert ctx.path_counts()["table_chunks"] == 6
+        ctx.close()
+    one.close()
+
+
 KNOBS = {  # knob -> (path counter that must be > 0 on the knob's handle, counter that must stay 0 there)
     "KOSK_TABLE_GEMM=0": ("limb_gemm", "table_gemm"),
     "KOSK_HASH_DMA=0": ("hash_plain", "hash_dma"),

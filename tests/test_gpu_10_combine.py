@@ -33,12 +33,15 @@ def test_cohort_members_come_and_go(torch_cuda, gpu_child):
     assert "combined_members_come_and_go ok 3" in out
 
 
-def test_line_of_record_shape(torch_cuda, gpu_child):
-    """tests/gpu_child_cases.py: line_of_record_shape -- bench.py's default arrangement (KOSK_COMBINE=3, three caller threads x 46
-    Kyber-768 proofs on device tapes read in place by merged 138-proof runs, raw resident entry points, resident public keys)
-    against an uncombined handle byte for byte and against the oracle (proof images, keys, both digest tables)."""
-    out = gpu_child("from tests.gpu_child_cases import line_of_record_shape; line_of_record_shape()")
-    assert "line_of_record_shape ok 3 46 3 callers per run 3.00" in out
+@pytest.mark.parametrize("callers,chunks", [(4, 1), (3, 1), (4, 3)])
+def test_line_of_record_shape(callers, chunks, torch_cuda, gpu_child):
+    """tests/gpu_child_cases.py: line_of_record_shape -- bench.py's arrangement (KOSK_COMBINE=4 by default, 3 for the cohorts-of-three
+    side run: that many caller threads x 46 Kyber-768 proofs on device tapes read in place by merged 184- / 138-proof runs, raw
+    resident entry points, resident public keys) against an uncombined handle byte for
+    byte and against the oracle (proof images, keys, both digest tables); once with the merged runs' digest tables going to the host
+    in three pieces (KOSK_TABLE_CHUNKS=3, opt-in)."""
+    out = gpu_child("from tests.gpu_child_cases import line_of_record_shape; line_of_record_shape(callers=%d, table_chunks=%d)" % (callers, chunks))
+    assert "line_of_record_shape ok 3 46 %d callers per run %d.00" % (callers, callers) in out
 
 
 def test_member_calls_larger_than_its_block_stay_in_its_block(torch_cuda, gpu_child):
