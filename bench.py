@@ -814,9 +814,13 @@ def main():
             "drained_run": {"steps": total, "ms_per_step": dt_drained / total * 1e3, "value": world * total * B / dt_drained,
                             "note": "the same run from first issue to last completion, barrier + synchronize on both sides (fill and drain included)"},
             "step_latency_ms": {"median": lats[len(lats) // 2] * 1e3, "p90": lats[int(len(lats) * 0.9)] * 1e3,
+                                "p99": lats[int(len(lats) * 0.99)] * 1e3, "max": lats[-1] * 1e3, "mean": sum(lats) / len(lats) * 1e3,
                                 "mean_in_keygen_call": sum(s_.t_prove for s_ in slots) / max(1, sum(s_.steps_done for s_ in slots)) * 1e3,
                                 "mean_in_verify_call": sum(s_.t_verify for s_ in slots) / max(1, sum(s_.steps_done for s_ in slots)) * 1e3,
-                                "note": "one slot's keygen + prove + verify of its %d proofs while the other slots run" % B},
+                                "per_cohort_mean": [round(sum(s_.t_prove + s_.t_verify for s_ in slots[c0:c0 + max(1, CMB)]) /
+                                                          max(1, sum(s_.steps_done for s_ in slots[c0:c0 + max(1, CMB)])) * 1e3, 3) for c0 in range(0, S, max(1, CMB))],
+                                "note": "one slot's keygen + prove + verify of its %d proofs while the other slots run; per_cohort_mean: the "
+                                        "same per cohort (every caller makes the same number of calls, so the slowest cohort sets the run's length)" % B},
             "roofline": roof,
             "combining": {"calls": sum(c_[0] for c_ in cstats), "mean_callers_per_run": (sum(c_[1] for c_ in cstats) / max(1, sum(c_[0] for c_ in cstats))),
                           "note": "resident calls that went through the combiner since the handles were created, and the mean number of "
