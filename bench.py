@@ -63,6 +63,30 @@ VIEW_MSG = {2: 452, 3: 472, 4: 524}
 TCOMM_MSG = {2: 308, 3: 320, 4: 332}
 
 
+def cgroup_cpu():
+    """(quota in cores or None, nr_throttled, throttled seconds) of this process's CPU cgroup (v2 or v1), None where unreadable: a
+    container with a CPU quota stalls EVERY thread for the rest of a 100 ms period once the quota is spent (CFS bandwidth control), which
+    shows in the line as a latency tail (step_latency_ms p99 / max) far above the median"""
+    quota = nthr = thr_s = None
+    try:
+        for base in ("/sys/fs/cgroup", "/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct"):
+            if os.path.exists(base + "/cpu.max"):
+                q, per = open(base + "/cpu.max").read().split()[:2]
+                quota = None if q == "max" else float(q) / float(per)
+            elif os.path.exists(base + "/cpu.cfs_quota_us"):
+                q, per = int(open(base + "/cpu.cfs_quota_us").read()), int(open(base + "/cpu.cfs_period_us").read())
+                quota = None if q <= 0 else q / per
+            if os.path.exists(base + "/cpu.stat"):
+                st = dict(l.split()[:2] for l in open(base + "/cpu.stat").read().splitlines() if len(l.split()) >= 2)
+                if "nr_throttled" in st:
+                    nthr = int(st["nr_throttled"])
+                    thr_s = int(st["throttled_usec"]) * 1e-6 if "throttled_usec" in st else int(st.get("throttled_time", 0)) * 1e-9
+                    break
+    except Exception:  # noqa: BLE001
+        pass
+    return quota, nthr, thr_s
+
+
 def tapes_for(first, count, nbytes):
     return [hashlib.shake_256(("kosk-tape-v1:%d" % (first + b)).encode()).digest(nbytes) for b in range(count)]
 
@@ -660,14 +684,26 @@ def main():
             dist.barrier()
 
     # conditioning (setup, untimed, independent of --warmup/--steps): clocks, runtime and worker threads of a fresh
-    # process ramp for a few hundred milliseconds
+    # process ramp for a few hundred milliseconds.  Two things found with tools/tail_probe.py (round 5) end here, not
+    # in the timed run: (1) the HIP runtime grows a system-memory pool by 8 MB chunks while the number of commands in flight is
+    # still rising (a KFD allocation + a 4 ms SVM ioctl under a runtime-wide lock inside a launch or copy call: every caller
+    # stalls 5-9 ms), three times within the first ~100 steps per caller; (2) the interpreter's cyclic collector: a full
+    # collection over the objects of torch / numpy holds the interpreter lock for 35-75 ms, and every caller thread needs that
+    # lock when its library call returns.  The harness's objects are collected and frozen here and the collector is off during
+    # the timed run (the library never calls into Python; the harness allocates no cycles in its loop).
+    import gc
+    gc.collect()
+    gc.freeze()
     t_cond = time.perf_counter()
     if want_gather:
         for _ in range(3):  # a fixed count: every rank must issue the same collectives
             run(2 * S)
     else:
-        while time.perf_counter() - t_cond < float(os.environ.get("KOSK_BENCH_CONDITION_S", "0.3")):
+        while time.perf_counter() - t_cond < float(os.environ.get("KOSK_BENCH_CONDITION_S", "0.5")):
             run(2 * S)
+    gc_was_enabled = gc.isenabled()
+    if os.environ.get("KOSK_BENCH_GC", "0") != "1":
+        gc.disable()
     for sl in slots:
         sl.c.profile_enable(True)
         if args.phase_stats:
@@ -676,10 +712,14 @@ def main():
     import resource
     barrier()
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    cg0 = cgroup_cpu()
     t_s, comp, lats = run(total)
     barrier()
     t_e = time.perf_counter()
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    cg1 = cgroup_cpu()
+    if gc_was_enabled:
+        gc.enable()
     # The timed window is exactly K steps, from the completion of step W to the completion of step W + K.  The members of a
     # cohort complete together and the cohorts of a run tend to stay in phase, so completions come in bursts of up to S steps:
     # one window of a few tens of steps lands anywhere between "just before a burst" and "just after one" (+-10 % at the driver's
@@ -827,6 +867,13 @@ def main():
                                   "callers served by the run a call ended up in"} if CMB > 1 else None,
             "host_cpu_cores_busy": round(host_cpu_s / max(dt_drained, 1e-9), 2),
             "host_cpus_usable": len(os.sched_getaffinity(0)),
+            "harness": {"python_gc_in_timed_run": os.environ.get("KOSK_BENCH_GC", "0") == "1",
+                        "note": "the interpreter's cyclic collector is off during the timed run (objects collected and frozen before the conditioning "
+                                "runs): a full collection holds the interpreter lock 35-75 ms and every caller thread needs it when its library "
+                                "call returns (tools/tail_probe.py, DESIGN 15.11); KOSK_BENCH_GC=1 leaves it on"},
+            "cgroup_cpu": {"quota_cores": cg1[0], "throttled_periods_in_run": (cg1[1] - cg0[1]) if cg1[1] is not None and cg0[1] is not None else None,
+                           "throttled_ms_in_run": round((cg1[2] - cg0[2]) * 1e3, 3) if cg1[2] is not None and cg0[2] is not None else None,
+                           "note": "CPU quota of the container and how often / how long the kernel stalled its threads during the timed run (cpu.stat)"},
             "kernels_in_pipeline": kern,
             "profiled_kernel_ms_per_step": round(sum(v["total_ms"] for v in kern.values()) / max(1, (hv or {}).get("launches", 0)), 4),
             "prove_phase_ms": dict(zip(["host_pre", "gpu_commit", "fs_alpha_host", "gpu_relation", "fs_open_host", "gpu_assemble", "d2h"],
