@@ -94,7 +94,7 @@ Ctx::~Ctx()
     if (ev_kg) (void)hipEventDestroy(ev_kg);
     for (auto e : timer_ev)
         if (e) (void)hipEventDestroy(e);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (stream && !stream_shared) (void)hipStreamDestroy(stream);
 }
 
 static int upload_table(Ctx &c, GemmTable &t, const std::vector<uint16_t> &A, int M, int Kdim)
@@ -556,6 +556,24 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
             // stream), unlike every other stream of the library -- documented with the knob
             HIPCHK(hipExtStreamCreateWithCUMask(&c.stream, (uint32_t)mask.size(), mask.data()));
             c.n_simd = 4 * mine;
+        } else if (const char *e = getenv("KOSK_SHARE_STREAMS")) {
+            // experiment (round 5): the contexts of this process are dealt round the first n streams instead of getting one each, so
+            // that two cohorts pipeline on ONE hardware queue (one's kernels run during the other's host rounds).  The shared
+            // streams are never destroyed (like the side stream).
+            static std::mutex mu;
+            static std::vector<hipStream_t> shared;
+            static size_t next = 0;
+            const size_t nshare = (size_t)std::max(1, atoi(e));
+            std::lock_guard<std::mutex> lk(mu);
+            if (shared.size() < nshare) {
+                hipStream_t st = nullptr;
+                HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                shared.push_back(st);
+                c.stream = st;
+            } else {
+                c.stream = shared[next++ % nshare];
+            }
+            c.stream_shared = true;
         } else {
             HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
         }

@@ -307,6 +307,7 @@ struct Ctx {
     // (INTEGRATION.md 6): folded where it only multiplies / converts to ZZ_p, raw in its non-reducing add / sub and comparisons
     bool strict_encoding = false;
     bool small_copy_kernel = true; // KOSK_SMALL_COPY_KERNEL=0: hipMemcpyAsync for the small copies too (copy_small)
+    bool stream_shared = false;    // KOSK_SHARE_STREAMS: the stream belongs to the process, not to this context
     bool alpha_direct = true;      // KOSK_ALPHA_DIRECT=0: the challenge vectors are copied into HBM in front of k_coef_limbs / k_pow_table
                                    // instead of being read by those kernels from the page-locked host table
     bool host_register = true;       // KOSK_REGISTER=0: staging copies only, even for buffers the caller page-locked itself.  (KOSK_REGISTER=2 of

@@ -5,8 +5,8 @@ mkdir -p $(dirname $out); : >> $out
 for rep in $(seq 1 $reps); do
   for spec in "$@"; do
     name=${spec%%=*}; kv=${spec#*=}
-    if [ "$kv" = "-" ]; then j=$(python bench.py $bargs --no-kernels --no-cpu-baseline 2>/dev/null | tail -1)
-    else j=$(env $kv python bench.py $bargs --no-kernels --no-cpu-baseline 2>/dev/null | tail -1); fi
+    if [ "$kv" = "-" ]; then j=$(timeout -k 5 90 python bench.py $bargs --no-kernels --no-cpu-baseline 2>/dev/null | tail -1)
+    else j=$(timeout -k 5 90 env $kv python bench.py $bargs --no-kernels --no-cpu-baseline 2>/dev/null | tail -1); fi
     python3 - "$name [$bargs]" "$j" >> $out <<'PY'
 import json, sys
 try:
