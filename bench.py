@@ -48,13 +48,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 
 CONFIGS = {  # 1-based config number -> (kyber_k, proofs per GPU per step, default slots, host threads per slot, handles per cohort)
-    # configs 2 and 3: twelve caller threads, each with its own handle and its own 46-proof calls; the library serves the calls of
-    # a cohort of four handles with one pipeline run (KOSK_COMBINE=4, include/kosk_mi355x.h), i.e. three merged runs in flight.
-    # (Round 4: nine callers in cohorts of three.  With round 5's kernels -- persistent table product, streaming beta / gamma kernel --
-    # the four-caller cohort went from 133 k proofs/s at 4.0 ms per call to 157-166 k at 3.3 ms, the three-caller one from 147 k to
-    # 148-150 k at 2.75 ms: `cohorts_of_three` in the line is that arrangement on the same box, for a like-for-like comparison.)
-    2: dict(k=2, batch=46, slots=12, threads=6, combine=4, what="Kyber-512 (KYBER_K=2), 46 proofs = 66 884 party lanes per GPU per step"),
-    3: dict(k=3, batch=46, slots=12, threads=6, combine=4, what="Kyber-768 (KYBER_K=3), 46 proofs = 66 884 party lanes per GPU per step"),
+    # configs 2 and 3: eighteen caller threads, each with its own handle and its own 46-proof calls; the library serves the calls of
+    # a cohort of six handles with one pipeline run (KOSK_COMBINE=6, include/kosk_mi355x.h), i.e. three merged runs of 276 proofs in
+    # flight.  The default line is bound by the GPU, and the kernels are the more efficient the more proofs a launch
+    # serves: on one box, alternating, cohorts of three / four / five / six give 150 / 161-164 / 170-175 / 179-184 k proofs/s at
+    # 2.7 / 3.3 / 3.9 / 4.5 ms per call (profiles/r05_cohort_size.txt); eight per cohort is bound by the container's 16 host cores.
+    # Round 4's line was cohorts of three, the first half of round 5 cohorts of four: `cohorts_of_three` and `cohorts_of_four` in
+    # the line are those arrangements on the same box, for a like-for-like comparison.  Four Fiat-Shamir workers per caller (24 per
+    # merged run: its 35 groups of eight tables) instead of six: one busy core less at a slightly higher rate.
+    2: dict(k=2, batch=46, slots=18, threads=4, combine=6, what="Kyber-512 (KYBER_K=2), 46 proofs = 66 884 party lanes per GPU per step"),
+    3: dict(k=3, batch=46, slots=18, threads=4, combine=6, what="Kyber-768 (KYBER_K=3), 46 proofs = 66 884 party lanes per GPU per step"),
     4: dict(k=4, batch=91, slots=9, threads=6, combine=3, what="Kyber-1024 (KYBER_K=4), 91 proofs = 132 314 party lanes per GPU per step "
                                                     "(2^20 lanes over 8 GPUs, proof-aligned), digest tables all-gathered after each commitment round"),
     5: dict(k=3, batch=512, slots=4, threads=8, what="Kyber-768 (KYBER_K=3), 512 verifiable keygens per GPU per step (4096 over 8 GPUs, throughput mode)"),
@@ -939,9 +942,9 @@ def main():
                 line["drop_in"] = json.loads(sub_[-1])
             except Exception as e:  # noqa: BLE001
                 line["drop_in"] = {"error": repr(e)[:400]}
-            # two side runs as fresh child processes with their own host-thread budget, reported NEXT TO the line of record, never as
+            # side runs as fresh child processes with their own host-thread budget, reported NEXT TO the line of record, never as
             # `value`: the same workload WITHOUT call combining (every handle on its own: the round-3 arrangement, 6 slots), and the
-            # throughput-leaning arrangement (15 callers in 3 cohorts of 5: more proofs per launch, more latency per call)
+            # lower-latency arrangements of rounds 4 and 5a (cohorts of three / four)
             import subprocess
             env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("KOSK_HOST_THREADS", "KOSK_BLOCKING_SYNC", "KOSK_COMBINE", "KOSK_BENCH_COMBINE", "KOSK_BENCH_SLOTS")}
 
@@ -975,8 +978,8 @@ def main():
                                                 "(round 3's line of record); not the line of record")
             line["cohorts_of_three"] = side_run(9, 3, "python bench.py --combine 3 --slots 9: nine callers, three per merged run (138 proofs per launch): round 4's line of "
                                                       "record (147.6 k proofs/s at 2.8 ms there), on this box for a like-for-like comparison; not the line of record")
-            line["cohorts_of_five"] = side_run(15, 5, "python bench.py --combine 5 --slots 15: fifteen callers, five per merged run (more proofs per launch at "
-                                                      "more latency per call); not the line of record")
+            line["cohorts_of_four"] = side_run(12, 4, "python bench.py --combine 4 --slots 12: twelve callers, four per merged run (184 proofs per launch; less latency "
+                                                      "per call, fewer proofs per launch than the default's six); not the line of record")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(k, tapes, min(args.cpu_proofs, B))

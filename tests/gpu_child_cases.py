@@ -318,7 +318,7 @@ def combined_calls(k, threads=6, rounds=4, min_merge=0.5):
 
 def line_of_record_shape(k=3, per=46, callers=3, rounds=3, table_chunks=1):
     """The shape bench.py's line of record runs (bench.py: Slot.step), checked byte for byte: `callers` caller threads of ONE cohort
-    (KOSK_COMBINE=callers: 4 is the bench's default since round 5, 3 was round 4's), each with 46 Kyber-768 proofs per call on DEVICE tapes with a 64-byte-aligned stride that a merged run reads in
+    (KOSK_COMBINE=callers: 6 is the bench's default since round 5, 4 and 3 its side runs), each with 46 Kyber-768 proofs per call on DEVICE tapes with a 64-byte-aligned stride that a merged run reads in
     place (the tape pointer table of the first kernel), the raw resident entry points with the key generation's pk / sk staying
     resident for the verifier (pk == NULL) -- so every launch covers 138 proofs: the single-buffer instantiation of the commitment
     hash (3 174 waves), three rounds of row blocks in the expansion product.  Every caller's pk / sk / proof images / both digest

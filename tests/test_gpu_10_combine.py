@@ -33,10 +33,10 @@ def test_cohort_members_come_and_go(torch_cuda, gpu_child):
     assert "combined_members_come_and_go ok 3" in out
 
 
-@pytest.mark.parametrize("callers,chunks", [(4, 1), (3, 1), (4, 3)])
+@pytest.mark.parametrize("callers,chunks", [(6, 1), (4, 1), (3, 1), (4, 3)])
 def test_line_of_record_shape(callers, chunks, torch_cuda, gpu_child):
-    """tests/gpu_child_cases.py: line_of_record_shape -- bench.py's arrangement (KOSK_COMBINE=4 by default, 3 for the cohorts-of-three
-    side run: that many caller threads x 46 Kyber-768 proofs on device tapes read in place by merged 184- / 138-proof runs, raw
+    """tests/gpu_child_cases.py: line_of_record_shape -- bench.py's arrangement (KOSK_COMBINE=6 by default, 4 and 3 for the side runs:
+    that many caller threads x 46 Kyber-768 proofs on device tapes read in place by merged 276- / 184- / 138-proof runs, raw
     resident entry points, resident public keys) against an uncombined handle byte for
     byte and against the oracle (proof images, keys, both digest tables); once with the merged runs' digest tables going to the host
     in three pieces (KOSK_TABLE_CHUNKS=3, opt-in)."""

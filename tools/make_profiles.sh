@@ -13,7 +13,7 @@ grep -a '^{"metric"' $out/bench_under_rocprof.log | tail -1 > $out/${tag}_bench_
 echo "stats done"
 # 2. one slot: GPU-busy per step
 tools/gpu_busy.sh $out/busy 80 > $out/${tag}_gpu_busy_1slot.txt 2>&1
-BUSY_STEPS=60 BUSY_ARGS="--slots 4 --combine 4" tools/gpu_busy.sh $out/busy4 80 > $out/${tag}_gpu_busy_1cohort.txt 2>&1
+BUSY_STEPS=60 BUSY_ARGS="--slots 6 --combine 6" tools/gpu_busy.sh $out/busy6 80 > $out/${tag}_gpu_busy_1cohort.txt 2>&1
 BUSY_STEPS=60 BUSY_ARGS="--slots 3 --combine 3" tools/gpu_busy.sh $out/busy3 80 > $out/${tag}_gpu_busy_1cohort_of_three.txt 2>&1
 echo "busy done"
 # 3. PMC passes (separate, no other tracing domains)
@@ -40,9 +40,9 @@ with open("%s/%s_pmc_fetch_write.csv" % (out, tag), "w", newline="") as fo:
         w = W.get(k, [1, 0.0])
         f_kb, w_kb = v / n, w[1] / max(1, w[0])
         wr.writerow([k[0], k[1], n, "%.0f" % f_kb, "%.0f" % w_kb, "%.1f" % ((2 * f_kb + w_kb) / 1024)])
-# in-pipeline view hash: the k_commit_hash_dma<16,220,...> dispatch of the 184-proof merged run (1472 threads per proof); the
+# in-pipeline view hash: the k_commit_hash_dma<16,220,...> dispatch of the 276-proof merged run (1472 threads per proof); the
 # 65 536-lane calibration dispatch has a different grid
-hv = [(k, v) for k, v in F.items() if "k_commit_hash" in k[0] and "<16, 220" in k[0] and k[1] % 1472 == 0 and k[1] // 1472 <= 184]
+hv = [(k, v) for k, v in F.items() if "k_commit_hash" in k[0] and "<16, 220" in k[0] and k[1] % 1472 == 0 and k[1] // 1472 <= 276]
 if hv:
     k, (n, v) = max(hv, key=lambda kv: kv[0][1])
     w = W[k]

@@ -12,8 +12,8 @@ for c in 2 4 5; do
   echo "config $c: $(python3 -c "import json,sys; j=json.loads(open('$out/bench_config$c.json').read().strip().splitlines()[-1]); print(j['value'], j['step_latency_ms']['median'])")"
 done
 timeout -k 10 120 python tools/latency_one.py 3 > $out/latency_one.txt 2>&1; cat $out/latency_one.txt
-timeout -k 10 200 python tools/stress_combine.py 12 9000 0 > $out/soak.txt 2>&1; tail -2 $out/soak.txt
-timeout -k 10 200 python tools/stress_combine.py 12 1500 50 >> $out/soak.txt 2>&1; tail -1 $out/soak.txt
+KOSK_HOST_THREADS=4 timeout -k 10 200 python tools/stress_combine.py 18 6000 0 > $out/soak.txt 2>&1; tail -2 $out/soak.txt
+KOSK_HOST_THREADS=4 timeout -k 10 200 python tools/stress_combine.py 18 1000 50 >> $out/soak.txt 2>&1; tail -1 $out/soak.txt
 timeout -k 10 900 tools/make_profiles.sh r05 > $out/make_profiles.log 2>&1; tail -3 $out/make_profiles.log
 cp -r gpurun_out/prof/r05_* gpurun_out/prof/traffic.json $out/ 2>/dev/null
 echo final done
