@@ -516,8 +516,8 @@ class Slot:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1200)
-    ap.add_argument("--warmup", type=int, default=120)
+    ap.add_argument("--steps", type=int, default=3600)  # ~1 s of timed window at the default configuration (18 callers x 200 calls)
+    ap.add_argument("--warmup", type=int, default=180)
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS), help="BASELINE.json workload, 1-based (see the module docstring)")
     ap.add_argument("--kyber-k", type=int, default=0, help="override the configuration's KYBER_K")
     ap.add_argument("--batch", type=int, default=0, help="override the configuration's proofs per GPU per step")
@@ -702,7 +702,7 @@ def main():
         for _ in range(3):  # a fixed count: every rank must issue the same collectives
             run(2 * S)
     else:
-        while time.perf_counter() - t_cond < float(os.environ.get("KOSK_BENCH_CONDITION_S", "0.5")):
+        while time.perf_counter() - t_cond < float(os.environ.get("KOSK_BENCH_CONDITION_S", "1.0")):
             run(2 * S)
     gc_was_enabled = gc.isenabled()
     if os.environ.get("KOSK_BENCH_GC", "0") != "1":
