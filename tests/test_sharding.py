@@ -143,7 +143,7 @@ def test_config3_two_ranks_on_one_gpu_rehearsal():
         port = sock.getsockname()[1]
     env = dict(os.environ, KOSK_BENCH_REHEARSE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--slots", "3"]
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--slots", "3", "--combine", "3"]  # one cohort of three per rank
     r = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
