@@ -54,10 +54,11 @@ CONFIGS = {  # 1-based config number -> (kyber_k, proofs per GPU per step, defau
     # serves: on one box, alternating, cohorts of three / four / five / six give 150 / 161-164 / 170-175 / 179-184 k proofs/s at
     # 2.7 / 3.3 / 3.9 / 4.5 ms per call (profiles/r05_cohort_size.txt); eight per cohort is bound by the container's 16 host cores.
     # Round 4's line was cohorts of three, the first half of round 5 cohorts of four: `cohorts_of_three` and `cohorts_of_four` in
-    # the line are those arrangements on the same box, for a like-for-like comparison.  Four Fiat-Shamir workers per caller (24 per
-    # merged run: its 35 groups of eight tables) instead of six: one busy core less at a slightly higher rate.
-    2: dict(k=2, batch=46, slots=18, threads=4, combine=6, what="Kyber-512 (KYBER_K=2), 46 proofs = 66 884 party lanes per GPU per step"),
-    3: dict(k=3, batch=46, slots=18, threads=4, combine=6, what="Kyber-768 (KYBER_K=3), 46 proofs = 66 884 party lanes per GPU per step"),
+    # the line are those arrangements on the same box, for a like-for-like comparison.  Three Fiat-Shamir workers per caller (18 per
+    # merged run: its 35 groups of eight tables in two rounds) instead of six, and no pre-wake spinning (Slot.__init__): 10.6-10.9 busy
+    # host cores instead of 13.7-14.3 at the same rate (profiles/r05_host18.txt).
+    2: dict(k=2, batch=46, slots=18, threads=3, combine=6, what="Kyber-512 (KYBER_K=2), 46 proofs = 66 884 party lanes per GPU per step"),
+    3: dict(k=3, batch=46, slots=18, threads=3, combine=6, what="Kyber-768 (KYBER_K=3), 46 proofs = 66 884 party lanes per GPU per step"),
     4: dict(k=4, batch=91, slots=9, threads=6, combine=3, what="Kyber-1024 (KYBER_K=4), 91 proofs = 132 314 party lanes per GPU per step "
                                                     "(2^20 lanes over 8 GPUs, proof-aligned), digest tables all-gathered after each commitment round"),
     5: dict(k=3, batch=512, slots=4, threads=8, what="Kyber-768 (KYBER_K=3), 512 verifiable keygens per GPU per step (4096 over 8 GPUs, throughput mode)"),
@@ -429,7 +430,10 @@ class Slot:
         env["KOSK_COMBINE"] = str(combine)
         if combine > 1:
             env["KOSK_COMBINE_IDLE_US"] = os.environ.get("KOSK_COMBINE_IDLE_US", "20000")
-            if os.environ.get("KOSK_BLOCKING_SYNC") == "1":  # few host cores per rank (host_budget): nobody spins, a run's callers sleep to its end
+            # the callers of a merged run sleep to its end, without the library's 400 us of pre-wake spinning, (a) when host cores are
+            # scarce (host_budget) and (b) in cohorts of five and more: fifteen members spinning for the last 400 us of every run cost 2-3
+            # busy cores and no longer buy throughput (profiles/r05_host18.txt; at three per cohort the pre-wake was +4.7 %, round 4)
+            if os.environ.get("KOSK_BLOCKING_SYNC") == "1" or combine >= 5:
                 env["KOSK_COMBINE_PREWAKE_US"] = os.environ.get("KOSK_COMBINE_PREWAKE_US", "0")
         self.c = _with_env(env, lambda: api.Kosk(kyber_k=k, max_batch=B, device=device))
         self.B, self.nsets = B, nsets
@@ -948,11 +952,11 @@ def main():
             import subprocess
             env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("KOSK_HOST_THREADS", "KOSK_BLOCKING_SYNC", "KOSK_COMBINE", "KOSK_BENCH_COMBINE", "KOSK_BENCH_SLOTS")}
 
-            def side_run(slots_, combine_, note):
+            def side_run(slots_, combine_, note, threads_=6):  # threads_: Fiat-Shamir workers per caller (the smaller arrangements keep the six they were tuned with)
                 cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", str(args.config), "--combine", str(combine_), "--slots", str(slots_),
                        "--steps", str(max(20, K // 2) // slots_ * slots_ + slots_), "--warmup", str(max(4, W // 2)), "--no-kernels", "--no-cpu-baseline"]
                 try:
-                    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+                    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=dict(env, KOSK_HOST_THREADS=str(threads_)) if threads_ else env)
                     sub = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                     if r.returncode != 0 or not sub:
                         raise RuntimeError("rc %d: %s" % (r.returncode, (r.stderr or "")[-300:]))
@@ -966,7 +970,7 @@ def main():
                 except Exception as e:  # noqa: BLE001  (TimeoutExpired, a missing key, bad JSON ...)
                     return {"error": repr(e)[:400]}
             # one cohort ALONE on the GPU (three callers, one merged run in flight): the graded kernel's launch time without co-running kernels
-            oc_ = side_run(CMB, CMB, "python bench.py --combine %d --slots %d: ONE cohort alone on the GPU; its view-commitment launches are not stretched by "
+            oc_ = side_run(CMB, CMB, threads_=0, note="python bench.py --combine %d --slots %d: ONE cohort alone on the GPU; its view-commitment launches are not stretched by "
                                      "other cohorts' kernels; not the line of record" % (CMB, CMB))
             line["one_cohort_alone"] = oc_
             if line.get("roofline") is not None and oc_.get("hash_view_avg_us"):
