@@ -86,6 +86,20 @@ def test_host_budget_per_rank():
     assert bench.host_budget(64, 8, 6, 6) == (3, True)        # 8 cores per rank: the floor of three
     assert bench.host_budget(8, 8, 4, 8) == (3, True)
     assert bench.host_budget(1, 1, 1, 6) == (3, True)
+    # the default configuration since round 5: three cohorts of six callers with three workers each (18 per merged run)
+    assert bench.CONFIGS[3]["slots"] == 18 and bench.CONFIGS[3]["combine"] == 6 and bench.CONFIGS[3]["threads"] == 3
+    assert bench.host_budget(256, 1, 3, 18) == (18, False)    # one rank on a whole host: 3 per caller, spinning waits
+    assert bench.host_budget(256, 8, 3, 18) == (18, True)     # a rank of eight on 32 cores: sleeping waits, still 18 // 6 = 3 per caller
+    assert bench.host_budget(64, 8, 3, 18) == (5, True)       # 8 cores per rank: 2 * 8 // 3 = 5 per cohort -> the floor of three per caller
+
+
+def test_cgroup_cpu_reads_or_declines():
+    """bench.py's cgroup_cpu: (quota in cores or None, throttled periods or None, throttled seconds or None), never an exception --
+    the line's `cgroup_cpu` object says whether the container's CPU quota stalled the run"""
+    import bench
+    q, n, t = bench.cgroup_cpu()
+    assert q is None or q > 0
+    assert (n is None) == (t is None) and (n is None or (n >= 0 and t >= 0))
 
 
 @pytest.mark.gpu
