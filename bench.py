@@ -59,7 +59,7 @@ CONFIGS = {  # 1-based config number -> (kyber_k, proofs per GPU per step, defau
     # host cores instead of 13.7-14.3 at the same rate (profiles/r05_host18.txt).
     2: dict(k=2, batch=46, slots=18, threads=3, combine=6, what="Kyber-512 (KYBER_K=2), 46 proofs = 66 884 party lanes per GPU per step"),
     3: dict(k=3, batch=46, slots=18, threads=3, combine=6, what="Kyber-768 (KYBER_K=3), 46 proofs = 66 884 party lanes per GPU per step"),
-    4: dict(k=4, batch=91, slots=9, threads=6, combine=3, what="Kyber-1024 (KYBER_K=4), 91 proofs = 132 314 party lanes per GPU per step "
+    4: dict(k=4, batch=91, slots=9, threads=3, combine=3, prewake_us=0, what="Kyber-1024 (KYBER_K=4), 91 proofs = 132 314 party lanes per GPU per step "
                                                     "(2^20 lanes over 8 GPUs, proof-aligned), digest tables all-gathered after each commitment round"),
     5: dict(k=3, batch=512, slots=4, threads=8, what="Kyber-768 (KYBER_K=3), 512 verifiable keygens per GPU per step (4096 over 8 GPUs, throughput mode)"),
 }
@@ -421,7 +421,7 @@ def host_budget(usable_cores, local_world, slots, threads):
 class Slot:
     """One pipeline slot: a library context with its tape bank in HBM (and, for config 4, its own process group)."""
 
-    def __init__(self, api, torch, k, B, device, first_tape, nsets, partition=None, combine=1):
+    def __init__(self, api, torch, k, B, device, first_tape, nsets, partition=None, combine=1, prewake_us=None):
         # partition = (i, n): the slot's stream may only use CU partition i of n (KOSK_CU_PARTITION, read by kosk_create)
         env = {"KOSK_CU_PARTITION": "%d/%d" % partition} if partition and partition[1] > 1 else {}
         # combine = C > 1: the handle joins a cohort of C handles whose resident calls the library merges (KOSK_COMBINE).  The slots
@@ -433,8 +433,9 @@ class Slot:
             # the callers of a merged run sleep to its end, without the library's 400 us of pre-wake spinning, (a) when host cores are
             # scarce (host_budget) and (b) in cohorts of five and more: fifteen members spinning for the last 400 us of every run cost 2-3
             # busy cores and no longer buy throughput (profiles/r05_host18.txt; at three per cohort the pre-wake was +4.7 %, round 4)
-            if os.environ.get("KOSK_BLOCKING_SYNC") == "1" or combine >= 5:
-                env["KOSK_COMBINE_PREWAKE_US"] = os.environ.get("KOSK_COMBINE_PREWAKE_US", "0")
+            # (c) where the configuration says so (config 4's 273-proof runs of three callers: the same rate with 1.3 cores fewer)
+            if os.environ.get("KOSK_BLOCKING_SYNC") == "1" or combine >= 5 or prewake_us is not None:
+                env["KOSK_COMBINE_PREWAKE_US"] = os.environ.get("KOSK_COMBINE_PREWAKE_US", str(prewake_us or 0))
         self.c = _with_env(env, lambda: api.Kosk(kyber_k=k, max_batch=B, device=device))
         self.B, self.nsets = B, nsets
         self.stride = (self.c.tape_bytes + 63) // 64 * 64
@@ -605,7 +606,7 @@ def main():
 
     from mpcith_kyber_kosk_amd import api, sharding
     P_ = max(1, args.partitions)
-    slots = [Slot(api, torch, k, B, local_rank, ((rank * S + si) * args.tape_sets) * B, args.tape_sets, partition=(si % P_, P_), combine=CMB) for si in range(S)]
+    slots = [Slot(api, torch, k, B, local_rank, ((rank * S + si) * args.tape_sets) * B, args.tape_sets, partition=(si % P_, P_), combine=CMB, prewake_us=cfg.get("prewake_us")) for si in range(S)]
     ctx = slots[0].c
     tapes = slots[0].first_tapes
     if want_gather:
