@@ -406,16 +406,42 @@ def drop_in(api, torch, k, B, tapes, device):
     return out
 
 
+def usable_host_cores():
+    """cores this process can really run on: the scheduler affinity, cut to the container's CPU quota (cgroup v2 cpu.max / v1 cfs quota).
+    A GPU box shows 256 hardware threads to a lease whose quota is 16 cores: sizing the host side by the affinity alone made every rank of an
+    8-GPU job assume 32 cores, and CFS bandwidth control then stalls ALL threads of the container for the rest of each 100 ms period."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    quota = cgroup_cpu()[0]
+    if quota is not None and quota > 0:
+        return max(1, min(aff, int(quota)))  # whole cores (a 15.5-core quota is 15 usable cores)
+    return aff
+
+
 def host_budget(usable_cores, local_world, slots, threads):
-    """(host threads per slot, sleep instead of spin) for a rank that shares `usable_cores` with local_world - 1 other ranks and
-    runs `slots` pipeline slots.  With a core for every slot thread nothing changes; when cores are scarce (an 8-GPU node with
-    few cores per GPU) the slots' waits sleep on events and the Fiat-Shamir pools shrink -- but never below three threads per
-    slot: the pool threads sleep between the four hash rounds of a step, so twice as many of them as cores is harmless, while
-    fewer than three would stretch every round (46 proofs = 6 groups of 8 AVX-512 lanes)."""
+    """(host threads per slot, sleep instead of spin) for a rank that shares `usable_cores` (usable_host_cores(): affinity cut to the
+    cgroup quota) with local_world - 1 other ranks and runs `slots` pipeline slots.  With a core for every slot thread nothing changes;
+    when cores are scarce (an 8-GPU node with few cores per GPU) the slots' waits sleep on events and the Fiat-Shamir pools shrink --
+    down to three threads per slot while the rank has at least four cores (the pool threads sleep between the four hash rounds of a step,
+    so twice as many of them as cores is harmless, while fewer than three would stretch every round: 46 proofs = 6 groups of 8 AVX-512
+    lanes), and down to two below that (eight ranks on a 16-core quota: two cores per rank)."""
     cores_per_rank = max(1, usable_cores // max(1, local_world))
     if cores_per_rank >= slots * (threads + 1):
         return threads, False
-    return max(3, min(threads, 2 * cores_per_rank // slots)), True
+    floor = 3 if cores_per_rank >= 4 else 2
+    return max(floor, min(threads, 2 * cores_per_rank // slots)), True
+
+
+def threads_per_caller(budget_threads, blocking, combine, cores_per_rank):
+    """Fiat-Shamir workers per handle from host_budget's per-slot figure: a merged run led by a cohort's first member uses `combine` times
+    as many.  Floor three per caller, two when the rank has fewer than four cores; at most four when the waits sleep (few cores per rank)."""
+    floor = 3 if cores_per_rank >= 4 else 2
+    t = max(floor, budget_threads // max(1, combine))
+    if blocking and combine > 1:
+        t = min(t, 4 if cores_per_rank >= 4 else 2)
+    return t
 
 
 class Slot:
@@ -559,15 +585,11 @@ def main():
         CMB = 1
     # host cores this rank can count on: when they are scarce (an 8-GPU node with few cores per GPU), the slots' waits sleep on
     # events instead of spinning and the Fiat-Shamir pools shrink; with 32+ cores per rank nothing changes
-    try:
-        usable_cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        usable_cores = os.cpu_count() or 1
+    usable_cores = usable_host_cores()  # scheduler affinity cut to the cgroup CPU quota (a lease shows 256 hardware threads and has 16 cores)
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    cores_per_rank = max(1, usable_cores // local_world)
     threads, blocking = host_budget(usable_cores, local_world, -(-S // CMB), cfg["threads"] * CMB)
-    threads = max(3, threads // CMB)  # per handle; a merged run led by a cohort's first member uses CMB times as many
-    if blocking and CMB > 1:
-        threads = min(threads, 4)  # few cores per rank (an 8-GPU node): 12 + 4 + 4 host workers per cohort of three
+    threads = threads_per_caller(threads, blocking, CMB, cores_per_rank)  # per handle; a merged run led by a cohort's first member uses CMB times as many
     if blocking:
         os.environ.setdefault("KOSK_BLOCKING_SYNC", "1")
     os.environ.setdefault("KOSK_HOST_THREADS", str(threads))
@@ -790,6 +812,19 @@ def main():
                                                                                      "pci_bus_id": int(r_[3]), "pci_device_id": int(r_[4])} for r_ in all_.cpu().tolist()]}
         except Exception as e:  # noqa: BLE001
             rccl_info = {"world": world, "error": repr(e)[:300]}
+        # every rank's host side: busy cores, usable cores (affinity cut to the cgroup quota), CFS throttling inside the run -- the
+        # quantities that decide an N-GPU curve on a container with a CPU quota (rank 0's own figures are top-level fields of the line)
+        try:
+            hs_ = torch.tensor([[rank, host_cpu_s / max(dt_drained, 1e-9), usable_cores, cg1[0] if cg1[0] is not None else -1.0,
+                                 (cg1[1] - cg0[1]) if cg1[1] is not None and cg0[1] is not None else -1.0,
+                                 (cg1[2] - cg0[2]) * 1e3 if cg1[2] is not None and cg0[2] is not None else -1.0]], dtype=torch.float64, device=cdev)
+            hall_ = torch.empty((world, 6), dtype=torch.float64, device=cdev)
+            dist.all_gather_into_tensor(hall_, hs_)
+            host_per_rank = [{"rank": int(r_[0]), "host_cpu_cores_busy": round(r_[1], 2), "host_cores_usable": int(r_[2]),
+                              "cgroup_quota_cores": None if r_[3] < 0 else r_[3], "throttled_periods_in_run": None if r_[4] < 0 else int(r_[4]),
+                              "throttled_ms_in_run": None if r_[5] < 0 else round(r_[5], 3)} for r_ in hall_.cpu().tolist()]
+        except Exception as e:  # noqa: BLE001
+            host_per_rank = {"error": repr(e)[:300]}
         if not want_gather:
             # result gather (not on the data path): one digest per rank over its last batch of proofs
             pr = slots[0].c.fetch_proofs(B)
@@ -874,7 +909,7 @@ def main():
                           "note": "resident calls that went through the combiner since the handles were created, and the mean number of "
                                   "callers served by the run a call ended up in"} if CMB > 1 else None,
             "host_cpu_cores_busy": round(host_cpu_s / max(dt_drained, 1e-9), 2),
-            "host_cpus_usable": len(os.sched_getaffinity(0)),
+            "host_cpus_usable": usable_cores, "host_cpus_affinity": len(os.sched_getaffinity(0)), "host_cores_per_rank": cores_per_rank,
             "harness": {"python_gc_in_timed_run": os.environ.get("KOSK_BENCH_GC", "0") == "1",
                         "note": "the interpreter's cyclic collector is off during the timed run (objects collected and frozen before the conditioning "
                                 "runs): a full collection holds the interpreter lock 35-75 ms and every caller thread needs it when its library "
@@ -899,6 +934,7 @@ def main():
             line["digest_allgather"] = gather_info
         if dist is not None:
             line["rccl"] = rccl_info
+            line["host_per_rank"] = host_per_rank
         if args.config == 5 and not custom:
             # batch-of-1 latency: one verifiable keygen + verify alone on an idle GPU
             c1 = api.Kosk(kyber_k=k, max_batch=1, device=local_rank)

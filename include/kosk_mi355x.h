@@ -39,6 +39,34 @@ size_t kosk_tape_bytes(int kyber_k);
 int kosk_proof_field(int kyber_k, int idx, size_t *offset, size_t *size);
 
 int kosk_create(kosk_ctx **ctx, int device, int kyber_k, int max_batch);
+
+/* ---- Per-handle options (round 6).  The reference has no run-time configuration at all (kosk.hpp:18-24 takes pointers, nothing
+ * else); what a HOST must decide per handle -- how its calls are batched, what the verifier accepts, where the Fiat-Shamir rounds
+ * run, how its threads wait -- is this struct, not the process environment.  kosk_options_init() fills in "not given" for every
+ * field (the library's defaults apply); kosk_create_ex() with opt == NULL is kosk_create().  Fields the caller sets win over the
+ * environment variables of the same name, which kosk_create() still honours. */
+enum { KOSK_FS_HOST = 0, KOSK_FS_DEVICE = 1 };
+typedef struct kosk_options {
+    uint32_t size;              /* sizeof(kosk_options) as the caller compiled it (set by kosk_options_init) */
+    int32_t streams;            /* sub-batches of a batch call in flight on separate HIP streams, 1..8 (KOSK_STREAMS); 0: not given = 1 */
+    int32_t combine;            /* handles per cohort whose resident calls are merged, 2..8 (KOSK_COMBINE, see below); 0: not given, 1: off */
+    int32_t combine_wait_us;    /* longest wait of a call for the cohort's other members (default 5000); < 0: not given */
+    int32_t combine_idle_us;    /* a member that left a call longer ago than this is not waited for (default 1000); < 0: not given */
+    int32_t combine_prewake_us; /* how long the sleeping callers of a merged run may spin for its return (default 400); < 0: not given */
+    int32_t strict_encoding;    /* verifier: 1 (DEFAULT) a u16 element >= q in any record the reference reads marks the proof malformed;
+                                 * 0 the reference-following mode (accepts what the reference accepts: non-canonical encodings are then
+                                 * malleable); < 0: not given */
+    int32_t fs_mode;            /* KOSK_FS_HOST: the Fiat-Shamir hashes run on the host's cores (digest tables cross PCIe, four host
+                                 * round trips per prove + verify); KOSK_FS_DEVICE: one wave per proof hashes the tables in HBM, alpha /
+                                 * I / the verifier's I' == I stay on the device, the resident calls have no host round trip; < 0: not given */
+    int32_t host_threads;       /* Fiat-Shamir / key-assembly workers of this handle (KOSK_HOST_THREADS); 0: not given */
+    int32_t blocking_sync;      /* 1: the handle's host waits sleep on events instead of spinning (few cores per GPU); < 0: not given */
+    int32_t hooks_unmerged;     /* 1: while this handle has a round hook (kosk_set_round_hook) its calls never join a merged run: the hook
+                                 * then always fires on the handle's OWN calling thread (thread-local state, blocking hooks); 0 / < 0: merged */
+    int32_t reserved[6];        /* zero */
+} kosk_options;
+void kosk_options_init(kosk_options *opt);
+int kosk_create_ex(kosk_ctx **ctx, int device, int kyber_k, int max_batch, const kosk_options *opt);
 void kosk_destroy(kosk_ctx *ctx);
 const char *kosk_last_error(const kosk_ctx *ctx); /* ctx may be NULL: error of the last failed kosk_create */
 int kosk_set_randombytes(kosk_ctx *ctx, kosk_randombytes_fn fn, void *user); /* NULL: OS entropy */
@@ -207,6 +235,18 @@ int kosk_sha3_256_batch(kosk_ctx *ctx, const uint8_t *d_in, size_t in_stride, si
  * wave, 64-bit rotations exchanged by DPP, 32 messages per wave (csrc/kosk_keccak_split_dev.hpp; BASELINE.json north_star names
  * this layout; the pipeline's hashes use one lane per state, which is faster at its wave counts -- DESIGN.md 8) */
 int kosk_sha3_256_batch_pair(kosk_ctx *ctx, const uint8_t *d_in, size_t in_stride, size_t inlen, uint8_t *d_out, int n);
+/* sha3_256 of n LONG messages, one WAVE per message: one Keccak state spread over the 64 lanes
+ * of a wave, a 32-bit word of the bit-interleaved state per lane, theta / pi / chi exchanged through LDS (csrc/kosk_fs_dev.hpp) --
+ * the layout for a strictly sequential chain: ~2 us per permutation where the one-state-per-lane sponge needs ~9 us when its wave
+ * runs alone.  d_in and in_stride must be multiples of 8.        kyber/fips202.c:745-754 */
+int kosk_sha3_256_batch_wave(kosk_ctx *ctx, const uint8_t *d_in, size_t in_stride, size_t inlen, uint8_t *d_out, int n);
+/* kosk_fs_alpha / kosk_fs_opened (below) on n digest tables [1454][32] in HBM, table_stride bytes apart (multiples of 8): what a
+ * handle in device Fiat-Shamir mode runs between its commitment kernels and their consumers (mlwe_prover.cpp:130-153, :445-474).
+ * d_alpha: n x 80 u16 (70 + 2K derived, zeros behind); d_h1 / d_ch: optional n x 32 bytes, the tables' sha3_256.
+ * d_sel: n rows of sel_stride u16 -- I in [0, 150), at 160 + w the number of unopened parties below 64 w (w = 0..23), at 192 the
+ * opened parties ascending and at 352 their positions in I; d_rest: n rows of sel_stride u16, the ascending complement (1304). */
+int kosk_fs_alpha_device(kosk_ctx *ctx, const uint8_t *d_tables, size_t table_stride, int n, uint16_t *d_alpha, uint8_t *d_h1);
+int kosk_fs_opened_device(kosk_ctx *ctx, const uint8_t *d_tables, size_t table_stride, int n, uint16_t *d_sel, uint16_t *d_rest, int sel_stride, uint8_t *d_ch);
 /* shake256(out, outlen, in, inlen)                           kyber/fips202.c:723-734 */
 int kosk_shake256_batch(kosk_ctx *ctx, const uint8_t *d_in, size_t in_stride, size_t inlen,
                         uint8_t *d_out, size_t outlen, int n);

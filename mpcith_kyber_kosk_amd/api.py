@@ -28,6 +28,8 @@ def _load():
         "kosk_proof_bytes": (sz, [C.c_int]), "kosk_tape_bytes": (sz, [C.c_int]),
         "kosk_proof_field": (C.c_int, [C.c_int, C.c_int, C.POINTER(sz), C.POINTER(sz)]),
         "kosk_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int]),
+        "kosk_options_init": (None, [vp]),
+        "kosk_create_ex": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp]),
         "kosk_destroy": (None, [vp]),
         "kosk_last_error": (C.c_char_p, [vp]),
         "kosk_set_randombytes": (C.c_int, [vp, vp, vp]),
@@ -65,6 +67,9 @@ def _load():
         "kosk_sha3_256_batch": (C.c_int, [vp, vp, sz, sz, vp, C.c_int]),
         "kosk_shake256_batch": (C.c_int, [vp, vp, sz, sz, vp, sz, C.c_int]),
         "kosk_sha3_256_batch_pair": (C.c_int, [vp, vp, sz, sz, vp, C.c_int]),
+        "kosk_sha3_256_batch_wave": (C.c_int, [vp, vp, sz, sz, vp, C.c_int]),
+        "kosk_fs_alpha_device": (C.c_int, [vp, vp, sz, C.c_int, vp, vp]),
+        "kosk_fs_opened_device": (C.c_int, [vp, vp, sz, C.c_int, vp, vp, C.c_int, vp]),
         "kosk_commit_hash_lanes": (C.c_int, [vp, vp, sz, C.c_int, vp, C.c_int, vp]),
         "kosk_ntt256_batch": (C.c_int, [vp, vp, vp, C.c_int]),
         "kosk_lagrange_expand": (C.c_int, [vp, vp, vp, C.c_int]),
@@ -104,7 +109,28 @@ EXPORTS = ["kosk_pk_bytes", "kosk_sk_bytes", "kosk_proof_bytes", "kosk_tape_byte
            "kosk_resident_digests", "kosk_set_round_hook", "kosk_phase_seconds", "kosk_path_count", "kosk_host_threads", "kosk_sha3_256_batch_pair", "kosk_verifiable_keygen_batch_compact", "kosk_verify_batch_compact", "kosk_host_alloc", "kosk_host_free", "kosk_sha3_256_batch",
            "kosk_shake256_batch", "kosk_commit_hash_lanes", "kosk_ntt256_batch", "kosk_lagrange_expand",
            "kosk_recon_secrets", "kosk_profile_enable", "kosk_profile_read", "kosk_profile_read_units", "kosk_combine_stats", "kosk_stream_timer_start", "kosk_stream_timer_stop", "kosk_device_synchronize", "kosk_streams", "kosk_commit_launch_groups", "kosk_resident_proofs", "kosk_keygen", "kosk_fs_alpha",
-           "kosk_fs_opened", "kosk_host_sha3_256", "kosk_host_shake256", "kosk_host_sha3_256_multi", "kosk_lagrange_table"]
+           "kosk_fs_opened", "kosk_host_sha3_256", "kosk_host_shake256", "kosk_host_sha3_256_multi", "kosk_lagrange_table",
+           "kosk_options_init", "kosk_create_ex", "kosk_sha3_256_batch_wave", "kosk_fs_alpha_device", "kosk_fs_opened_device"]
+
+
+class KoskOptions(C.Structure):
+    """kosk_options of include/kosk_mi355x.h (per-handle configuration, round 6); build with options(**fields)"""
+    _fields_ = [("size", C.c_uint32), ("streams", C.c_int32), ("combine", C.c_int32), ("combine_wait_us", C.c_int32),
+                ("combine_idle_us", C.c_int32), ("combine_prewake_us", C.c_int32), ("strict_encoding", C.c_int32), ("fs_mode", C.c_int32),
+                ("host_threads", C.c_int32), ("blocking_sync", C.c_int32), ("hooks_unmerged", C.c_int32), ("reserved", C.c_int32 * 6)]
+
+
+FS_HOST, FS_DEVICE = 0, 1
+
+
+def options(**fields):
+    o = KoskOptions()
+    lib.kosk_options_init(C.byref(o))
+    for k_, v_ in fields.items():
+        if k_ not in dict(KoskOptions._fields_) or k_ in ("size", "reserved"):
+            raise KoskError("unknown option " + k_)
+        setattr(o, k_, int(v_))
+    return o
 
 
 def pk_bytes(k): return lib.kosk_pk_bytes(k)
@@ -166,11 +192,18 @@ class Kosk:
       verify(pi, pk) -> list[bool]                         kyber_kosk_verify
     """
 
-    def __init__(self, kyber_k=2, max_batch=1, device=0):
+    def __init__(self, kyber_k=2, max_batch=1, device=0, **opts):
+        """opts: fields of kosk_options (streams, combine, strict_encoding, fs_mode, host_threads, blocking_sync, ...): the handle is
+        then created with kosk_create_ex; without any, with kosk_create (library defaults and the KOSK_* environment)"""
         self.k = kyber_k
         self.max_batch = max_batch
         self._h = C.c_void_p()
-        if lib.kosk_create(C.byref(self._h), device, kyber_k, max_batch):
+        if opts:
+            self._opts = options(**opts)
+            rc = lib.kosk_create_ex(C.byref(self._h), device, kyber_k, max_batch, C.byref(self._opts))
+        else:
+            rc = lib.kosk_create(C.byref(self._h), device, kyber_k, max_batch)
+        if rc:
             raise KoskError("kosk_create: " + lib.kosk_last_error(None).decode())
         self.pk_bytes, self.sk_bytes = pk_bytes(kyber_k), sk_bytes(kyber_k)
         self.proof_bytes, self.tape_bytes = proof_bytes(kyber_k), tape_bytes(kyber_k)
@@ -359,7 +392,8 @@ class Kosk:
         return list(out)
 
     PROFILE_IDS = ["hash_tcomm", "hash_view", "gemm_expand1", "gemm_expand2", "lincomb", "ntt_f", "assemble",
-                   "v_hash_tcomm", "v_hash_view", "v_interp_build", "v_gemm_interp", "v_gemm_expand", "v_gemm_recon", "v_lincomb", "hash_tcomm_tail", "hash_view_tail"]
+                   "v_hash_tcomm", "v_hash_view", "v_interp_build", "v_gemm_interp", "v_gemm_expand", "v_gemm_recon", "v_lincomb", "hash_tcomm_tail", "hash_view_tail",
+                   "fs_alpha", "fs_opened", "v_fs_alpha", "v_fs_opened"]
 
     def profile_enable(self, on=True):
         self._chk(lib.kosk_profile_enable(self._h, int(on)), "profile_enable")
@@ -390,7 +424,7 @@ class Kosk:
         return a.value, b.value
 
     PATH_IDS = ["hash_dma", "hash_plain", "hash_primer", "table_gemm", "limb_gemm", "copy_direct", "copy_staged", "graph_replay",
-                "ntt_fp32", "ntt_int", "digest_direct", "digest_copy", "copy_kernel", "small_copy_kernel", "lincomb_oneshot", "lincomb_stream", "assemble_fields", "assemble_groups", "table_chunks"]
+                "ntt_fp32", "ntt_int", "digest_direct", "digest_copy", "copy_kernel", "small_copy_kernel", "lincomb_oneshot", "lincomb_stream", "assemble_fields", "assemble_groups", "table_chunks", "fs_device", "fs_host"]
 
     def path_counts(self):
         """{name: launches / copies} of the alternative kernel and copy paths on this handle since it was created"""
@@ -432,6 +466,15 @@ class Kosk:
 
     def sha3_256_batch_pair(self, d_in, in_stride, inlen, d_out, n):
         self._chk(lib.kosk_sha3_256_batch_pair(self._h, d_in, in_stride, inlen, d_out, n), "sha3_256_batch_pair")
+
+    def sha3_256_batch_wave(self, d_in, in_stride, inlen, d_out, n):
+        self._chk(lib.kosk_sha3_256_batch_wave(self._h, d_in, in_stride, inlen, d_out, n), "sha3_256_batch_wave")
+
+    def fs_alpha_device(self, d_tables, table_stride, n, d_alpha, d_h1=None):
+        self._chk(lib.kosk_fs_alpha_device(self._h, d_tables, table_stride, n, d_alpha, d_h1), "fs_alpha_device")
+
+    def fs_opened_device(self, d_tables, table_stride, n, d_sel, d_rest, sel_stride, d_ch=None):
+        self._chk(lib.kosk_fs_opened_device(self._h, d_tables, table_stride, n, d_sel, d_rest, sel_stride, d_ch), "fs_opened_device")
 
     def shake256_batch(self, d_in, in_stride, inlen, d_out, outlen, n):
         self._chk(lib.kosk_shake256_batch(self._h, d_in, in_stride, inlen, d_out, outlen, n), "shake256_batch")

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libkosk_mi355x.so")
-HIP_SOURCES = ["kosk_kernels.hip", "kosk_verify_kernels.hip", "kosk_keygen_kernels.hip", "kosk_compact.hip", "kosk_ctx.cpp", "kosk_verify.cpp", "kosk_split.cpp", "kosk_capi.cpp"]
+HIP_SOURCES = ["kosk_kernels.hip", "kosk_verify_kernels.hip", "kosk_keygen_kernels.hip", "kosk_compact.hip", "kosk_fs_kernels.hip", "kosk_ctx.cpp", "kosk_verify.cpp", "kosk_split.cpp", "kosk_capi.cpp"]
 CXX_SOURCES = ["kosk_host.cpp"]
 COMMON = ["-O3", "-std=c++20", "-fPIC"]
 

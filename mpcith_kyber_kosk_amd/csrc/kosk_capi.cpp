@@ -59,6 +59,7 @@ struct kosk_ctx {
     Cohort *cohort = nullptr;    // KOSK_COMBINE: this handle is member `member_i` of a cohort, sub[0] a view of its arena
     int member_i = -1;
     long merged_calls = 0, merged_members = 0; // resident calls of this handle served by a run, and the members those runs served
+    bool hooks_unmerged = false; // kosk_options::hooks_unmerged: with a round hook set, this handle's resident calls run on their own
 
     ~kosk_ctx()
     {
@@ -227,13 +228,35 @@ int kosk_proof_field(int k, int idx, size_t *offset, size_t *size)
     return 0;
 }
 
-int kosk_create(kosk_ctx **ctx, int device, int kyber_k, int max_batch)
+void kosk_options_init(kosk_options *opt)
+{
+    if (!opt) return;
+    memset(opt, 0, sizeof *opt);
+    opt->size = (uint32_t)sizeof *opt;
+    opt->combine_wait_us = opt->combine_idle_us = opt->combine_prewake_us = -1;
+    opt->strict_encoding = opt->fs_mode = opt->blocking_sync = opt->hooks_unmerged = -1;
+}
+int kosk_create(kosk_ctx **ctx, int device, int kyber_k, int max_batch) { return kosk_create_ex(ctx, device, kyber_k, max_batch, nullptr); }
+
+int kosk_create_ex(kosk_ctx **ctx, int device, int kyber_k, int max_batch, const kosk_options *user_opt)
 {
     if (!ctx) return -1;
     *ctx = nullptr;
     kosk_ctx *h = nullptr;
     try {
         g_create_err.clear();
+        kosk_options o;
+        kosk_options_init(&o);
+        if (user_opt) { // a caller compiled against a shorter (older) struct leaves the tail at "not given"
+            if (user_opt->size < 8 || user_opt->size > 4096) { g_create_err = "kosk_create_ex: options.size is not set (call kosk_options_init first)"; return -1; }
+            memcpy(&o, user_opt, std::min<size_t>(user_opt->size, sizeof o));
+            o.size = (uint32_t)sizeof o;
+        }
+        CtxOpts co_;
+        co_.host_threads = o.host_threads > 0 ? o.host_threads : 0;
+        co_.blocking_sync = o.blocking_sync;
+        co_.strict_encoding = o.strict_encoding;
+        co_.fs_device = o.fs_mode < 0 ? -1 : (o.fs_mode == KOSK_FS_DEVICE ? 1 : 0);
         if (const char *e = getenv("AMD_DIRECT_DISPATCH"))
             if (atoi(e) == 0 && e[0] != '\0') {
                 // measured on ROCm 7.2 (tools/stress.py): with direct dispatch off, hipStreamSynchronize returned before
@@ -241,14 +264,17 @@ int kosk_create(kosk_ctx **ctx, int device, int kyber_k, int max_batch)
                 g_create_err = "AMD_DIRECT_DISPATCH=0 is not supported: stream synchronisation does not cover D2H copies in that mode";
                 return -1;
             }
-        int S = 1; // KOSK_STREAMS: sub-batches in flight per handle (1 measured best at 46 proofs: kernels sit on latency floors)
-        if (const char *e = getenv("KOSK_STREAMS")) S = atoi(e) > 0 ? atoi(e) : S;
+        int S = 1; // streams: sub-batches in flight per handle (1 measured best at 46 proofs: kernels sit on latency floors)
+        if (o.streams > 0) S = o.streams;
+        else if (const char *e = getenv("KOSK_STREAMS")) S = atoi(e) > 0 ? atoi(e) : S;
         if (S > max_batch) S = max_batch > 0 ? max_batch : 1;
         if (S > 8) S = 8;
         h = new kosk_ctx();
         h->max_batch = max_batch;
-        int W = 1; // KOSK_COMBINE: handles per cohort (needs KOSK_STREAMS=1)
-        if (const char *e = getenv("KOSK_COMBINE")) W = atoi(e) > 1 ? (atoi(e) > 8 ? 8 : atoi(e)) : 1;
+        h->hooks_unmerged = o.hooks_unmerged > 0;
+        int W = 1; // combine: handles per cohort (needs streams = 1)
+        if (o.combine > 0) W = o.combine > 8 ? 8 : o.combine;
+        else if (const char *e = getenv("KOSK_COMBINE")) W = atoi(e) > 1 ? (atoi(e) > 8 ? 8 : atoi(e)) : 1;
         if (W > 1 && S == 1 && max_batch >= 1) {
             std::lock_guard<std::mutex> lk(g_cohort_mu);
             Cohort *co = nullptr;
@@ -259,14 +285,17 @@ int kosk_create(kosk_ctx **ctx, int device, int kyber_k, int max_batch)
                 std::unique_ptr<Cohort> fresh(new Cohort());
                 fresh->device = device; fresh->k = kyber_k; fresh->per = max_batch;
                 int wait_us = 5000, idle_us = 1000;
-                if (const char *e = getenv("KOSK_COMBINE_WAIT_US")) wait_us = atoi(e) >= 0 ? atoi(e) : wait_us;
-                if (const char *e = getenv("KOSK_COMBINE_IDLE_US")) idle_us = atoi(e) >= 0 ? atoi(e) : idle_us;
+                if (o.combine_wait_us >= 0) wait_us = o.combine_wait_us;
+                else if (const char *e = getenv("KOSK_COMBINE_WAIT_US")) wait_us = atoi(e) >= 0 ? atoi(e) : wait_us;
+                if (o.combine_idle_us >= 0) idle_us = o.combine_idle_us;
+                else if (const char *e = getenv("KOSK_COMBINE_IDLE_US")) idle_us = atoi(e) >= 0 ? atoi(e) : idle_us;
                 int prewake_us = 400; // how long a member whose run has announced its end may spin for it (0: members sleep to the end)
-                if (const char *e = getenv("KOSK_COMBINE_PREWAKE_US")) prewake_us = atoi(e) >= 0 ? atoi(e) : prewake_us;
+                if (o.combine_prewake_us >= 0) prewake_us = o.combine_prewake_us;
+                else if (const char *e = getenv("KOSK_COMBINE_PREWAKE_US")) prewake_us = atoi(e) >= 0 ? atoi(e) : prewake_us;
                 fresh->comb.reset(new Combiner(W, wait_us, idle_us, prewake_us));
                 fresh->member.assign((size_t)W, nullptr);
                 if ((long)W * max_batch > 1 << 20) { g_create_err = "KOSK_COMBINE x max_batch too large"; delete h; return -1; }
-                if (ctx_create(&fresh->arena, device, kyber_k, W * max_batch, g_create_err, 1)) { delete h; return -1; }
+                if (ctx_create(&fresh->arena, device, kyber_k, W * max_batch, g_create_err, 1, co_)) { delete h; return -1; }
                 if (ensure_verify_workspace(*fresh->arena)) { // views share it: allocated with the arena, not on first use
                     g_create_err = fresh->arena->err;
                     delete fresh->arena;
@@ -301,7 +330,7 @@ int kosk_create(kosk_ctx **ctx, int device, int kyber_k, int max_batch)
         const int per = (max_batch + S - 1) / S;
         for (int i = 0; i < S; i++) {
             Ctx *c = nullptr;
-            if (ctx_create(&c, device, kyber_k, per, g_create_err, S)) {
+            if (ctx_create(&c, device, kyber_k, per, g_create_err, S, co_)) {
                 delete h;
                 return -1;
             }
@@ -463,6 +492,7 @@ static int combined_keygen(kosk_ctx *h, int n, const KeygenCall &call)
     }
     CombineReq r;
     r.kind = call.tapes ? CK_KEYGEN : CK_ALONE; // the stateful randombytes callback is per handle
+    if (h->hooks_unmerged && h->c->round_hook) r.kind = CK_ALONE; // the hook must fire on this caller's own thread (kosk_options::hooks_unmerged)
     r.n = n;
     r.full = n == co.per;
     r.args = const_cast<KeygenCall *>(&call);
@@ -509,6 +539,7 @@ static int combined_verify(kosk_ctx *h, int n, const VerifyCall &call)
     }
     CombineReq r;
     r.kind = call.pk ? CK_VERIFY_PK_GIVEN : CK_VERIFY_PK_RESIDENT;
+    if (h->hooks_unmerged && h->c->round_hook) r.kind = CK_ALONE;
     r.n = n;
     r.full = n == co.per;
     r.args = const_cast<VerifyCall *>(&call);
@@ -976,6 +1007,51 @@ int kosk_sha3_256_batch_pair(kosk_ctx *ctx, const uint8_t *d_in, size_t in_strid
     ctx->clear_err();
     HIPCHK_C(hipSetDevice(c.device));
     HIPCHK_C(launch_sha3_msgs_pair(d_in, in_stride, (int)inlen, d_out, 32, 32, n, 0x06, c.stream));
+    return 0;
+    GUARD_END
+}
+
+// sha3_256 of n LONG messages, one wave per message (the sponge of the device Fiat-Shamir rounds, kosk_fs_kernels.hip)
+int kosk_sha3_256_batch_wave(kosk_ctx *ctx, const uint8_t *d_in, size_t in_stride, size_t inlen, uint8_t *d_out, int n)
+{
+    if (!ctx || !d_in || !d_out || n < 1 || inlen > (size_t)1 << 30 || (reinterpret_cast<uintptr_t>(d_in) & 7) || (in_stride & 7)) return bad_args(ctx, __func__);
+    GUARD(ctx)
+    Ctx &c = *ctx->c;
+    ctx->clear_err();
+    HIPCHK_C(hipSetDevice(c.device));
+    FsArgs fa{};
+    fa.in = d_in; fa.in_stride = in_stride; fa.len = (int)inlen; fa.out_digest = d_out;
+    HIPCHK_C(launch_fs_chain(fa, FS_DIGEST, n, c.stream));
+    return 0;
+    GUARD_END
+}
+// kosk_fs_alpha / kosk_fs_opened for n digest tables in HBM (what the device Fiat-Shamir mode of a handle runs inside its calls)
+int kosk_fs_alpha_device(kosk_ctx *ctx, const uint8_t *d_tables, size_t table_stride, int n, uint16_t *d_alpha, uint8_t *d_h1)
+{
+    if (!ctx || !d_tables || !d_alpha || n < 1 || (reinterpret_cast<uintptr_t>(d_tables) & 7) || (table_stride & 7)) return bad_args(ctx, __func__);
+    GUARD(ctx)
+    Ctx &c = *ctx->c;
+    ctx->clear_err();
+    HIPCHK_C(hipSetDevice(c.device));
+    FsArgs fa{};
+    fa.in = d_tables; fa.in_stride = table_stride; fa.len = NPARTY * 32; fa.out_digest = d_h1;
+    fa.alpha = d_alpha; fa.alpha_stride = 80; fa.J = c.P.J;
+    HIPCHK_C(launch_fs_chain(fa, FS_ALPHA, n, c.stream));
+    return 0;
+    GUARD_END
+}
+int kosk_fs_opened_device(kosk_ctx *ctx, const uint8_t *d_tables, size_t table_stride, int n, uint16_t *d_sel, uint16_t *d_rest, int sel_stride, uint8_t *d_ch)
+{
+    if (!ctx || !d_tables || !d_sel || !d_rest || n < 1 || sel_stride < NREST || sel_stride < SEL_OPOS + NOPEN ||
+        (reinterpret_cast<uintptr_t>(d_tables) & 7) || (table_stride & 7)) return bad_args(ctx, __func__);
+    GUARD(ctx)
+    Ctx &c = *ctx->c;
+    ctx->clear_err();
+    HIPCHK_C(hipSetDevice(c.device));
+    FsArgs fa{};
+    fa.in = d_tables; fa.in_stride = table_stride; fa.len = NPARTY * 32; fa.out_digest = d_ch;
+    fa.I = d_sel; fa.rest = d_rest; fa.sel_stride = sel_stride;
+    HIPCHK_C(launch_fs_chain(fa, FS_OPENED, n, c.stream));
     return 0;
     GUARD_END
 }

@@ -11,6 +11,8 @@
 // part of the same rows.
 #include "kosk_ctx.hpp"
 
+#include <atomic>
+
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -469,7 +471,7 @@ static int build_tables(Ctx &c)
     return 0;
 }
 
-int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &err, int host_share)
+int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &err, int host_share, const CtxOpts &opts)
 {
     Ctx *cp = new Ctx();
     Ctx &c = *cp;
@@ -494,6 +496,7 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     const int cpus = host_cpu_count() / (host_share > 0 ? host_share : 1);
     c.nthreads = cpus > 8 ? 8 : (cpus < 1 ? 1 : cpus);
     if (const char *e = getenv("KOSK_HOST_THREADS")) c.nthreads = atoi(e) > 0 ? (atoi(e) > 64 ? 64 : atoi(e)) : c.nthreads;
+    if (opts.host_threads > 0) c.nthreads = opts.host_threads > 64 ? 64 : opts.host_threads;
     c.pool = pool_create();
     c.nthreads = pool_reserve(c.pool, c.nthreads);
     c.base_threads = c.nthreads;
@@ -525,6 +528,12 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
         c.cu_part_n = n;
     }
     if (const char *e = getenv("KOSK_CU_MASK_LAYOUT")) c.cu_mask_layout = atoi(e) != 0;
+    if (const char *e = getenv("KOSK_FS_DEVICE")) c.fs_device = atoi(e) != 0;
+    // what the caller's options struct decides wins over the environment (kosk_create_ex)
+    if (opts.blocking_sync >= 0) c.blocking_sync = opts.blocking_sync != 0;
+    if (opts.strict_encoding >= 0) c.strict_encoding = opts.strict_encoding != 0;
+    if (opts.fs_device >= 0) c.fs_device = opts.fs_device != 0;
+    if (c.fs_device) c.table_chunks = 1; // no digest table leaves HBM: nothing to cut into pieces
 
     auto body = [&]() -> int {
         HIPCHK(hipSetDevice(device));
@@ -928,6 +937,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         if (!s->pk || !s->sk) { c.err = "pk / sk output buffers are required"; return -1; }
     if (!keygen && !c.tape_cur) { c.err = "no resident prover inputs: call kosk_stage_prover_inputs first"; return -1; }
     if (!keygen) c.tape_segs.count = 0;
+    c.chunk_n = 0; // pieces of an EARLIER call's table copy (an error return between copy_round_table and table_done leaves them behind)
     HIPCHK(hipSetDevice(c.device));
     const Params &P = c.P;
     const RowMap &rm = c.rm;
@@ -956,11 +966,22 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         // the host's table: written by the hash launch itself (HashArgs::out_host), or copied behind it
         h1.out_host = c.digest_direct ? c.h_dig : nullptr;
         HIPCHK(commit_hash_batch(c, h1, n, K, false, st));
+        if (c.fs_device) return 0; // the table stays where it is: the chain kernel below hashes it in HBM
         if (!c.digest_direct) HIPCHK(copy_round_table(c, c.h_dig, c.d_dig1, n));
         if (!c.capturing) c.path_n[c.digest_direct ? PATH_DIGEST_DIRECT : PATH_DIGEST_COPY]++;
         return 0;
     }, c.tape_cur, c.tape_cur_stride)) return -1; // the tape pointer is baked into the captured launch: part of the graph's key
-    HIPCHK(hipEventRecord(c.ev, st)); // the Tcomm digests are on the host once this event has passed
+    HIPCHK(hipEventRecord(c.ev, st)); // the Tcomm digests are on the host (device Fiat-Shamir: complete in HBM) once this event has passed
+    if (c.fs_device) {
+        // ---- Fiat-Shamir round 1 on the device: h1 = sha3_256(Tcomm[0..N)), alpha = BE16(PRF(h1, 1)) % q, one wave per proof   :130-153
+        FsArgs fa{};
+        fa.in = c.d_dig1; fa.in_stride = (size_t)NPARTY * 32; fa.len = NPARTY * 32;
+        fa.alpha = c.d_alpha; fa.alpha_stride = 80; fa.J = P.J;
+        c.prof_begin(PR_FS_ALPHA, n);
+        HIPCHK(launch_fs_chain(fa, FS_ALPHA, n, st));
+        c.prof_end(PR_FS_ALPHA);
+        c.path_n[PATH_FS_DEVICE]++;
+    }
     c.phase_sec[PH_P1_ISSUE] = now_sec() - t0;
 
     // ---- P1B: what neither Tcomm nor alpha needs is queued behind the digest copy BEFORE the host waits for it, and runs
@@ -981,13 +1002,21 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         keys_done = true;
     }
     c.kg_on_host_pending = false;
-    HIPCHK(wait_event(c, first_event(c), 0, n)); // the table, or its first piece (copy_round_table)
-    t1 = now_sec(); c.phase_sec[PH_GPU_COMMIT] = t1 - t0; t0 = t1;
-    hipError_t gate_err = hipSuccess;
-    const std::function<void(int)> gate = [&c, &gate_err](int b) {
-        const hipError_t e = table_gate_wait(c, b);
-        if (e != hipSuccess) gate_err = e;
+    // device Fiat-Shamir: the host has nothing to wait for here unless somebody wants to be told that the round's table is complete
+    auto any_hook = [&]() {
+        bool h = c.round_hook != nullptr;
+        for (const KeygenIn *s = keygen; s; s = s->next) h |= s->hook != nullptr;
+        return h;
     };
+    const bool hooks = c.fs_device && any_hook();
+    if (!c.fs_device || hooks) HIPCHK(wait_event(c, first_event(c), 0, n)); // the table, or its first piece (copy_round_table)
+    t1 = now_sec(); c.phase_sec[PH_GPU_COMMIT] = t1 - t0; t0 = t1;
+    std::atomic<int> gate_err_a{(int)hipSuccess}; // written by several pool workers
+    const std::function<void(int)> gate = [&c, &gate_err_a](int b) {
+        const hipError_t e = table_gate_wait(c, b);
+        if (e != hipSuccess) gate_err_a.store((int)e, std::memory_order_relaxed);
+    };
+#define gate_err ((hipError_t)gate_err_a.load(std::memory_order_relaxed))
     // a round's table is complete in HBM: the hook of every caller of this run with ITS block of the table (a merged run), else the
     // context's own hook with the whole batch
     auto fire_hooks = [&](int rnd, const uint8_t *d_table) {
@@ -1004,13 +1033,16 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
             first += cnt;
         }
     };
-    fire_hooks(0, c.d_dig1);
+    if (!c.fs_device || hooks) fire_hooks(0, c.d_dig1);
 
     // ---- Fiat-Shamir round 1 on the host
     if (keygen && !keys_done) finish_keygen_segs(c, n, *keygen);
-    fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool, c.chunk_n > 1 ? &gate : nullptr);
-    HIPCHK(gate_err);
-    HIPCHK(table_done(c));
+    if (!c.fs_device) {
+        fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool, c.chunk_n > 1 ? &gate : nullptr);
+        HIPCHK(gate_err);
+        HIPCHK(table_done(c));
+        c.path_n[PATH_FS_HOST]++;
+    }
     t1 = now_sec(); c.phase_sec[PH_FS_ALPHA] = t1 - t0; t0 = t1;
 
     // ---- P2: beta, gamma, r, NTT_r on every evaluation point (per proof a [J x M] x [M x 1710] product mod q, :159-203),
@@ -1019,7 +1051,8 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         // (round 5) the challenge vectors are read by k_coef_limbs straight from the page-locked host table (160 bytes per proof): one
         // launch less between the host's round and the product; KOSK_SMALL_COPY_KERNEL=0 keeps the explicit copy
         const uint16_t *alpha_src = c.h_alpha;
-        if (!c.small_copy_kernel || !c.alpha_direct) {
+        if (c.fs_device) alpha_src = c.d_alpha; // written by the chain kernel
+        else if (!c.small_copy_kernel || !c.alpha_direct) {
             HIPCHK(copy_small(c, c.d_alpha, 0, c.h_alpha, 0, (size_t)n * 80 * 2, 1, hipMemcpyHostToDevice, st));
             alpha_src = c.d_alpha;
         }
@@ -1046,9 +1079,22 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     ha.out = c.d_dig2;
     ha.out_host = c.digest_direct ? c.h_dig2 : nullptr;
     HIPCHK(commit_hash_batch(c, ha, n, K, true, st));
-    if (!c.digest_direct) HIPCHK(copy_round_table(c, c.h_dig2, c.d_dig2, n));
-    c.path_n[c.digest_direct ? PATH_DIGEST_DIRECT : PATH_DIGEST_COPY]++;
+    if (!c.fs_device) {
+        if (!c.digest_direct) HIPCHK(copy_round_table(c, c.h_dig2, c.d_dig2, n));
+        c.path_n[c.digest_direct ? PATH_DIGEST_DIRECT : PATH_DIGEST_COPY]++;
+    }
     HIPCHK(hipEventRecord(c.ev, st));
+    if (c.fs_device) {
+        // ---- Fiat-Shamir round 2 on the device: ch = sha3_256(ch_seeds), I from PRF(ch, 1) with the reference's probing, its complement,
+        // the window boundaries and the sorted opened list, straight into the rows the wire-image kernel reads   :445-474
+        FsArgs fa{};
+        fa.in = c.d_dig2; fa.in_stride = (size_t)NPARTY * 32; fa.len = NPARTY * 32;
+        fa.I = c.d_I; fa.rest = c.d_rest; fa.sel_stride = c.sel_stride;
+        c.prof_begin(PR_FS_OPENED, n);
+        HIPCHK(launch_fs_chain(fa, FS_OPENED, n, st));
+        c.prof_end(PR_FS_OPENED);
+        c.path_n[PATH_FS_DEVICE]++;
+    }
     c.phase_sec[PH_P2_ISSUE] = now_sec() - t0;
 
     // ---- P2B: the NTT-domain half of the relation is not hashed, only opened; queued behind the digest copy before the
@@ -1074,21 +1120,28 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         return 0;
     })) return -1;
 
-    HIPCHK(wait_event(c, first_event(c), 1, n));
-    t1 = now_sec(); c.phase_sec[PH_GPU_RELATION] = t1 - t0; t0 = t1;
-    fire_hooks(1, c.d_dig2);
+    if (!c.fs_device || hooks) {
+        HIPCHK(wait_event(c, first_event(c), 1, n));
+        t1 = now_sec(); c.phase_sec[PH_GPU_RELATION] = t1 - t0; t0 = t1;
+        fire_hooks(1, c.d_dig2);
+    }
 
     // ---- Fiat-Shamir round 2 on the host
     // I, its complement, and the complement entries owned by each aligned 64-party window (k_assemble_fields), all derived by
     // the worker that hashed the proof's table
-    fs_opened_batch(n, c.h_dig2, (size_t)NPARTY * 32, c.h_I, c.h_rest, c.sel_stride, c.nthreads, c.pool, true, c.chunk_n > 1 ? &gate : nullptr);
-    HIPCHK(gate_err);
-    HIPCHK(table_done(c));
+    if (!c.fs_device) {
+        fs_opened_batch(n, c.h_dig2, (size_t)NPARTY * 32, c.h_I, c.h_rest, c.sel_stride, c.nthreads, c.pool, true, c.chunk_n > 1 ? &gate : nullptr);
+        HIPCHK(gate_err);
+        HIPCHK(table_done(c));
+        c.path_n[PATH_FS_HOST]++;
+    }
     t1 = now_sec(); c.phase_sec[PH_FS_OPEN] = t1 - t0; t0 = t1;
 
     // ---- P3: wire image
     if (run_segment(c, Ctx::SEG_P3, n, [&]() -> int {
-        if (!c.is_view) {
+        if (c.fs_device) {
+            // the lists are in HBM already (k_fs_chain<FS_OPENED>)
+        } else if (!c.is_view) {
             HIPCHK(copy_small(c, c.d_I, 0, c.h_I, 0, ((size_t)c.max_batch + n) * c.sel_stride * 2, 1, hipMemcpyHostToDevice, st)); // I and its complement
         } else { // a view's lists sit inside the arena's two blocks: other views' lists lie between them
             HIPCHK(copy_small(c, c.d_I, 0, c.h_I, 0, (size_t)n * c.sel_stride * 2, 1, hipMemcpyHostToDevice, st));
@@ -1124,6 +1177,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     c.prof_collect();
     if (device_error_check(c)) return -1; // e.g. the key generation's gen_matrix hit its block limit: pk / sk / proofs are not valid
     return 0;
+#undef gate_err
 }
 
 int fetch_proofs(Ctx &c, int n, uint8_t *pi, bool registered)

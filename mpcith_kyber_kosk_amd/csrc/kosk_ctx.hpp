@@ -65,11 +65,11 @@ enum Phase { PH_HOST_PRE = 0, PH_GPU_COMMIT, PH_FS_ALPHA, PH_GPU_RELATION, PH_FS
 // HIP-event timing of individual launches on the ctx stream (bench.py roofline leg)
 enum ProfId { PR_HASH_TCOMM = 0, PR_HASH_VIEW, PR_GEMM_EXPAND1, PR_GEMM_EXPAND2, PR_LINCOMB, PR_NTT_F, PR_ASSEMBLE,
               PR_V_HASH_TCOMM, PR_V_HASH_VIEW, PR_V_INTERP_BUILD, PR_V_GEMM_INTERP, PR_V_GEMM_EXPAND, PR_V_GEMM_RECON,
-              PR_V_LINCOMB, PR_HASH_TCOMM_TAIL, PR_HASH_VIEW_TAIL, PR_COUNT };
+              PR_V_LINCOMB, PR_HASH_TCOMM_TAIL, PR_HASH_VIEW_TAIL, PR_FS_ALPHA, PR_FS_OPENED, PR_V_FS_ALPHA, PR_V_FS_OPENED, PR_COUNT };
 
 enum PathId { PATH_HASH_DMA = 0, PATH_HASH_PLAIN, PATH_HASH_PRIMER, PATH_TABLE_GEMM, PATH_LIMB_GEMM, PATH_COPY_DIRECT, PATH_COPY_STAGED,
               PATH_GRAPH_REPLAY, PATH_NTT_FP32, PATH_NTT_INT, PATH_DIGEST_DIRECT, PATH_DIGEST_COPY, PATH_COPY_KERNEL, PATH_SMALL_COPY_KERNEL,
-              PATH_LINCOMB_ONESHOT, PATH_LINCOMB_STREAM, PATH_ASSEMBLE_FIELDS, PATH_ASSEMBLE_GROUPS, PATH_TABLE_CHUNKS, PATH_COUNT };
+              PATH_LINCOMB_ONESHOT, PATH_LINCOMB_STREAM, PATH_ASSEMBLE_FIELDS, PATH_ASSEMBLE_GROUPS, PATH_TABLE_CHUNKS, PATH_FS_DEVICE, PATH_FS_HOST, PATH_COUNT };
 
 struct GemmTable {
     uint8_t *d = nullptr; // limb matrix (kosk_device.hpp)
@@ -302,10 +302,18 @@ struct Ctx {
     // (105 k against 133-137 k proofs/s: the copy takes the same 117 us, but the kernels running beside it stretch by 1.5-1.9 x;
     // profiles/r04_copy_kernel.txt), so it is an experiment knob only
     int copy_waves = 0;
-    // KOSK_STRICT_ENCODING=1: the verifier marks a proof malformed (fail bit 0) when ANY u16 element of a record the reference reads
-    // is >= q (rounds 1-4).  Default 0: such elements are treated exactly as the reference treats them, record by record
-    // (INTEGRATION.md 6): folded where it only multiplies / converts to ZZ_p, raw in its non-reducing add / sub and comparisons
-    bool strict_encoding = false;
+    // strict_encoding (kosk_options::strict_encoding, KOSK_STRICT_ENCODING; DEFAULT 1 since round 6): the verifier marks a proof malformed
+    // (fail bit 0) when ANY u16 element of a record the reference reads is >= q -- no honest prover emits one, and accepting them makes
+    // proofs malleable (v and v + q verify alike).  0 = the reference-following mode of round 5: such elements are treated exactly as
+    // the reference treats them, record by record: folded where it only multiplies / converts to ZZ_p, raw in its
+    // non-reducing add / sub and comparisons; pinned against the oracle by two differential suites, opt-in for parity work
+    bool strict_encoding = true;
+    // Fiat-Shamir aggregation on the device (kosk_options::fs_mode = KOSK_FS_DEVICE, or KOSK_FS_DEVICE=1 for kosk_create): the four
+    // sha3_256 chains of a prove + verify over the 46.5 KB digest tables run as one wave per proof where the tables are, the challenge
+    // vectors / opened lists / the verifier's I' == I never leave HBM, and the resident calls have NO host round trip left: no digest
+    // table crosses PCIe, the host neither hashes nor waits between segments (kosk_fs_kernels.hip).  Host mode (default)
+    // is the path of rounds 1-5
+    bool fs_device = false;
     bool small_copy_kernel = true; // KOSK_SMALL_COPY_KERNEL=0: hipMemcpyAsync for the small copies too (copy_small)
     bool stream_shared = false;    // KOSK_SHARE_STREAMS: the stream belongs to the process, not to this context
     bool alpha_direct = true;      // KOSK_ALPHA_DIRECT=0: the challenge vectors are copied into HBM in front of k_coef_limbs / k_pow_table
@@ -380,8 +388,15 @@ int run_segment(Ctx &c, int seg, int n, F &&body, const void *key_ptr = nullptr,
     return 0;
 }
 
+// what kosk_create_ex's options struct decides per context (-1 / 0 = not given: the environment variable of the same name, then the default)
+struct CtxOpts {
+    int host_threads = 0;    // KOSK_HOST_THREADS
+    int blocking_sync = -1;  // KOSK_BLOCKING_SYNC
+    int strict_encoding = -1; // KOSK_STRICT_ENCODING
+    int fs_device = -1;      // KOSK_FS_DEVICE
+};
 // host_share: sub-contexts of the same handle that share this process's CPUs (divides the host thread budget)
-int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &err, int host_share = 1);
+int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &err, int host_share = 1, const CtxOpts &opts = CtxOpts());
 // a view of `arena` starting at proof `first` whose own callers send up to `own_batch` proofs per call; reserve_threads: host
 // workers created now (a merged run led by this view uses base_threads x members of them)
 int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx **out, std::string &err);

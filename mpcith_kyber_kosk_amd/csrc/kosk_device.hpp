@@ -307,6 +307,27 @@ hipError_t launch_sha3_msgs(const uint8_t *in, size_t in_stride, int len, uint8_
 // the same on the lane-pair sponge (32 messages per wave; kosk_keccak_split_dev.hpp)
 hipError_t launch_sha3_msgs_pair(const uint8_t *in, size_t in_stride, int len, uint8_t *out, size_t out_stride, int outlen, int n,
                                  int domain, hipStream_t st);
+// ---- Fiat-Shamir aggregation on the device (kosk_fs_kernels.hip): one wave per proof hashes the proof's digest table where the
+// commitment kernel wrote it and derives the challenge from the digest (mlwe_prover.cpp:130-153, :445-474; mlwe_verifier.cpp:37-65, :634-683)
+enum FsMode { FS_DIGEST = 0, FS_ALPHA = 1, FS_OPENED = 2, FS_CHECK = 3 };
+struct FsArgs {
+    const uint8_t *in;   // [n] messages, in_stride bytes apart; base and stride multiples of 8 (the digest tables: 1454 x 32 bytes per proof)
+    size_t in_stride;
+    int len;             // bytes hashed per message
+    uint8_t *out_digest; // optional [n][32]: sha3_256 of every message (FS_DIGEST: the result; else h1 / ch for whoever wants them)
+    // FS_ALPHA: alpha[proof][alpha_stride], J = 70 + 2K entries derived, zeros behind them up to 80
+    uint16_t *alpha;
+    int alpha_stride, J;
+    // FS_OPENED (prover): rows of the opened-list tables (kosk_params.hpp: I, SEL_WIN, SEL_OSORT, SEL_OPOS; the ascending complement)
+    uint16_t *I, *rest;
+    int sel_stride;
+    // FS_CHECK (verifier): the recomputed list against field I of the proof image, bit FB_OPENED_SET of fail[proof] on a mismatch
+    const uint8_t *proof;
+    size_t image_stride;
+    uint32_t off_I;
+    uint32_t *fail;
+};
+hipError_t launch_fs_chain(const FsArgs &A, int mode, int n, hipStream_t st);
 // HBM -> page-locked host memory with nwg one-wave workgroups (k_copy_to_host); bytes, both pointers: multiples of 16
 hipError_t launch_copy_to_host(const void *d_src, void *h_dst, size_t bytes, int nwg, hipStream_t st);
 bool copy_small_ok(const void *src, size_t src_stride, const void *dst, size_t dst_stride, size_t row_bytes);

@@ -13,6 +13,7 @@
 //       operator W2 (256x813), recon_secrets_2ddeg                        :469-571
 //   V10 view hashes of the opened parties -> host: I' == I                :584-683
 // Every check sets a bit of fail[proof]; the verify bit is fail == 0.
+#include <atomic>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -244,6 +245,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     const uint8_t *himg = c.host_img;
     const size_t himg_stride = c.host_img_stride;
     c.host_img = nullptr;
+    c.chunk_n = 0; // (see prove_resident)
     if (n < 1 || n > c.call_cap) { c.err = "batch size out of range"; return -1; }
     // a merged call (kosk_combine.hpp): `segs` lists the callers' parts, each with its own keys and result bytes
     const VerifySeg whole{n, pk, ok, nullptr, nullptr, nullptr};
@@ -319,7 +321,9 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     // how the host gets its two digest tables (see Ctx::h_imgdig): the 1304 digests per proof and table that the proof itself
     // carries come from the caller's host copy of the images when there is one, else over the side stream, starting now; only the
     // 150 recomputed ones per proof follow each round's hash on the context's own stream
-    const bool split_tables = !c.verify_tables || himg != nullptr;
+    // device Fiat-Shamir: both tables are put together in HBM anyway (k_disassemble_fields copies the images' 1304 digests per table,
+    // the opened-party hashes store their 150), hashed there, and the host sees nothing of them
+    const bool split_tables = !c.fs_device && (!c.verify_tables || himg != nullptr);
     if (split_tables && !himg) {
         const size_t w = (size_t)NREST * 32;
         for (int r = 0; r < 2; r++) {
@@ -342,7 +346,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     // ---- V0: opened list from the image, validated and expanded on the GPU (no host round trip); the host
     // only needs the list itself for the final Fiat-Shamir comparison and receives it with the first digests
     HIPCHK(launch_opened_setup(c.d_proof, c.image_stride, P.off[F_I], c.d_I, c.d_rest, c.d_isort, c.d_hrange, c.sel_stride, c.d_fail, n, st));
-    HIPCHK(copy_small(c, c.h_Iimg, 2 * NOPEN, c.d_proof + P.off[F_I], c.image_stride, 2 * NOPEN, n, hipMemcpyDeviceToHost, st));
+    if (!c.fs_device) HIPCHK(copy_small(c, c.h_Iimg, 2 * NOPEN, c.d_proof + P.off[F_I], c.image_stride, 2 * NOPEN, n, hipMemcpyDeviceToHost, st));
 
 
     // ---- V1: scatter, gate outputs on opened columns, Tcomm of the opened parties
@@ -352,11 +356,22 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     c.prof_begin(PR_V_HASH_TCOMM, n);
     HIPCHK(launch_opened_hash(oh, K, false, n, st)); // Tcomm of the opened parties, read from the image   :22-35
     c.prof_end(PR_V_HASH_TCOMM);
+    if (c.fs_device) return 0;
     if (split_tables) HIPCHK(copy_table_to_host(c, c.h_odig, c.d_odig, dig_bytes));
     else HIPCHK(copy_round_table(c, c.h_dig, c.d_dig1, n)); // in pieces (Ctx::table_chunks), never in a captured segment
     return 0;
-    }, split_tables ? c.h_odig : c.h_dig)) return -1; // which table copy the captured segment holds is part of its graph's key
-    HIPCHK(hipEventRecord(c.ev, st)); // the opened parties' Tcomm digests are on the host once this event has passed
+    }, c.fs_device ? nullptr : split_tables ? c.h_odig : c.h_dig)) return -1; // which table copy the captured segment holds is part of its graph's key
+    HIPCHK(hipEventRecord(c.ev, st)); // the opened parties' Tcomm digests are on the host (device Fiat-Shamir: the table is complete in HBM) once this event has passed
+    if (c.fs_device) {
+        // ---- alpha on the device from the verifier's own table   mlwe_verifier.cpp:37-65
+        FsArgs fa{};
+        fa.in = c.d_dig1; fa.in_stride = (size_t)NPARTY * 32; fa.len = NPARTY * 32;
+        fa.alpha = c.d_alpha; fa.alpha_stride = 80; fa.J = P.J;
+        c.prof_begin(PR_V_FS_ALPHA, n);
+        HIPCHK(launch_fs_chain(fa, FS_ALPHA, n, st));
+        c.prof_end(PR_V_FS_ALPHA);
+        c.path_n[PATH_FS_DEVICE]++;
+    }
     t1 = now_sec(); c.phase_sec[PH_V1_ISSUE] = t1 - t0; t0 = t1;
 
     // ---- alpha-independent GPU work, issued before the host hashes so that it runs meanwhile: interpolation of
@@ -417,12 +432,19 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     return 0;
     })) return -1;
 
-    HIPCHK(wait_event(c, first_event(c), 3, n));
-    hipError_t gate_err = hipSuccess;
-    const std::function<void(int)> gate = [&c, &gate_err](int b) { // whole tables in pieces: a worker waits for the piece it reaches
-        const hipError_t e = table_gate_wait(c, b);
-        if (e != hipSuccess) gate_err = e;
+    auto any_hook = [&]() {
+        bool h = c.round_hook != nullptr;
+        for (const VerifySeg *sg = segs; sg; sg = sg->next) h |= sg->hook != nullptr;
+        return h;
     };
+    const bool hooks = c.fs_device && any_hook();
+    if (!c.fs_device || hooks) HIPCHK(wait_event(c, first_event(c), 3, n));
+    std::atomic<int> gate_err_a{(int)hipSuccess};
+    const std::function<void(int)> gate = [&c, &gate_err_a](int b) { // whole tables in pieces: a worker waits for the piece it reaches
+        const hipError_t e = table_gate_wait(c, b);
+        if (e != hipSuccess) gate_err_a.store((int)e, std::memory_order_relaxed);
+    };
+#define gate_err ((hipError_t)gate_err_a.load(std::memory_order_relaxed))
     if (split_tables && !himg) HIPCHK(hipEventSynchronize(c.ev_img[0])); // the images' Tcomm fields (under way since the call began)
     t1 = now_sec(); c.phase_sec[PH_V1_WAIT] = t1 - t0; t0 = t1;
     auto fire_hooks = [&](int rnd, const uint8_t *d_table) { // as in prove_resident: per caller of a merged run, else the context's own
@@ -438,10 +460,11 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
             first += s->count;
         }
     };
-    fire_hooks(0, c.d_dig1);
+    if (!c.fs_device || hooks) fire_hooks(0, c.d_dig1);
 
     // ---- host: alpha while the GPU works
-    {
+    if (!c.fs_device) {
+        c.path_n[PATH_FS_HOST]++;
         const std::function<void(int)> prep = table_prep(0);
         fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool, split_tables ? &prep : c.chunk_n > 1 ? &gate : nullptr);
         HIPCHK(gate_err);
@@ -450,7 +473,8 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     t1 = now_sec(); c.phase_sec[PH_V_FS_ALPHA] = t1 - t0; t0 = t1;
     if (run_segment(c, Ctx::SEG_V2, n, [&]() -> int {
     const uint16_t *alpha_src = c.h_alpha; // read from the page-locked host table by k_pow_table itself (as the prover's k_coef_limbs)
-    if (!c.small_copy_kernel || !c.alpha_direct) {
+    if (c.fs_device) alpha_src = c.d_alpha;
+    else if (!c.small_copy_kernel || !c.alpha_direct) {
         HIPCHK(copy_small(c, c.d_alpha, 0, c.h_alpha, 0, (size_t)n * 80 * 2, 1, hipMemcpyHostToDevice, st));
         alpha_src = c.d_alpha;
     }
@@ -480,9 +504,21 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     c.prof_begin(PR_V_HASH_VIEW, n);
     HIPCHK(launch_opened_hash(oh, K, true, n, st));
     c.prof_end(PR_V_HASH_VIEW);
-    if (split_tables) HIPCHK(copy_table_to_host(c, c.h_odig, c.d_odig, dig_bytes));
-    else HIPCHK(copy_round_table(c, c.h_dig, c.d_dig2, n));
-    HIPCHK(hipEventRecord(c.ev, st));
+    if (c.fs_device) {
+        // ---- I' on the device, compared with the proof's own list: fail bit FB_OPENED_SET   mlwe_verifier.cpp:634-683
+        HIPCHK(hipEventRecord(c.ev, st));
+        FsArgs fa{};
+        fa.in = c.d_dig2; fa.in_stride = (size_t)NPARTY * 32; fa.len = NPARTY * 32;
+        fa.proof = c.d_proof; fa.image_stride = c.image_stride; fa.off_I = (uint32_t)P.off[F_I]; fa.fail = c.d_fail;
+        c.prof_begin(PR_V_FS_OPENED, n);
+        HIPCHK(launch_fs_chain(fa, FS_CHECK, n, st));
+        c.prof_end(PR_V_FS_OPENED);
+        c.path_n[PATH_FS_DEVICE]++;
+    } else {
+        if (split_tables) HIPCHK(copy_table_to_host(c, c.h_odig, c.d_odig, dig_bytes));
+        else HIPCHK(copy_round_table(c, c.h_dig, c.d_dig2, n));
+        HIPCHK(hipEventRecord(c.ev, st));
+    }
     t1 = now_sec(); c.phase_sec[PH_V2_ISSUE] = t1 - t0; t0 = t1;
 
     // ---- V2B: the checks that feed no hash run while the host derives the opened set: reconstruction of the 140
@@ -515,6 +551,22 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     return 0;
     })) return -1;
 
+    if (c.fs_device) {
+        if (hooks) {
+            HIPCHK(wait_event(c, c.ev, 4, n));
+            fire_hooks(1, c.d_dig2);
+        }
+        if (c.near_end_hook) c.near_end_hook();
+        HIPCHK(stream_sync_site(c, 5, n)); // the only wait of the call: fail masks of V2B, the chain's bit among them
+        c.prof_collect();
+        if (device_error_check(c)) return -1;
+        int b = 0;
+        for (const VerifySeg *sg = segs; sg; sg = sg->next)
+            for (int i = 0; i < sg->count; i++, b++) sg->ok[i] = c.h_fail[b] == 0;
+        c.phase_sec[PH_V2_WAIT] = now_sec() - t0;
+        c.phase_sec[PH_V_FS_OPEN] = 0;
+        return 0;
+    }
     HIPCHK(wait_event(c, first_event(c), 4, n)); // the view digests (or their first piece) are on the host; V2B keeps running
     if (split_tables && !himg) HIPCHK(hipEventSynchronize(c.ev_img[1]));
     t1 = now_sec(); c.phase_sec[PH_V2_WAIT] = t1 - t0; t0 = t1;
@@ -543,6 +595,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     }
     c.phase_sec[PH_V_FS_OPEN] = now_sec() - t0;
     return 0;
+#undef gate_err
 }
 
 } // namespace kosk

@@ -316,7 +316,7 @@ def combined_calls(k, threads=6, rounds=4, min_merge=0.5):
     print("combined_calls ok", k, "mean callers per run %.2f" % (members / calls))
 
 
-def line_of_record_shape(k=3, per=46, callers=3, rounds=3, table_chunks=1):
+def line_of_record_shape(k=3, per=46, callers=3, rounds=3, table_chunks=1, fs_device=0):
     """The shape bench.py's line of record runs (bench.py: Slot.step), checked byte for byte: `callers` caller threads of ONE cohort
     (KOSK_COMBINE=callers: 6 is the bench's default since round 5, 4 and 3 its side runs), each with 46 Kyber-768 proofs per call on DEVICE tapes with a 64-byte-aligned stride that a merged run reads in
     place (the tape pointer table of the first kernel), the raw resident entry points with the key generation's pk / sk staying
@@ -331,8 +331,10 @@ def line_of_record_shape(k=3, per=46, callers=3, rounds=3, table_chunks=1):
     from mpcith_kyber_kosk_amd import api
     lib = api.lib
     plain = api.Kosk(kyber_k=k, max_batch=per)
-    hs = [_kosk(k, per, KOSK_COMBINE=callers, KOSK_COMBINE_WAIT_US=5000000, KOSK_COMBINE_IDLE_US=2000000, KOSK_TABLE_CHUNKS=table_chunks)
-          for _ in range(callers)]
+    # fs_device=1: the cohort runs its Fiat-Shamir rounds on the GPU (kosk_options::fs_mode through the environment twin KOSK_FS_DEVICE);
+    # `plain`, the handle everything is compared with, hashes on the host
+    hs = [_kosk(k, per, KOSK_COMBINE=callers, KOSK_COMBINE_WAIT_US=5000000, KOSK_COMBINE_IDLE_US=2000000, KOSK_TABLE_CHUNKS=table_chunks,
+                KOSK_FS_DEVICE=fs_device) for _ in range(callers)]
     stride = (plain.tape_bytes + 63) // 64 * 64
     nsets = rounds
     tapes = {(t, r): [oracle.tape_bytes_for(k, 20000 + ((t * nsets) + r) * per + b) for b in range(per)] for t in range(callers) for r in range(nsets)}
@@ -406,10 +408,13 @@ def line_of_record_shape(k=3, per=46, callers=3, rounds=3, table_chunks=1):
     assert sum(h.path_counts()["hash_dma"] for h in hs) > 0 and all(h.path_counts()["hash_plain"] == 0 for h in hs), pc
     # one copy per round by default; KOSK_TABLE_CHUNKS=n: every merged run's four tables reached the host in pieces
     nchunked = sum(h.path_counts()["table_chunks"] for h in hs)
-    assert (nchunked == 0) if table_chunks < 2 else (nchunked >= 4 * nsets), nchunked
+    assert (nchunked == 0) if (table_chunks < 2 or fs_device) else (nchunked >= 4 * nsets), nchunked
+    nfs_dev, nfs_host, ncopy = (sum(h.path_counts()[nm] for h in hs) for nm in ("fs_device", "fs_host", "digest_copy"))
+    assert (nfs_dev >= 4 * nsets and nfs_host == 0 and ncopy == 0) if fs_device else (nfs_dev == 0 and nfs_host >= 4 * nsets), (nfs_dev, nfs_host, ncopy)
+    assert plain.path_counts()["fs_device"] == 0
     for h in hs + [plain]:
         h.close()
-    print("line_of_record_shape ok", k, per, callers, "callers per run %.2f" % (members / calls))
+    print("line_of_record_shape ok", k, per, callers, "callers per run %.2f" % (members / calls), "fs_device" if fs_device else "fs_host")
 
 
 def member_big_batch_stays_in_its_block(k=3, per=3):

@@ -148,7 +148,7 @@ def test_verify_congruent_encodings_match_oracle(k, oracle, torch_cuda):
     the accepted.  mlwe_verifier.cpp:97-124, ss.cpp:37-54, gf3329.c:274-284."""
     from mpcith_kyber_kosk_amd import api
     p = oracle.params(k)
-    ctx = api.Kosk(kyber_k=k, max_batch=64)
+    ctx = api.Kosk(kyber_k=k, max_batch=64, strict_encoding=0)  # the reference-following mode (round 6: opt-in; the default rejects every u16 >= q it reads)
     assert ctx.path_counts is not None
     pks, sks, pis = ctx.verifiable_keygen([oracle.tape_bytes_for(k, 130 + k)])
     pi = pis[0]
@@ -239,7 +239,7 @@ def test_verify_crafted_hash_consistent_non_canonical_proofs(k, oracle, torch_cu
     for tidx, items in crafts:
         pk, sk, pi = oracle.crafted_verifiable_keygen(k, oracle.tape_bytes_for(k, tidx), items)
         pks.append(pk); pis.append(pi)
-    ctx = api.Kosk(kyber_k=k, max_batch=len(pis))
+    ctx = api.Kosk(kyber_k=k, max_batch=len(pis), strict_encoding=0)  # reference-following mode
     got = ctx.verify(pis, pks)
     masks = ctx.fail_masks(len(pis))
     opened_fields = (0, 1, 6, 7, 9, 10, 11, 12, 17, 18, 19, 20)
@@ -255,18 +255,16 @@ def test_verify_crafted_hash_consistent_non_canonical_proofs(k, oracle, torch_cu
     ctx.close()
 
 
-def test_strict_encoding_knob_rejects_what_the_reference_accepts(oracle, torch_cuda):
-    """KOSK_STRICT_ENCODING=1 (rounds 1-4): a u16 >= q in any record the reference reads marks the proof malformed (fail bit 0),
-    whatever the reference would do with it; records it never reads stay unchecked."""
+def test_default_verifier_is_strict_about_encodings(oracle, torch_cuda):
+    """The production default (rounds 1-4, and again since round 6: kosk_options::strict_encoding = 1): a u16 >= q in any record the
+    reference reads marks the proof malformed (fail bit 0), whatever the reference would do with it -- no honest prover emits one, and
+    accepting them makes proofs malleable; records the reference never reads stay unchecked.  The reference-following mode is opt-in
+    (strict_encoding = 0 / KOSK_STRICT_ENCODING=0): it accepts the same five proofs the oracle accepts."""
     import os
     from mpcith_kyber_kosk_amd import api
     k = 3
     p = oracle.params(k)
-    os.environ["KOSK_STRICT_ENCODING"] = "1"
-    try:
-        ctx = api.Kosk(kyber_k=k, max_batch=8)
-    finally:
-        os.environ.pop("KOSK_STRICT_ENCODING", None)
+    ctx = api.Kosk(kyber_k=k, max_batch=8)
     pks, sks, pis = ctx.verifiable_keygen([oracle.tape_bytes_for(k, 133)])
     pi = pis[0]
     I = [int.from_bytes(pi[p.off[5] + 2 * i:p.off[5] + 2 * i + 2], "little") for i in range(150)]
@@ -286,17 +284,27 @@ def test_strict_encoding_knob_rejects_what_the_reference_accepts(oracle, torch_c
     for t in cases:  # the reference (oracle) accepts all five
         assert oracle.kosk_verify(k, t, pks[0])[0]
     ctx.close()
+    os.environ["KOSK_STRICT_ENCODING"] = "0"  # the environment twin of the option, read by kosk_create
+    try:
+        lax = api.Kosk(kyber_k=k, max_batch=8)
+    finally:
+        os.environ.pop("KOSK_STRICT_ENCODING", None)
+    assert lax.verify(cases, [pks[0]] * 5) == [True] * 5 and lax.fail_masks(5) == [0] * 5
+    lax.close()
+    strict = api.Kosk(kyber_k=k, max_batch=8, strict_encoding=1)  # the option wins over the environment either way
+    assert strict.verify(cases, [pks[0]] * 5) == [False, False, False, True, True]
+    strict.close()
 
 
 def test_verify_non_canonical_elements(oracle, torch_cuda):
     """u16 values >= q never come out of an honest prover.  Where the reference never reads a record, any bytes are accepted,
     by the reference, the oracle and this verifier alike.  Where it does read, this verifier does what the reference does with
-    the raw value (round 5; rounds 1-4 rejected outright, now KOSK_STRICT_ENCODING=1): DIFFERENT residues below are rejected by
+    the raw value in its reference-following mode (round 5; the default rejects such a proof outright): DIFFERENT residues below are rejected by
     the check they break, the congruent s + r share by the raw comparison of mlwe_verifier.cpp:234."""
     from mpcith_kyber_kosk_amd import api
     k = 3
     p = oracle.params(k)
-    ctx = api.Kosk(kyber_k=k, max_batch=8)
+    ctx = api.Kosk(kyber_k=k, max_batch=8, strict_encoding=0)  # reference-following mode: the masks below name the reference's own checks
     pks, sks, pis = ctx.verifiable_keygen([oracle.tape_bytes_for(k, 77)])
     pi = pis[0]
     I = [int.from_bytes(pi[p.off[5] + 2 * i:p.off[5] + 2 * i + 2], "little") for i in range(150)]

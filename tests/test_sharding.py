@@ -84,13 +84,34 @@ def test_host_budget_per_rank():
     assert bench.host_budget(256, 8, 4, 6) == (6, False)      # 32 cores per rank >= 4 x 7
     assert bench.host_budget(128, 8, 6, 6) == (5, True)       # 16 cores per rank, 6 slots: 2 * 16 // 6 = 5
     assert bench.host_budget(64, 8, 6, 6) == (3, True)        # 8 cores per rank: the floor of three
-    assert bench.host_budget(8, 8, 4, 8) == (3, True)
-    assert bench.host_budget(1, 1, 1, 6) == (3, True)
+    assert bench.host_budget(8, 8, 4, 8) == (2, True)         # one core per rank: the floor of two
+    assert bench.host_budget(1, 1, 1, 6) == (2, True)
     # the default configuration since round 5: three cohorts of six callers with three workers each (18 per merged run)
     assert bench.CONFIGS[3]["slots"] == 18 and bench.CONFIGS[3]["combine"] == 6 and bench.CONFIGS[3]["threads"] == 3
     assert bench.host_budget(256, 1, 3, 18) == (18, False)    # one rank on a whole host: 3 per caller, spinning waits
     assert bench.host_budget(256, 8, 3, 18) == (18, True)     # a rank of eight on 32 cores: sleeping waits, still 18 // 6 = 3 per caller
     assert bench.host_budget(64, 8, 3, 18) == (5, True)       # 8 cores per rank: 2 * 8 // 3 = 5 per cohort -> the floor of three per caller
+    assert bench.threads_per_caller(5, True, 6, 8) == 3
+    # the driver's container (round 5): 256 hardware threads visible, a CPU quota of 16 cores, eight ranks -> two cores per rank:
+    # sleeping waits and two workers per caller (what the quota-blind budget got wrong: it assumed 32 cores per rank and spun)
+    assert bench.host_budget(16, 8, 3, 18) == (2, True)
+    assert bench.threads_per_caller(2, True, 6, 16 // 8) == 2
+    assert bench.threads_per_caller(18, False, 6, 256) == 3
+    assert bench.threads_per_caller(18, True, 6, 32) == 3
+
+
+def test_usable_host_cores_honours_the_cgroup_quota(monkeypatch):
+    """usable cores = min(scheduler affinity, cgroup CPU quota in whole cores); no quota -> the affinity"""
+    import bench
+    aff = len(os.sched_getaffinity(0))
+    monkeypatch.setattr(bench, "cgroup_cpu", lambda: (16.0, 0, 0.0))
+    assert bench.usable_host_cores() == min(aff, 16)
+    monkeypatch.setattr(bench, "cgroup_cpu", lambda: (2.5, 0, 0.0))
+    assert bench.usable_host_cores() == min(aff, 2)
+    monkeypatch.setattr(bench, "cgroup_cpu", lambda: (0.5, 0, 0.0))
+    assert bench.usable_host_cores() == 1
+    monkeypatch.setattr(bench, "cgroup_cpu", lambda: (None, None, None))
+    assert bench.usable_host_cores() == aff
 
 
 def test_cgroup_cpu_reads_or_declines():

