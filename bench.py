@@ -447,13 +447,14 @@ def threads_per_caller(budget_threads, blocking, combine, cores_per_rank):
 class Slot:
     """One pipeline slot: a library context with its tape bank in HBM (and, for config 4, its own process group)."""
 
-    def __init__(self, api, torch, k, B, device, first_tape, nsets, partition=None, combine=1, prewake_us=None):
+    def __init__(self, api, torch, k, B, device, first_tape, nsets, partition=None, combine=1, prewake_us=None, fs="host"):
         # partition = (i, n): the slot's stream may only use CU partition i of n (KOSK_CU_PARTITION, read by kosk_create)
         env = {"KOSK_CU_PARTITION": "%d/%d" % partition} if partition and partition[1] > 1 else {}
         # combine = C > 1: the handle joins a cohort of C handles whose resident calls the library merges (KOSK_COMBINE).  The slots
         # are closed loops that pause between the bench's runs (conditioning, barrier, timed run): members stay "expected" by
         # their cohort for 20 ms instead of the library's default 1 ms, so that a run's first calls merge like all the others
         env["KOSK_COMBINE"] = str(combine)
+        env["KOSK_FS_DEVICE"] = "1" if fs == "device" else "0"  # where the Fiat-Shamir hashes run (kosk_options::fs_mode; --fs)
         if combine > 1:
             env["KOSK_COMBINE_IDLE_US"] = os.environ.get("KOSK_COMBINE_IDLE_US", "20000")
             # the callers of a merged run sleep to its end, without the library's 400 us of pre-wake spinning, (a) when host cores are
@@ -558,6 +559,9 @@ def main():
     ap.add_argument("--combine", type=int, default=int(os.environ.get("KOSK_BENCH_COMBINE", "0")),
                     help="handles per cohort (KOSK_COMBINE): the resident calls of the slots of a cohort are served by one merged pipeline "
                          "run; 0 = the configuration's default, 1 = every slot on its own (the round-3 arrangement)")
+    ap.add_argument("--fs", default=os.environ.get("KOSK_BENCH_FS", ""), choices=["", "host", "device"],
+                    help="where the Fiat-Shamir aggregation hashes run: host (the cores hash the digest tables, which cross PCIe) or device "
+                         "(one wave per proof hashes them in HBM, no host round trip inside a call); default: the configuration's")
     ap.add_argument("--partitions", type=int, default=int(os.environ.get("KOSK_BENCH_PARTITIONS", "1")),
                     help="CU partitions of the GPU (whole XCDs for 2, 4, 8): slot i runs on partition i %% P only")
     ap.add_argument("--phase-stats", action="store_true", help="mean of the library's phase clocks over every step (diagnostic; one extra ABI call per step)")
@@ -579,6 +583,7 @@ def main():
         from mpcith_kyber_kosk_amd import api
         print(json.dumps(drop_in(api, torch, k, B, tapes_for(0, B, api.tape_bytes(k)), 0)))
         return
+    FS = args.fs or cfg.get("fs", "host")
     S = args.slots if args.slots > 0 else cfg["slots"]
     CMB = args.combine if args.combine > 0 else (cfg.get("combine", 1) if not args.batch else 1)
     if args.partitions > 1:
@@ -628,7 +633,7 @@ def main():
 
     from mpcith_kyber_kosk_amd import api, sharding
     P_ = max(1, args.partitions)
-    slots = [Slot(api, torch, k, B, local_rank, ((rank * S + si) * args.tape_sets) * B, args.tape_sets, partition=(si % P_, P_), combine=CMB, prewake_us=cfg.get("prewake_us")) for si in range(S)]
+    slots = [Slot(api, torch, k, B, local_rank, ((rank * S + si) * args.tape_sets) * B, args.tape_sets, partition=(si % P_, P_), combine=CMB, prewake_us=cfg.get("prewake_us"), fs=FS) for si in range(S)]
     ctx = slots[0].c
     tapes = slots[0].first_tapes
     if want_gather:
@@ -890,6 +895,9 @@ def main():
                        "sharding": "by proof", "pipeline_slots_per_gpu": S, "handles_per_cohort": CMB,
                        "call_combining": ("KOSK_COMBINE=%d: %d caller threads, one handle and one %d-proof call each; the library serves the "
                                           "calls of a cohort of %d handles with one pipeline run" % (CMB, S, B, CMB)) if CMB > 1 else "off",
+                       "fiat_shamir": FS + (": one wave per proof hashes each digest table in HBM (k_fs_chain), alpha / I / the verifier's I' == I stay on "
+                                            "the device, no digest table crosses PCIe and a resident call has no host round trip" if FS == "device" else
+                                            ": the host's cores hash the four 46.5 KB digest tables per proof, which cross PCIe (four host round trips per step)"),
                        "cu_partitions": P_, "tape_sets_per_slot": args.tape_sets,
                        "host_threads_per_slot": os.environ.get("KOSK_HOST_THREADS"), "host_waits": "sleep" if os.environ.get("KOSK_BLOCKING_SYNC") == "1" else "spin",
                        "timing": "steady-state window of exactly K steps (completion of step W to completion of step W+K, slots running continuously), "
@@ -989,8 +997,8 @@ def main():
             import subprocess
             env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("KOSK_HOST_THREADS", "KOSK_BLOCKING_SYNC", "KOSK_COMBINE", "KOSK_BENCH_COMBINE", "KOSK_BENCH_SLOTS")}
 
-            def side_run(slots_, combine_, note, threads_=6):  # threads_: Fiat-Shamir workers per caller (the smaller arrangements keep the six they were tuned with)
-                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", str(args.config), "--combine", str(combine_), "--slots", str(slots_),
+            def side_run(slots_, combine_, note, threads_=6, fs_=None):  # threads_: Fiat-Shamir workers per caller (the smaller arrangements keep the six they were tuned with)
+                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", str(args.config), "--fs", fs_ or FS, "--combine", str(combine_), "--slots", str(slots_),
                        "--steps", str(max(20, K // 2) // slots_ * slots_ + slots_), "--warmup", str(max(4, W // 2)), "--no-kernels", "--no-cpu-baseline"]
                 try:
                     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=dict(env, KOSK_HOST_THREADS=str(threads_)) if threads_ else env)
@@ -1003,7 +1011,7 @@ def main():
                             "hash_view_avg_us": (j.get("kernels_in_pipeline", {}).get("hash_view") or {}).get("avg_us"),
                             "hash_view_proofs_per_launch": (j.get("kernels_in_pipeline", {}).get("hash_view") or {}).get("proofs_per_launch"),
                             "step_latency_ms_median": (j.get("step_latency_ms") or {}).get("median"),
-                            "host_cpu_cores_busy": j.get("host_cpu_cores_busy"), "note": note}
+                            "host_cpu_cores_busy": j.get("host_cpu_cores_busy"), "fiat_shamir": fs_ or FS, "note": note}
                 except Exception as e:  # noqa: BLE001  (TimeoutExpired, a missing key, bad JSON ...)
                     return {"error": repr(e)[:400]}
             # one cohort ALONE on the GPU (three callers, one merged run in flight): the graded kernel's launch time without co-running kernels
@@ -1015,6 +1023,28 @@ def main():
                 line["roofline"]["alone_us"] = oc_["hash_view_avg_us"]
                 line["roofline"]["alone_proofs_per_launch"] = ppl_
                 line["roofline"]["alone_frac"] = ppl_ * 1454 * (VIEW_MSG[k] + 32) / (oc_["hash_view_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            # the same arrangement driven by a NATIVE caller loop (examples/throughput.cpp: std::thread callers on the C ABI, the same
+            # tape banks, every verify bit asserted) as a child process: what a C++ host -- the reference is one -- would run; proofs/s
+            # and busy host cores without the interpreter lock.  Reported next to `value`, never instead of it.
+            def native_run(fs_):
+                exe = os.path.join(ROOT, "examples", "throughput")
+                if not os.path.exists(exe):
+                    return {"error": "examples/throughput is not built (__graft_entry__.build() builds it)"}
+                cmd = [exe, "--k", str(k), "--batch", str(B), "--callers", str(S), "--combine", str(CMB), "--fs", fs_, "--threads", str(threads),
+                       "--steps", str(max(K, 20)), "--warmup", str(W), "--tape-sets", str(args.tape_sets), "--device", str(local_rank)]
+                try:
+                    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+                    sub = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                    if r.returncode != 0 or not sub:
+                        raise RuntimeError("rc %d: %s" % (r.returncode, (r.stderr or "")[-300:]))
+                    return json.loads(sub[-1])
+                except Exception as e:  # noqa: BLE001
+                    return {"error": repr(e)[:400]}
+            line["native_callers"] = native_run(FS)
+            other_ = "host" if FS == "device" else "device"
+            line["native_callers_fs_" + other_] = native_run(other_)
+            line["fiat_shamir_" + other_] = side_run(S, CMB, threads_=0, fs_=other_, note="python bench.py --fs %s: the line of record's arrangement with the Fiat-Shamir "
+                                                     "hashes on the %s; not the line of record" % (other_, other_))
             line["uncombined"] = side_run(6, 1, "python bench.py --combine 1 --slots 6: six independent handles, every launch serves one 46-proof call "
                                                 "(round 3's line of record); not the line of record")
             line["cohorts_of_three"] = side_run(9, 3, "python bench.py --combine 3 --slots 9: nine callers, three per merged run (138 proofs per launch): round 4's line of "

@@ -142,4 +142,117 @@ __device__ __forceinline__ void fs_permute(uint32_t &a, uint32_t *x, const FsLan
     }
 }
 
+// ---- Variant B: no LDS memory at all.  Columns of FIVE lanes that never straddle a 16-lane row,
+//   lane(x, y, h) = 32 h + (x < 3 ? 5 x : 16 + 5 (x - 3)) + y,
+// so a column's sum is three DPP-fused xors (row_shr:1, :2, :1; it lands on the lane y = 4), and both exchanges are ds_bpermute_b32
+// gathers: theta two (the sums of columns x - 1 and x + 1), pi / chi three (the pre-images of words x, x + 1, x + 2 of the lane's row,
+// rotated by their owners before they are sent).  The idle lanes (15, 26..31 of each half) hold junk no active lane ever reads.
+// tools/fs_chain_model.py: WaveB.
+__device__ __forceinline__ int fs_lane_b(int x, int y, int h) { return 32 * h + (x < 3 ? 5 * x : 16 + 5 * (x - 3)) + y; }
+
+struct FsLaneB {
+    uint32_t sCm, sCp, s0, s1, s2; // byte addresses (lane * 4) for ds_bpermute_b32
+    uint32_t sh_theta, sh_rho;
+    uint32_t half;
+    int word;
+};
+
+__device__ __forceinline__ int fs_rho_of(int x, int y)
+{
+    int rot = 0;
+    for (int t = 0, wx = 1, wy = 0; t < 24; t++) {
+        if (wx == x && wy == y) rot = ((t + 1) * (t + 2) / 2) & 63;
+        const int nx = wy, ny = (2 * wx + 3 * wy) % 5;
+        wx = nx; wy = ny;
+    }
+    return rot;
+}
+
+__device__ __forceinline__ FsLaneB fs_lane_setup_b(int lane)
+{
+    FsLaneB L;
+    const int h = lane >> 5, r = lane & 31;
+    const int x = r < 15 ? r / 5 : r >= 16 && r < 26 ? 3 + (r - 16) / 5 : 5;
+    const int y = r < 15 ? r % 5 : r >= 16 && r < 26 ? (r - 16) % 5 : 0;
+    L.half = (uint32_t)h;
+    if (x >= 5) {
+        L.word = 63;
+        L.sCm = L.sCp = L.s0 = L.s1 = L.s2 = (uint32_t)lane * 4;
+        L.sh_theta = L.sh_rho = 0;
+        return L;
+    }
+    L.word = x + 5 * y;
+    L.sCm = 4u * (uint32_t)fs_lane_b((x + 4) % 5, 4, h);
+    L.sCp = 4u * (uint32_t)fs_lane_b((x + 1) % 5, 4, 1 - h);
+    L.sh_theta = h == 0 ? 31u : 0u;
+    const int rot = fs_rho_of(x, y);
+    const int k = (rot >> 1) + (((rot & 1) && h == 1) ? 1 : 0);
+    L.sh_rho = (uint32_t)((32 - k) & 31);
+    uint32_t src[3];
+    for (int j = 0; j < 3; j++) { // word (x + j, y) of the permuted state sits, rotated, on the lane of its pre-image under pi
+        const int X = (x + j) % 5, Y = y, ys = X, xs = (3 * (Y - 3 * X + 15)) % 5, hs = h ^ (fs_rho_of(xs, ys) & 1);
+        src[j] = 4u * (uint32_t)fs_lane_b(xs, ys, hs);
+    }
+    L.s0 = src[0]; L.s1 = src[1]; L.s2 = src[2];
+    return L;
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t fs_dpp_xor(uint32_t moved, uint32_t other) // dpp(moved) ^ other, one v_xor_b32_dpp
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)moved, CTRL, 0xF, 0xF, true) ^ other;
+}
+
+__device__ __forceinline__ void fs_permute_b(uint32_t &a, const FsLaneB &L, const FsRc &rc)
+{
+#pragma unroll
+    for (int r = 0; r < 24; r++) {
+        const uint32_t t1 = fs_dpp_xor<0x111>(a, a);   // row_shr:1
+        const uint32_t t2 = fs_dpp_xor<0x112>(t1, t1); // row_shr:2
+        const uint32_t c = fs_dpp_xor<0x111>(t2, a);   // the column's sum on its lane y = 4
+        const uint32_t cm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)L.sCm, (int)c);
+        const uint32_t cp = (uint32_t)__builtin_amdgcn_ds_bpermute((int)L.sCp, (int)c);
+        a = kx3(a, cm, __builtin_amdgcn_alignbit(cp, cp, L.sh_theta));
+        a = __builtin_amdgcn_alignbit(a, a, L.sh_rho);
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)L.s0, (int)a);
+        const uint32_t b1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)L.s1, (int)a);
+        const uint32_t b2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)L.s2, (int)a);
+        a = kchi(b0, b1, b2) ^ rc.v[r];
+    }
+}
+
+// The two variants behind one face (k_fs_chain is a template over it)
+struct FsSpongeLds {
+    FsLane L;
+    FsRc rc;
+    uint32_t *x;
+    __device__ __forceinline__ void setup(int lane, uint32_t *xw)
+    {
+        L = fs_lane_setup(lane);
+        rc = fs_rc_setup(L);
+        x = xw;
+        if (lane < 4) xw[FSW_ZERO + lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void permute(uint32_t &a) const { fs_permute(a, x, L, rc); }
+    __device__ __forceinline__ uint32_t half() const { return L.half; }
+    __device__ __forceinline__ int word() const { return L.word; }
+    static __device__ __forceinline__ int lane_of(int x_, int y_, int h_) { return 6 * x_ + y_ + 32 * h_; }
+};
+struct FsSpongeBperm {
+    FsLaneB L;
+    FsRc rc;
+    __device__ __forceinline__ void setup(int lane, uint32_t *)
+    {
+        L = fs_lane_setup_b(lane);
+        FsLane t;
+        t.half = L.half; t.word = L.word;
+        rc = fs_rc_setup(t);
+    }
+    __device__ __forceinline__ void permute(uint32_t &a) const { fs_permute_b(a, L, rc); }
+    __device__ __forceinline__ uint32_t half() const { return L.half; }
+    __device__ __forceinline__ int word() const { return L.word; }
+    static __device__ __forceinline__ int lane_of(int x_, int y_, int h_) { return fs_lane_b(x_, y_, h_); }
+};
+
 } // namespace kosk

@@ -15,6 +15,9 @@
 // kyber/fips202.c:461-485, :723-734 (shake256), :745-754 (sha3_256); kyber/symmetric-shake.c:41-51 (kyber_shake256_prf).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "kosk_device.hpp"
 #include "kosk_fs_dev.hpp"
 
@@ -53,7 +56,7 @@ __device__ __forceinline__ uint2 fs_last_word(const uint8_t *tail, int rem, int 
     return make_uint2(lo, hi);
 }
 
-template <int MODE>
+template <int MODE, class SP>
 __global__ __launch_bounds__(64) void k_fs_chain(FsArgs A)
 {
     __shared__ __align__(16) uint32_t xw[FSW_WORDS];
@@ -64,16 +67,16 @@ __global__ __launch_bounds__(64) void k_fs_chain(FsArgs A)
 
     const int lane = threadIdx.x, b = blockIdx.x;
     __builtin_amdgcn_s_setprio(3); // a chain is latency, not throughput: its wave issues first wherever it shares a SIMD
-    const FsLane L = fs_lane_setup(lane);
-    const FsRc rc = fs_rc_setup(L);
-    if (lane < 4) xw[FSW_ZERO + lane] = 0;
-    __builtin_amdgcn_wave_barrier();
+    SP sp;
+    sp.setup(lane, xw);
+    const int word = sp.word();
+    const uint32_t half = sp.half();
 
     // ---- sha3_256 of the table
     const uint8_t *src = A.in + (size_t)b * A.in_stride;
     const int nfull = A.len / 136, rem = A.len - nfull * 136;
-    const bool ld = L.word < 17;
-    const uint8_t *mine = src + 8 * (ld ? L.word : 0);
+    const bool ld = word < 17;
+    const uint8_t *mine = src + 8 * (ld ? word : 0);
     uint32_t a = 0;
     uint2 pf[FS_PF];
 #pragma unroll
@@ -85,22 +88,22 @@ __global__ __launch_bounds__(64) void k_fs_chain(FsArgs A)
                 const uint2 m = pf[j];
                 const int nb = blk + j + FS_PF;
                 pf[j] = (ld && nb < nfull) ? fs_load_word(mine + (size_t)136 * nb) : make_uint2(0, 0);
-                a ^= fs_deinterleave_half(m.x, m.y, L.half); // (lanes beyond word 16 loaded zeros)
-                fs_permute(a, xw, L, rc);
+                a ^= fs_deinterleave_half(m.x, m.y, half); // (lanes beyond word 16 loaded zeros)
+                sp.permute(a);
             }
         }
     }
     {
-        const uint2 m = ld ? fs_last_word(src + (size_t)136 * nfull, rem, L.word, 0x06u) : make_uint2(0, 0);
-        a ^= fs_deinterleave_half(m.x, m.y, L.half);
-        fs_permute(a, xw, L, rc);
+        const uint2 m = ld ? fs_last_word(src + (size_t)136 * nfull, rem, word, 0x06u) : make_uint2(0, 0);
+        a ^= fs_deinterleave_half(m.x, m.y, half);
+        sp.permute(a);
     }
     if (A.out_digest) { // words 0..3 = lanes 6 x (+ 32)
         st[lane] = a;
         __builtin_amdgcn_wave_barrier();
         if (lane < 4) {
             uint32_t lo, hi;
-            fs_interleave(st[6 * lane], st[6 * lane + 32], lo, hi);
+            fs_interleave(st[SP::lane_of(lane, 0, 0)], st[SP::lane_of(lane, 0, 1)], lo, hi);
             *reinterpret_cast<uint2 *>(A.out_digest + (size_t)b * 32 + 8 * lane) = make_uint2(lo, hi);
         }
         __builtin_amdgcn_wave_barrier();
@@ -110,21 +113,21 @@ __global__ __launch_bounds__(64) void k_fs_chain(FsArgs A)
     // ---- SHAKE256-PRF(digest, nonce 1): the digest's words are the new block's words 0..3 as they stand (still interleaved)
     {
         uint32_t lo = 0, hi = 0;
-        if (L.word == 4) lo = 0x1F01u;      // nonce byte 1, then the SHAKE domain byte (33 bytes absorbed)
-        if (L.word == 16) hi = 0x80000000u; // last byte of the 136-byte rate
-        const uint32_t pad = fs_deinterleave_half(lo, hi, L.half);
-        a = (L.word < 4 ? a : 0u) ^ pad;
+        if (word == 4) lo = 0x1F01u;      // nonce byte 1, then the SHAKE domain byte (33 bytes absorbed)
+        if (word == 16) hi = 0x80000000u; // last byte of the 136-byte rate
+        const uint32_t pad = fs_deinterleave_half(lo, hi, half);
+        a = (word < 4 ? a : 0u) ^ pad;
     }
     constexpr int NSQ = MODE == FS_ALPHA ? 2 : 3;
 #pragma unroll 1
     for (int s = 0; s < NSQ; s++) {
-        fs_permute(a, xw, L, rc);
+        sp.permute(a);
         st[lane] = a;
         __builtin_amdgcn_wave_barrier();
         if (lane < 17) {
             const int x = lane % 5, y = lane / 5;
             uint32_t lo, hi;
-            fs_interleave(st[6 * x + y], st[6 * x + y + 32], lo, hi);
+            fs_interleave(st[SP::lane_of(x, y, 0)], st[SP::lane_of(x, y, 1)], lo, hi);
             *reinterpret_cast<uint2 *>(sq + 136 * s + 8 * lane) = make_uint2(lo, hi);
         }
         __builtin_amdgcn_wave_barrier();
@@ -197,16 +200,25 @@ __global__ __launch_bounds__(64) void k_fs_chain(FsArgs A)
 
 } // namespace
 
+template <class SP>
+static void fs_launch(const FsArgs &A, int mode, int n, hipStream_t st)
+{
+    switch (mode) {
+    case FS_DIGEST: hipLaunchKernelGGL((k_fs_chain<FS_DIGEST, SP>), dim3(n), dim3(64), 0, st, A); break;
+    case FS_ALPHA: hipLaunchKernelGGL((k_fs_chain<FS_ALPHA, SP>), dim3(n), dim3(64), 0, st, A); break;
+    case FS_OPENED: hipLaunchKernelGGL((k_fs_chain<FS_OPENED, SP>), dim3(n), dim3(64), 0, st, A); break;
+    default: hipLaunchKernelGGL((k_fs_chain<FS_CHECK, SP>), dim3(n), dim3(64), 0, st, A); break;
+    }
+}
+
 hipError_t launch_fs_chain(const FsArgs &A, int mode, int n, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
-    switch (mode) {
-    case FS_DIGEST: hipLaunchKernelGGL(k_fs_chain<FS_DIGEST>, dim3(n), dim3(64), 0, st, A); break;
-    case FS_ALPHA: hipLaunchKernelGGL(k_fs_chain<FS_ALPHA>, dim3(n), dim3(64), 0, st, A); break;
-    case FS_OPENED: hipLaunchKernelGGL(k_fs_chain<FS_OPENED>, dim3(n), dim3(64), 0, st, A); break;
-    case FS_CHECK: hipLaunchKernelGGL(k_fs_chain<FS_CHECK>, dim3(n), dim3(64), 0, st, A); break;
-    default: return hipErrorInvalidValue;
-    }
+    if (mode < FS_DIGEST || mode > FS_CHECK) return hipErrorInvalidValue;
+    // KOSK_FS_SPONGE=lds: the LDS-memory exchanges (variant A of kosk_fs_dev.hpp); default the ds_bpermute / DPP variant B
+    static const bool lds = getenv("KOSK_FS_SPONGE") && !strcmp(getenv("KOSK_FS_SPONGE"), "lds");
+    if (lds) fs_launch<FsSpongeLds>(A, mode, n, st);
+    else fs_launch<FsSpongeBperm>(A, mode, n, st);
     return hipGetLastError();
 }
 

@@ -168,6 +168,106 @@ def self_check(table_bytes=1454 * 32):
     return True
 
 
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Variant B (csrc/kosk_fs_dev.hpp, FS_SPONGE_BPERMUTE): no LDS memory at all.  Columns of FIVE lanes that never straddle a 16-lane
+# row -- lane(x, y, h) = 32 h + (5 x if x < 3 else 16 + 5 (x - 3)) + y -- so that the column sums are three DPP-fused xors
+# (row_shr:1, :2, :1: the sum lands on the lane y = 4), and both exchanges are ds_bpermute_b32 gathers (theta: two, pi/chi: three).
+# Idle lanes (15, 26..31 of each half) hold junk that no active lane ever reads.
+def lane_b(x, y, h):
+    return 32 * h + (5 * x if x < 3 else 16 + 5 * (x - 3)) + y
+
+
+def tables_b():
+    t = {k: np.zeros(64, np.int64) for k in ("act", "w", "h", "sCm", "sCp", "sh_theta", "sh_rho", "s0", "s1", "s2")}
+    t["w"][:] = 63
+    for l in range(64):
+        for k in ("sCm", "sCp", "s0", "s1", "s2"):
+            t[k][l] = l  # idle lanes gather from themselves
+    for h in range(2):
+        for x in range(5):
+            for y in range(5):
+                l = lane_b(x, y, h)
+                t["act"][l], t["w"][l], t["h"][l] = 1, x + 5 * y, h
+                t["sCm"][l] = lane_b((x + 4) % 5, 4, h)
+                t["sCp"][l] = lane_b((x + 1) % 5, 4, 1 - h)
+                t["sh_theta"][l] = 31 if h == 0 else 0
+                rot = RHO[x][y]
+                k = (rot >> 1) + (1 if (rot & 1) and h == 1 else 0)
+                t["sh_rho"][l] = (32 - k) & 31
+                # what this lane needs after pi: words (x, y), (x + 1, y), (x + 2, y) of B, half h -- each sits, already rotated,
+                # on the lane of its pre-image under pi: (xs, ys) with ys = X, 2 xs + 3 ys = Y, and the half it came from
+                for j, key in enumerate(("s0", "s1", "s2")):
+                    X, Y = (x + j) % 5, y
+                    ys = X
+                    xs = (3 * (Y - 3 * X)) % 5
+                    hs = h ^ (RHO[xs][ys] & 1)
+                    assert (2 * xs + 3 * ys) % 5 == Y
+                    t[key][l] = lane_b(xs, ys, hs)
+    return t
+
+
+def row_shr(v, n):
+    """DPP row_shr:n with bound_ctrl: lane i of a 16-lane row receives lane i - n of the same row, zero when there is none"""
+    out = np.zeros_like(v)
+    for l in range(64):
+        if (l & 15) >= n:
+            out[l] = v[l - n]
+    return out
+
+
+class WaveB(Wave):
+    def __init__(self):
+        self.t = tables_b()
+        self.a = np.zeros(64, np.uint64)
+        rc = round_constants()
+        self.rc = np.zeros((24, 64), np.uint64)
+        for r in range(24):
+            e, o = deinterleave(rc[r])
+            self.rc[r][lane_b(0, 0, 0)], self.rc[r][lane_b(0, 0, 1)] = e, o
+
+    def permute(self):
+        t = self.t
+        M = np.uint64(0xFFFFFFFF)
+        for r in range(24):
+            a = self.a
+            t1 = row_shr(a, 1) ^ a
+            t2 = row_shr(t1, 2) ^ t1
+            c = row_shr(t2, 1) ^ a  # on the lane y = 4 of every column: the column's sum
+            cm, cp = c[t["sCm"]], c[t["sCp"]]
+            a = a ^ cm ^ rotl32(cp, t["sh_theta"])
+            a = rotl32(a, t["sh_rho"])
+            b0, b1, b2 = a[t["s0"]], a[t["s1"]], a[t["s2"]]
+            self.a = (b0 ^ ((~b1) & b2 & M) ^ self.rc[r]) & M
+
+    def absorb_words(self, words):
+        for i, w in enumerate(words):
+            e, o = deinterleave(w)
+            self.a[lane_b(i % 5, i // 5, 0)] ^= np.uint64(e)
+            self.a[lane_b(i % 5, i // 5, 1)] ^= np.uint64(o)
+
+    def word(self, i):
+        return interleave(int(self.a[lane_b(i % 5, i // 5, 0)]), int(self.a[lane_b(i % 5, i // 5, 1)]))
+
+
+def self_check_b():
+    global Wave
+    keep = Wave
+    try:
+        Wave = WaveB  # sponge() builds a Wave
+        rng = np.random.default_rng(66)
+        for n in (0, 1, 135, 136, 137, 1000, 1454 * 32):
+            m = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+            assert sponge(m, 136, 0x06, 32) == hashlib.sha3_256(m).digest(), n
+        key = rng.integers(0, 256, 33, dtype=np.uint8).tobytes()
+        assert sponge(key, 136, 0x1F, 300) == hashlib.shake_256(key).digest(300)
+    finally:
+        Wave = keep
+    return True
+
+
 if __name__ == "__main__":
     self_check()
-    print("fs_chain_model: lane model == hashlib (sha3_256 of a 46 528-byte table, shake256, edge lengths)")
+    self_check_b()
+    print("fs_chain_model: both lane models (LDS exchanges; DPP + ds_bpermute) == hashlib (sha3_256 of a 46 528-byte table, shake256, edge lengths)")
