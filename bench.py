@@ -49,7 +49,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spe
 
 CONFIGS = {  # 1-based config number -> (kyber_k, proofs per GPU per step, default slots, host threads per slot, handles per cohort)
     # configs 2 and 3: eighteen caller threads, each with its own handle and its own 46-proof calls; the library serves the calls of
-    # a cohort of six handles with one pipeline run (KOSK_COMBINE=6, include/kosk_mi355x.h), i.e. three merged runs of 276 proofs in
+    # a cohort of six handles with one pipeline run (kosk_options::combine = 6, include/kosk_mi355x.h), i.e. three merged runs of 276 proofs in
     # flight.  The default line is bound by the GPU, and the kernels are the more efficient the more proofs a launch
     # serves: on one box, alternating, cohorts of three / four / five / six give 150 / 161-164 / 170-175 / 179-184 k proofs/s at
     # 2.7 / 3.3 / 3.9 / 4.5 ms per call (profiles/r05_cohort_size.txt); eight per cohort is bound by the container's 16 host cores.
@@ -205,41 +205,25 @@ def kernel_microbench(ctx, torch, k, lanes=65536, reps=20):
     out["ntt256"] = {"polys": lanes, "us": ms * 1e3, "GBps": lanes * 1024 / ms / 1e6,
                      "frac_hbm_peak": lanes * 1024 / ms / 1e6 / HBM_PEAK_GBS, "arithmetic": "integer Montgomery (default)",
                      "checked": check_ntt("ntt256")}
-    outp.zero_()
-    # the opt-in packed-fp32 butterflies (KOSK_NTT_FP32=1; operands pinned to VGPRs, see k_ntt256_fp32's HAZARD note)
-    from mpcith_kyber_kosk_amd import api
-    old = os.environ.get("KOSK_NTT_FP32")
-    os.environ["KOSK_NTT_FP32"] = "1"
-    cf = api.Kosk(kyber_k=k, max_batch=1)
-    if old is None:
-        del os.environ["KOSK_NTT_FP32"]
-    else:
-        os.environ["KOSK_NTT_FP32"] = old
-    for _ in range(3):
-        cf.ntt256_batch(polys.data_ptr(), outp.data_ptr(), lanes)
-    cf.synchronize()
-    cf.timer_start()
-    for _ in range(reps):
-        cf.ntt256_batch(polys.data_ptr(), outp.data_ptr(), lanes)
-    ms = cf.timer_stop_ms() / reps
-    cf.close()
-    out["ntt256_packed_fp32"] = {"polys": lanes, "us": ms * 1e3, "GBps": lanes * 1024 / ms / 1e6,
-                                 "frac_hbm_peak": lanes * 1024 / ms / 1e6 / HBM_PEAK_GBS, "arithmetic": "packed fp32, opt-in (KOSK_NTT_FP32=1)",
-                                 "checked": check_ntt("ntt256_packed_fp32")}
+    # the Fiat-Shamir chain: sha3_256 of 276 digest tables of 46 528 bytes, one wave per table (k_fs_chain: 343 sequential permutations)
+    nt, L = 276, 1454 * 32
+    tabs = torch.randint(0, 256, (nt, L), dtype=torch.uint8, device="cuda", generator=g)
+    dg = torch.zeros((nt, 32), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.sha3_256_batch_wave(tabs.data_ptr(), L, L, dg.data_ptr(), nt)
+    ctx.synchronize()
+    ctx.timer_start()
+    for _ in range(5):
+        ctx.sha3_256_batch_wave(tabs.data_ptr(), L, L, dg.data_ptr(), nt)
+    ms = ctx.timer_stop_ms() / 5
+    for i in (0, nt - 1):
+        if dg[i].cpu().numpy().tobytes() != hashlib.sha3_256(tabs[i].cpu().numpy().tobytes()).digest():
+            raise RuntimeError("fs chain: digest %d differs from hashlib.sha3_256" % i)
+    out["fs_chain_sha3_long"] = {"tables": nt, "bytes_per_table": L, "permutations_per_chain": L // 136 + 1, "us": ms * 1e3,
+                                 "us_per_permutation": ms * 1e3 / (L // 136 + 1),
+                                 "note": "one Keccak state per WAVE (a word per lane, DPP column sums + ds_bpermute exchanges): the latency of one "
+                                         "sequential chain, not a throughput figure", "checked": "first and last digest == hashlib.sha3_256"}
     return out
-
-
-def _with_env(env, fn):
-    old = {n_: os.environ.get(n_) for n_ in env}
-    os.environ.update({n_: str(v) for n_, v in env.items()})
-    try:
-        return fn()
-    finally:
-        for n_, v in old.items():
-            if v is None:
-                os.environ.pop(n_, None)
-            else:
-                os.environ[n_] = v
 
 
 def link_rate(torch, device, mib=256):
@@ -284,7 +268,7 @@ def drop_in(api, torch, k, B, tapes, device):
     out = {"link": link_rate(torch, "cuda:%d" % device)}
     n = 6 * B
     cb = lib.kosk_compact_proof_bytes(k)
-    mk = lambda: _with_env({"KOSK_STREAMS": "3"}, lambda: api.Kosk(kyber_k=k, max_batch=3 * B, device=device))
+    mk = lambda: api.Kosk(kyber_k=k, max_batch=3 * B, device=device, streams=3)
     prover, verifier = mk(), mk()
     pb, pkb, skb, tb = prover.proof_bytes, prover.pk_bytes, prover.sk_bytes, prover.tape_bytes
     blob = C.create_string_buffer(b"".join(tapes) * 6, tb * n)
@@ -399,7 +383,7 @@ def drop_in(api, torch, k, B, tapes, device):
     out["two_threads_fraction_of_link_d2h"] = {k_: v / lk["both_directions_GBps_each"] for k_, v in per_dir.items()}
     out["proofs_per_s"] = best
     out["note"] = ("kyber_verifiable_keygen + kyber_kosk_verify through the drop-in calls on host pointers, %d proofs per call in chunks of %d, "
-                   "KOSK_STREAMS=3; unit proofs/s; every verify bit asserted" % (n, B))
+                   "streams = 3; unit proofs/s; every verify bit asserted" % (n, B))
     for p_ in pinv:
         lib.kosk_host_free(p_)
     prover.close(); verifier.close()
@@ -423,7 +407,8 @@ def usable_host_cores():
 def host_budget(usable_cores, local_world, slots, threads):
     """(host threads per slot, sleep instead of spin) for a rank that shares `usable_cores` (usable_host_cores(): affinity cut to the
     cgroup quota) with local_world - 1 other ranks and runs `slots` pipeline slots.  With a core for every slot thread nothing changes;
-    when cores are scarce (an 8-GPU node with few cores per GPU) the slots' waits sleep on events and the Fiat-Shamir pools shrink --
+    when cores are scarce (an 8-GPU node with few cores per GPU) the Fiat-Shamir pools shrink and, below twelve cores per rank, the slots'
+    waits sleep on events --
     down to three threads per slot while the rank has at least four cores (the pool threads sleep between the four hash rounds of a step,
     so twice as many of them as cores is harmless, while fewer than three would stretch every round: 46 proofs = 6 groups of 8 AVX-512
     lanes), and down to two below that (eight ranks on a 16-core quota: two cores per rank)."""
@@ -431,7 +416,10 @@ def host_budget(usable_cores, local_world, slots, threads):
     if cores_per_rank >= slots * (threads + 1):
         return threads, False
     floor = 3 if cores_per_rank >= 4 else 2
-    return max(floor, min(threads, 2 * cores_per_rank // slots)), True
+    # sleeping waits below a dozen cores per rank; from there up the default waits (a nap through most of the expected phase, then a
+    # short spin) measured the same rate at one to two busy cores FEWER than sleeping on events (profiles/r05_host18.txt: 10.6-10.9
+    # against 11.4-11.9 on a lease with a 16-core quota, never throttled)
+    return max(floor, min(threads, 2 * cores_per_rank // slots)), cores_per_rank < 12
 
 
 def threads_per_caller(budget_threads, blocking, combine, cores_per_rank):
@@ -447,23 +435,20 @@ def threads_per_caller(budget_threads, blocking, combine, cores_per_rank):
 class Slot:
     """One pipeline slot: a library context with its tape bank in HBM (and, for config 4, its own process group)."""
 
-    def __init__(self, api, torch, k, B, device, first_tape, nsets, partition=None, combine=1, prewake_us=None, fs="host"):
-        # partition = (i, n): the slot's stream may only use CU partition i of n (KOSK_CU_PARTITION, read by kosk_create)
-        env = {"KOSK_CU_PARTITION": "%d/%d" % partition} if partition and partition[1] > 1 else {}
-        # combine = C > 1: the handle joins a cohort of C handles whose resident calls the library merges (KOSK_COMBINE).  The slots
-        # are closed loops that pause between the bench's runs (conditioning, barrier, timed run): members stay "expected" by
+    def __init__(self, api, torch, k, B, device, first_tape, nsets, combine=1, prewake_us=None, fs="host", threads=0, blocking=False):
+        # combine = C > 1: the handle joins a cohort of C handles whose resident calls the library merges (kosk_options::combine).  The
+        # slots are closed loops that pause between the bench's runs (conditioning, barrier, timed run): members stay "expected" by
         # their cohort for 20 ms instead of the library's default 1 ms, so that a run's first calls merge like all the others
-        env["KOSK_COMBINE"] = str(combine)
-        env["KOSK_FS_DEVICE"] = "1" if fs == "device" else "0"  # where the Fiat-Shamir hashes run (kosk_options::fs_mode; --fs)
+        opts = dict(combine=max(1, combine), fs_mode=api.FS_DEVICE if fs == "device" else api.FS_HOST, host_threads=threads, blocking_sync=int(bool(blocking)))
         if combine > 1:
-            env["KOSK_COMBINE_IDLE_US"] = os.environ.get("KOSK_COMBINE_IDLE_US", "20000")
-            # the callers of a merged run sleep to its end, without the library's 400 us of pre-wake spinning, (a) when host cores are
-            # scarce (host_budget) and (b) in cohorts of five and more: fifteen members spinning for the last 400 us of every run cost 2-3
-            # busy cores and no longer buy throughput (profiles/r05_host18.txt; at three per cohort the pre-wake was +4.7 %, round 4)
+            opts["combine_idle_us"] = 20000
+            # the callers of a merged run sleep to its end, without the library's 400 us of pre-wake spinning, (a) when the waits sleep
+            # (few host cores, host_budget) and (b) in cohorts of five and more: fifteen members spinning for the last 400 us of every run
+            # cost 2-3 busy cores and no longer buy throughput (profiles/r05_host18.txt; at three per cohort the pre-wake was +4.7 %, round 4)
             # (c) where the configuration says so (config 4's 273-proof runs of three callers: the same rate with 1.3 cores fewer)
-            if os.environ.get("KOSK_BLOCKING_SYNC") == "1" or combine >= 5 or prewake_us is not None:
-                env["KOSK_COMBINE_PREWAKE_US"] = os.environ.get("KOSK_COMBINE_PREWAKE_US", str(prewake_us or 0))
-        self.c = _with_env(env, lambda: api.Kosk(kyber_k=k, max_batch=B, device=device))
+            if blocking or combine >= 5 or prewake_us is not None:
+                opts["combine_prewake_us"] = int(os.environ.get("KOSK_BENCH_PREWAKE_US", prewake_us or 0))
+        self.c = api.Kosk(kyber_k=k, max_batch=B, device=device, **opts)
         self.B, self.nsets = B, nsets
         self.stride = (self.c.tape_bytes + 63) // 64 * 64
         import numpy as np
@@ -557,13 +542,12 @@ def main():
                     help="independent batches kept in flight per GPU (own HIP stream + host threads each); 0 = the configuration's "
                          "default.  Never depends on --steps.")
     ap.add_argument("--combine", type=int, default=int(os.environ.get("KOSK_BENCH_COMBINE", "0")),
-                    help="handles per cohort (KOSK_COMBINE): the resident calls of the slots of a cohort are served by one merged pipeline "
+                    help="handles per cohort (kosk_options::combine): the resident calls of the slots of a cohort are served by one merged pipeline "
                          "run; 0 = the configuration's default, 1 = every slot on its own (the round-3 arrangement)")
     ap.add_argument("--fs", default=os.environ.get("KOSK_BENCH_FS", ""), choices=["", "host", "device"],
                     help="where the Fiat-Shamir aggregation hashes run: host (the cores hash the digest tables, which cross PCIe) or device "
                          "(one wave per proof hashes them in HBM, no host round trip inside a call); default: the configuration's")
-    ap.add_argument("--partitions", type=int, default=int(os.environ.get("KOSK_BENCH_PARTITIONS", "1")),
-                    help="CU partitions of the GPU (whole XCDs for 2, 4, 8): slot i runs on partition i %% P only")
+    ap.add_argument("--threads", type=int, default=int(os.environ.get("KOSK_BENCH_THREADS", "0")), help="Fiat-Shamir workers per caller (0: the host budget's)")
     ap.add_argument("--phase-stats", action="store_true", help="mean of the library's phase clocks over every step (diagnostic; one extra ABI call per step)")
     ap.add_argument("--tape-sets", type=int, default=4, help="distinct resident tape sets per slot, rotated step by step")
     ap.add_argument("--cpu-proofs", type=int, default=12, help="bounded CPU baseline sample (about 13 s)")
@@ -583,11 +567,8 @@ def main():
         from mpcith_kyber_kosk_amd import api
         print(json.dumps(drop_in(api, torch, k, B, tapes_for(0, B, api.tape_bytes(k)), 0)))
         return
-    FS = args.fs or cfg.get("fs", "host")
     S = args.slots if args.slots > 0 else cfg["slots"]
     CMB = args.combine if args.combine > 0 else (cfg.get("combine", 1) if not args.batch else 1)
-    if args.partitions > 1:
-        CMB = 1
     # host cores this rank can count on: when they are scarce (an 8-GPU node with few cores per GPU), the slots' waits sleep on
     # events instead of spinning and the Fiat-Shamir pools shrink; with 32+ cores per rank nothing changes
     usable_cores = usable_host_cores()  # scheduler affinity cut to the cgroup CPU quota (a lease shows 256 hardware threads and has 16 cores)
@@ -595,9 +576,15 @@ def main():
     cores_per_rank = max(1, usable_cores // local_world)
     threads, blocking = host_budget(usable_cores, local_world, -(-S // CMB), cfg["threads"] * CMB)
     threads = threads_per_caller(threads, blocking, CMB, cores_per_rank)  # per handle; a merged run led by a cohort's first member uses CMB times as many
-    if blocking:
-        os.environ.setdefault("KOSK_BLOCKING_SYNC", "1")
-    os.environ.setdefault("KOSK_HOST_THREADS", str(threads))
+    # Where the Fiat-Shamir hashes run.  On the host they cost four to five busy cores per GPU and four PCIe copies of 46.5 KB per proof,
+    # and give the higher rate when the cores exist (177-180 k against 115 k proofs/s on one GPU, profiles/r06_fs_device.txt); on the
+    # device a rank needs under four cores with this Python harness (1.4 per cohort).  Not given: the device below six cores per rank
+    # (eight ranks on a 16-core quota could not even run the host's hashing), else the host.
+    FS = args.fs or cfg.get("fs") or ("device" if cores_per_rank < 6 else "host")
+    if args.threads > 0:
+        threads = args.threads
+    if os.environ.get("KOSK_BENCH_BLOCKING") in ("0", "1"):
+        blocking = os.environ["KOSK_BENCH_BLOCKING"] == "1"
     # stdout carries exactly ONE line (the JSON): whatever libraries print there (RCCL's version banner on the first
     # communicator, for one) goes to stderr instead
     sys.stdout.flush()
@@ -632,8 +619,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from mpcith_kyber_kosk_amd import api, sharding
-    P_ = max(1, args.partitions)
-    slots = [Slot(api, torch, k, B, local_rank, ((rank * S + si) * args.tape_sets) * B, args.tape_sets, partition=(si % P_, P_), combine=CMB, prewake_us=cfg.get("prewake_us"), fs=FS) for si in range(S)]
+    slots = [Slot(api, torch, k, B, local_rank, ((rank * S + si) * args.tape_sets) * B, args.tape_sets, combine=CMB, prewake_us=cfg.get("prewake_us"), fs=FS,
+                  threads=threads, blocking=blocking) for si in range(S)]
     ctx = slots[0].c
     tapes = slots[0].first_tapes
     if want_gather:
@@ -847,33 +834,28 @@ def main():
         roof = None
         if hv:
             # every launch of the view-commitment kernel inside the timed run, whatever it served: a merged run of a cohort hashes
-            # the batches of 1..C callers with one launch (`proofs_per_launch` is the mean), and with KOSK_HASH_SPLIT=1 a round is
-            # two launches (ids hash_view / hash_view_tail).  achieved = bytes those launches served / time they took.
+            # the batches of 1..C callers with one launch (`proofs_per_launch` is the mean).  achieved = bytes those launches served / time they took.
             ppl = hv["proofs_per_launch"]
             lanes_per_launch = ppl * 1454
             nbytes = lanes_per_launch * (VIEW_MSG[k] + 32)
             ach = nbytes / (hv["avg_us"] * 1e-6) / 1e9
-            traffic, tsrc = None, None
+            traffic, tsrc, extrap = None, None, False
             tfile = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tfile) and k == 3 and B == 46:
                 tj = json.load(open(tfile))
                 per_lane = tj.get("hash_view_hbm_bytes_per_lane")
                 if per_lane:  # PMC bytes of the same kernel at a 138-proof launch (tools/pmc_workload.py), per party lane
                     traffic = int(round(per_lane * lanes_per_launch))
-                    tsrc = "%s; measured on a %d-lane launch, scaled by lanes to this run's mean launch" % (tj.get("source"), tj.get("hash_view_lanes_per_launch", 0))
+                    pmc_lanes = tj.get("hash_view_lanes_per_launch", 0)
+                    extrap = abs(pmc_lanes - lanes_per_launch) > 0.02 * lanes_per_launch
+                    tsrc = "%s; measured on a %d-lane launch%s" % (tj.get("source"), pmc_lanes, ", scaled by lanes to this run's mean launch" if extrap else " (this run's launch size)")
             roof = {"kernel": "k_commit_hash_dma (SHA3-256 view commitment, prover; %.1f callers' batches = %.0f party lanes per launch on average)"
                               % (ppl / B, lanes_per_launch),
                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": traffic, "traffic_source": tsrc, "traffic_extrapolated": traffic is not None, "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": hv["avg_us"],
+                    "traffic": traffic, "traffic_source": tsrc, "traffic_extrapolated": bool(traffic is not None and extrap), "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": hv["avg_us"],
                     "lanes_per_launch": lanes_per_launch, "launches": hv["launches"],
                     "note": "HIP events on the stream of the handle that led the (merged) run, inside the timed run; %d handles in %d cohorts "
                             "share the GPU, so a launch's duration includes co-running kernels of other runs" % (S, -(-S // CMB))}
-            hvt = kern.get("hash_view_tail")
-            if hvt:
-                tl = hvt["proofs_per_launch"] * 1454
-                roof["second_launch"] = {"lanes_per_launch": tl, "avg_launch_us": hvt["avg_us"],
-                                         "achieved": tl * (VIEW_MSG[k] + 32) / (hvt["avg_us"] * 1e-6) / 1e9,
-                                         "note": "KOSK_HASH_SPLIT=1: the round's last proofs, latency-bound, behind the first launch"}
             ht = kern.get("hash_tcomm")
             if ht:
                 ht["GBps"] = ht["proofs_per_launch"] * 1454 * (TCOMM_MSG[k] + 32) / (ht["avg_us"] * 1e-6) / 1e9
@@ -893,13 +875,13 @@ def main():
                                    "verifier), randomness tapes resident in HBM, a different tape set every step",
                        "baseline_config": "configs[%d]" % (args.config - 1), "kyber_k": k, "proofs_per_gpu": B, "party_lanes_per_gpu": B * 1454,
                        "sharding": "by proof", "pipeline_slots_per_gpu": S, "handles_per_cohort": CMB,
-                       "call_combining": ("KOSK_COMBINE=%d: %d caller threads, one handle and one %d-proof call each; the library serves the "
+                       "call_combining": ("kosk_options::combine = %d: %d caller threads, one handle and one %d-proof call each; the library serves the "
                                           "calls of a cohort of %d handles with one pipeline run" % (CMB, S, B, CMB)) if CMB > 1 else "off",
                        "fiat_shamir": FS + (": one wave per proof hashes each digest table in HBM (k_fs_chain), alpha / I / the verifier's I' == I stay on "
                                             "the device, no digest table crosses PCIe and a resident call has no host round trip" if FS == "device" else
                                             ": the host's cores hash the four 46.5 KB digest tables per proof, which cross PCIe (four host round trips per step)"),
-                       "cu_partitions": P_, "tape_sets_per_slot": args.tape_sets,
-                       "host_threads_per_slot": os.environ.get("KOSK_HOST_THREADS"), "host_waits": "sleep" if os.environ.get("KOSK_BLOCKING_SYNC") == "1" else "spin",
+                       "tape_sets_per_slot": args.tape_sets,
+                       "host_threads_per_slot": threads, "host_waits": "sleep" if blocking else "nap + spin",
                        "timing": "steady-state window of exactly K steps (completion of step W to completion of step W+K, slots running continuously), "
                                  "mean over the %d adjacent window positions W..W+%d: completions come in bursts of a cohort's calls" % (nwin, nwin - 1)},
             "drained_run": {"steps": total, "ms_per_step": dt_drained / total * 1e3, "value": world * total * B / dt_drained,
@@ -982,7 +964,7 @@ def main():
             # memory, and nothing that could go wrong there may take the measured line with it
             try:
                 import subprocess
-                env_ = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("KOSK_HOST_THREADS", "KOSK_BLOCKING_SYNC", "KOSK_COMBINE", "KOSK_BENCH_COMBINE", "KOSK_BENCH_SLOTS")}
+                env_ = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("KOSK_BENCH_THREADS", "KOSK_BENCH_BLOCKING", "KOSK_BENCH_COMBINE", "KOSK_BENCH_SLOTS", "KOSK_BENCH_FS")}
                 r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", "drop_in", "--config", str(args.config)], stdout=subprocess.PIPE,
                                     stderr=subprocess.PIPE, text=True, timeout=600, env=env_)
                 sub_ = [ln for ln in r_.stdout.splitlines() if ln.startswith("{")]
@@ -995,13 +977,13 @@ def main():
             # `value`: the same workload WITHOUT call combining (every handle on its own: the round-3 arrangement, 6 slots), and the
             # lower-latency arrangements of rounds 4 and 5a (cohorts of three / four)
             import subprocess
-            env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("KOSK_HOST_THREADS", "KOSK_BLOCKING_SYNC", "KOSK_COMBINE", "KOSK_BENCH_COMBINE", "KOSK_BENCH_SLOTS")}
+            env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("KOSK_BENCH_THREADS", "KOSK_BENCH_BLOCKING", "KOSK_BENCH_COMBINE", "KOSK_BENCH_SLOTS", "KOSK_BENCH_FS")}
 
             def side_run(slots_, combine_, note, threads_=6, fs_=None):  # threads_: Fiat-Shamir workers per caller (the smaller arrangements keep the six they were tuned with)
                 cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", str(args.config), "--fs", fs_ or FS, "--combine", str(combine_), "--slots", str(slots_),
                        "--steps", str(max(20, K // 2) // slots_ * slots_ + slots_), "--warmup", str(max(4, W // 2)), "--no-kernels", "--no-cpu-baseline"]
                 try:
-                    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=dict(env, KOSK_HOST_THREADS=str(threads_)) if threads_ else env)
+                    r = subprocess.run(cmd + (["--threads", str(threads_)] if threads_ else []), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
                     sub = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                     if r.returncode != 0 or not sub:
                         raise RuntimeError("rc %d: %s" % (r.returncode, (r.stderr or "")[-300:]))

@@ -164,8 +164,8 @@ int main(int argc, char **argv)
     long fs_dev = 0, fs_host = 0;
     for (auto &c : cs) {
         long v = 0;
-        if (!kosk_path_count(c.h, 19, &v)) fs_dev += v;
-        if (!kosk_path_count(c.h, 20, &v)) fs_host += v;
+        if (!kosk_path_count(c.h, 9, &v)) fs_dev += v;
+        if (!kosk_path_count(c.h, 10, &v)) fs_host += v;
     }
     double tp = 0, tv = 0;
     long st = 0;

@@ -48,8 +48,8 @@ int kosk_create(kosk_ctx **ctx, int device, int kyber_k, int max_batch);
 enum { KOSK_FS_HOST = 0, KOSK_FS_DEVICE = 1 };
 typedef struct kosk_options {
     uint32_t size;              /* sizeof(kosk_options) as the caller compiled it (set by kosk_options_init) */
-    int32_t streams;            /* sub-batches of a batch call in flight on separate HIP streams, 1..8 (KOSK_STREAMS); 0: not given = 1 */
-    int32_t combine;            /* handles per cohort whose resident calls are merged, 2..8 (KOSK_COMBINE, see below); 0: not given, 1: off */
+    int32_t streams;            /* sub-batches of a batch call in flight on separate HIP streams, 1..8; 0: not given = 1 */
+    int32_t combine;            /* handles per cohort whose resident calls are merged, 2..8 (call combining, see below); 0: not given, 1: off */
     int32_t combine_wait_us;    /* longest wait of a call for the cohort's other members (default 5000); < 0: not given */
     int32_t combine_idle_us;    /* a member that left a call longer ago than this is not waited for (default 1000); < 0: not given */
     int32_t combine_prewake_us; /* how long the sleeping callers of a merged run may spin for its return (default 400); < 0: not given */
@@ -59,7 +59,7 @@ typedef struct kosk_options {
     int32_t fs_mode;            /* KOSK_FS_HOST: the Fiat-Shamir hashes run on the host's cores (digest tables cross PCIe, four host
                                  * round trips per prove + verify); KOSK_FS_DEVICE: one wave per proof hashes the tables in HBM, alpha /
                                  * I / the verifier's I' == I stay on the device, the resident calls have no host round trip; < 0: not given */
-    int32_t host_threads;       /* Fiat-Shamir / key-assembly workers of this handle (KOSK_HOST_THREADS); 0: not given */
+    int32_t host_threads;       /* Fiat-Shamir / key-assembly workers of this handle; 0: not given */
     int32_t blocking_sync;      /* 1: the handle's host waits sleep on events instead of spinning (few cores per GPU); < 0: not given */
     int32_t hooks_unmerged;     /* 1: while this handle has a round hook (kosk_set_round_hook) its calls never join a merged run: the hook
                                  * then always fires on the handle's OWN calling thread (thread-local state, blocking hooks); 0 / < 0: merged */
@@ -162,21 +162,15 @@ int kosk_verify_batch_compact(kosk_ctx *ctx, int n, const uint8_t *in, const uin
 int kosk_fetch_proofs_compact(kosk_ctx *ctx, int n, uint8_t *out);        /* like kosk_fetch_proofs */
 int kosk_stage_verifier_inputs_compact(kosk_ctx *ctx, int n, const uint8_t *in, const uint8_t *pk); /* like kosk_stage_verifier_inputs */
 
-/* Which of the alternative kernel / copy paths ran on this handle since kosk_create (the runtime knobs of INTEGRATION.md 5 are
- * read from the environment by kosk_create, per handle).  ids: 0 commitment hash with LDS-DMA staging, 1 without (KOSK_HASH_DMA=0
- * or a layout it cannot take), 2 placement primer launches (KOSK_HASH_PRIMER=1), 3 shared-table products on k_table_gemm,
- * 4 products on the generic limb GEMM (KOSK_TABLE_GEMM=0, grouped products), 5 proof images copied straight between HBM and
- * page-locked caller memory (kosk_host_alloc or locked by the caller), 6 through the pinned staging buffer (pageable caller memory, KOSK_REGISTER=0),
- * 7 hipGraph segment replays (KOSK_GRAPHS=1), 8 / 9 NTT launches of the packed-fp32 / integer kernel, 10 prover commitment rounds
- * whose digest table was written to the host's table by the hash launch itself (KOSK_DIGEST_DIRECT=1), 11 rounds that copied it
- * behind the launch (default), 12 digest tables copied to the host by the library's own few-wave copy kernel (KOSK_COPY_WAVES=n;
- * default 0: the runtime's hipMemcpyAsync, which measured faster for the pipeline as a whole), 13 small copies between HBM and the
- * library's own page-locked buffers (challenge vectors, opened lists, key records, fail masks) made by a copy kernel instead of
- * hipMemcpyAsync (default; KOSK_SMALL_COPY_KERNEL=0 turns it off), 14 / 15 prover beta / gamma / r launches of the one-shot kernel of rounds
- * 2-4 (KOSK_LINCOMB_FUSED=2) / of the streaming kernel (default), 16 / 17 proof images put together by the per-field kernel of rounds 1-4
- * (KOSK_ASSEMBLE_GROUPS=0) / by the grouped kernel (default: opened-party records from dense window gathers). */
+/* Which kernel / copy paths ran on this handle since it was created (the tests of the fallbacks and of the Fiat-Shamir mode assert on
+ * these).  ids: 0 commitment hash with LDS-DMA staging, 1 without (a layout the staged kernel cannot take: unaligned rows, a lane map),
+ * 2 shared-table products on k_table_gemm / k_table_gemm_p, 3 products on the generic limb GEMM (grouped products, unaligned callers of the
+ * kernel-level entry points), 4 proof images copied straight between HBM and page-locked caller memory (kosk_host_alloc or locked by the
+ * caller), 5 through the pinned staging buffer (pageable caller memory), 6 hipGraph segment replays (KOSK_GRAPHS=1), 7 commitment rounds
+ * whose digest table was copied to the host (host Fiat-Shamir mode), 8 small copies between HBM and the library's own page-locked buffers
+ * made by a copy kernel, 9 Fiat-Shamir rounds hashed on the device (k_fs_chain), 10 on the host. */
 int kosk_path_count(const kosk_ctx *ctx, int id, long *count);
-/* host worker threads per sub-context (<= 8, <= CPUs of the process / KOSK_STREAMS; all created by kosk_create) */
+/* host worker threads per sub-context (kosk_options::host_threads; else <= 8, <= CPUs of the process / streams; all created by kosk_create) */
 int kosk_host_threads(const kosk_ctx *ctx);
 
 /* wall seconds of the phases of the last prove / verify on this context (16 values: host_pre, gpu_commit,
@@ -193,25 +187,29 @@ int kosk_phase_seconds(const kosk_ctx *ctx, double *out, int n);
  * instead of graphs (diagnostic: changes the launch overhead being measured).  on = 0: off. */
 int kosk_profile_enable(kosk_ctx *ctx, int on);
 int kosk_profile_read(const kosk_ctx *ctx, int id, double *total_ms, long *launches);
-/* the same plus the proofs those launches served: a merged run of a cohort (KOSK_COMBINE, below) serves several callers'
+/* the same plus the proofs those launches served: a merged run of a cohort (call combining, below) serves several callers'
  * batches per launch, and its launches are timed on the handle that led the run */
 int kosk_profile_read_units(const kosk_ctx *ctx, int id, double *total_ms, long *launches, long *proofs);
 
 /* ---- Call combining (no reference counterpart: the reference is one call, one proof, one thread -- kosk.hpp:18-24).
- * With KOSK_COMBINE = C (2..8, needs KOSK_STREAMS=1) in the environment of kosk_create, handles of equal (device, kyber_k,
+ * With kosk_options::combine = C (2..8, needs streams = 1), handles created with equal (device, kyber_k,
  * max_batch) are grouped into cohorts of C that share one workspace, and the resident calls kosk_verifiable_keygen_resident /
  * kosk_verify_resident_pk that neighbouring members of a cohort make at about the same time -- each from its own thread --
  * are served by ONE pipeline run over all their proofs: every launch then covers 2..C callers' batches, which is what the
  * chip-filling kernels need (a 46-proof launch leaves the commitment hash at one and a bit rounds of waves per SIMD).  Per
  * call nothing changes: same arguments, same results byte for byte, each caller gets its own pk / sk / verify bits / fail
  * masks / resident proofs (kosk_resident_proofs, kosk_resident_digests point at the member's own block).  A member's call
- * waits at most KOSK_COMBINE_WAIT_US (default 5000) for the other members, and only for those that are inside a call or left
- * one less than KOSK_COMBINE_IDLE_US (default 1000) ago: a lone caller is never delayed, callers that loop fall into step after
+ * waits at most combine_wait_us (default 5000) for the other members, and only for those that are inside a call or left
+ * one less than combine_idle_us (default 1000) ago: a lone caller is never delayed, callers that loop fall into step after
  * one or two calls (a request whose kind is in the minority of its window is held back once, so that callers alternating
  * keygen / verify in opposite phase meet).  The callers of a merged run sleep while it executes and are woken shortly before its
- * end (they then spin at most KOSK_COMBINE_PREWAKE_US, default 400, for the return).  Calls that draw randomness through
+ * end (they then spin at most combine_prewake_us, default 400, for the return).  Calls that draw randomness through
  * the callback (tapes == NULL) and every other entry point run unmerged on the member's own block.  A member's round hook
- * (kosk_set_round_hook) fires from a merged run as well, with that member's block of the table, on the thread of the run's leader.  All handles of a cohort must be destroyed before the process ends (the last one frees the workspace).
+ * (kosk_set_round_hook) fires from a merged run as well, with that member's block of the table, ON THE THREAD OF THE RUN'S LEADER while
+ * the member's own caller sleeps inside its call: a hook that relies on thread-local state (a current device, a stream context, a
+ * thread-affine communicator) or that blocks must opt out with kosk_options::hooks_unmerged = 1, which keeps the calls of a handle
+ * with a hook out of merged runs.  A cohort is formed by handles whose options agree (combine, strict_encoding, fs_mode,
+ * host_threads, blocking_sync).  All handles of a cohort must be destroyed before the process ends (the last one frees the workspace).
  * kosk_combine_stats: resident calls of THIS handle that went through the combiner, and the sum over those calls of the
  * members their run served (members / calls = mean callers per launch; both 0 for a handle outside a cohort). */
 int kosk_combine_stats(const kosk_ctx *ctx, long *calls, long *members);
@@ -222,9 +220,7 @@ int kosk_stream_timer_stop(kosk_ctx *ctx, double *ms);
 
 /* ---- kernel-level entry points on DEVICE pointers (stream 0 of the ctx) ----
  * Used by the parity tests and by bench.py's roofline leg.  Every stream of the library is a NON-BLOCKING HIP stream: it is not
- * ordered against the legacy null stream (nor against any other stream of the caller) -- with ONE exception: a handle created
- * with KOSK_CU_PARTITION=i/n runs on a CU-masked stream, which HIP can only create as a blocking stream (null-stream work of
- * the application then waits for that handle's kernels and vice versa).  Device buffers handed to these entry
+ * ordered against the legacy null stream (nor against any other stream of the caller).  Device buffers handed to these entry
  * points -- and device tapes / keys handed to the resident calls -- must be complete before the call (synchronise the stream
  * that produced them), and kosk_device_synchronize() must have returned before another stream reads the outputs. */
 
@@ -264,22 +260,17 @@ int kosk_lagrange_expand(kosk_ctx *ctx, const uint16_t *d_y407, uint16_t *d_shar
 /* recon_secrets_ddeg / recon_secrets_2ddeg (ss.cpp:37-73): in n x 1454 u16, out n x 256 u16 */
 int kosk_recon_secrets(kosk_ctx *ctx, const uint16_t *d_shares, uint16_t *d_secrets, int n, int two_d);
 int kosk_device_synchronize(kosk_ctx *ctx);
-/* Proofs of an n-proof batch hashed by the first launch of a commitment round (mlwe_prover.cpp:116-127, :397-444): n unless
- * the handle was created with KOSK_HASH_SPLIT=1, which cuts a round whose waves would spill a few waves into another round
- * of the SIMDs (n = 46 on a 256-CU device: 44, the other 2 proofs follow in a second, small launch).
- * For callers that time the launches (kosk_profile_read ids 0/1 = first launch, 14/15 = second). */
-int kosk_commit_launch_groups(const kosk_ctx *ctx, int n, int *main_groups);
-/* number of sub-batches a handle keeps in flight on separate HIP streams (env KOSK_STREAMS, default 1) */
+/* number of sub-batches a handle keeps in flight on separate HIP streams (kosk_options::streams, default 1) */
 int kosk_streams(const kosk_ctx *ctx);
 /* device pointer / stride of the resident proof images of sub-batch 0, for callers chaining work in HBM
- * (with KOSK_STREAMS=1 this is the whole batch) */
+ * (with streams = 1 this is the whole batch) */
 int kosk_resident_proofs(kosk_ctx *ctx, void **d_proofs, size_t *stride);
 /* The per-party commitment digests in HBM: round 0 = Tcomm[1454][32] of every proof of the last batch
  * (mlwe_prover.cpp:116-127, the input of sha3_256(Tcomm[0..N)) at :130-135), round 1 = the view commitments
  * (:397-444, input of :445-449); `stride` = bytes per proof (1454 * 32).  This is what a multi-GPU job all-gathers
- * (RCCL) after each commitment round (BASELINE.json configs[3]).  Needs KOSK_STREAMS=1. */
+ * (RCCL) after each commitment round (BASELINE.json configs[3]).  Needs streams = 1. */
 int kosk_resident_digests(kosk_ctx *ctx, int round, void **d_digests, size_t *stride);
-/* Called on the calling thread -- for a call served by a merged run of a cohort (KOSK_COMBINE): on the thread of the caller that
+/* Called on the calling thread -- for a call served by a merged run of a cohort (call combining): on the thread of the caller that
  * leads the run, while this handle's own caller sleeps inside its call -- as soon as a round's table is complete in HBM (role 0
  * prover / 1 verifier; round as above; bytes = n * 1454 * 32; d_digests = this handle's own block); the context's stream may
  * already be running the kernels of the next segment, none of which writes the tables.  The place to start that all-gather so that it overlaps the host's Fiat-Shamir hashing.

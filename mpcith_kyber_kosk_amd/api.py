@@ -82,7 +82,6 @@ def _load():
         "kosk_stream_timer_stop": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "kosk_device_synchronize": (C.c_int, [vp]),
         "kosk_streams": (C.c_int, [vp]),
-        "kosk_commit_launch_groups": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
         "kosk_resident_proofs": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
         "kosk_keygen": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp]),
         "kosk_fs_alpha": (C.c_int, [C.c_int, vp, vp]),
@@ -108,7 +107,7 @@ EXPORTS = ["kosk_pk_bytes", "kosk_sk_bytes", "kosk_proof_bytes", "kosk_tape_byte
            "kosk_stage_verifier_inputs", "kosk_verify_resident", "kosk_verifiable_keygen_resident", "kosk_verify_resident_pk",
            "kosk_resident_digests", "kosk_set_round_hook", "kosk_phase_seconds", "kosk_path_count", "kosk_host_threads", "kosk_sha3_256_batch_pair", "kosk_verifiable_keygen_batch_compact", "kosk_verify_batch_compact", "kosk_host_alloc", "kosk_host_free", "kosk_sha3_256_batch",
            "kosk_shake256_batch", "kosk_commit_hash_lanes", "kosk_ntt256_batch", "kosk_lagrange_expand",
-           "kosk_recon_secrets", "kosk_profile_enable", "kosk_profile_read", "kosk_profile_read_units", "kosk_combine_stats", "kosk_stream_timer_start", "kosk_stream_timer_stop", "kosk_device_synchronize", "kosk_streams", "kosk_commit_launch_groups", "kosk_resident_proofs", "kosk_keygen", "kosk_fs_alpha",
+           "kosk_recon_secrets", "kosk_profile_enable", "kosk_profile_read", "kosk_profile_read_units", "kosk_combine_stats", "kosk_stream_timer_start", "kosk_stream_timer_stop", "kosk_device_synchronize", "kosk_streams", "kosk_resident_proofs", "kosk_keygen", "kosk_fs_alpha",
            "kosk_fs_opened", "kosk_host_sha3_256", "kosk_host_shake256", "kosk_host_sha3_256_multi", "kosk_lagrange_table",
            "kosk_options_init", "kosk_create_ex", "kosk_sha3_256_batch_wave", "kosk_fs_alpha_device", "kosk_fs_opened_device"]
 
@@ -392,7 +391,7 @@ class Kosk:
         return list(out)
 
     PROFILE_IDS = ["hash_tcomm", "hash_view", "gemm_expand1", "gemm_expand2", "lincomb", "ntt_f", "assemble",
-                   "v_hash_tcomm", "v_hash_view", "v_interp_build", "v_gemm_interp", "v_gemm_expand", "v_gemm_recon", "v_lincomb", "hash_tcomm_tail", "hash_view_tail",
+                   "v_hash_tcomm", "v_hash_view", "v_interp_build", "v_gemm_interp", "v_gemm_expand", "v_gemm_recon", "v_lincomb",
                    "fs_alpha", "fs_opened", "v_fs_alpha", "v_fs_opened"]
 
     def profile_enable(self, on=True):
@@ -423,8 +422,8 @@ class Kosk:
         self._chk(lib.kosk_combine_stats(self._h, C.byref(a), C.byref(b)), "combine_stats")
         return a.value, b.value
 
-    PATH_IDS = ["hash_dma", "hash_plain", "hash_primer", "table_gemm", "limb_gemm", "copy_direct", "copy_staged", "graph_replay",
-                "ntt_fp32", "ntt_int", "digest_direct", "digest_copy", "copy_kernel", "small_copy_kernel", "lincomb_oneshot", "lincomb_stream", "assemble_fields", "assemble_groups", "table_chunks", "fs_device", "fs_host"]
+    PATH_IDS = ["hash_dma", "hash_plain", "table_gemm", "limb_gemm", "copy_direct", "copy_staged", "graph_replay", "digest_copy", "small_copy_kernel",
+                "fs_device", "fs_host"]
 
     def path_counts(self):
         """{name: launches / copies} of the alternative kernel and copy paths on this handle since it was created"""
@@ -446,12 +445,6 @@ class Kosk:
         ms = C.c_double()
         self._chk(lib.kosk_stream_timer_stop(self._h, C.byref(ms)), "timer_stop")
         return ms.value
-
-    def commit_launch_groups(self, n):
-        """proofs hashed by the first of the (one or two) launches of a commitment round of an n-proof batch"""
-        m = C.c_int()
-        self._chk(lib.kosk_commit_launch_groups(self._h, n, C.byref(m)), "commit_launch_groups")
-        return m.value
 
     @property
     def streams(self):

@@ -37,6 +37,7 @@ struct kosk_ctx;
 // resident calls are served by merged pipeline runs (kosk_combine.hpp)
 struct Cohort {
     int device = 0, k = 0, per = 0;
+    CtxOpts opts; // what the members' options asked of the shared context: a handle only joins a cohort created with the same
     Ctx *arena = nullptr;
     std::unique_ptr<Combiner> comb;
     std::vector<kosk_ctx *> member;
@@ -266,7 +267,6 @@ int kosk_create_ex(kosk_ctx **ctx, int device, int kyber_k, int max_batch, const
             }
         int S = 1; // streams: sub-batches in flight per handle (1 measured best at 46 proofs: kernels sit on latency floors)
         if (o.streams > 0) S = o.streams;
-        else if (const char *e = getenv("KOSK_STREAMS")) S = atoi(e) > 0 ? atoi(e) : S;
         if (S > max_batch) S = max_batch > 0 ? max_batch : 1;
         if (S > 8) S = 8;
         h = new kosk_ctx();
@@ -274,27 +274,25 @@ int kosk_create_ex(kosk_ctx **ctx, int device, int kyber_k, int max_batch, const
         h->hooks_unmerged = o.hooks_unmerged > 0;
         int W = 1; // combine: handles per cohort (needs streams = 1)
         if (o.combine > 0) W = o.combine > 8 ? 8 : o.combine;
-        else if (const char *e = getenv("KOSK_COMBINE")) W = atoi(e) > 1 ? (atoi(e) > 8 ? 8 : atoi(e)) : 1;
         if (W > 1 && S == 1 && max_batch >= 1) {
             std::lock_guard<std::mutex> lk(g_cohort_mu);
             Cohort *co = nullptr;
             int idx = -1;
             for (Cohort *x : g_cohorts)
-                if (x->device == device && x->k == kyber_k && x->per == max_batch && x->comb->width() == W && (idx = x->comb->join()) >= 0) { co = x; break; }
+                if (x->device == device && x->k == kyber_k && x->per == max_batch && x->comb->width() == W && x->opts.host_threads == co_.host_threads &&
+                    x->opts.blocking_sync == co_.blocking_sync && x->opts.strict_encoding == co_.strict_encoding && x->opts.fs_device == co_.fs_device &&
+                    (idx = x->comb->join()) >= 0) { co = x; break; }
             if (!co) {
                 std::unique_ptr<Cohort> fresh(new Cohort());
-                fresh->device = device; fresh->k = kyber_k; fresh->per = max_batch;
+                fresh->device = device; fresh->k = kyber_k; fresh->per = max_batch; fresh->opts = co_;
                 int wait_us = 5000, idle_us = 1000;
                 if (o.combine_wait_us >= 0) wait_us = o.combine_wait_us;
-                else if (const char *e = getenv("KOSK_COMBINE_WAIT_US")) wait_us = atoi(e) >= 0 ? atoi(e) : wait_us;
                 if (o.combine_idle_us >= 0) idle_us = o.combine_idle_us;
-                else if (const char *e = getenv("KOSK_COMBINE_IDLE_US")) idle_us = atoi(e) >= 0 ? atoi(e) : idle_us;
                 int prewake_us = 400; // how long a member whose run has announced its end may spin for it (0: members sleep to the end)
                 if (o.combine_prewake_us >= 0) prewake_us = o.combine_prewake_us;
-                else if (const char *e = getenv("KOSK_COMBINE_PREWAKE_US")) prewake_us = atoi(e) >= 0 ? atoi(e) : prewake_us;
                 fresh->comb.reset(new Combiner(W, wait_us, idle_us, prewake_us));
                 fresh->member.assign((size_t)W, nullptr);
-                if ((long)W * max_batch > 1 << 20) { g_create_err = "KOSK_COMBINE x max_batch too large"; delete h; return -1; }
+                if ((long)W * max_batch > 1 << 20) { g_create_err = "combine x max_batch too large"; delete h; return -1; }
                 if (ctx_create(&fresh->arena, device, kyber_k, W * max_batch, g_create_err, 1, co_)) { delete h; return -1; }
                 if (ensure_verify_workspace(*fresh->arena)) { // views share it: allocated with the arena, not on first use
                     g_create_err = fresh->arena->err;
@@ -620,7 +618,7 @@ int kosk_set_round_hook(kosk_ctx *ctx, kosk_round_fn fn, void *user)
 {
     if (!ctx) return -1;
     GUARD(ctx)
-    if (fn && ctx->sub.size() > 1) { ctx->err = "kosk_set_round_hook needs KOSK_STREAMS=1 (one digest table per round)"; return -1; }
+    if (fn && ctx->sub.size() > 1) { ctx->err = "kosk_set_round_hook needs streams = 1 (one digest table per round)"; return -1; }
     for (Ctx *c : ctx->sub) { c->round_hook = fn; c->round_user = user; }
     return 0;
     GUARD_END
@@ -629,7 +627,7 @@ int kosk_resident_digests(kosk_ctx *ctx, int round, void **d_digests, size_t *st
 {
     if (!ctx || round < 0 || round > 1) return bad_args(ctx, __func__);
     GUARD(ctx)
-    if (ctx->sub.size() > 1) { ctx->err = "kosk_resident_digests needs KOSK_STREAMS=1 (sub-batches keep separate tables)"; return -1; }
+    if (ctx->sub.size() > 1) { ctx->err = "kosk_resident_digests needs streams = 1 (sub-batches keep separate tables)"; return -1; }
     if (d_digests) *d_digests = round ? ctx->c->d_dig2 : ctx->c->d_dig1;
     if (stride) *stride = (size_t)NPARTY * 32;
     return 0;
@@ -955,19 +953,13 @@ int kosk_device_synchronize(kosk_ctx *ctx)
     return 0;
     GUARD_END
 }
-int kosk_commit_launch_groups(const kosk_ctx *ctx, int n, int *main_groups)
-{
-    if (!ctx || n < 1 || !main_groups) return bad_args(ctx, __func__);
-    *main_groups = commit_hash_groups(*ctx->c, n);
-    return 0;
-}
 int kosk_streams(const kosk_ctx *ctx) { return ctx ? (int)ctx->sub.size() : -1; }
 
 int kosk_resident_proofs(kosk_ctx *ctx, void **d_proofs, size_t *stride)
 {
     if (!ctx) return -1;
     GUARD(ctx)
-    if (ctx->sub.size() > 1) { ctx->err = "kosk_resident_proofs needs KOSK_STREAMS=1 (sub-batches keep separate images)"; return -1; }
+    if (ctx->sub.size() > 1) { ctx->err = "kosk_resident_proofs needs streams = 1 (sub-batches keep separate images)"; return -1; }
     if (d_proofs) *d_proofs = ctx->c->d_proof;
     if (stride) *stride = ctx->c->image_stride;
     return 0;
@@ -1075,9 +1067,8 @@ int kosk_commit_hash_lanes(kosk_ctx *ctx, const uint16_t *d_rows, size_t row_str
     ha.out = d_out;
     ha.out_lanes_per_group = n_lanes;
     int variant = 0;
-    HIPCHK_C(launch_commit_hash(ha, 1, c.P.K, with_prefix != 0, c.stream, c.hash_opts(), &variant));
+    HIPCHK_C(launch_commit_hash(ha, 1, c.P.K, with_prefix != 0, c.stream, &variant));
     c.path_n[(variant & 1) ? PATH_HASH_DMA : PATH_HASH_PLAIN]++;
-    if (variant & 2) c.path_n[PATH_HASH_PRIMER]++;
     return 0;
     GUARD_END
 }
@@ -1094,9 +1085,8 @@ int kosk_ntt256_batch(kosk_ctx *ctx, const int16_t *d_in, int16_t *d_out, int n)
     na.out = d_out;
     na.npg = n;
     na.npoly = n;
-    na.out_canonical = 0; na.fp32 = c.ntt_fp32;
+    na.out_canonical = 0;
     HIPCHK_C(launch_ntt(na, c.stream));
-    c.path_n[c.ntt_fp32 ? PATH_NTT_FP32 : PATH_NTT_INT]++;
     return 0;
     GUARD_END
 }

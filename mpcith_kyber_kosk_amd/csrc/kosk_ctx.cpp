@@ -60,10 +60,6 @@ Ctx::~Ctx()
         for (auto e : pe)
             if (e) (void)hipEventDestroy(e);
     if (ev_sync) (void)hipEventDestroy(ev_sync);
-    for (auto e : ev_img)
-        if (e) (void)hipEventDestroy(e);
-    for (auto e : ev_chunk)
-        if (e) (void)hipEventDestroy(e);
     if (is_view) {
         if (h_err) (void)hipHostFree(h_err);
         // a view owns its events, host workers and compact staging; tables, workspace and the stream belong to the arena
@@ -79,12 +75,12 @@ Ctx::~Ctx()
         return; // the stream is the arena's
     }
     void *dev[] = {t_expand.d, t_recon_d.d, t_recon_2d.d, t_expand.dfrag, t_recon_d.dfrag, t_recon_2d.dfrag, d_fresh_rows, d_gemm1_rows, d_gemm2_rows, d_off, d_fields, d_asm_groups, d_asm_elems,
-                   d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_kg, d_sehat, d_t, d_alpha, d_I, d_pwT, d_limbs, d_linA, d_coef, d_lin_rows,
+                   d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_kg, d_sehat, d_t, d_alpha, d_I, d_pwT, d_limbs, d_coef, d_lin_rows,
                    d_gather, d_gather2, d_O, d_w, d_ell, d_sec, d_sec_u1, d_sec_u2, d_fail, d_inv, d_invlimb, d_vfields,
                    d_vrowtab, d_rows_bg, d_rows_isrc, d_rows_idst, d_rows_u, d_fact, d_invfact, d_node_of, d_isort, d_hrange, d_odig};
     for (void *p : dev)
         if (p) (void)hipFree(p);
-    void *host[] = {h_err, h_tape, h_dig, h_dig2, h_proof, h_alpha, h_I, h_fail, h_Iimg, h_kg, h_odig, h_imgdig};
+    void *host[] = {h_err, h_tape, h_dig, h_dig2, h_proof, h_alpha, h_I, h_fail, h_Iimg, h_kg, h_odig};
     for (void *p : host)
         if (p) (void)hipHostFree(p);
     if (d_compact) (void)hipFree(d_compact);
@@ -96,7 +92,7 @@ Ctx::~Ctx()
     if (ev_kg) (void)hipEventDestroy(ev_kg);
     for (auto e : timer_ev)
         if (e) (void)hipEventDestroy(e);
-    if (stream && !stream_shared) (void)hipStreamDestroy(stream);
+    if (stream) (void)hipStreamDestroy(stream);
 }
 
 static int upload_table(Ctx &c, GemmTable &t, const std::vector<uint16_t> &A, int M, int Kdim)
@@ -119,43 +115,14 @@ static int upload_table(Ctx &c, GemmTable &t, const std::vector<uint16_t> &A, in
     return 0;
 }
 
-// The commitment hashes run one party lane per thread, 23 waves per proof.  A SIMD with ONE such wave finishes a batch in
-// about 60 % of the time a SIMD with two needs, so a launch of r whole rounds of waves plus a few more
-// (46 proofs: 1 058 waves on 1 024 SIMDs) costs r + 1 rounds.  With KOSK_HASH_SPLIT=1 such a batch is hashed in two
-// launches: the proofs that fill whole rounds first, the few remaining ones in a second, small launch behind it.  Opt-in:
-// it pays only together with the placement primer and on an otherwise idle GPU (see k_hash_primer; measured in
-// profiles/r02_hash_placement.txt), the default is one launch per round.
-int commit_hash_groups(const Ctx &c, int n)
-{
-    const int wpp = (NPARTY + 63) / 64, total = n * wpp, rem = total % c.n_simd;
-    if (!c.hash_split || total <= c.n_simd || rem == 0 || rem * 8 >= c.n_simd) return n;
-    return (total - rem) / wpp;
-}
-
+// one commitment round of n proofs: a single launch, timed under the round's profile id
 static hipError_t commit_hash_batch(Ctx &c, const HashArgs &ha, int n, int K, bool view, hipStream_t st)
 {
-    const int n_main = commit_hash_groups(c, n);
-    c.prof_begin(view ? PR_HASH_VIEW : PR_HASH_TCOMM, n_main);
+    c.prof_begin(view ? PR_HASH_VIEW : PR_HASH_TCOMM, n);
     int variant = 0;
-    auto count = [&]() {
-        if (c.capturing) return; // a captured launch runs at replay time (PATH_GRAPH_REPLAY counts those)
-        c.path_n[(variant & 1) ? PATH_HASH_DMA : PATH_HASH_PLAIN]++;
-        if (variant & 2) c.path_n[PATH_HASH_PRIMER]++;
-    };
-    hipError_t e = launch_commit_hash(ha, n_main, K, view, st, c.hash_opts(), &variant);
-    count();
+    const hipError_t e = launch_commit_hash(ha, n, K, view, st, &variant);
+    if (!c.capturing) c.path_n[(variant & 1) ? PATH_HASH_DMA : PATH_HASH_PLAIN]++; // a captured launch runs at replay time (PATH_GRAPH_REPLAY counts those)
     c.prof_end(view ? PR_HASH_VIEW : PR_HASH_TCOMM);
-    if (e != hipSuccess || n_main == n) return e;
-    HashArgs t = ha;
-    t.rows += (size_t)n_main * ha.group_stride;
-    if (t.prefix) t.prefix += (size_t)n_main * ha.out_lanes_per_group * 32;
-    t.out += (size_t)n_main * ha.out_lanes_per_group * 32;
-    if (t.out_host) t.out_host += (size_t)n_main * ha.out_lanes_per_group * 32;
-    if (t.lane_map) t.lane_map += (size_t)n_main * ha.lane_map_stride;
-    c.prof_begin(view ? PR_HASH_VIEW_TAIL : PR_HASH_TCOMM_TAIL, n - n_main);
-    e = launch_commit_hash(t, n - n_main, K, view, st, c.hash_opts(), &variant);
-    count();
-    c.prof_end(view ? PR_HASH_VIEW_TAIL : PR_HASH_TCOMM_TAIL);
     return e;
 }
 
@@ -171,64 +138,17 @@ int device_error_check(Ctx &c)
     return -1;
 }
 
-hipError_t copy_table_to_host(Ctx &c, void *h_dst, const void *d_src, size_t bytes)
-{
-    if (c.copy_waves > 0 && bytes >= ((size_t)1 << 15) && bytes % 16 == 0) {
-        if (!c.capturing) c.path_n[PATH_COPY_KERNEL]++;
-        return launch_copy_to_host(d_src, h_dst, bytes, c.copy_waves, c.stream);
-    }
-    return hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c.stream);
-}
-
 hipError_t copy_round_table(Ctx &c, uint8_t *h_dst, const uint8_t *d_src, int n)
 {
-    const size_t per_proof = (size_t)NPARTY * 32;
-    c.chunk_n = 0;
-    int nch = c.table_chunks < Ctx::TABLE_CHUNKS_MAX ? c.table_chunks : Ctx::TABLE_CHUNKS_MAX;
-    if (nch < 2 || n < 48 || c.capturing || c.use_graphs || c.copy_waves > 0 || !c.ev_chunk[0]) return copy_table_to_host(c, h_dst, d_src, (size_t)n * per_proof);
-    const int per = ((n + nch - 1) / nch + 7) & ~7; // whole 8-proof groups of the host's eight-way SHA-3
-    nch = (n + per - 1) / per;
-    if (nch < 2) return copy_table_to_host(c, h_dst, d_src, (size_t)n * per_proof);
-    for (int k = 0; k < nch; k++) {
-        const int first = k * per, cnt = (first + per <= n ? per : n - first);
-        const hipError_t e = hipMemcpyAsync(h_dst + (size_t)first * per_proof, d_src + (size_t)first * per_proof, (size_t)cnt * per_proof, hipMemcpyDeviceToHost, c.stream);
-        if (e != hipSuccess) return e;
-        if (k + 1 < nch) {
-            const hipError_t e2 = hipEventRecord(c.ev_chunk[k], c.stream);
-            if (e2 != hipSuccess) return e2;
-        }
-    }
-    __atomic_store_n(&c.chunk_passed, 0, __ATOMIC_RELEASE);
-    c.chunk_per = per;
-    c.chunk_n = nch;
-    c.path_n[PATH_TABLE_CHUNKS]++;
-    return hipSuccess;
-}
-
-// called by the host's workers in front of a proof's table (fs_*_batch's prep hook): the piece that holds it has landed.  Pieces
-// land in order, so the highest piece seen is all the state there is; several workers may wait for the same event.
-hipError_t table_gate_wait(Ctx &c, int proof)
-{
-    const int k = proof / c.chunk_per;
-    if (k <= 0 || __atomic_load_n(&c.chunk_passed, __ATOMIC_ACQUIRE) >= k) return hipSuccess;
-    const hipError_t e = hipEventSynchronize(k + 1 < c.chunk_n ? c.ev_chunk[k] : c.ev);
-    if (e != hipSuccess) return e;
-    int seen = __atomic_load_n(&c.chunk_passed, __ATOMIC_RELAXED);
-    while (seen < k && !__atomic_compare_exchange_n(&c.chunk_passed, &seen, k, true, __ATOMIC_RELEASE, __ATOMIC_RELAXED)) {}
-    return hipSuccess;
-}
-
-hipError_t table_done(Ctx &c)
-{
-    if (c.chunk_n < 2) return hipSuccess;
-    c.chunk_n = 0;
-    return hipEventSynchronize(c.ev); // behind the last piece: passed already unless no worker reached it
+    // the runtime's copy: every kernel-driven store into host memory measured slower for the pipeline as a whole, and so did the table in
+    // pieces with an event behind each (profiles/r04_copy_kernel.txt, r05_copy_kernel.txt, r05_table_chunks.txt; both removed in round 6)
+    return hipMemcpyAsync(h_dst, d_src, (size_t)n * NPARTY * 32, hipMemcpyDeviceToHost, c.stream);
 }
 
 hipError_t copy_small(Ctx &c, void *dst, size_t dst_stride, const void *src, size_t src_stride, size_t row_bytes, size_t nrows, hipMemcpyKind kind, hipStream_t st)
 {
     if (!row_bytes || !nrows) return hipSuccess;
-    if (c.small_copy_kernel && copy_small_ok(src, src_stride, dst, dst_stride, row_bytes)) {
+    if (copy_small_ok(src, src_stride, dst, dst_stride, row_bytes)) {
         if (!c.capturing) c.path_n[PATH_SMALL_COPY_KERNEL]++;
         return launch_copy_small(src, src_stride, dst, dst_stride, row_bytes, nrows, st);
     }
@@ -299,7 +219,7 @@ int gemm_modq(Ctx &c, const uint8_t *A, size_t a_gstride, int Mpad, int M, int K
         ta.B = nullptr; ta.BRT = 0;
         ta.src = s.src; ta.src_gstride = s.gstride; ta.src_rows = s.rows; ta.src_rstride = s.rstride; ta.src_koff = s.koff;
         ta.src_canonical = s.canonical;
-        if (c.table_gemm && table_gemm_usable(ta)) {
+        if (table_gemm_usable(ta)) {
             HIPCHK(launch_table_gemm(ta, reinterpret_cast<uint16_t *>(c.d_limbs), c.stream));
             if (!c.capturing) c.path_n[PATH_TABLE_GEMM]++;
             return 0;
@@ -495,7 +415,6 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     // sub-contexts of the handle; the workers exist before the first call (no thread is ever created inside a batch call)
     const int cpus = host_cpu_count() / (host_share > 0 ? host_share : 1);
     c.nthreads = cpus > 8 ? 8 : (cpus < 1 ? 1 : cpus);
-    if (const char *e = getenv("KOSK_HOST_THREADS")) c.nthreads = atoi(e) > 0 ? (atoi(e) > 64 ? 64 : atoi(e)) : c.nthreads;
     if (opts.host_threads > 0) c.nthreads = opts.host_threads > 64 ? 64 : opts.host_threads;
     c.pool = pool_create();
     c.nthreads = pool_reserve(c.pool, c.nthreads);
@@ -503,37 +422,15 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
     c.reserved_threads = c.nthreads;
     c.own_batch = max_batch;
     c.call_cap = max_batch;
+    // debug knobs: everything a host decides per handle is in kosk_options, not in the environment
     if (const char *e = getenv("KOSK_GRAPHS")) c.use_graphs = atoi(e) != 0;
-    if (const char *e = getenv("KOSK_LINCOMB_FUSED")) c.lincomb_fused = atoi(e) < 0 ? 1 : (atoi(e) > 2 ? 1 : atoi(e));
-    if (const char *e = getenv("KOSK_NTT_FP32")) c.ntt_fp32 = atoi(e) != 0;
-    if (const char *e = getenv("KOSK_BLOCKING_SYNC")) c.blocking_sync = atoi(e) != 0;
     if (const char *e = getenv("KOSK_WAIT_NAP")) c.wait_nap = atoi(e) != 0;
-    if (const char *e = getenv("KOSK_TABLE_CHUNKS")) c.table_chunks = atoi(e);
-    if (const char *e = getenv("KOSK_HASH_SPLIT")) c.hash_split = atoi(e) != 0;
-    if (const char *e = getenv("KOSK_HASH_DMA")) c.hash_dma = atoi(e) != 0;
-    if (const char *e = getenv("KOSK_HASH_PRIMER")) c.hash_primer = atoi(e) != 0;
-    if (const char *e = getenv("KOSK_TABLE_GEMM")) c.table_gemm = atoi(e) != 0;
     if (const char *e = getenv("KOSK_REGISTER")) c.host_register = atoi(e) != 0;
-    if (const char *e = getenv("KOSK_DIGEST_DIRECT")) c.digest_direct = atoi(e) != 0;
-    if (const char *e = getenv("KOSK_STRICT_ENCODING")) c.strict_encoding = atoi(e) != 0;
-    if (const char *e = getenv("KOSK_ASSEMBLE_GROUPS")) c.assemble_groups = atoi(e) != 0;
-    if (const char *e = getenv("KOSK_SMALL_COPY_KERNEL")) c.small_copy_kernel = atoi(e) != 0;
-    if (const char *e = getenv("KOSK_ALPHA_DIRECT")) c.alpha_direct = atoi(e) != 0;
-    if (const char *e = getenv("KOSK_COPY_WAVES")) c.copy_waves = atoi(e) >= 0 ? (atoi(e) > 65535 ? 65535 : atoi(e)) : c.copy_waves;
     if (const char *e = getenv("KOSK_DEBUG_XOF_BLOCKS")) c.xof_max_blocks = atoi(e) > 0 ? atoi(e) : c.xof_max_blocks;
-    if (const char *e = getenv("KOSK_CU_PARTITION")) {
-        int i = 0, n = 0;
-        if (sscanf(e, "%d/%d", &i, &n) != 2 || n < 1 || i < 0 || i >= n) { c.err = "KOSK_CU_PARTITION must be i/n with 0 <= i < n"; return fail(); }
-        c.cu_part_i = i;
-        c.cu_part_n = n;
-    }
-    if (const char *e = getenv("KOSK_CU_MASK_LAYOUT")) c.cu_mask_layout = atoi(e) != 0;
-    if (const char *e = getenv("KOSK_FS_DEVICE")) c.fs_device = atoi(e) != 0;
-    // what the caller's options struct decides wins over the environment (kosk_create_ex)
+    // what the caller's options struct decides (kosk_create_ex)
     if (opts.blocking_sync >= 0) c.blocking_sync = opts.blocking_sync != 0;
     if (opts.strict_encoding >= 0) c.strict_encoding = opts.strict_encoding != 0;
     if (opts.fs_device >= 0) c.fs_device = opts.fs_device != 0;
-    if (c.fs_device) c.table_chunks = 1; // no digest table leaves HBM: nothing to cut into pieces
 
     auto body = [&]() -> int {
         HIPCHK(hipSetDevice(device));
@@ -542,56 +439,11 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
             HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
             if (cus > 0) c.n_simd = 4 * cus;
         }
-        if (c.cu_part_n > 1) {
-            // KOSK_CU_PARTITION=i/n: this context's kernels run on partition i of n equal CU partitions only (whole XCDs, each
-            // with its own L2, when n divides 8).  A 46-proof batch that is small for 256 CUs is a large batch for 64 of them:
-            // its launches sit well above the one-wave-per-SIMD step of the commitment hashes, and contexts on different
-            // partitions do not stretch each other's kernels.
-            int cus = 0;
-            HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-            const int nx = 8, per_xcd = cus / nx;
-            if (cus <= 0 || cus % nx || c.cu_part_n > cus) { c.err = "KOSK_CU_PARTITION: unsupported CU count / partition count"; return -1; }
-            std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
-            int mine = 0;
-            for (int bit = 0; bit < cus; bit++) {
-                // bit -> (XCD, CU inside it): layout 0 deals consecutive bits round the XCDs (how workgroups are dealt),
-                // layout 1 numbers the CUs XCD after XCD (KOSK_CU_MASK_LAYOUT; round 3 measured the round-robin one to be the
-                // one that maps to whole XCDs on this driver: profiles/r03_partition_sweep.txt)
-                const int xcd = c.cu_mask_layout ? bit / per_xcd : bit % nx, idx = c.cu_mask_layout ? bit % per_xcd : bit / nx;
-                const int ordered = xcd * per_xcd + idx;
-                if ((long)ordered * c.cu_part_n / cus == c.cu_part_i) { mask[(size_t)bit >> 5] |= 1u << (bit & 31); mine++; }
-            }
-            // NOTE: hipExtStreamCreateWithCUMask takes no flags: this stream is a BLOCKING stream (ordered against the legacy null
-            // stream), unlike every other stream of the library -- documented with the knob
-            HIPCHK(hipExtStreamCreateWithCUMask(&c.stream, (uint32_t)mask.size(), mask.data()));
-            c.n_simd = 4 * mine;
-        } else if (const char *e = getenv("KOSK_SHARE_STREAMS")) {
-            // experiment (round 5): the contexts of this process are dealt round the first n streams instead of getting one each, so
-            // that two cohorts pipeline on ONE hardware queue (one's kernels run during the other's host rounds).  The shared
-            // streams are never destroyed (like the side stream).
-            static std::mutex mu;
-            static std::vector<hipStream_t> shared;
-            static size_t next = 0;
-            const size_t nshare = (size_t)std::max(1, atoi(e));
-            std::lock_guard<std::mutex> lk(mu);
-            if (shared.size() < nshare) {
-                hipStream_t st = nullptr;
-                HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-                shared.push_back(st);
-                c.stream = st;
-            } else {
-                c.stream = shared[next++ % nshare];
-            }
-            c.stream_shared = true;
-        } else {
-            HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-        }
+        HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
         HIPCHK(hipEventCreateWithFlags(&c.ev_kg, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
         if (c.blocking_sync) HIPCHK(hipEventCreateWithFlags(&c.ev_sync, hipEventDisableTiming | hipEventBlockingSync));
         else if (c.wait_nap) HIPCHK(hipEventCreateWithFlags(&c.ev_sync, hipEventDisableTiming));
-        if (c.table_chunks > 1)
-            for (auto &e : c.ev_chunk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
         for (auto &pe : c.prof_ev)
             for (auto &e : pe) HIPCHK(hipEventCreate(&e));
         if (build_tables(c)) return -1;
@@ -642,7 +494,6 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
         // data operand of the largest GEMM: every fresh sharing of every proof (<= 256 per proof), 13 k-steps
         c.limb_cap = ((B * 256 + 63) / 64 * 64 / 16) * (size_t)13 * 2048;
         HIPCHK(dev(&c.d_limbs, (size_t)(256 / 16) * 13 * 2048));
-        if (!c.lincomb_fused) HIPCHK(dev(&c.d_linA, 2 * (size_t)(1792 / 16) * 2 * 2048)); // only the unfused path stores the transposed f rows
         HIPCHK(dev(&c.d_coef, 2 * (size_t)8 * 2 * 2048));
         HIPCHK(dev(&c.d_fail, 1));
         HIPCHK(host(&c.h_tape, c.tape_stride));
@@ -684,9 +535,6 @@ int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx
     // took 2.8 ms instead of 1.6).  Calls end with a stream synchronisation, so members never leave work behind for each other.
     c.use_graphs = false; // stream capture is per stream: not with several callers on one
     c.ev = nullptr; c.ev_kg = nullptr; c.ev_sync = nullptr; c.pool = nullptr;
-    for (auto &e : c.ev_img) e = nullptr;
-    for (auto &e : c.ev_chunk) e = nullptr;
-    c.chunk_n = 0;
     c.host_img = nullptr;
     c.h_err = nullptr;
     for (auto &e : c.timer_ev) e = nullptr;
@@ -710,11 +558,8 @@ int ctx_make_view(Ctx &arena, int first, int own_batch, int reserve_threads, Ctx
         HIPCHK(hipEventCreateWithFlags(&c.ev_kg, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
         if (c.blocking_sync) HIPCHK(hipEventCreateWithFlags(&c.ev_sync, hipEventDisableTiming | hipEventBlockingSync));
         else if (c.wait_nap) HIPCHK(hipEventCreateWithFlags(&c.ev_sync, hipEventDisableTiming));
-        if (c.table_chunks > 1)
-            for (auto &e : c.ev_chunk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
         for (auto &pe : c.prof_ev)
             for (auto &e : pe) HIPCHK(hipEventCreate(&e));
-        for (auto &e : c.ev_img) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
         HIPCHK(halloc(&c.h_err, 16)); // a view's kernels report to the view's own word
         memset(c.h_err, 0, 16 * sizeof(uint32_t));
         return 0;
@@ -832,7 +677,7 @@ int issue_keygen(Ctx &c, int n, bool sampled)
     NttArgs na{};
     na.in = c.d_se; na.in_gstride = c.se_stride; na.src_off = nullptr;
     na.out = c.d_sehat; na.out_gstride = c.se_stride; na.dst_off = nullptr;
-    na.npg = 2 * K; na.npoly = 2 * K * n; na.out_canonical = 0; na.fp32 = c.ntt_fp32;
+    na.npg = 2 * K; na.npoly = 2 * K * n; na.out_canonical = 0;
     HIPCHK(launch_ntt(na, c.stream)); // polyvec_ntt(s), polyvec_ntt(e)   kosk.cpp:39-40
     HIPCHK(launch_keygen_pack(c.d_A, c.key_stride, c.d_sehat, c.se_stride, c.d_seeds, c.kg_rec, c.d_t, c.d_pk, c.pk_stride, c.d_sb,
                               c.sb_stride, K, n, c.stream));
@@ -915,10 +760,9 @@ int issue_sharing_front(Ctx &c, int n, FrontPart part, bool with_keygen)
         na.dst_off = c.d_off + c.off_ntt1_dst + ntt_first;
         na.npg = ntt_count;
         na.npoly = ntt_count * n;
-        na.out_canonical = 1; na.fp32 = c.ntt_fp32;
+        na.out_canonical = 1;
         c.prof_begin(PR_NTT_F, n);
         HIPCHK(launch_ntt(na, st));
-        if (!c.capturing) c.path_n[c.ntt_fp32 ? PATH_NTT_FP32 : PATH_NTT_INT]++;
         c.prof_end(PR_NTT_F);
     }
     if (matvec) HIPCHK(launch_matvec_ntt(c.d_A, c.key_stride, c.d_P, c.proof_stride, rm.shat, rm.nttas, K, n, st)); // :284-285
@@ -937,14 +781,12 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         if (!s->pk || !s->sk) { c.err = "pk / sk output buffers are required"; return -1; }
     if (!keygen && !c.tape_cur) { c.err = "no resident prover inputs: call kosk_stage_prover_inputs first"; return -1; }
     if (!keygen) c.tape_segs.count = 0;
-    c.chunk_n = 0; // pieces of an EARLIER call's table copy (an error return between copy_round_table and table_done leaves them behind)
     HIPCHK(hipSetDevice(c.device));
     const Params &P = c.P;
     const RowMap &rm = c.rm;
     const int K = P.K;
     hipStream_t st = c.stream;
     double t0 = now_sec(), t1;
-    const size_t a_gstride = (size_t)(1792 / 16) * 2 * 2048; // limb matrix of one proof's f (or NTT f) rows, transposed
 
     HashArgs ha{};
     ha.rows = c.d_P;
@@ -963,12 +805,10 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         HashArgs h1 = ha;
         h1.prefix = nullptr;
         h1.out = c.d_dig1;
-        // the host's table: written by the hash launch itself (HashArgs::out_host), or copied behind it
-        h1.out_host = c.digest_direct ? c.h_dig : nullptr;
         HIPCHK(commit_hash_batch(c, h1, n, K, false, st));
         if (c.fs_device) return 0; // the table stays where it is: the chain kernel below hashes it in HBM
-        if (!c.digest_direct) HIPCHK(copy_round_table(c, c.h_dig, c.d_dig1, n));
-        if (!c.capturing) c.path_n[c.digest_direct ? PATH_DIGEST_DIRECT : PATH_DIGEST_COPY]++;
+        HIPCHK(copy_round_table(c, c.h_dig, c.d_dig1, n));
+        if (!c.capturing) c.path_n[PATH_DIGEST_COPY]++;
         return 0;
     }, c.tape_cur, c.tape_cur_stride)) return -1; // the tape pointer is baked into the captured launch: part of the graph's key
     HIPCHK(hipEventRecord(c.ev, st)); // the Tcomm digests are on the host (device Fiat-Shamir: complete in HBM) once this event has passed
@@ -989,7 +829,6 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     // the f rows for the beta/gamma product
     if (run_segment(c, Ctx::SEG_P1B, n, [&]() -> int {
         HIPCHK(launch_post_gates(c.d_P, c.proof_stride, rm, n, st));
-        if (!c.lincomb_fused) HIPCHK(launch_cols_to_limbs(c.d_P, c.proof_stride, rm.f, rm.tf, P.M, c.d_linA, a_gstride, n, st));
         return 0;
     })) return -1;
     // the host half of the key generation (sk = NTT(s) bytes || pk || H(pk) || z per proof) needs only the key records, which left
@@ -1009,14 +848,8 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         return h;
     };
     const bool hooks = c.fs_device && any_hook();
-    if (!c.fs_device || hooks) HIPCHK(wait_event(c, first_event(c), 0, n)); // the table, or its first piece (copy_round_table)
+    if (!c.fs_device || hooks) HIPCHK(wait_event(c, c.ev, 0, n)); // the table
     t1 = now_sec(); c.phase_sec[PH_GPU_COMMIT] = t1 - t0; t0 = t1;
-    std::atomic<int> gate_err_a{(int)hipSuccess}; // written by several pool workers
-    const std::function<void(int)> gate = [&c, &gate_err_a](int b) {
-        const hipError_t e = table_gate_wait(c, b);
-        if (e != hipSuccess) gate_err_a.store((int)e, std::memory_order_relaxed);
-    };
-#define gate_err ((hipError_t)gate_err_a.load(std::memory_order_relaxed))
     // a round's table is complete in HBM: the hook of every caller of this run with ITS block of the table (a merged run), else the
     // context's own hook with the whole batch
     auto fire_hooks = [&](int rnd, const uint8_t *d_table) {
@@ -1038,9 +871,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     // ---- Fiat-Shamir round 1 on the host
     if (keygen && !keys_done) finish_keygen_segs(c, n, *keygen);
     if (!c.fs_device) {
-        fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool, c.chunk_n > 1 ? &gate : nullptr);
-        HIPCHK(gate_err);
-        HIPCHK(table_done(c));
+        fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool);
         c.path_n[PATH_FS_HOST]++;
     }
     t1 = now_sec(); c.phase_sec[PH_FS_ALPHA] = t1 - t0; t0 = t1;
@@ -1048,40 +879,22 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     // ---- P2: beta, gamma, r, NTT_r on every evaluation point (per proof a [J x M] x [M x 1710] product mod q, :159-203),
     // s + r / e + r (:222-245), then the view commitments, which read nothing else of the relation phase
     if (run_segment(c, Ctx::SEG_P2, n, [&]() -> int {
-        // (round 5) the challenge vectors are read by k_coef_limbs straight from the page-locked host table (160 bytes per proof): one
-        // launch less between the host's round and the product; KOSK_SMALL_COPY_KERNEL=0 keeps the explicit copy
-        const uint16_t *alpha_src = c.h_alpha;
-        if (c.fs_device) alpha_src = c.d_alpha; // written by the chain kernel
-        else if (!c.small_copy_kernel || !c.alpha_direct) {
-            HIPCHK(copy_small(c, c.d_alpha, 0, c.h_alpha, 0, (size_t)n * 80 * 2, 1, hipMemcpyHostToDevice, st));
-            alpha_src = c.d_alpha;
-        }
+        // host mode: the challenge vectors are read by k_coef_limbs straight from the page-locked host table (160 bytes per proof): no copy
+        // launch between the host's round and the product; device mode: from where the chain kernel wrote them
+        const uint16_t *alpha_src = c.fs_device ? c.d_alpha : c.h_alpha;
         c.prof_begin(PR_LINCOMB, n);
         HIPCHK(launch_coef_limbs(alpha_src, P.J, P.M, c.d_coef, n, st));
-        if (c.lincomb_fused) {
-            HIPCHK(launch_lincomb_fused(c.d_P, c.proof_stride, rm, c.d_coef, c.d_P, c.d_lin_rows, P.J, n, st, c.lincomb_fused)); // includes s + r, e + r
-            if (!c.capturing) c.path_n[c.lincomb_fused == 2 ? PATH_LINCOMB_ONESHOT : PATH_LINCOMB_STREAM]++;
-        } else {
-            GemmArgs ga{};
-            ga.A = c.d_linA; ga.a_gstride = a_gstride; ga.Mpad = 1792; ga.M = NPTS; ga.KS = 2;
-            ga.B = c.d_coef; ga.BRT = 2 * n * 8;
-            ga.C = c.d_P; ga.c_gstride = c.proof_stride; ga.c_rows = c.d_lin_rows; ga.c_rstride = RS; ga.c_off = 0;
-            ga.npg = P.J; ga.npg_pad = 128; ga.ngroups = 2 * n; ga.grouped = 1; ga.c_gdiv = 2; ga.c_rows_gstride = 128;
-            HIPCHK(launch_gemm(ga, st));
-            if (!c.capturing) c.path_n[PATH_LIMB_GEMM]++;
-        }
+        HIPCHK(launch_lincomb_stream(c.d_P, c.proof_stride, rm, c.d_coef, c.d_P, c.d_lin_rows, P.J, n, st)); // includes s + r, e + r
         c.prof_end(PR_LINCOMB);
-        if (!c.lincomb_fused) HIPCHK(launch_post_open(c.d_P, c.proof_stride, rm, n, st));
         return 0;
     })) return -1;
     // the graded kernel stays a plain launch so that HIP events can bracket it inside the timed region
     ha.prefix = c.d_dig1;
     ha.out = c.d_dig2;
-    ha.out_host = c.digest_direct ? c.h_dig2 : nullptr;
     HIPCHK(commit_hash_batch(c, ha, n, K, true, st));
     if (!c.fs_device) {
-        if (!c.digest_direct) HIPCHK(copy_round_table(c, c.h_dig2, c.d_dig2, n));
-        c.path_n[c.digest_direct ? PATH_DIGEST_DIRECT : PATH_DIGEST_COPY]++;
+        HIPCHK(copy_round_table(c, c.h_dig2, c.d_dig2, n));
+        c.path_n[PATH_DIGEST_COPY]++;
     }
     HIPCHK(hipEventRecord(c.ev, st));
     if (c.fs_device) {
@@ -1109,7 +922,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         na.out = reinterpret_cast<int16_t *>(c.d_P);
         na.out_gstride = c.proof_stride;
         na.dst_off = c.d_off + c.off_nttsr_er;
-        na.out_canonical = 1; na.fp32 = c.ntt_fp32;
+        na.out_canonical = 1;
         HIPCHK(launch_relation_ntt(na, c.d_A, c.key_stride, c.d_P, c.proof_stride, rm, n, st)); // NTT, A o NTT(s+r) (:287-288), tails
         const GemmSrc x2src{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, 0, XLEN};
         const GemmDst x2dst{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, EXP_OFF};
@@ -1121,7 +934,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     })) return -1;
 
     if (!c.fs_device || hooks) {
-        HIPCHK(wait_event(c, first_event(c), 1, n));
+        HIPCHK(wait_event(c, c.ev, 1, n));
         t1 = now_sec(); c.phase_sec[PH_GPU_RELATION] = t1 - t0; t0 = t1;
         fire_hooks(1, c.d_dig2);
     }
@@ -1130,9 +943,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     // I, its complement, and the complement entries owned by each aligned 64-party window (k_assemble_fields), all derived by
     // the worker that hashed the proof's table
     if (!c.fs_device) {
-        fs_opened_batch(n, c.h_dig2, (size_t)NPARTY * 32, c.h_I, c.h_rest, c.sel_stride, c.nthreads, c.pool, true, c.chunk_n > 1 ? &gate : nullptr);
-        HIPCHK(gate_err);
-        HIPCHK(table_done(c));
+        fs_opened_batch(n, c.h_dig2, (size_t)NPARTY * 32, c.h_I, c.h_rest, c.sel_stride, c.nthreads, c.pool, true);
         c.path_n[PATH_FS_HOST]++;
     }
     t1 = now_sec(); c.phase_sec[PH_FS_OPEN] = t1 - t0; t0 = t1;
@@ -1150,7 +961,6 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         AssembleArgs aa{};
         aa.P = c.d_P;
         aa.proof_stride = c.proof_stride;
-        aa.fields = c.d_fields;
         aa.rowtab = c.d_rowtab;
         aa.opened = c.d_I;
         aa.rest = c.d_rest;
@@ -1159,13 +969,11 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         aa.dig2 = c.d_dig2;
         aa.proof = c.d_proof;
         aa.image_stride = c.image_stride;
-        aa.plan = c.pplan;
         aa.groups = c.d_asm_groups;
         aa.elems = c.d_asm_elems;
         aa.ngroups = c.n_asm_groups;
         c.prof_begin(PR_ASSEMBLE, n);
-        HIPCHK(launch_assemble(aa, c.nfields, P.off[F_TCOMM], P.off[F_COMM], P.off[F_I], n, st, c.assemble_groups));
-        if (!c.capturing) c.path_n[c.assemble_groups ? PATH_ASSEMBLE_GROUPS : PATH_ASSEMBLE_FIELDS]++;
+        HIPCHK(launch_assemble(aa, P.off[F_TCOMM], P.off[F_COMM], P.off[F_I], n, st));
         c.prof_end(PR_ASSEMBLE);
         if (c.near_end_hook) c.near_end_hook(); // the last kernel is queued: a merged run's sleeping callers get ready for the return
         return 0;
@@ -1177,7 +985,6 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
     c.prof_collect();
     if (device_error_check(c)) return -1; // e.g. the key generation's gen_matrix hit its block limit: pk / sk / proofs are not valid
     return 0;
-#undef gate_err
 }
 
 int fetch_proofs(Ctx &c, int n, uint8_t *pi, bool registered)

@@ -65,11 +65,10 @@ enum Phase { PH_HOST_PRE = 0, PH_GPU_COMMIT, PH_FS_ALPHA, PH_GPU_RELATION, PH_FS
 // HIP-event timing of individual launches on the ctx stream (bench.py roofline leg)
 enum ProfId { PR_HASH_TCOMM = 0, PR_HASH_VIEW, PR_GEMM_EXPAND1, PR_GEMM_EXPAND2, PR_LINCOMB, PR_NTT_F, PR_ASSEMBLE,
               PR_V_HASH_TCOMM, PR_V_HASH_VIEW, PR_V_INTERP_BUILD, PR_V_GEMM_INTERP, PR_V_GEMM_EXPAND, PR_V_GEMM_RECON,
-              PR_V_LINCOMB, PR_HASH_TCOMM_TAIL, PR_HASH_VIEW_TAIL, PR_FS_ALPHA, PR_FS_OPENED, PR_V_FS_ALPHA, PR_V_FS_OPENED, PR_COUNT };
+              PR_V_LINCOMB, PR_FS_ALPHA, PR_FS_OPENED, PR_V_FS_ALPHA, PR_V_FS_OPENED, PR_COUNT };
 
-enum PathId { PATH_HASH_DMA = 0, PATH_HASH_PLAIN, PATH_HASH_PRIMER, PATH_TABLE_GEMM, PATH_LIMB_GEMM, PATH_COPY_DIRECT, PATH_COPY_STAGED,
-              PATH_GRAPH_REPLAY, PATH_NTT_FP32, PATH_NTT_INT, PATH_DIGEST_DIRECT, PATH_DIGEST_COPY, PATH_COPY_KERNEL, PATH_SMALL_COPY_KERNEL,
-              PATH_LINCOMB_ONESHOT, PATH_LINCOMB_STREAM, PATH_ASSEMBLE_FIELDS, PATH_ASSEMBLE_GROUPS, PATH_TABLE_CHUNKS, PATH_FS_DEVICE, PATH_FS_HOST, PATH_COUNT };
+enum PathId { PATH_HASH_DMA = 0, PATH_HASH_PLAIN, PATH_TABLE_GEMM, PATH_LIMB_GEMM, PATH_COPY_DIRECT, PATH_COPY_STAGED,
+              PATH_GRAPH_REPLAY, PATH_DIGEST_COPY, PATH_SMALL_COPY_KERNEL, PATH_FS_DEVICE, PATH_FS_HOST, PATH_COUNT };
 
 struct GemmTable {
     uint8_t *d = nullptr; // limb matrix (kosk_device.hpp)
@@ -154,7 +153,6 @@ struct Ctx {
     AsmGroup *d_asm_groups = nullptr; // the grouped image kernel's tables (build_tables)
     AsmElem *d_asm_elems = nullptr;
     int n_asm_groups = 0;
-    bool assemble_groups = true; // KOSK_ASSEMBLE_GROUPS=0: the per-field kernel of rounds 1-4
     int nfields = 0;
     std::vector<FieldDesc> h_fields;
     std::vector<int16_t> h_rowtab;
@@ -184,7 +182,7 @@ struct Ctx {
     uint16_t *d_alpha = nullptr, *d_I = nullptr, *d_rest = nullptr;
     int32_t *d_pwT = nullptr;
     uint8_t *d_limbs = nullptr; // limb-matrix staging of the GEMM data operand
-    uint8_t *d_linA = nullptr, *d_coef = nullptr; // K3 operands: transposed f / NTT-f rows, alpha-power coefficients
+    uint8_t *d_coef = nullptr; // K3 operand: alpha-power coefficients as a limb matrix
     int16_t *d_lin_rows = nullptr; // [2][128] output rows of the lincomb GEMM (beta/r, gamma/NTT_r)
     size_t limb_cap = 0;
     // verifier workspace (allocated on first use, kosk_verify.cpp)
@@ -209,32 +207,15 @@ struct Ctx {
     uint32_t *d_fail = nullptr;      // [proof] bit mask of failed checks (FailBit)
     uint16_t *h_Iimg = nullptr;      // I fields as read from the proof images
     // The verifier's host needs both digest tables whole (mlwe_verifier.cpp:40-44, :648-652), but only 150 entries per proof and
-    // round are NEW -- the rest are fields of the proof image.  Those cross PCIe once, on the device's side stream, as soon as the
-    // call starts (or not at all when the caller handed the proofs over in host memory: host_img); behind each round's hash only
-    // the 150 recomputed digests per proof follow (4.8 KB instead of 46.5 KB on the critical path), and the host puts the
-    // table together (assemble_digest_table).  Used when the caller's host images are at hand (no early copy needed at all);
-    // for resident proofs it is opt-in (KOSK_VERIFY_SPLIT=1: measured slower than whole tables behind each hash).
+    // round are NEW -- the rest are fields of the proof image.  When the caller handed the proofs over in host memory (host_img:
+    // kosk_verify_batch) the host reads those 1304 digests per table straight from the caller's images, only the 150 recomputed ones per
+    // proof follow each round's hash (4.8 KB instead of 46.5 KB on the critical path), and the host puts the table together
+    // (assemble_digest_table).  For resident proofs the whole tables are copied behind each hash (the split with early copies on a
+    // side stream measured slower and is gone since round 6: profiles/r04_digest_paths.txt).
     uint8_t *d_odig = nullptr, *h_odig = nullptr; // [proof][NOPEN][32] recomputed digests of the opened parties (one round at a time)
-    uint8_t *h_imgdig = nullptr;                  // [proof][2][NREST][32] fields Tcomm and comm of the images
-    hipStream_t side_stream = nullptr;            // process-wide, one per device (side_stream_for): never destroyed
-    hipEvent_t ev_img[2] = {nullptr, nullptr};    // the two fields have landed in h_imgdig
-    bool verify_tables = true; // whole tables behind each hash unless the call has host images (or KOSK_VERIFY_SPLIT=1)
     const uint8_t *host_img = nullptr;            // the caller's host copy of the proof images of THIS call (kosk_verify_batch)
     size_t host_img_stride = 0;
     hipEvent_t ev = nullptr;
-    // KOSK_TABLE_CHUNKS=n (default 1: one copy per round; opt-in, measured slower): a round's [n][1454][32] digest table goes to the
-    // host in up to TABLE_CHUNKS_MAX pieces of whole 8-proof groups with an event behind each but the last (which has `ev`); the host
-    // starts its round when the FIRST piece has landed and a worker that reaches a later piece waits for that piece's event
-    // (table_gate_wait).  The copy (57 GB/s) and the host's hashing run at about the same rate, so one run ALONE saves most of the
-    // copy time per round -- but with three cohorts sharing the GPU the gaps it closes were already filled by the other cohorts'
-    // kernels, and the extra copies and the workers' event waits cost 1-4 % (profiles/r05_table_chunks.txt).
-    // Plain launches only (an event inside a captured segment would be a graph node), batches of >= 48.
-    static constexpr int TABLE_CHUNKS_MAX = 4;
-    int table_chunks = 1;
-    hipEvent_t ev_chunk[TABLE_CHUNKS_MAX - 1] = {nullptr, nullptr, nullptr};
-    int chunk_n = 0;          // pieces of the table copy under way (0: one copy, nobody looks at the gate)
-    int chunk_per = 0;        // proofs per piece
-    int chunk_passed = 0;     // highest piece known to have landed (atomic builtins: Ctx is copied for views)
     std::vector<uint16_t> v_I2, v_rest2; // the verifier's recomputed opened lists (kept across calls: two fresh 0.4 MB vectors per call were
                                          // an mmap, a page fault per page and a munmap on the tail of every verify call)
     std::function<void()> near_end_hook; // set by a merged run's executor: called once when only the call's tail is left (kosk_combine.hpp: near_end)
@@ -255,7 +236,6 @@ struct Ctx {
     hipEvent_t ev_sync = nullptr; // KOSK_BLOCKING_SYNC=1: every host wait sleeps on an event instead of spinning (few host cores per GPU)
     bool blocking_sync = false;
     int n_simd = 1024;      // SIMDs of the device (4 per CU)
-    bool hash_split = false; // KOSK_HASH_SPLIT=1: cut a commitment launch at whole rounds of the SIMDs (see commit_hash_groups)
     hipEvent_t timer_ev[2] = {nullptr, nullptr}; // kosk_stream_timer_start / _stop
     // compact wire format staging (allocated on first use)
     CompactPlan cplan{};
@@ -287,21 +267,6 @@ struct Ctx {
     SegGraph seg[SEG_COUNT];
     bool use_graphs = false; // KOSK_GRAPHS=1 turns them on (measured on ROCm 7.2: no gain over plain launches)
     bool capturing = false;
-    int ntt_fp32 = 0; // KOSK_NTT_FP32=1: packed-fp32 NTT kernel (see its HAZARD note in kosk_kernels.hip); default integer
-    int lincomb_fused = 1; // KOSK_LINCOMB_FUSED: 1 the streaming kernel k_lincomb_stream (default, round 5), 2 the one-shot kernel of rounds 2-4
-                           // (k_lincomb_fused), 0 a separate transposition pass + the generic GEMM
-    // kernel / copy path choices, read from the environment when the context is created (per handle, never per process)
-    bool hash_dma = true;      // KOSK_HASH_DMA=0: commitment hashes without the LDS-DMA staging (k_commit_hash)
-    bool hash_primer = false;  // KOSK_HASH_PRIMER=1: placement primer in front of a commitment launch (k_hash_primer)
-    bool table_gemm = true;    // KOSK_TABLE_GEMM=0: shared-table products through the generic limb GEMM
-    // KOSK_DIGEST_DIRECT=1: the prover's commitment launches also store every digest into the host's page-locked table (no copy
-    // behind the launch).  Measured slower with merged runs, neutral without (profiles/r04_digest_direct.txt): default off
-    bool digest_direct = false;
-    // KOSK_COPY_WAVES=n (default 0 = the runtime's hipMemcpyAsync): the digest tables go to the host through k_copy_to_host with n
-    // one-wave workgroups instead of the runtime's one-element-per-thread blit kernel.  Measured WORSE at every n from 128 to 2 048
-    // (105 k against 133-137 k proofs/s: the copy takes the same 117 us, but the kernels running beside it stretch by 1.5-1.9 x;
-    // profiles/r04_copy_kernel.txt), so it is an experiment knob only
-    int copy_waves = 0;
     // strict_encoding (kosk_options::strict_encoding, KOSK_STRICT_ENCODING; DEFAULT 1 since round 6): the verifier marks a proof malformed
     // (fail bit 0) when ANY u16 element of a record the reference reads is >= q -- no honest prover emits one, and accepting them makes
     // proofs malleable (v and v + q verify alike).  0 = the reference-following mode of round 5: such elements are treated exactly as
@@ -314,16 +279,9 @@ struct Ctx {
     // table crosses PCIe, the host neither hashes nor waits between segments (kosk_fs_kernels.hip).  Host mode (default)
     // is the path of rounds 1-5
     bool fs_device = false;
-    bool small_copy_kernel = true; // KOSK_SMALL_COPY_KERNEL=0: hipMemcpyAsync for the small copies too (copy_small)
-    bool stream_shared = false;    // KOSK_SHARE_STREAMS: the stream belongs to the process, not to this context
-    bool alpha_direct = true;      // KOSK_ALPHA_DIRECT=0: the challenge vectors are copied into HBM in front of k_coef_limbs / k_pow_table
-                                   // instead of being read by those kernels from the page-locked host table
     bool host_register = true;       // KOSK_REGISTER=0: staging copies only, even for buffers the caller page-locked itself.  (KOSK_REGISTER=2 of
                                      // rounds 2-4 -- the library page-locking PAGEABLE caller memory for a call -- is gone: both process aborts on
                                      // record happened inside calls that had just done that, and neither was ever reproduced or explained)
-    int cu_part_i = 0, cu_part_n = 1; // KOSK_CU_PARTITION=i/n: the stream is restricted to partition i of n CU partitions
-    int cu_mask_layout = 0;           // KOSK_CU_MASK_LAYOUT: how CU-mask bits map to XCDs (0 round-robin, 1 XCD-major)
-    unsigned hash_opts() const { return (hash_dma ? HASH_OPT_DMA : 0u) | (hash_primer ? HASH_OPT_PRIMER : 0u); }
     // which of those paths really ran on this context (kosk_path_count): the tests of the knobs assert on these
     long path_n[PATH_COUNT] = {0};
 
@@ -408,21 +366,12 @@ hipError_t stream_sync(Ctx &c);
 // KOSK_WAIT_NAP=1), n = the batch size the wait belongs to; site < 0: a plain wait
 hipError_t wait_event(Ctx &c, hipEvent_t ev, int site, int n);
 hipError_t stream_sync_site(Ctx &c, int site, int n);
-// a digest table (or any 16-byte aligned block) from HBM into the context's page-locked host memory, on the context's stream
-hipError_t copy_table_to_host(Ctx &c, void *h_dst, const void *d_src, size_t bytes);
-// a round's digest table of n proofs, in pieces when the call qualifies (Ctx::table_chunks); the caller records c.ev behind it.
-// first_event(c): what the host's round waits for before it starts; table_gate(c): the per-proof hook of fs_*_batch (nullptr when
-// the table came in one piece); table_done(c): every piece has landed (after the round)
+// a round's digest table of n proofs from HBM into the context's page-locked host memory, on the context's stream (the caller records c.ev behind it)
 hipError_t copy_round_table(Ctx &c, uint8_t *h_dst, const uint8_t *d_src, int n);
-inline hipEvent_t first_event(const Ctx &c) { return c.chunk_n > 1 ? c.ev_chunk[0] : c.ev; }
-hipError_t table_gate_wait(Ctx &c, int proof);
-hipError_t table_done(Ctx &c);
 // a small copy between HBM and one of the library's OWN page-locked host buffers, rows x row_bytes (kernel or hipMemcpy[2D]Async)
 hipError_t copy_small(Ctx &c, void *dst, size_t dst_stride, const void *src, size_t src_stride, size_t row_bytes, size_t nrows, hipMemcpyKind kind, hipStream_t st);
 // after the stream has been synchronised: -1 (with c.err set, the word cleared) if a kernel of this context raised an error
 int device_error_check(Ctx &c);
-// proofs of an n-proof batch that the FIRST of the two commitment-hash launches takes (n: a single launch)
-int commit_hash_groups(const Ctx &c, int n);
 int gemm_modq(Ctx &c, const uint8_t *A, size_t a_gstride, int Mpad, int M, int KS, const GemmSrc &s, const GemmDst &d,
               int npg, int ngroups, bool grouped, const uint8_t *Afrag = nullptr);
 inline int gemm_modq(Ctx &c, const GemmTable &t, const GemmSrc &s, const GemmDst &d, int npg, int ngroups)
@@ -454,8 +403,6 @@ int prove_prepared(Ctx &c, int n, const uint8_t *inst, const uint8_t *rand_in, c
                    size_t tape_stride, uint8_t *pi);
 int stage_verifier_inst(Ctx &c, int n, const uint8_t *pi, const uint8_t *inst);
 int ensure_verify_workspace(Ctx &c);
-// the device's one side stream of this process (copies that must not queue behind a context's kernels); nullptr on failure
-hipStream_t side_stream_for(int device);
 // direct: the host buffer is page-locked (copied to / from straight, no staging)
 int fetch_proofs_compact(Ctx &c, int n, uint8_t *out, bool direct = false);
 int stage_verifier_inputs_compact(Ctx &c, int n, const uint8_t *in, const uint8_t *pk, bool direct = false);

@@ -29,10 +29,6 @@ struct HashArgs {
     const uint8_t *prefix;     // [group][out_lanes_per_group][32], read at the output index
     uint8_t *out;              // [group][out_lanes_per_group][32]
     int out_lanes_per_group;
-    // optional second copy of every digest, same layout, in page-locked HOST memory the GPU can write (hipHostMalloc): the
-    // host's Fiat-Shamir round needs the whole table, and stored from here it crosses PCIe while the launch's other waves still
-    // hash -- no device-to-host copy kernel behind the launch (mlwe_prover.cpp:130-135, :445-449 read Tcomm / comm on the CPU)
-    uint8_t *out_host;
 };
 
 struct NttArgs {
@@ -49,7 +45,6 @@ struct NttArgs {
     // output position and bit cmp_bit of cmp_fail[group] is set on a mismatch (NTT(beta_j) == gamma_j, mlwe_verifier.cpp:110-124)
     uint32_t *cmp_fail;
     int cmp_delta, cmp_bit;
-    int fp32; // 1: the packed-fp32 butterflies (k_ntt256_fp32; KOSK_NTT_FP32=1 at kosk_create), 0: integer Montgomery
     uint32_t npg_magic; // floor(2^32 / npg), filled in by the launchers: polynomial -> (group, index) without an integer division
 };
 inline uint32_t ntt_npg_magic(int npg) { return npg <= 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / (uint32_t)npg); }
@@ -183,9 +178,8 @@ constexpr int ASM_MAX_GROUPS = 8;
 struct AssembleArgs {
     const uint16_t *P;
     size_t proof_stride;
-    const FieldDesc *fields;
     const int16_t *rowtab;
-    const AsmGroup *groups; // grouped kernel
+    const AsmGroup *groups;
     const AsmElem *elems;
     int ngroups;
     const uint16_t *opened, *rest; // [proof][sel_stride]
@@ -193,7 +187,6 @@ struct AssembleArgs {
     const uint8_t *dig1, *dig2; // [proof][NPARTY][32]
     uint8_t *proof;
     size_t image_stride;
-    FieldPlan plan;
 };
 
 // ---- verifier (kosk_verify_kernels.hip) ----
@@ -297,11 +290,8 @@ hipError_t launch_keygen_pack(const int16_t *A, size_t A_stride, const int16_t *
 hipError_t launch_decode_pk(const uint8_t *pk, size_t pk_stride, uint16_t *t_out, int16_t *A, size_t A_stride, int K, int n, hipStream_t st,
                             XofGuard xof = XofGuard());
 
-// opts: HASH_OPT_DMA = LDS-DMA staged kernel where the layout allows it (KOSK_HASH_DMA, default on), HASH_OPT_PRIMER = placement
-// primer launch in front (KOSK_HASH_PRIMER, default off); *variant: bit 0 the DMA kernel ran, bit 1 the primer was launched
-enum : unsigned { HASH_OPT_DMA = 1u, HASH_OPT_PRIMER = 2u };
-hipError_t launch_commit_hash(const HashArgs &a, int ngroups, int K, bool view, hipStream_t st, unsigned opts = HASH_OPT_DMA,
-                              int *variant = nullptr);
+// the LDS-DMA staged kernel runs where the layout allows it (aligned rows, no lane map), else the plain kernel; *variant: bit 0 the DMA kernel ran
+hipError_t launch_commit_hash(const HashArgs &a, int ngroups, int K, bool view, hipStream_t st, int *variant = nullptr);
 hipError_t launch_sha3_msgs(const uint8_t *in, size_t in_stride, int len, uint8_t *out, size_t out_stride,
                             int outlen, int n, int domain, hipStream_t st);
 // the same on the lane-pair sponge (32 messages per wave; kosk_keccak_split_dev.hpp)
@@ -328,8 +318,6 @@ struct FsArgs {
     uint32_t *fail;
 };
 hipError_t launch_fs_chain(const FsArgs &A, int mode, int n, hipStream_t st);
-// HBM -> page-locked host memory with nwg one-wave workgroups (k_copy_to_host); bytes, both pointers: multiples of 16
-hipError_t launch_copy_to_host(const void *d_src, void *h_dst, size_t bytes, int nwg, hipStream_t st);
 bool copy_small_ok(const void *src, size_t src_stride, const void *dst, size_t dst_stride, size_t row_bytes);
 hipError_t launch_copy_small(const void *src, size_t src_stride, void *dst, size_t dst_stride, size_t row_bytes, size_t nrows, hipStream_t st);
 hipError_t launch_rows_copy(const uint16_t *src, size_t src_stride, uint16_t *dst, size_t dst_stride, int count,
@@ -366,23 +354,17 @@ hipError_t launch_gemm(const GemmArgs &a, hipStream_t st);
 // table products (shared table, 407-wide u16 input rows) with the data rows resident in LDS; `sink` = 4 KiB of scratch
 bool table_gemm_usable(const GemmArgs &a);
 hipError_t launch_table_gemm(const GemmArgs &a, uint16_t *sink, hipStream_t st);
-// K3 on the matrix cores (prover): transposed f / NTT-f rows and the alpha-power coefficient matrix as limb matrices
-hipError_t launch_cols_to_limbs(const uint16_t *P, size_t proof_stride, int row_f, int row_tf, int M, uint8_t *A, size_t a_gstride,
-                                int nproofs, hipStream_t st);
-// beta/gamma/r/NTT_r rows of every proof from its f / NTT f rows, plus s + r and e + r (the k_post_open step) in the epilogue
-// variant 1: the streaming kernel (k_lincomb_stream, persistent workgroups, prefetched inputs; default), 2: the one-shot kernel of
-// rounds 2-4 (k_lincomb_fused)
-hipError_t launch_lincomb_fused(const uint16_t *P, size_t proof_stride, const RowMap &rm, const uint8_t *coef, uint16_t *C,
-                                const int16_t *lin_rows, int J, int nproofs, hipStream_t st, int variant = 1);
+// K3 on the matrix cores (prover): beta / gamma / r / NTT_r rows of every proof from its f / NTT f rows and the alpha-power coefficient
+// matrix (k_coef_limbs), plus s + r and e + r in the epilogue (k_lincomb_stream: persistent workgroups, prefetched inputs)
+hipError_t launch_lincomb_stream(const uint16_t *P, size_t proof_stride, const RowMap &rm, const uint8_t *coef, uint16_t *C,
+                                 const int16_t *lin_rows, int J, int nproofs, hipStream_t st);
 hipError_t launch_coef_limbs(const uint16_t *alpha, int J, int M, uint8_t *B, int nproofs, hipStream_t st);
 hipError_t launch_pow_table(const uint16_t *alpha, int J, int M, int32_t *pwT, int nproofs, hipStream_t st);
 hipError_t launch_lincomb(const LincombArgs &a, int nproofs, hipStream_t st);
 hipError_t launch_post_gates(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st);
-hipError_t launch_post_open(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st);
 hipError_t launch_copy_tails(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st);
 hipError_t launch_post_relation(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st);
-// grouped: k_assemble_groups (round 5, default), else the one-shot per-field kernel of rounds 1-4 (KOSK_ASSEMBLE_GROUPS=0)
-hipError_t launch_assemble(const AssembleArgs &a, int nfields, size_t off_tcomm, size_t off_comm, size_t off_I,
-                           int nproofs, hipStream_t st, bool grouped = false);
+// the proof wire image (k_assemble_groups: opened-party records from dense window gathers)
+hipError_t launch_assemble(const AssembleArgs &a, size_t off_tcomm, size_t off_comm, size_t off_I, int nproofs, hipStream_t st);
 
 } // namespace kosk

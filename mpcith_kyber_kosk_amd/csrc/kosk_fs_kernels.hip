@@ -215,7 +215,9 @@ hipError_t launch_fs_chain(const FsArgs &A, int mode, int n, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
     if (mode < FS_DIGEST || mode > FS_CHECK) return hipErrorInvalidValue;
-    // KOSK_FS_SPONGE=lds: the LDS-memory exchanges (variant A of kosk_fs_dev.hpp); default the ds_bpermute / DPP variant B
+    // variant B of kosk_fs_dev.hpp (DPP column sums + ds_bpermute exchanges).  Variant A (exchanges through LDS memory) measured 4 % slower
+    // (2.26-2.35 against 2.14-2.28 us per permutation, profiles/r06_fs_chain.txt) and is compiled only for tools/fs_chain_time.py's A/B
+    // (KOSK_FS_SPONGE=lds, a debug knob)
     static const bool lds = getenv("KOSK_FS_SPONGE") && !strcmp(getenv("KOSK_FS_SPONGE"), "lds");
     if (lds) fs_launch<FsSpongeLds>(A, mode, n, st);
     else fs_launch<FsSpongeBperm>(A, mode, n, st);

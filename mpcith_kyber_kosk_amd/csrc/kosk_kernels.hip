@@ -130,11 +130,6 @@ __global__ __launch_bounds__(64) void k_commit_hash(HashArgs a)
     uint4 *o = reinterpret_cast<uint4 *>(a.out + dig);
     o[0] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
     o[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
-    if (a.out_host) {
-        uint4 *oh = reinterpret_cast<uint4 *>(a.out_host + dig);
-        oh[0] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
-        oh[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
-    }
 }
 
 // The same hash with the message rows staged through LDS by LDS-DMA (global_load_lds_dwordx4): one wave-instruction
@@ -240,44 +235,24 @@ __global__ __launch_bounds__(64) void k_commit_hash_dma(HashArgs a)
     };
     run(std::make_integer_sequence<int, NBLK>{});
     // The wave's 64 digests are 2 KiB of consecutive table bytes.  Through LDS (the staging buffer is free now) so that every
-    // store instruction writes 1 KiB of CONSECUTIVE bytes, 16 per lane -- whole lines for HBM, and full-size posted writes for
-    // the copy that goes straight to the host's table over PCIe (lane l's own 32 bytes would be two half-dense instructions)
+    // store instruction writes 1 KiB of CONSECUTIVE bytes, 16 per lane -- whole lines for HBM (lane l's own 32 bytes would be two
+    // half-dense instructions)
     uint4 *sd = reinterpret_cast<uint4 *>(&stage[0][0]);
     sd[2 * tl] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
     sd[2 * tl + 1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
     __syncthreads(); // one wave per workgroup: orders the LDS writes above against the reads below
     const size_t base16 = ((size_t)g * a.out_lanes_per_group + (size_t)bx * 64) * 2; // 16-byte units
     uint4 *o = reinterpret_cast<uint4 *>(a.out) + base16;
-    uint4 *oh = a.out_host ? reinterpret_cast<uint4 *>(a.out_host) + base16 : nullptr;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int c = j * 64 + tl; // chunk c = half (c & 1) of the digest of lane c >> 1
         if (bx * 64 + (c >> 1) < a.lanes_per_group) {
             const uint4 v = sd[c];
             o[c] = v;
-            if (oh) oh[c] = v;
         }
     }
     (void)live;
     (void)dig;
-}
-
-// Placement primer for the commitment hashes.  A launch of ~1 000 one-wave workgroups lands one wave per SIMD only when
-// the launch before it on the GPU had the same shape: directly behind any other large kernel (the table product, the fused
-// lincomb) about 4 % of the SIMDs get two of the waves and as many stay empty -- same wave-cycles, 54 % more busy time
-// (profiles/r02_hash_placement.txt), and the hash takes 68 us instead of 45.  The state survives idle time.  This kernel has
-// the hash's launch shape (one wave per workgroup, the same LDS footprint), keeps its waves resident for a few microseconds so
-// that the whole grid is placed at once, and does nothing else; the hash launched behind it gets the even placement.
-// Opt-in (KOSK_HASH_PRIMER=1, with KOSK_HASH_SPLIT=1): alone on the GPU the 44-proof launch then takes 33 / 44 us instead of
-// 49 / 65 us, but with several pipeline slots sharing the GPU other kernels decide the placement anyway and the extra
-// launches cost 6 % of the throughput (profiles/r02_hash_placement.txt).
-template <int NBUF>
-__global__ __launch_bounds__(64) void k_hash_primer(int *sink)
-{
-    __shared__ __attribute__((aligned(16))) uint16_t stage[NBUF][72 * 64];
-    if (threadIdx.x == 0) stage[0][0] = (uint16_t)blockIdx.x; // keep the allocation
-    __builtin_amdgcn_s_sleep(100); // 64 x 100 clocks ~ 2.8 us: longer than the dispatch of the grid
-    if (sink && stage[0][0] == 0xFFFFu && threadIdx.x == 0) *sink = 1; // never: block indices stay below 65 535 here
 }
 
 // SHA3-256 / SHAKE256 of n byte messages of equal length stored message-major.
@@ -414,7 +389,6 @@ struct PreArgs {
     int16_t *kg_se;      // [proof][2K][256] s then e
     size_t kg_se_stride;
     XofGuard xof;
-    int pair; // roles G, N, A on the lane-pair sponge (kosk_keygen_dev.hpp: kp_*): 32 sponges per 64-thread block instead of 64
 };
 constexpr int PRE_SLICES = 8; // fresh sharings per role-B block
 __device__ __forceinline__ const uint8_t *pre_tape(const PreArgs &a, int b)
@@ -426,41 +400,6 @@ __device__ __forceinline__ const uint8_t *pre_tape(const PreArgs &a, int b)
 #pragma unroll
     for (int k = 1; k < 8; k++) base = j == k ? a.segs.ptr[k] : base;
     return base + (size_t)(b - j * a.segs.per) * a.tape_stride;
-}
-
-__device__ __forceinline__ void pre_expand_f(const PreArgs &a, int t)
-{
-    if (t >= a.M * a.nproofs) return;
-    const int b = t / a.M, i = t % a.M;
-    const uint64_t *seed = reinterpret_cast<const uint64_t *>(pre_tape(a, b) + 64 + 32 * i);
-    KState s;
-    kstate_zero(s);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        s.lo[k] = (uint32_t)seed[k];
-        s.hi[k] = (uint32_t)(seed[k] >> 32);
-    }
-    s.lo[4] = (uint32_t)(uint8_t)i | (0x1Fu << 8);
-    s.hi[16] = 0x80000000u;
-    uint16_t *dst = a.P + (size_t)b * a.proof_stride + (size_t)(a.row_f + i) * RS;
-    // 512 bytes = 3 full 136-byte squeezes + 104 bytes
-#pragma unroll 1
-    for (int blk = 0; blk < 4; blk++) {
-        keccak_f1600_dev(s);
-#pragma unroll
-        for (int w = 0; w < 17; w++) {
-            if (blk == 3 && w >= 13) break;
-            uint32_t o[2];
-#pragma unroll
-            for (int hf = 0; hf < 2; hf++) {
-                const uint32_t v = hf ? s.hi[w] : s.lo[w];
-                const uint32_t h0 = v & 0xFFFFu, h1 = v >> 16;
-                const uint32_t be0 = ((h0 & 0xFF) << 8) | (h0 >> 8), be1 = ((h1 & 0xFF) << 8) | (h1 >> 8);
-                o[hf] = (be0 % (uint32_t)Q) | ((be1 % (uint32_t)Q) << 16);
-            }
-            *reinterpret_cast<uint2 *>(dst + blk * 68 + w * 4) = make_uint2(o[0], o[1]);
-        }
-    }
 }
 
 __device__ __forceinline__ void pre_tape_randoms(const PreArgs &a, int idx, int lane)
@@ -504,30 +443,6 @@ __device__ __forceinline__ void pre_witness_secrets(const PreArgs &a, int idx, i
             }
         }
     }
-}
-
-__device__ __forceinline__ void pre_gen_matrix(const PreArgs &a, int t)
-{
-    const int KK = a.K * a.K;
-    if (t >= a.nproofs * KK) return;
-    const int b = t / KK, ij = t - b * KK, i = ij / a.K, j = ij - i * a.K;
-    uint32_t pub[8], noise[8];
-    kg_seed_hash(pre_tape(a, b), a.K, pub, noise);
-    kg_gen_matrix(pub, i, j, a.kg_A + (size_t)b * a.kg_A_stride + (size_t)ij * 256, a.xof);
-}
-
-__device__ __forceinline__ void pre_noise(const PreArgs &a, int t)
-{
-    if (t >= a.nproofs * 2 * a.K) return;
-    const int b = t / (2 * a.K), nonce = t - b * 2 * a.K;
-    uint32_t pub[8], noise[8];
-    kg_seed_hash(pre_tape(a, b), a.K, pub, noise);
-    if (nonce == 0) {
-        uint32_t *o = reinterpret_cast<uint32_t *>(a.kg_seeds + (size_t)b * a.kg_seed_stride);
-#pragma unroll
-        for (int q = 0; q < 8; q++) { o[q] = pub[q]; o[8 + q] = noise[q]; }
-    }
-    kg_noise(noise, nonce, a.eta1, a.kg_se + (size_t)b * a.kg_se_stride + (size_t)nonce * 256);
 }
 
 // ---- roles A, G, N on the lane-pair sponge: pair pr = thread >> 1 of the role's range, hi = the lane that holds the high halves ----
@@ -594,13 +509,14 @@ __global__ __launch_bounds__(64) void k_prover_pre(PreArgs a)
     // and the thousands of short role-B workgroups stream through beside them.  With B in front of G (rounds 1-3) the launch took
     // B's streaming time PLUS G's chain: 100 us at 138 proofs, 73 us at 46.
     int blk = blockIdx.x;
-    const int th = a.pair ? blk * 32 + ((int)threadIdx.x >> 1) : blk * 64 + (int)threadIdx.x; // sponge index inside the role's range
+    // roles G, N, A run on the lane-pair sponge (kosk_keygen_dev.hpp: kp_*): 32 sponges per 64-thread block
+    const int pr = blk * 32 + ((int)threadIdx.x >> 1); // sponge index inside the role's range
     const bool hi = threadIdx.x & 1;
-    if (blk < a.nbG) return a.pair ? pre_gen_matrix_pair(a, th, hi) : pre_gen_matrix(a, th);
+    if (blk < a.nbG) return pre_gen_matrix_pair(a, pr, hi);
     blk -= a.nbG;
-    if (blk < a.nbN) return a.pair ? pre_noise_pair(a, blk * 32 + ((int)threadIdx.x >> 1), hi) : pre_noise(a, blk * 64 + (int)threadIdx.x);
+    if (blk < a.nbN) return pre_noise_pair(a, blk * 32 + ((int)threadIdx.x >> 1), hi);
     blk -= a.nbN;
-    if (blk < a.nbA) return a.pair ? pre_expand_f_pair(a, blk * 32 + ((int)threadIdx.x >> 1), hi) : pre_expand_f(a, blk * 64 + (int)threadIdx.x);
+    if (blk < a.nbA) return pre_expand_f_pair(a, blk * 32 + ((int)threadIdx.x >> 1), hi);
     blk -= a.nbA;
     if (blk < a.nbB) return pre_tape_randoms(a, blk, threadIdx.x);
     pre_witness_secrets(a, blk - a.nbB, threadIdx.x);
@@ -855,147 +771,6 @@ __global__ __launch_bounds__(256) void k_ntt256(NttArgs a)
     ntt256_stage(x, lds);
     lds_barrier();
     ntt256_transform<PLAIN>(a, blockIdx.x * NTT_PPB, lds);
-}
-
-// ---- K5, packed-fp32 variant (opt-in: KOSK_NTT_FP32=1) ---------------------------------------------------------
-// The integer butterfly costs ~44 SIMD cycles (24/32-bit multiplies are half rate: profiles/r02_probe_keccak.txt); in
-// packed fp32 a PAIR of butterflies is six full-rate instructions.  Exact: every value is an integer below 2^24, products
-// and sums are exact, and  t = p - rint(p / q) q  (rint by the 1.5 * 2^23 trick) is the residue within +-(q/2 + 2).
-// Zetas are the plain roots, so the residues are those of ntt.c:80-95 + poly_reduce (poly.c:261-265).
-// HAZARD (root-caused in round 2, tools/ntt_lab.hip, profiles/r02_ntt_lab.txt): with the constants and uniform zetas as
-// SGPR / literal source operands -- what hipcc emits for the natural code -- this kernel returned wrong polynomials in
-// 85 % of its launches while an int8-MFMA kernel ran on another stream (one butterfly's product came out 0 for one
-// 16-lane group), and in none with VALU, packed-fp32 or HBM load generators; with every operand of the packed
-// instructions in VGPRs it is clean (0 of 6 322 launches under the same MFMA load), as are mul/add kept apart, the integer
-// kernel, and isolated FMA instructions with SGPR operands (tools/fma_probe.hip).  The pipeline runs MFMA GEMMs beside
-// everything, so the operands below are pinned to VGPRs (asm "+v") and the integer kernel stays the default.
-typedef float v2f __attribute__((ext_vector_type(2)));
-__constant__ static const ZetaTableF kZetasF = ZetaTableF();
-constexpr int NTT_FSTRIDE = 16 * 20 + 16; // floats per polynomial in the fp32 transposition buffer (rows of 16 padded to 20)
-
-struct NttFConst {
-    v2f qinv, magic, q;
-};
-__device__ __forceinline__ v2f nttf_red(v2f p, const NttFConst &k) // |p| < 2^24 -> residue in [-q/2 - 2, q/2 + 2]
-{
-    const v2f r = (p * k.qinv + k.magic) - k.magic;
-    return p - r * k.q;
-}
-__device__ __forceinline__ void nttf_bfly(v2f &lo, v2f &hi, v2f z, const NttFConst &k)
-{
-    asm volatile("" : "+v"(z)); // VGPR operand, never an SGPR pair (see HAZARD above)
-    const v2f t = nttf_red(hi * z, k);
-    hi = lo - t;
-    lo = lo + t;
-}
-
-__global__ __launch_bounds__(256) void k_ntt256_fp32(NttArgs a)
-{
-    __shared__ __attribute__((aligned(16))) float ldsf[NTT_PPB * NTT_FSTRIDE];
-    int16_t *lds16 = reinterpret_cast<int16_t *>(ldsf); // the int16 staging image lives in the same memory
-    const int tid = threadIdx.x, p0 = blockIdx.x * NTT_PPB;
-    NttFConst kc;
-    kc.qinv = (v2f){1.0f / (float)Q, 1.0f / (float)Q};
-    kc.magic = (v2f){12582912.0f, 12582912.0f};
-    kc.q = (v2f){(float)Q, (float)Q};
-    asm volatile("" : "+v"(kc.qinv), "+v"(kc.magic), "+v"(kc.q));
-
-    for (int c = tid; c < NTT_PPB * 32; c += 256) {
-        const int pl = c >> 5, ch = c & 31, p = p0 + pl;
-        if (p < a.npoly) {
-            const int g = p / a.npg, i = p - g * a.npg;
-            const size_t off = (size_t)g * a.in_gstride + (a.src_off ? (size_t)a.src_off[i] : (size_t)i * 256);
-            *reinterpret_cast<uint4 *>(lds16 + pl * 2 * NTT_FSTRIDE + ch * 8) = *reinterpret_cast<const uint4 *>(a.in + off + ch * 8);
-        }
-    }
-    __syncthreads();
-    const int pl = tid >> 4, l = tid & 15;
-    const int16_t *mine16 = lds16 + pl * 2 * NTT_FSTRIDE;
-    float *minef = ldsf + pl * NTT_FSTRIDE;
-    // P[q] = (r[2q], r[2q+1]); coefficient index of r[i] is l + 16 i
-    v2f P[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) P[q] = (v2f){(float)mine16[l + 32 * q], (float)mine16[l + 32 * q + 16]};
-    __syncthreads(); // the fp32 image overwrites the staging bytes
-    {
-        const v2f z = {kZetasF.z[1], kZetasF.z[1]};
-#pragma unroll
-        for (int q = 0; q < 4; q++) nttf_bfly(P[q], P[q + 4], z, kc);
-    }
-#pragma unroll
-    for (int b = 0; b < 2; b++) {
-        const v2f z = {kZetasF.z[2 + b], kZetasF.z[2 + b]};
-#pragma unroll
-        for (int q = 0; q < 2; q++) nttf_bfly(P[4 * b + q], P[4 * b + q + 2], z, kc);
-    }
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-        const v2f z = {kZetasF.z[4 + b], kZetasF.z[4 + b]};
-        nttf_bfly(P[2 * b], P[2 * b + 1], z, kc);
-    }
-#pragma unroll
-    for (int m = 0; m < 4; m++) { // len = 16: the two halves of one pair, regrouped with their own zetas
-        v2f lo = {P[2 * m].x, P[2 * m + 1].x}, hi = {P[2 * m].y, P[2 * m + 1].y};
-        const v2f z = {kZetasF.z[8 + 2 * m], kZetasF.z[8 + 2 * m + 1]};
-        nttf_bfly(lo, hi, z, kc);
-        lo = nttf_red(lo, kc); // the one mid-way reduction: keeps every later product below 2^24
-        hi = nttf_red(hi, kc);
-        minef[l + 20 * (4 * m)] = lo.x;
-        minef[l + 20 * (4 * m + 1)] = hi.x;
-        minef[l + 20 * (4 * m + 2)] = lo.y;
-        minef[l + 20 * (4 * m + 3)] = hi.y;
-    }
-    __syncthreads();
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(minef + 20 * l);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 v = src[q];
-            P[2 * q] = (v2f){v.x, v.y};
-            P[2 * q + 1] = (v2f){v.z, v.w};
-        }
-    }
-    { // coefficient index 16 l + c with P[q] = (c = 2q, 2q + 1): zeta index = 128/len + j/(2 len)
-        const v2f z8 = {kZetasF.z[16 + l], kZetasF.z[16 + l]};
-#pragma unroll
-        for (int q = 0; q < 4; q++) nttf_bfly(P[q], P[q + 4], z8, kc);
-        const v2f z4a = {kZetasF.z[32 + 2 * l], kZetasF.z[32 + 2 * l]}, z4b = {kZetasF.z[33 + 2 * l], kZetasF.z[33 + 2 * l]};
-#pragma unroll
-        for (int q = 0; q < 2; q++) { nttf_bfly(P[q], P[q + 2], z4a, kc); nttf_bfly(P[4 + q], P[6 + q], z4b, kc); }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const v2f z2 = {kZetasF.z[64 + 4 * l + q], kZetasF.z[64 + 4 * l + q]};
-            nttf_bfly(P[2 * q], P[2 * q + 1], z2, kc);
-        }
-    }
-    const int p = p0 + pl;
-    if (p < a.npoly) {
-        uint32_t w[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const v2f rr = nttf_red(P[q], kc);
-            int32_t x0 = (int32_t)rr.x, x1 = (int32_t)rr.y; // integers in [-q/2 - 2, q/2 + 2]
-            if (a.out_canonical) {
-                x0 += x0 < 0 ? Q : 0;
-                x1 += x1 < 0 ? Q : 0;
-            } else { // the centred representative of poly_reduce: [-(q-1)/2, (q-1)/2]
-                x0 += x0 < -(Q / 2) ? Q : (x0 > Q / 2 ? -Q : 0);
-                x1 += x1 < -(Q / 2) ? Q : (x1 > Q / 2 ? -Q : 0);
-            }
-            w[q] = ((uint32_t)x0 & 0xFFFFu) | ((uint32_t)x1 << 16);
-        }
-        const int g = p / a.npg, i = p - g * a.npg;
-        const size_t off = (size_t)g * a.out_gstride + (a.dst_off ? (size_t)a.dst_off[i] : (size_t)i * 256);
-        uint4 *o = reinterpret_cast<uint4 *>(a.out + off + 16 * l);
-        if (a.cmp_fail) {
-            const uint4 c0 = o[a.cmp_delta / 8], c1 = o[a.cmp_delta / 8 + 1];
-            if (c0.x != w[0] || c0.y != w[1] || c0.z != w[2] || c0.w != w[3] || c1.x != w[4] || c1.y != w[5] || c1.z != w[6] || c1.w != w[7])
-                atomicOr(&a.cmp_fail[g], 1u << a.cmp_bit);
-        } else {
-            o[0] = make_uint4(w[0], w[1], w[2], w[3]);
-            o[1] = make_uint4(w[4], w[5], w[6], w[7]);
-        }
-    }
 }
 
 // K6  r_i = tomont(Barrett(sum_l basemul(A[i][l], v[l])))      polyvec.c:202-214, poly.c:307-313
@@ -1442,7 +1217,7 @@ __global__ __launch_bounds__(512, (KS <= 7 && NBT == 3) ? 2 : 1) void k_table_ge
 // chunks and converts the same rows), its eight waves taking the block's chunks round-robin as before.  The NEXT block's rows are
 // fetched and converted inside this block's chunk loop, one 32-byte item per thread and chunk iteration -- loaded at the top of
 // the iteration, converted and written to the OTHER half of the LDS buffer behind its epilogue -- so the only thing between two
-// blocks is a barrier.  Same fragments, same arithmetic, same stores: bit-identical to k_table_gemm (KOSK_TG_PERSIST=0 runs that).
+// blocks is a barrier.  Same fragments, same arithmetic, same stores: bit-identical to the one-block-per-workgroup kernel of rounds 2-4 (k_table_gemm, which still serves the 13-k-step product).
 // CANON: the source rows hold canonical values (everything the pipelines produce): packed conversion; otherwise gm_split16 (folds).
 template <int KS, int NBT, bool CANON>
 __global__ __launch_bounds__(512, 1) void k_table_gemm_p(GemmArgs a, int nchunks, int nblk, int wide_stores, uint32_t npg_magic)
@@ -1617,168 +1392,16 @@ __global__ __launch_bounds__(512, 1) void k_table_gemm_p(GemmArgs a, int nchunks
     }
 }
 
-// ---- K3 (prover) on the matrix cores: out_j[x] = sum_k Coef[j][k] * in_k[x] as the same GEMM -----
-// "A" operand: the 77 f (or NTT f) rows of one proof transposed: limb-matrix row = evaluation point x,
-// k = row index (padded to 128).  Loads are coalesced along x.
+// ---- K3 (prover) on the matrix cores: out_j[x] = sum_k Coef[j][k] * in_k[x], per proof a [76 x 77] x [77 x 1710] product.
+// (Rounds 2-4 ran it as a transposition pass + the generic GEMM, then as the one-shot kernel k_lincomb_fused -- one workgroup per
+// (proof, f | NTT f, 128 points); both are gone since round 6, their measurements are in profiles/r05_* and DESIGN.md 15.2.)
 constexpr int LC_JPAD = 80;  // padded J in the alpha / power tables
-constexpr int LIN_MPAD = 1792, LIN_K = 128;
-__global__ __launch_bounds__(256) void k_cols_to_limbs(const uint16_t *__restrict__ P, size_t proof_stride, int row_f, int row_tf,
-                                                       int M, uint8_t *__restrict__ A, size_t a_gstride)
-{
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ch = blockIdx.y * 4 + (threadIdx.x >> 6); // 16-row chunk of the k dimension
-    const int gg = blockIdx.z, b = gg >> 1, which = gg & 1;
-    const uint16_t *src = P + (size_t)b * proof_stride + (size_t)(which ? row_tf : row_f) * RS + x;
-    uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
-    if (x < NPTS) {
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int k = ch * 16 + q;
-            if (k < M) {
-                int c0, c1;
-                limb_split(gf_center(src[(size_t)k * RS]), c0, c1);
-                lo[q >> 2] |= ((uint32_t)c0 & 0xFFu) << (8 * (q & 3));
-                hi[q >> 2] |= ((uint32_t)c1 & 0xFFu) << (8 * (q & 3));
-            }
-        }
-    }
-    uint8_t *d = A + (size_t)gg * a_gstride + limb_offset(x, ch * 16, 0, LIN_MPAD / 16);
-    *reinterpret_cast<uint4 *>(d) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-    *reinterpret_cast<uint4 *>(d + 1024) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-}
-
-// ---- K3 (prover) fused: the f rows are transposed and limb-split INSIDE the product's staging -------------------
-// One workgroup = (proof, f | NTT f, 128 evaluation points): the 77 x 128 input values are read row-wise (coalesced
-// 2-byte gathers, 64 per thread, all in flight), written to LDS as the [point][k] limb tiles the MFMA A operand wants,
-// the coefficient limb matrix (k_coef_limbs) of the proof is copied next to it, and 128 x 128 x 128 is multiplied in
-// two column halves.  Replaces k_cols_to_limbs + k_gemm_modq<true> and their 90 MB round trip through HBM.
 constexpr int LF_A_BYTES = 2 * 8 * 2048, LF_B_BYTES = 2 * 8 * 2048; // 2 k-steps x 8 row tiles x (2 limbs x 1 KiB)
-__global__ __launch_bounds__(256) void k_lincomb_fused(const uint16_t *P, size_t proof_stride, int row_f, int row_tf, int M,
-                                                       const uint8_t *__restrict__ coef, int BRT, uint16_t *C,
-                                                       const int16_t *__restrict__ lin_rows, int J, int K, int row_s, int row_e,
-                                                       int row_sr, int row_er, int ngroups)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t lds[LF_A_BYTES + LF_B_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w & 1, wn = w >> 1;
-    // One-dimensional grid, remapped so that the point blocks of one (proof, f | NTT f) group -- which all read the same 32 KiB of
-    // coefficient tiles -- run on ONE XCD (consecutive workgroup ids go round the 8 XCDs, each with its own L2): virtual id =
-    // position in this XCD's sequence; with the 2D grid every XCD fetched every group's tiles (PMC: 71 MB for 48 MB algorithmic)
-    constexpr int MB = (NPTS + 127) / 128;
-    const int vid = xcd_virtual_id(); // the launcher pads the grid to a multiple of 8
-    const int g = vid / MB;
-    if (g >= ngroups) return;
-    const int b = g >> 1, which = g & 1;
-    const int m0 = (vid - g * MB) * 128;
-    // B: this group's coefficient tiles, 2 k-steps x 16 KiB contiguous each
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(coef + ((size_t)ks * BRT + (size_t)g * 8) * 2048) + tid;
-        uint4 *dst = reinterpret_cast<uint4 *>(lds + LF_A_BYTES + ks * 16384) + tid;
-#pragma unroll
-        for (int q = 0; q < 4; q++) dst[256 * q] = src[256 * q];
-    }
-    // A: thread -> (point pair x = m0 + 2 (pidx & 63), 16-row chunk ch = pidx >> 6) for pidx = tid + 256 i: one 4-byte
-    // load per row brings two points (rows are 4-byte aligned, m0 is even; NPTS is even, so a pair is live or dead as one)
-    const uint16_t *src0 = P + (size_t)b * proof_stride + (size_t)(which ? row_tf : row_f) * RS + m0;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int pidx = tid + 256 * i, xl = (pidx & 63) * 2, ch = pidx >> 6;
-        const bool live = m0 + xl < NPTS;
-        uint32_t v[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int k = ch * 16 + q;
-            v[q] = (live && k < M) ? *reinterpret_cast<const uint32_t *>(src0 + (size_t)k * RS + xl) : 0u;
-        }
-#pragma unroll
-        for (int pt = 0; pt < 2; pt++) {
-            uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                int c0, c1;
-                limb_split(gf_center(pt ? v[q] >> 16 : v[q] & 0xFFFFu), c0, c1);
-                lo[q >> 2] |= ((uint32_t)c0 & 0xFFu) << (8 * (q & 3));
-                hi[q >> 2] |= ((uint32_t)c1 & 0xFFu) << (8 * (q & 3));
-            }
-            // point x of the 128 goes to MFMA row tile 2 (x >> 5) + ((x >> 2) & 1), row 4 ((x >> 3) & 3) + (x & 3): an output
-            // lane (row group g = lane >> 4) then holds points 8 g .. 8 g + 3 in the even tile of a pair and 8 g + 4 .. 8 g + 7
-            // in the odd one -- eight consecutive points, ONE 16-byte store per output row instead of two 8-byte ones
-            const int x = xl + pt;
-            const int xt = (x >> 5) * 2 + ((x >> 2) & 1), xr = ((x >> 3) & 3) * 4 + (x & 3);
-            uint8_t *d = lds + ((ch >> 2) * 8 + xt) * 2048 + xr * 64 + (((ch & 3) ^ limb_swz(xr)) << 4);
-            *reinterpret_cast<uint4 *>(d) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-            *reinterpret_cast<uint4 *>(d + 1024) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-        }
-    }
-    __syncthreads();
-    const int frag = (lane & 15) * 64 + (((lane >> 4) ^ limb_swz(lane & 15)) << 4);
-    uint16_t *Cb = C + (size_t)b * proof_stride;
-#pragma unroll 1
-    for (int nh = 0; nh < 2; nh++) { // output columns j = nh * 64 + wn * 32 + ...
-        if (nh * 64 + wn * 32 >= J) break;
-        v4i s0[4][2], s1[4][2], s2[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++) { s0[i][j] = (v4i){0, 0, 0, 0}; s1[i][j] = s0[i][j]; s2[i][j] = s0[i][j]; }
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            const uint8_t *la = lds + (ks * 8 + wm * 4) * 2048 + frag;
-            const uint8_t *lb = lds + LF_A_BYTES + (ks * 8 + nh * 4 + wn * 2) * 2048 + frag;
-            v4i a0[4], a1[4], b0[2], b1[2];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                a0[i] = *reinterpret_cast<const v4i *>(la + i * 2048);
-                a1[i] = *reinterpret_cast<const v4i *>(la + i * 2048 + 1024);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                b0[j] = *reinterpret_cast<const v4i *>(lb + j * 2048);
-                b1[j] = *reinterpret_cast<const v4i *>(lb + j * 2048 + 1024);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    s0[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[i], b0[j], s0[i][j], 0, 0, 0);
-                    s1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[i], b1[j], s1[i][j], 0, 0, 0);
-                    s1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[i], b0[j], s1[i][j], 0, 0, 0);
-                    s2[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[i], b1[j], s2[i][j], 0, 0, 0);
-                }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int jo = nh * 64 + wn * 32 + j * 16 + (lane & 15);
-            if (jo >= J) continue;
-            uint16_t *crow = Cb + (size_t)lin_rows[which * 128 + jo] * RS;
-#pragma unroll
-            for (int ip = 0; ip < 2; ip++) { // tile pair: eight consecutive points per lane (see the staging above)
-                const int m = m0 + wm * 64 + ip * 32 + (lane >> 4) * 8;
-                if (m >= NPTS) continue; // the last live group (1704..1711) ends two points inside the row padding (RS = 1728), as before
-                uint32_t v[8];
-#pragma unroll
-                for (int h = 0; h < 2; h++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        v[4 * h + r] = gf_reduce_limbs(s0[2 * ip + h][j][r], s1[2 * ip + h][j][r], s2[2 * ip + h][j][r]);
-                const uint32_t pw[4] = {v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
-                *reinterpret_cast<uint4 *>(crow + m) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
-                if (which == 0 && jo >= NCHK) { // r rows: s + r_i, e + r_{K+i} on the spot (mlwe_prover.cpp:222-245)
-                    const int idx = jo - NCHK;
-                    const int src_row = idx < K ? row_s + idx : row_e + (idx - K), dst_row = idx < K ? row_sr + idx : row_er + (idx - K);
-                    const uint4 sv = *reinterpret_cast<const uint4 *>(Cb + (size_t)src_row * RS + m);
-                    *reinterpret_cast<uint4 *>(Cb + (size_t)dst_row * RS + m) = make_uint4(gf_add_pair(sv.x, pw[0]), gf_add_pair(sv.y, pw[1]), gf_add_pair(sv.z, pw[2]), gf_add_pair(sv.w, pw[3]));
-                }
-            }
-        }
-    }
-}
 
-// ---- K3 (prover), streaming form (round 5; default).  Same product, same operand tiles, same epilogue as k_lincomb_fused, but a
+// ---- K3 (prover), streaming form (round 5).  The [point][k] limb tiles of the MFMA A operand are built in LDS from row-wise reads; a
 // workgroup is PERSISTENT over a run of consecutive (group, 128-point block) units of the launch (the flattened list is dealt evenly
 // over two workgroups per CU: 7 or 8 blocks each at 138 proofs):
-//   * the coefficient tiles of a group are copied to LDS once per run of that group's blocks, not once per block (k_lincomb_fused:
+//   * the coefficient tiles of a group are copied to LDS once per run of that group's blocks, not once per block (the one-shot kernel:
 //     every one of a group's 14 blocks re-read 32 KiB from L2: 124 MB of L2 -> LDS per launch for 62 MB of input), and only the five
 //     16-column tiles that J <= 80 needs (20 KiB);
 //   * the NEXT block's 77 x 128 input values are already in flight (20 dwords per thread, issued right after the barrier that
@@ -2128,18 +1751,6 @@ __global__ __launch_bounds__(256) void k_post_gates(uint16_t *__restrict__ P, si
     }
 }
 
-// sr = s + r_i, er = e + r_{i+K} on every evaluation point   mlwe_prover.cpp:222-245
-__global__ __launch_bounds__(256) void k_post_open(uint16_t *__restrict__ P, size_t proof_stride, RowMap rm)
-{
-    const int x = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (x >= NPTS) return;
-    uint16_t *Pb = P + (size_t)b * proof_stride + x;
-    for (int i = 0; i < rm.K; i++) {
-        Pb[(size_t)(rm.sr + i) * RS] = (uint16_t)gf_add(Pb[(size_t)(rm.s + i) * RS], Pb[(size_t)(rm.r + i) * RS]);
-        Pb[(size_t)(rm.er + i) * RS] = (uint16_t)gf_add(Pb[(size_t)(rm.e + i) * RS], Pb[(size_t)(rm.r + rm.K + i) * RS]);
-    }
-}
-
 // sr_rnd / er_rnd / ntt_Asr_rnd tails: values at points 256..406 of the re-shared
 // rows are those of sr / er / sr                          mlwe_prover.cpp:234-237, :312-314
 __global__ __launch_bounds__(192) void k_copy_tails(uint16_t *__restrict__ P, size_t proof_stride, RowMap rm)
@@ -2205,80 +1816,6 @@ __device__ __forceinline__ void asm_gather(const uint16_t *Pb, uint32_t voff, co
     }
 }
 
-// One wave per (field, 64 parties): for the fields of unopened parties the 64 parties are those of one ALIGNED window of
-// 64 party columns (a single 128-byte line per row read, PMC: 125 -> 35 MB fetched), for opened fields 64 entries of I.
-// No workgroup barrier: the wave gathers its whole tile (independent loads), then streams it out.
-__global__ __launch_bounds__(64) void k_assemble_fields(AssembleArgs a, uint32_t off_tcomm, uint32_t off_comm, uint32_t off_I,
-                                                        int blocks_per_proof, int nproofs)
-{
-    // One-dimensional grid in XCD-aware order (xcd_virtual_id): the three 64-party chunks of an opened field gather scattered
-    // columns of the SAME rows; on three different XCDs each L2 fetched nearly every line of those rows (PMC: 100 MB for 33 MB
-    // of rows), on one XCD the lines are fetched once.
-    const int vid = xcd_virtual_id();
-    const int b = vid / blocks_per_proof, bx = vid - b * blocks_per_proof;
-    if (b >= nproofs) return;
-    { // blocks past the field tiles: Tcomm / comm of the unopened parties and the list I itself (64 u16 per block)
-        const int nfield_blocks = a.plan.nrest * NWIN + a.plan.nopen * ((NOPEN + 63) / 64);
-        if (bx >= nfield_blocks) {
-            const int q = (bx - nfield_blocks) * 64 + threadIdx.x;
-            uint8_t *img = a.proof + (size_t)b * a.image_stride;
-            if (q < NREST * 16) {
-                const int i = q >> 4, w = q & 15;
-                const size_t src = ((size_t)b * NPARTY + a.rest[(size_t)b * a.sel_stride + i]) * 32 + 2 * w;
-                reinterpret_cast<uint16_t *>(img + off_tcomm)[q] = *reinterpret_cast<const uint16_t *>(a.dig1 + src);
-                reinterpret_cast<uint16_t *>(img + off_comm)[q] = *reinterpret_cast<const uint16_t *>(a.dig2 + src);
-            }
-            if (q < NOPEN) reinterpret_cast<uint16_t *>(img + off_I)[q] = a.opened[(size_t)b * a.sel_stride + q];
-            return;
-        }
-    }
-    // the tile is kept in IMAGE order (party-major, no padding): the second phase is a straight copy.
-    __shared__ __attribute__((aligned(16))) uint16_t tile[ASM_TILE];
-    const int x = bx, lane = threadIdx.x;
-    const bool kind = x < a.plan.nrest * NWIN; // unopened parties
-    const uint16_t *orow = a.opened + (size_t)b * a.sel_stride;
-    int i0, cnt, f;
-    if (kind) {
-        const int win = x % NWIN;
-        f = a.plan.rest_ids[x / NWIN];
-        i0 = orow[SEL_WIN + win];
-        cnt = (int)orow[SEL_WIN + win + 1] - i0;
-    } else {
-        const int y = x - a.plan.nrest * NWIN, nch = (NOPEN + 63) / 64;
-        f = a.plan.open_ids[y / nch];
-        i0 = (y % nch) * 64;
-        cnt = min(64, NOPEN - i0);
-    }
-    if (cnt <= 0) return;
-    const FieldDesc fd = a.fields[f];
-    const uint16_t *sel = kind ? a.rest + (size_t)b * a.sel_stride : orow;
-    {
-        // Every load of the record is issued before the first LDS write: the launch is latency-bound -- its waves sit in s_waitcnt 76 %
-        // of their lifetime (profiles/r04_wire_pmc.txt) with 32 loads in flight each.  Written as scalar row base + one 32-bit lane
-        // offset (global_load ... saddr), so that 80 loads in flight cost 80 data registers and ONE address register.  Lanes past the
-        // block's last party load their neighbour's column (same cache line) and write nothing: no divergence around the loads.
-        const uint16_t *Pb = a.P + (size_t)b * a.proof_stride; // uniform
-        const uint32_t voff = 2u * (uint32_t)(NSEC + sel[i0 + min(lane, cnt - 1)]);
-        const int16_t *rt = a.rowtab + fd.rowtab_off;
-        uint16_t *t = tile + lane * fd.width;
-        const bool live = lane < cnt;
-        if (fd.width <= 4) asm_gather<4>(Pb, voff, rt, fd.width, t, live);
-        else if (fd.width <= 16) asm_gather<16>(Pb, voff, rt, fd.width, t, live);
-        else asm_gather<80>(Pb, voff, rt, fd.width, t, live);
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-    // image rows [i0, i0+cnt) are contiguous; the start is only 2-byte aligned in general: u16 head, u32 body, u16 tail
-    uint16_t *out = reinterpret_cast<uint16_t *>(a.proof + (size_t)b * a.image_stride + fd.off) + (size_t)i0 * fd.width;
-    const int n16 = cnt * fd.width;
-    const int head = (int)((reinterpret_cast<uintptr_t>(out) >> 1) & 1);
-    const int body = (n16 - head) >> 1;
-    if (lane == 0 && head) out[0] = tile[0];
-    uint32_t *out32 = reinterpret_cast<uint32_t *>(out + head);
-    for (int q = lane; q < body; q += 64) out32[q] = (uint32_t)tile[head + 2 * q] | ((uint32_t)tile[head + 2 * q + 1] << 16);
-    if (lane == 1 && head + 2 * body < n16) out[n16 - 1] = tile[n16 - 1];
-}
-
 // ---- K8, grouped form (round 5; default).  k_assemble_fields gathers the records of the OPENED parties 64 entries of I at a time:
 // 64 scattered columns, i.e. about 20 different 128-byte lines per row and load instruction, where a window of 64 adjacent columns
 // is ONE line -- three quarters of the launch's line requests for a tenth of its bytes (232 rows x 3 chunks x ~20 lines against 203
@@ -2289,7 +1826,7 @@ __global__ __launch_bounds__(64) void k_assemble_fields(AssembleArgs a, uint32_t
 //   * fields of opened parties: the window's 64 columns gathered densely, and the records of the window's opened parties (6.6 on
 //     average; the host's Fiat-Shamir round leaves them sorted with their positions in I, SEL_OSORT / SEL_OPOS) written from the
 //     LDS tile; a window without an opened party does nothing.
-// Same image bytes as k_assemble_fields (KOSK_ASSEMBLE_GROUPS=0 runs that).
+// Same image bytes as the per-field kernel of rounds 1-4 (k_assemble_fields, removed in round 6).
 // A block = (group, window).  The window's 64 columns of the group's rows are gathered DENSE with 8-byte loads: lane = (row slot
 // lane >> 4, column quad lane & 15), so one instruction brings four whole 128-byte lines (four rows) where a 2-byte-per-lane gather
 // brings one -- the launch is bound by the number of load instructions, not by bytes (measured: the same dense gather with 2-byte
@@ -2410,42 +1947,6 @@ __global__ __launch_bounds__(64) void k_assemble_groups(AssembleArgs a, uint32_t
     else asm_group_block<20>(a, g, b, w, tile, rank_s, el_s);
 }
 
-// Device-to-host copy of a digest table with FEW waves (experiment, KOSK_COPY_WAVES).  The runtime's own copy (hipMemcpyAsync into
-// page-locked memory) is a blit kernel with one 16-byte element per thread on this pool (no SDMA, profiles/r04_sdma_probe.txt):
-// 6 144 waves for the 6.4 MB of a 138-proof round, parked on PCIe stores for 112 us.  The idea here: one wave per workgroup walks
-// the table in 1 KiB pieces with eight pieces in flight (the link needs ~120 KB in flight) and leaves the wave slots to the other
-// cohorts' kernels.  Measured: the copy takes the same time and the kernels beside it get SLOWER (table product 230 against 137 us,
-// fused lincomb 295 against 160 us), 105 k against 133-137 k proofs/s at 128 .. 2 048 waves alike -- default off.
-// MODE 1 (experiment, KOSK_COPY_MODE=1): the same with non-temporal stores (the write-combining hint of the ISA's `nt` bit)
-template <int MODE>
-__global__ __launch_bounds__(64) void k_copy_to_host_m(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
-{
-    const size_t stride = (size_t)gridDim.x * 64;
-    for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < n16; i += stride) {
-        const uint4 v = src[i];
-        if (MODE == 1) {
-            __builtin_nontemporal_store(v.x, &dst[i].x); __builtin_nontemporal_store(v.y, &dst[i].y);
-            __builtin_nontemporal_store(v.z, &dst[i].z); __builtin_nontemporal_store(v.w, &dst[i].w);
-        } else {
-            dst[i] = v;
-        }
-    }
-}
-
-__global__ __launch_bounds__(64) void k_copy_to_host(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
-{
-    const size_t stride = (size_t)gridDim.x * 64;
-    size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
-    for (; i + 7 * stride < n16; i += 8 * stride) {
-        uint4 v[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = src[i + q * stride];
-#pragma unroll
-        for (int q = 0; q < 8; q++) dst[i + q * stride] = v[q];
-    }
-    for (; i < n16; i += stride) dst[i] = src[i];
-}
-
 // The SMALL copies of a step between HBM and the library's own page-locked (device-mapped) host buffers -- challenge vectors and
 // opened lists in, key records, opened lists of the images and fail masks out; 0.5 .. 700 KB -- as a kernel instead of
 // hipMemcpyAsync: on this runtime every copy is a blit kernel with a ~12 us dependency gap in front of it
@@ -2474,24 +1975,22 @@ __global__ __launch_bounds__(256) void k_rows_copy(const uint16_t *__restrict__ 
 // host-side launchers
 // =========================================================================
 template <int PW, int NR>
-static int launch_hash_t(const HashArgs &a, int ngroups, hipStream_t st, unsigned opts)
+static int launch_hash_t(const HashArgs &a, int ngroups, hipStream_t st)
 {
     dim3 grid((a.lanes_per_group + 63) / 64, ngroups);
     const long waves = (long)grid.x * grid.y;
     // LDS-DMA staging needs 16-byte aligned 128-byte row segments per wave and readable row padding up to the last
     // wave's 64th lane (true for the row matrix: RS = 1728 = 256 + 23 * 64)
-    const bool dma_ok = (opts & HASH_OPT_DMA) && !a.lane_map && a.row_stride % 8 == 0 && a.group_stride % 8 == 0 && a.col_off % 8 == 0 &&
+    const bool dma_ok = !a.lane_map && a.row_stride % 8 == 0 && a.group_stride % 8 == 0 && a.col_off % 8 == 0 &&
                         (reinterpret_cast<uintptr_t>(a.rows) & 15) == 0 && a.col_off + (int)grid.x * 64 <= a.row_stride &&
                         (!PW || (reinterpret_cast<uintptr_t>(a.prefix) & 15) == 0);
     if (dma_ok) {
         // up to ~2 waves per SIMD the next block's DMA runs under this block's permutation (two buffers, 18 KiB per wave);
         // beyond that one buffer (4 waves per SIMD fit) and occupancy hides the landing
         const dim3 grid1((unsigned)waves);
-        const bool primer = (opts & HASH_OPT_PRIMER) && waves >= 256 && waves <= 2 * 1024 + 256; // opt-in, see k_hash_primer
-        if (primer) hipLaunchKernelGGL((k_hash_primer<2>), grid1, dim3(64), 0, st, (int *)nullptr);
         if (waves <= 2 * 1024 + 256) hipLaunchKernelGGL((k_commit_hash_dma<PW, NR, 2>), grid1, dim3(64), 0, st, a);
         else hipLaunchKernelGGL((k_commit_hash_dma<PW, NR, 1>), grid1, dim3(64), 0, st, a);
-        return primer ? 3 : 1;
+        return 1;
     }
     // fewer than ~3 waves per SIMD (1024 SIMDs): nothing else hides the row loads -> pipelined variant
     if (waves < 3 * 1024) hipLaunchKernelGGL((k_commit_hash<PW, NR, true>), grid, dim3(64), 0, st, a);
@@ -2499,18 +1998,18 @@ static int launch_hash_t(const HashArgs &a, int ngroups, hipStream_t st, unsigne
     return 0;
 }
 
-hipError_t launch_commit_hash(const HashArgs &a, int ngroups, int K, bool view, hipStream_t st, unsigned opts, int *variant)
+hipError_t launch_commit_hash(const HashArgs &a, int ngroups, int K, bool view, hipStream_t st, int *variant)
 {
     // rows hashed per party: Tcomm 2(K+M); view (6+8 eta1)K + 2M   (M = 71+2K)
     int v;
     if (!view) {
-        if (K == 2) v = launch_hash_t<0, 154>(a, ngroups, st, opts);
-        else if (K == 3) v = launch_hash_t<0, 160>(a, ngroups, st, opts);
-        else v = launch_hash_t<0, 166>(a, ngroups, st, opts);
+        if (K == 2) v = launch_hash_t<0, 154>(a, ngroups, st);
+        else if (K == 3) v = launch_hash_t<0, 160>(a, ngroups, st);
+        else v = launch_hash_t<0, 166>(a, ngroups, st);
     } else {
-        if (K == 2) v = launch_hash_t<16, 210>(a, ngroups, st, opts);
-        else if (K == 3) v = launch_hash_t<16, 220>(a, ngroups, st, opts);
-        else v = launch_hash_t<16, 246>(a, ngroups, st, opts);
+        if (K == 2) v = launch_hash_t<16, 210>(a, ngroups, st);
+        else if (K == 3) v = launch_hash_t<16, 220>(a, ngroups, st);
+        else v = launch_hash_t<16, 246>(a, ngroups, st);
     }
     if (variant) *variant = v;
     return hipGetLastError();
@@ -2529,18 +2028,6 @@ hipError_t launch_sha3_msgs_pair(const uint8_t *in, size_t in_stride, int len, u
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_sha3_msgs_pair, dim3((n + 31) / 32), dim3(64), 0, st, in, in_stride, len, out, out_stride, outlen, n, domain);
-    return hipGetLastError();
-}
-
-hipError_t launch_copy_to_host(const void *d_src, void *h_dst, size_t bytes, int nwg, hipStream_t st)
-{
-    if (!bytes) return hipSuccess;
-    if (bytes % 16 || (reinterpret_cast<uintptr_t>(d_src) & 15) || (reinterpret_cast<uintptr_t>(h_dst) & 15)) return hipErrorInvalidValue;
-    static const int mode = getenv("KOSK_COPY_MODE") ? atoi(getenv("KOSK_COPY_MODE")) : 0; // experiment knob (per process): 0 eight stores in flight per lane,
-    // 1 one non-temporal store at a time, 2 one plain store at a time (with nwg = bytes / 1 KiB this is the shape of the runtime's blit kernel)
-    if (mode == 1) hipLaunchKernelGGL(k_copy_to_host_m<1>, dim3(nwg), dim3(64), 0, st, reinterpret_cast<const uint4 *>(d_src), reinterpret_cast<uint4 *>(h_dst), bytes / 16);
-    else if (mode == 2) hipLaunchKernelGGL(k_copy_to_host_m<0>, dim3(nwg), dim3(64), 0, st, reinterpret_cast<const uint4 *>(d_src), reinterpret_cast<uint4 *>(h_dst), bytes / 16);
-    else hipLaunchKernelGGL(k_copy_to_host, dim3(nwg), dim3(64), 0, st, reinterpret_cast<const uint4 *>(d_src), reinterpret_cast<uint4 *>(h_dst), bytes / 16);
     return hipGetLastError();
 }
 
@@ -2582,10 +2069,7 @@ hipError_t launch_prover_pre(const uint8_t *tape, size_t tape_stride, uint16_t *
     a.witness_mode = witness_mode;
     a.se = se; a.se_stride = se_stride; a.rm = rm; a.eta1 = eta1;
     a.K = rm.K;
-    // KOSK_PRE_PAIR=0 (per process): one sponge per lane in roles G, N, A, as in rounds 1-4
-    static const bool pre_pair = !(getenv("KOSK_PRE_PAIR") && atoi(getenv("KOSK_PRE_PAIR")) == 0);
-    a.pair = pre_pair ? 1 : 0;
-    const int per = a.pair ? 32 : 64; // sponges per block
+    const int per = 32; // sponges per block (roles G, N, A: the lane-pair sponge)
     a.nbA = expand_f ? (M * nproofs + per - 1) / per : 0;
     a.nbB = 3 * ((slice_end - slice_begin + PRE_SLICES - 1) / PRE_SLICES) * nproofs;
     const int nbC = witness_mode ? 4 * nproofs : 0;
@@ -2616,9 +2100,7 @@ hipError_t launch_keygen(const uint8_t *tape, size_t tape_stride, uint8_t *seeds
     a.xof = xof;
     a.tape = tape; a.tape_stride = tape_stride; a.nproofs = n; a.eta1 = eta1; a.K = K;
     a.kg_seeds = seeds; a.kg_seed_stride = seed_stride; a.kg_A = A; a.kg_A_stride = A_stride; a.kg_se = se; a.kg_se_stride = se_stride;
-    static const bool pre_pair = !(getenv("KOSK_PRE_PAIR") && atoi(getenv("KOSK_PRE_PAIR")) == 0);
-    a.pair = pre_pair ? 1 : 0;
-    const int per = a.pair ? 32 : 64;
+    const int per = 32;
     a.nbG = (n * K * K + per - 1) / per;
     a.nbN = (n * 2 * K + per - 1) / per;
     hipLaunchKernelGGL(k_prover_pre, dim3(a.nbG + a.nbN), dim3(64), 0, st, a);
@@ -2630,15 +2112,12 @@ hipError_t launch_ntt(const NttArgs &args, hipStream_t st)
     if (args.npoly <= 0) return hipSuccess;
     NttArgs a = args;
     a.npg_magic = ntt_npg_magic(a.npg);
-    if (a.fp32) hipLaunchKernelGGL(k_ntt256_fp32, dim3((a.npoly + NTT_PPB - 1) / NTT_PPB), dim3(256), 0, st, a);
-    else {
-        // polynomials back to back in both buffers (kosk_ntt256_batch; the verifier's 140 x n secrets): no group / offset arithmetic
-        const bool plain = !a.src_off && !a.dst_off && !a.cmp_fail && (a.npg >= a.npoly || (a.in_gstride == (size_t)a.npg * 256 && a.out_gstride == (size_t)a.npg * 256)) &&
-                           (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
-        const dim3 grid((a.npoly + NTT_PPB - 1) / NTT_PPB);
-        if (plain) hipLaunchKernelGGL(k_ntt256<true>, grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(k_ntt256<false>, grid, dim3(256), 0, st, a);
-    }
+    // polynomials back to back in both buffers (kosk_ntt256_batch; the verifier's 140 x n secrets): no group / offset arithmetic
+    const bool plain = !a.src_off && !a.dst_off && !a.cmp_fail && (a.npg >= a.npoly || (a.in_gstride == (size_t)a.npg * 256 && a.out_gstride == (size_t)a.npg * 256)) &&
+                       (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
+    const dim3 grid((a.npoly + NTT_PPB - 1) / NTT_PPB);
+    if (plain) hipLaunchKernelGGL(k_ntt256<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_ntt256<false>, grid, dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
@@ -2680,46 +2159,34 @@ hipError_t launch_table_gemm(const GemmArgs &a, uint16_t *sink, hipStream_t st)
 {
     const int ntot = a.npg * a.ngroups;
     if (ntot <= 0) return hipSuccess;
-    // rows per workgroup: 48, or 64 where that needs fewer round-units on the chip's CUs (see k_table_gemm); 13 k-steps: 48 only
-    // (64 rows of 13 k-steps are 104 KiB of LDS and too many registers)
     static const int ncu = [] {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
         return cus;
     }();
-    const int nblk3 = (ntot + 47) / 48, nblk4 = (ntot + 63) / 64;
-    // KOSK_TG_WIDE=1 (process-wide experiment knob) turns the 64-row variant on.  Alone it should take 8 instead of 9 round-units at
-    // 29 946 rows; inside the three-cohort pipeline it changes nothing measurable (gemm_expand1 128-133 us with, 130-138 us
-    // without; 132-135 k against 133-137 k proofs/s, profiles/r04_sweeps.txt): default off
-    static const bool wide_ok = getenv("KOSK_TG_WIDE") && atoi(getenv("KOSK_TG_WIDE")) != 0;
-    const bool wide = wide_ok && a.KS == 7 && nblk3 >= 160 && ((nblk4 + ncu - 1) / ncu) * 4 < ((nblk3 + ncu - 1) / ncu) * 3;
-    const int nchunks = a.M / 16, nblk = wide ? nblk4 : nblk3;
-    // few data rows: split the table over several workgroups per row block so that the launch still covers the chip
-    int msplit = nblk >= 160 ? 1 : (256 + nblk - 1) / nblk;
-    if (msplit > nchunks) msplit = nchunks;
-    const int cpb = (nchunks + msplit - 1) / msplit;
-    msplit = (nchunks + cpb - 1) / cpb;
+    const int nblk = (ntot + 47) / 48, nchunks = a.M / 16; // 48 rows per block
     (void)sink;
-    // eight consecutive outputs per lane and 16-byte stores where the output rows allow it (KOSK_TG_STORE16=0: 8-byte stores only)
-    static const bool store16 = !(getenv("KOSK_TG_STORE16") && atoi(getenv("KOSK_TG_STORE16")) == 0);
-    const int ws = store16 && a.c_off % 8 == 0 && a.c_rstride % 8 == 0 && a.c_gstride % 8 == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0;
-    // persistent workgroups (k_table_gemm_p): one per CU, the (row block, table chunk) units dealt evenly; KOSK_TG_PERSIST=0 (per process): the
-    // one-block-per-workgroup kernel of rounds 2-4
-    static const bool persist = !(getenv("KOSK_TG_PERSIST") && atoi(getenv("KOSK_TG_PERSIST")) == 0);
-    if (persist && a.KS == 7 && !wide) {
-        const long total = (long)(nblk3) * nchunks;
+    // eight consecutive outputs per lane and 16-byte stores where the output rows allow it
+    const int ws = a.c_off % 8 == 0 && a.c_rstride % 8 == 0 && a.c_gstride % 8 == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0;
+    if (a.KS == 7) {
+        // persistent workgroups (k_table_gemm_p): one per CU, the (row block, table chunk) units dealt evenly.  (The one-block-per-workgroup
+        // kernel of rounds 2-4, its 64-row variant and the 8-byte-store epilogue are gone since round 6: profiles/r04_sweeps.txt)
+        const long total = (long)nblk * nchunks;
         // at least eight chunks per workgroup where the product is that large (a chunk per wave), never more workgroups than CUs
         long nwg = total / 8 < ncu ? total / 8 : ncu;
         if (nwg < 1) nwg = 1;
         const uint32_t magic = ntt_npg_magic(a.npg);
-        if (a.src_canonical) hipLaunchKernelGGL((k_table_gemm_p<7, 3, true>), dim3((unsigned)nwg), dim3(512), 0, st, a, nchunks, nblk3, ws, magic);
-        else hipLaunchKernelGGL((k_table_gemm_p<7, 3, false>), dim3((unsigned)nwg), dim3(512), 0, st, a, nchunks, nblk3, ws, magic);
+        if (a.src_canonical) hipLaunchKernelGGL((k_table_gemm_p<7, 3, true>), dim3((unsigned)nwg), dim3(512), 0, st, a, nchunks, nblk, ws, magic);
+        else hipLaunchKernelGGL((k_table_gemm_p<7, 3, false>), dim3((unsigned)nwg), dim3(512), 0, st, a, nchunks, nblk, ws, magic);
         return hipGetLastError();
     }
+    // 13 k-steps (recon_secrets_2ddeg, 24 rows per proof): few data rows, so the table is split over several workgroups per row block
+    int msplit = nblk >= 160 ? 1 : (256 + nblk - 1) / nblk;
+    if (msplit > nchunks) msplit = nchunks;
+    const int cpb = (nchunks + msplit - 1) / msplit;
+    msplit = (nchunks + cpb - 1) / cpb;
     const dim3 grid((unsigned)((nblk * msplit + 7) / 8 * 8));
-    if (a.KS == 7 && wide) hipLaunchKernelGGL((k_table_gemm<7, 1, 4>), grid, dim3(512), 0, st, a, nchunks, cpb, nblk, msplit, ws);
-    else if (a.KS == 7) hipLaunchKernelGGL((k_table_gemm<7, 1, 3>), grid, dim3(512), 0, st, a, nchunks, cpb, nblk, msplit, ws);
-    else hipLaunchKernelGGL((k_table_gemm<13, 1, 3>), grid, dim3(512), 0, st, a, nchunks, cpb, nblk, msplit, ws);
+    hipLaunchKernelGGL((k_table_gemm<13, 1, 3>), grid, dim3(512), 0, st, a, nchunks, cpb, nblk, msplit, ws);
     return hipGetLastError();
 }
 
@@ -2733,31 +2200,20 @@ hipError_t launch_gemm(const GemmArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_cols_to_limbs(const uint16_t *P, size_t proof_stride, int row_f, int row_tf, int M, uint8_t *A, size_t a_gstride,
-                                int nproofs, hipStream_t st)
+hipError_t launch_lincomb_stream(const uint16_t *P, size_t proof_stride, const RowMap &rm, const uint8_t *coef, uint16_t *C,
+                                 const int16_t *lin_rows, int J, int nproofs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_cols_to_limbs, dim3(LIN_MPAD / 64, LIN_K / 64, 2 * nproofs), dim3(256), 0, st, P, proof_stride, row_f, row_tf, M, A, a_gstride);
-    return hipGetLastError();
-}
-hipError_t launch_lincomb_fused(const uint16_t *P, size_t proof_stride, const RowMap &rm, const uint8_t *coef, uint16_t *C,
-                                const int16_t *lin_rows, int J, int nproofs, hipStream_t st, int variant)
-{
-    if (variant != 2 && J <= 16 * LS_JT && rm.M > 64 && rm.M <= 80) {
-        // the streaming kernel: the (group, point block) units dealt evenly over two persistent workgroups per CU
-        static const int ncu = [] {
-            int dev = 0, cus = 256;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
-            return cus;
-        }();
-        const int total = (NPTS + 127) / 128 * 2 * nproofs;
-        const int nwg = total < 2 * ncu ? total : 2 * ncu;
-        hipLaunchKernelGGL(k_lincomb_stream, dim3(nwg), dim3(256), 0, st, P, proof_stride, rm.f, rm.tf, rm.M, coef, 2 * nproofs * 8, C, lin_rows, J,
-                           rm.K, rm.s, rm.e, rm.sr, rm.er, 2 * nproofs);
-        return hipGetLastError();
-    }
-    const int nwg = ((NPTS + 127) / 128 * 2 * nproofs + 7) / 8 * 8;
-    hipLaunchKernelGGL(k_lincomb_fused, dim3(nwg), dim3(256), 0, st, P, proof_stride, rm.f, rm.tf, rm.M, coef,
-                       2 * nproofs * 8, C, lin_rows, J, rm.K, rm.s, rm.e, rm.sr, rm.er, 2 * nproofs);
+    if (J > 16 * LS_JT || rm.M <= 64 || rm.M > 80) return hipErrorInvalidValue; // (every Kyber parameter set: J = 74..78, M = 75..79)
+    // the (group, point block) units dealt evenly over two persistent workgroups per CU
+    static const int ncu = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+        return cus;
+    }();
+    const int total = (NPTS + 127) / 128 * 2 * nproofs;
+    const int nwg = total < 2 * ncu ? total : 2 * ncu;
+    hipLaunchKernelGGL(k_lincomb_stream, dim3(nwg), dim3(256), 0, st, P, proof_stride, rm.f, rm.tf, rm.M, coef, 2 * nproofs * 8, C, lin_rows, J,
+                       rm.K, rm.s, rm.e, rm.sr, rm.er, 2 * nproofs);
     return hipGetLastError();
 }
 hipError_t launch_coef_limbs(const uint16_t *alpha, int J, int M, uint8_t *B, int nproofs, hipStream_t st)
@@ -2789,11 +2245,6 @@ hipError_t launch_post_gates(uint16_t *P, size_t proof_stride, const RowMap &rm,
     else hipLaunchKernelGGL(k_post_gates<5>, g, dim3(256), 0, st, P, proof_stride, rm);
     return hipGetLastError();
 }
-hipError_t launch_post_open(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_post_open, dim3((NPTS + 255) / 256, nproofs), dim3(256), 0, st, P, proof_stride, rm);
-    return hipGetLastError();
-}
 hipError_t launch_copy_tails(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st)
 {
     hipLaunchKernelGGL(k_copy_tails, dim3(rm.K, nproofs), dim3(192), 0, st, P, proof_stride, rm);
@@ -2805,19 +2256,12 @@ hipError_t launch_post_relation(uint16_t *P, size_t proof_stride, const RowMap &
     return hipGetLastError();
 }
 
-hipError_t launch_assemble(const AssembleArgs &a, int nfields, size_t off_tcomm, size_t off_comm, size_t off_I,
-                           int nproofs, hipStream_t st, bool grouped)
+hipError_t launch_assemble(const AssembleArgs &a, size_t off_tcomm, size_t off_comm, size_t off_I, int nproofs, hipStream_t st)
 {
-    if (grouped && a.groups && a.ngroups > 0) {
-        const int bpp = a.ngroups * NWIN + (NREST * 16 + 63) / 64;
-        const long nwg = ((long)bpp * nproofs + 7) / 8 * 8;
-        hipLaunchKernelGGL(k_assemble_groups, dim3((unsigned)nwg), dim3(64), 0, st, a, (uint32_t)off_tcomm, (uint32_t)off_comm, (uint32_t)off_I, bpp, nproofs);
-        return hipGetLastError();
-    }
-    const int bpp = a.plan.nrest * NWIN + a.plan.nopen * ((NOPEN + 63) / 64) + (NREST * 16 + 63) / 64;
+    if (!a.groups || a.ngroups <= 0) return hipErrorInvalidValue;
+    const int bpp = a.ngroups * NWIN + (NREST * 16 + 63) / 64;
     const long nwg = ((long)bpp * nproofs + 7) / 8 * 8;
-    hipLaunchKernelGGL(k_assemble_fields, dim3((unsigned)nwg), dim3(64), 0, st, a, (uint32_t)off_tcomm, (uint32_t)off_comm, (uint32_t)off_I, bpp,
-                       nproofs);
+    hipLaunchKernelGGL(k_assemble_groups, dim3((unsigned)nwg), dim3(64), 0, st, a, (uint32_t)off_tcomm, (uint32_t)off_comm, (uint32_t)off_I, bpp, nproofs);
     return hipGetLastError();
 }
 

@@ -45,18 +45,6 @@ __device__ __forceinline__ void kg_load_seed(uint32_t (&seed)[8], const uint8_t 
     }
 }
 
-// buf = sha3_512(d[32] || K): dwords 0..7 public seed, 8..15 noise seed   (kosk.cpp:12-14: the reference hashes d || K)
-__device__ __forceinline__ void kg_seed_hash(const uint8_t *d32, int K, uint32_t (&pub)[8], uint32_t (&noise)[8])
-{
-    uint32_t d[8];
-    kg_load_seed(d, d32);
-    KState s;
-    kg_absorb(s, d, (uint32_t)K, 1, 72, 0x06);
-    keccak_f1600_dev(s);
-#pragma unroll
-    for (int l = 0; l < 4; l++) { pub[2 * l] = s.lo[l]; pub[2 * l + 1] = s.hi[l]; noise[2 * l] = s.lo[4 + l]; noise[2 * l + 1] = s.hi[4 + l]; }
-}
-
 // the 24 bits at bit offset 24 * T of the squeezed block
 template <int T>
 __device__ __forceinline__ uint32_t kg_triple(const KState &s)
@@ -65,32 +53,6 @@ __device__ __forceinline__ uint32_t kg_triple(const KState &s)
     if constexpr (sh == 0) return kdword<k>(s) & 0xFFFFFFu;
     else if constexpr (sh == 8) return kdword<k>(s) >> 8;
     else return __builtin_amdgcn_alignbit(kdword<k + 1>(s), kdword<k>(s), sh) & 0xFFFFFFu;
-}
-
-// A[i][j] (canonical, 256 coefficients at r) from the public seed; XOF input seed || j || i (gen_matrix, transposed == 0)
-__device__ __forceinline__ void kg_gen_matrix(const uint32_t (&pub)[8], int i, int j, int16_t *__restrict__ r, const XofGuard &xof)
-{
-    KState s;
-    kg_absorb(s, pub, (uint32_t)j | ((uint32_t)i << 8), 2, 168, 0x1F);
-    int ctr = 0;
-#pragma unroll 1
-    for (int blk = 0; blk < xof.max_blocks && ctr < 256; blk++) { // 3 blocks suffice with probability 1 - 2^-40; bounded anyway
-        keccak_f1600_dev(s);
-        auto parse = [&]<int... Ts>(std::integer_sequence<int, Ts...>) {
-            (([&] {
-                 const uint32_t x = kg_triple<Ts>(s);
-                 const uint32_t v0 = x & 0xFFFu, v1 = x >> 12;
-                 if (v0 < (uint32_t)Q && ctr < 256) r[ctr++] = (int16_t)v0;
-                 if (v1 < (uint32_t)Q && ctr < 256) r[ctr++] = (int16_t)v1;
-             }()),
-             ...);
-        };
-        parse(std::make_integer_sequence<int, 56>{}); // 168 bytes = 56 triples
-    }
-    if (ctr < 256) { // block limit reached (XofGuard): never a partly written polynomial, and the host hears about it
-        for (; ctr < 256; ctr++) r[ctr] = 0;
-        if (xof.err) *reinterpret_cast<volatile uint32_t *>(xof.err) = DEVERR_XOF_BLOCKS;
-    }
 }
 
 // 8 cbd2 coefficients from 32 bits / 4 cbd3 coefficients from 24 bits (cbd.c:58-107)
@@ -117,41 +79,6 @@ __device__ __forceinline__ uint2 kg_cbd3_triple(uint32_t x)
         o[q] = ((uint32_t)c0 & 0xFFFFu) | ((uint32_t)c1 << 16);
     }
     return make_uint2(o[0], o[1]);
-}
-
-// poly_getnoise_eta1(r, noise seed, nonce): 256 small signed coefficients at r (16-byte aligned)
-__device__ __forceinline__ void kg_noise(const uint32_t (&noise)[8], int nonce, int eta1, int16_t *__restrict__ r)
-{
-    KState s;
-    kg_absorb(s, noise, (uint32_t)nonce, 1, 136, 0x1F);
-    keccak_f1600_dev(s);
-    if (eta1 == 2) { // 128 bytes = 32 dwords, 8 coefficients each
-        auto go = [&]<int... Ws>(std::integer_sequence<int, Ws...>) {
-            ((reinterpret_cast<uint4 *>(r)[Ws] = kg_cbd2_word(kdword<Ws>(s))), ...);
-        };
-        go(std::make_integer_sequence<int, 32>{});
-    } else { // 192 bytes = 64 triples of 4 coefficients: 136 bytes of this block (45 triples + 1 byte), the rest from the next
-        auto go1 = [&]<int... Ts>(std::integer_sequence<int, Ts...>) {
-            ((reinterpret_cast<uint2 *>(r)[Ts] = kg_cbd3_triple(kg_triple<Ts>(s))), ...);
-        };
-        go1(std::make_integer_sequence<int, 45>{});
-        const uint32_t carry = kdword<33>(s) >> 24; // byte 135
-        keccak_f1600_dev(s);
-        // triple 45 = byte 135 of block 1 and bytes 0, 1 of block 2; triples 46.. start at byte 2 of block 2
-        reinterpret_cast<uint2 *>(r)[45] = kg_cbd3_triple(carry | ((kdword<0>(s) & 0xFFFFu) << 8));
-        auto go2 = [&]<int... Us>(std::integer_sequence<int, Us...>) {
-            (([&] {
-                 constexpr int bit = 16 + 24 * Us, k = bit / 32, sh = bit % 32; // bit offset inside block 2
-                 uint32_t x;
-                 if constexpr (sh == 0) x = kdword<k>(s) & 0xFFFFFFu;
-                 else if constexpr (sh == 8) x = kdword<k>(s) >> 8;
-                 else x = __builtin_amdgcn_alignbit(kdword<k + 1>(s), kdword<k>(s), sh) & 0xFFFFFFu;
-                 reinterpret_cast<uint2 *>(r)[46 + Us] = kg_cbd3_triple(x);
-             }()),
-             ...);
-        };
-        go2(std::make_integer_sequence<int, 18>{});
-    }
 }
 
 // ---- the same three samplers on the LANE-PAIR sponge (kosk_keccak_split_dev.hpp; round 5) -----------------------------------------

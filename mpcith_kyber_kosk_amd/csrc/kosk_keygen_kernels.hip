@@ -3,7 +3,7 @@
 // straight from the state registers.
 //   (seed hash, gen_matrix and noise sampling of the PROVER are roles of k_prover_pre, kosk_kernels.hip; their device
 //    functions live in kosk_keygen_dev.hpp)
-//   k_gen_matrix     SHAKE128(seed || j || i) + rej_uniform (verifier)             indcpa.c:124-145, :168-193
+//   k_gen_matrix_pair SHAKE128(seed || j || i) + rej_uniform (verifier)             indcpa.c:124-145, :168-193
 //   k_keygen_pack    t = A o NTT(s) * R^-1 * R + NTT(e), Barrett; pk / sk bytes    kosk.cpp:39-69, poly.c:124-139
 //   k_decode_pk      polyvec_frombytes + seed extraction                           kosk.cpp:94-97, poly.c:151-158
 #include <hip/hip_runtime.h>
@@ -20,20 +20,8 @@ namespace kosk {
 
 __constant__ static const ZetaTable kZetasKg = ZetaTable();
 
-// A[b][i][j][256] canonical from the 32-byte public seed found at seeds + b * seed_stride (the verifier's gen_matrix,
-// kosk.cpp:98-99; the prover's runs as a role of k_prover_pre, kosk_kernels.hip)
-__global__ __launch_bounds__(64) void k_gen_matrix(const uint8_t *__restrict__ seeds, size_t seed_stride, int16_t *__restrict__ A,
-                                                   size_t A_stride, int K, int n, XofGuard xof)
-{
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= n * K * K) return;
-    const int b = t / (K * K), ij = t - b * K * K, i = ij / K, j = ij - i * K;
-    uint32_t pub[8];
-    kg_load_seed(pub, seeds + (size_t)b * seed_stride);
-    kg_gen_matrix(pub, i, j, A + (size_t)b * A_stride + (size_t)ij * 256, xof);
-}
-
-// the same on the lane-pair sponge (kp_gen_matrix): 32 entries per 64-thread block
+// A[b][i][j][256] canonical from the 32-byte public seed found at seeds + b * seed_stride (the verifier's gen_matrix, kosk.cpp:98-99;
+// the prover's runs as a role of k_prover_pre, kosk_kernels.hip), on the lane-pair sponge (kp_gen_matrix): 32 entries per 64-thread block
 __global__ __launch_bounds__(64) void k_gen_matrix_pair(const uint8_t *__restrict__ seeds, size_t seed_stride, int16_t *__restrict__ A,
                                                         size_t A_stride, int K, int n, XofGuard xof)
 {
@@ -106,9 +94,7 @@ hipError_t launch_decode_pk(const uint8_t *pk, size_t pk_stride, uint16_t *t_out
 {
     hipLaunchKernelGGL(k_decode_pk, dim3(K, n), dim3(128), 0, st, pk, pk_stride, t_out, K);
     // gen_matrix from the seed stored behind the packed t (kosk.cpp:96-99)
-    static const bool pair = !(getenv("KOSK_PRE_PAIR") && atoi(getenv("KOSK_PRE_PAIR")) == 0);
-    if (pair) hipLaunchKernelGGL(k_gen_matrix_pair, dim3((n * K * K + 31) / 32), dim3(64), 0, st, pk + 384 * K, pk_stride, A, A_stride, K, n, xof);
-    else hipLaunchKernelGGL(k_gen_matrix, dim3((n * K * K + 63) / 64), dim3(64), 0, st, pk + 384 * K, pk_stride, A, A_stride, K, n, xof);
+    hipLaunchKernelGGL(k_gen_matrix_pair, dim3((n * K * K + 31) / 32), dim3(64), 0, st, pk + 384 * K, pk_stride, A, A_stride, K, n, xof);
     return hipGetLastError();
 }
 

@@ -49,25 +49,6 @@ static int upload_vec(Ctx &c, T **d, const std::vector<T> &v)
     return 0;
 }
 
-hipStream_t side_stream_for(int device)
-{
-    // One extra stream per device for the whole process, created on first use and kept: ROCm deals streams to its few hardware
-    // queues in creation order, and a side stream per context put the MAIN streams of different contexts on the same queue
-    // (what that costs).
-    static std::mutex mu;
-    static std::vector<std::pair<int, hipStream_t>> all;
-    std::lock_guard<std::mutex> lk(mu);
-    for (auto &p : all)
-        if (p.first == device) return p.second;
-    hipStream_t s = nullptr;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    all.emplace_back(device, s);
-    return s;
-}
-
 int ensure_verify_workspace(Ctx &c)
 {
     if (c.verify_ready) return 0;
@@ -180,26 +161,6 @@ int ensure_verify_workspace(Ctx &c)
     HIPCHK(dev(&c.d_odig, (size_t)NOPEN * 32));
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c.h_odig), B * NOPEN * 32, hipHostMallocDefault));
     c.reg_pp(&c.h_odig, (size_t)NOPEN * 32);
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c.h_imgdig), B * 2 * NREST * 32, hipHostMallocDefault));
-    c.reg_pp(&c.h_imgdig, (size_t)2 * NREST * 32);
-    // KOSK_VERIFY_SPLIT=1: also for RESIDENT proofs the host's tables are put together from the images' digest fields (copied
-    // early, beside the first kernels) and the 150 recomputed digests per proof.  Measured slower than copying the whole tables
-    // behind the hashes (profiles/r04_digest_paths.txt: the early copies are blit kernels that run against the verifier's first
-    // kernels), so the default splits only when the caller's host copy of the images makes the early copies unnecessary.
-    c.verify_tables = true;
-    if (const char *e = getenv("KOSK_VERIFY_SPLIT")) c.verify_tables = atoi(e) == 0;
-    // Where the early copies of the images' digest fields run.  Default: the device's legacy NULL stream (hipStream_t 0) -- it
-    // exists anyway and the library's non-blocking streams are not ordered against it.  KOSK_SIDE_STREAM=1: a stream of the
-    // library's own, one per device and process; measured on ROCm 7.2: the mere existence of that fifth stream next to the null
-    // stream and three cohort streams cost 20 % of the throughput (profiles/r04_side_stream.txt), whatever GPU_MAX_HW_QUEUES says.
-    c.side_stream = nullptr;
-    if (!c.verify_tables)
-        if (const char *e = getenv("KOSK_SIDE_STREAM"))
-            if (atoi(e) != 0) {
-                c.side_stream = side_stream_for(c.device);
-                if (!c.side_stream) c.verify_tables = true; // whole tables behind the hashes, as before
-            }
-    for (auto &e : c.ev_img) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | (c.blocking_sync ? hipEventBlockingSync : 0)));
     HIPCHK(hipStreamSynchronize(c.stream)); // every table and the zeroed opened matrix are in HBM before the first verifier kernel is queued
     c.verify_ready = true;
     return 0;
@@ -245,7 +206,6 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     const uint8_t *himg = c.host_img;
     const size_t himg_stride = c.host_img_stride;
     c.host_img = nullptr;
-    c.chunk_n = 0; // (see prove_resident)
     if (n < 1 || n > c.call_cap) { c.err = "batch size out of range"; return -1; }
     // a merged call (kosk_combine.hpp): `segs` lists the callers' parts, each with its own keys and result bytes
     const VerifySeg whole{n, pk, ok, nullptr, nullptr, nullptr};
@@ -318,27 +278,17 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     oh.sel_stride = c.sel_stride;
     oh.prefix = nullptr;
     oh.out = c.d_dig1;
-    // how the host gets its two digest tables (see Ctx::h_imgdig): the 1304 digests per proof and table that the proof itself
-    // carries come from the caller's host copy of the images when there is one, else over the side stream, starting now; only the
-    // 150 recomputed ones per proof follow each round's hash on the context's own stream
-    // device Fiat-Shamir: both tables are put together in HBM anyway (k_disassemble_fields copies the images' 1304 digests per table,
-    // the opened-party hashes store their 150), hashed there, and the host sees nothing of them
-    const bool split_tables = !c.fs_device && (!c.verify_tables || himg != nullptr);
-    if (split_tables && !himg) {
-        const size_t w = (size_t)NREST * 32;
-        for (int r = 0; r < 2; r++) {
-            HIPCHK(hipMemcpy2DAsync(c.h_imgdig + (size_t)r * w, 2 * w, c.d_proof + P.off[r ? F_COMM : F_TCOMM], c.image_stride, w, n,
-                                    hipMemcpyDeviceToHost, c.side_stream));
-            HIPCHK(hipEventRecord(c.ev_img[r], c.side_stream));
-        }
-    }
+    // how the host gets its two digest tables (see Ctx::d_odig): with the caller's host copy of the images at hand only the 150 recomputed
+    // digests per proof follow each round's hash, else the whole tables.  Device Fiat-Shamir: both tables are put together in HBM anyway
+    // (k_disassemble_fields copies the images' 1304 digests per table, the opened-party hashes store their 150), hashed there, and the
+    // host sees nothing of them
+    const bool split_tables = !c.fs_device && himg != nullptr;
     oh.out_compact = split_tables ? c.d_odig : nullptr;
     const size_t dig_bytes = split_tables ? (size_t)n * NOPEN * 32 : (size_t)n * NPARTY * 32;
     // the table of proof b for the host's hash of round r, put together on the worker that hashes it
     auto table_prep = [&](int r) {
         return std::function<void(int)>([&c, himg, himg_stride, r](int b) {
-            const size_t w = (size_t)NREST * 32;
-            const uint8_t *unopened = himg ? himg + (size_t)b * himg_stride + c.P.off[r ? F_COMM : F_TCOMM] : c.h_imgdig + (size_t)b * 2 * w + (size_t)r * w;
+            const uint8_t *unopened = himg + (size_t)b * himg_stride + c.P.off[r ? F_COMM : F_TCOMM];
             assemble_digest_table(c.h_dig + (size_t)b * NPARTY * 32, c.h_Iimg + (size_t)b * NOPEN, unopened, c.h_odig + (size_t)b * NOPEN * 32);
         });
     };
@@ -357,8 +307,8 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     HIPCHK(launch_opened_hash(oh, K, false, n, st)); // Tcomm of the opened parties, read from the image   :22-35
     c.prof_end(PR_V_HASH_TCOMM);
     if (c.fs_device) return 0;
-    if (split_tables) HIPCHK(copy_table_to_host(c, c.h_odig, c.d_odig, dig_bytes));
-    else HIPCHK(copy_round_table(c, c.h_dig, c.d_dig1, n)); // in pieces (Ctx::table_chunks), never in a captured segment
+    if (split_tables) HIPCHK(hipMemcpyAsync(c.h_odig, c.d_odig, dig_bytes, hipMemcpyDeviceToHost, st));
+    else HIPCHK(copy_round_table(c, c.h_dig, c.d_dig1, n));
     return 0;
     }, c.fs_device ? nullptr : split_tables ? c.h_odig : c.h_dig)) return -1; // which table copy the captured segment holds is part of its graph's key
     HIPCHK(hipEventRecord(c.ev, st)); // the opened parties' Tcomm digests are on the host (device Fiat-Shamir: the table is complete in HBM) once this event has passed
@@ -422,7 +372,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     na.out = reinterpret_cast<int16_t *>(c.d_P);
     na.out_gstride = c.proof_stride;
     na.dst_off = c.d_off + c.off_nttsr_er;
-    na.out_canonical = 1; na.fp32 = c.ntt_fp32;
+    na.out_canonical = 1;
     HIPCHK(launch_relation_ntt(na, c.d_A, c.key_stride, c.d_P, c.proof_stride, rm, n, st));
     {
         const GemmSrc xs{c.d_P, c.proof_stride, c.d_gemm2_rows, RS, 0, XLEN};
@@ -438,14 +388,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
         return h;
     };
     const bool hooks = c.fs_device && any_hook();
-    if (!c.fs_device || hooks) HIPCHK(wait_event(c, first_event(c), 3, n));
-    std::atomic<int> gate_err_a{(int)hipSuccess};
-    const std::function<void(int)> gate = [&c, &gate_err_a](int b) { // whole tables in pieces: a worker waits for the piece it reaches
-        const hipError_t e = table_gate_wait(c, b);
-        if (e != hipSuccess) gate_err_a.store((int)e, std::memory_order_relaxed);
-    };
-#define gate_err ((hipError_t)gate_err_a.load(std::memory_order_relaxed))
-    if (split_tables && !himg) HIPCHK(hipEventSynchronize(c.ev_img[0])); // the images' Tcomm fields (under way since the call began)
+    if (!c.fs_device || hooks) HIPCHK(wait_event(c, c.ev, 3, n));
     t1 = now_sec(); c.phase_sec[PH_V1_WAIT] = t1 - t0; t0 = t1;
     auto fire_hooks = [&](int rnd, const uint8_t *d_table) { // as in prove_resident: per caller of a merged run, else the context's own
         bool seg_hooks = false;
@@ -466,18 +409,12 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     if (!c.fs_device) {
         c.path_n[PATH_FS_HOST]++;
         const std::function<void(int)> prep = table_prep(0);
-        fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool, split_tables ? &prep : c.chunk_n > 1 ? &gate : nullptr);
-        HIPCHK(gate_err);
-        HIPCHK(table_done(c));
+        fs_alpha_batch(P, n, c.h_dig, (size_t)NPARTY * 32, c.h_alpha, 80, c.nthreads, c.pool, split_tables ? &prep : nullptr);
     }
     t1 = now_sec(); c.phase_sec[PH_V_FS_ALPHA] = t1 - t0; t0 = t1;
     if (run_segment(c, Ctx::SEG_V2, n, [&]() -> int {
-    const uint16_t *alpha_src = c.h_alpha; // read from the page-locked host table by k_pow_table itself (as the prover's k_coef_limbs)
-    if (c.fs_device) alpha_src = c.d_alpha;
-    else if (!c.small_copy_kernel || !c.alpha_direct) {
-        HIPCHK(copy_small(c, c.d_alpha, 0, c.h_alpha, 0, (size_t)n * 80 * 2, 1, hipMemcpyHostToDevice, st));
-        alpha_src = c.d_alpha;
-    }
+    // host mode: read from the page-locked host table by k_pow_table itself (as the prover's k_coef_limbs); device mode: from HBM
+    const uint16_t *alpha_src = c.fs_device ? c.d_alpha : c.h_alpha;
 
     // ---- V2/V3: beta, gamma, r, NTT_r on the opened columns; reconstruction and NTT check
     HIPCHK(launch_pow_table(alpha_src, P.J, P.M, c.d_pwT, n, st));
@@ -515,7 +452,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
         c.prof_end(PR_V_FS_OPENED);
         c.path_n[PATH_FS_DEVICE]++;
     } else {
-        if (split_tables) HIPCHK(copy_table_to_host(c, c.h_odig, c.d_odig, dig_bytes));
+        if (split_tables) HIPCHK(hipMemcpyAsync(c.h_odig, c.d_odig, dig_bytes, hipMemcpyDeviceToHost, st));
         else HIPCHK(copy_round_table(c, c.h_dig, c.d_dig2, n));
         HIPCHK(hipEventRecord(c.ev, st));
     }
@@ -541,7 +478,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     na.dst_off = nullptr;
     na.npg = NCHK;
     na.npoly = NCHK * n;
-    na.out_canonical = 1; na.fp32 = c.ntt_fp32;
+    na.out_canonical = 1;
     na.cmp_fail = c.d_fail; // NTT(beta_j) is compared with gamma_j (70 polynomials further) as it is produced
     na.cmp_delta = NCHK * 256;
     na.cmp_bit = FB_BETA_GAMMA;
@@ -567,8 +504,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
         c.phase_sec[PH_V_FS_OPEN] = 0;
         return 0;
     }
-    HIPCHK(wait_event(c, first_event(c), 4, n)); // the view digests (or their first piece) are on the host; V2B keeps running
-    if (split_tables && !himg) HIPCHK(hipEventSynchronize(c.ev_img[1]));
+    HIPCHK(wait_event(c, c.ev, 4, n)); // the view digests are on the host; V2B keeps running
     t1 = now_sec(); c.phase_sec[PH_V2_WAIT] = t1 - t0; t0 = t1;
     fire_hooks(1, c.d_dig2);
     if (c.near_end_hook) c.near_end_hook(); // only the host's last round is left: a merged run's sleeping callers get ready for the return
@@ -576,9 +512,7 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     std::vector<uint16_t> &I2 = c.v_I2, &rest2 = c.v_rest2; // every entry that is read below is written by fs_opened_batch first
     {
         const std::function<void(int)> prep = table_prep(1);
-        fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, I2.data(), rest2.data(), c.sel_stride, c.nthreads, c.pool, false, split_tables ? &prep : c.chunk_n > 1 ? &gate : nullptr);
-        HIPCHK(gate_err);
-        HIPCHK(table_done(c));
+        fs_opened_batch(n, c.h_dig, (size_t)NPARTY * 32, I2.data(), rest2.data(), c.sel_stride, c.nthreads, c.pool, false, split_tables ? &prep : nullptr);
     }
     HIPCHK(stream_sync_site(c, 5, n)); // fail masks of V2B
     c.prof_collect();
@@ -595,7 +529,6 @@ int verify_resident(Ctx &c, int n, uint8_t *ok, int pk_mode, const uint8_t *pk, 
     }
     c.phase_sec[PH_V_FS_OPEN] = now_sec() - t0;
     return 0;
-#undef gate_err
 }
 
 } // namespace kosk

@@ -185,70 +185,6 @@ struct OpenedMsg {
     }
 };
 
-template <int K, bool VIEW, int W0, int N>
-__device__ __forceinline__ void opened_absorb_block(KState &s, const OpenedHashArgs &a, const uint8_t *img, const uint16_t *col,
-                                                    const uint16_t *ocol, int i, const uint8_t *prefix)
-{
-    // message words W0 .. W0+N-1 (N <= 68) into lanes 0..16; with VIEW the first 16 words are the 32-byte prefix
-    using Msg = OpenedMsg<K, VIEW>;
-    constexpr int PW = VIEW ? 16 : 0, TOTAL = PW + Msg::WORDS;
-    auto put = [&](auto wc) {
-        constexpr int w = decltype(wc)::value; // word inside this block, even
-        constexpr int gw = W0 + w;
-        if constexpr (gw < TOTAL) {
-            uint32_t v;
-            if constexpr (gw + 1 < PW + 1 && gw < PW) v = *reinterpret_cast<const uint32_t *>(prefix + 2 * gw);
-            else {
-                v = Msg::template word<gw - PW>(a, img, col, ocol, i);
-                if constexpr (gw + 1 < TOTAL) v |= Msg::template word<gw + 1 - PW>(a, img, col, ocol, i) << 16;
-            }
-            if constexpr ((w & 2) == 0) s.lo[w / 4] ^= v;
-            else s.hi[w / 4] ^= v;
-        }
-    };
-    [&]<int... Is>(std::integer_sequence<int, Is...>) { (put(std::integral_constant<int, 2 * Is>{}), ...); }(std::make_integer_sequence<int, 34>{});
-    (void)N;
-}
-
-template <int K, bool VIEW>
-__global__ __launch_bounds__(64) void k_opened_hash(OpenedHashArgs a)
-{
-    const int i = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
-    if (i >= NOPEN) return;
-    using Msg = OpenedMsg<K, VIEW>;
-    constexpr int PW = VIEW ? 16 : 0, TOTAL = PW + Msg::WORDS, NBLK = TOTAL / 68 + 1;
-    const int party = a.opened[(size_t)b * a.sel_stride + i];
-    const uint8_t *img = a.proof + (size_t)b * a.image_stride;
-    const uint16_t *col = a.P + (size_t)b * a.proof_stride + NSEC + party; // s + r, e + r: recomputed shares of every party
-    const uint16_t *ocol = a.O + (size_t)b * a.o_stride + i;               // beta, gamma, u of the opened parties
-    const size_t dig = ((size_t)b * NPARTY + party) * 32;
-    const uint8_t *prefix = VIEW ? a.prefix + dig : nullptr;
-    KState s;
-    kstate_zero(s);
-    [&]<int... Bs>(std::integer_sequence<int, Bs...>) {
-        (([&] {
-             opened_absorb_block<K, VIEW, Bs * 68, 68>(s, a, img, col, ocol, i, prefix);
-             if constexpr (Bs == NBLK - 1) {
-                 constexpr int padbyte = 2 * TOTAL - (NBLK - 1) * 136;
-                 constexpr uint32_t padv = 0x06u << (8 * (padbyte % 4));
-                 if constexpr ((padbyte % 8) < 4) s.lo[padbyte / 8] ^= padv;
-                 else s.hi[padbyte / 8] ^= padv;
-                 s.hi[16] ^= 0x80000000u;
-             }
-             keccak_f1600_dev(s);
-         }()),
-         ...);
-    }(std::make_integer_sequence<int, NBLK>{});
-    uint4 *o = reinterpret_cast<uint4 *>(a.out + dig);
-    o[0] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
-    o[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
-    if (a.out_compact) {
-        uint4 *oc = reinterpret_cast<uint4 *>(a.out_compact + ((size_t)b * NOPEN + i) * 32);
-        oc[0] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
-        oc[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
-    }
-}
-
 // The same hashes on the LANE-PAIR sponge (kosk_keccak_split_dev.hpp; round 5, default): one state on two adjacent lanes -- the even
 // lane holds the low halves of the 25 words, the odd lane the high halves -- 120 instead of 180 vector instructions per lane and
 // round.  These launches are 3 (5 with pairs) waves per proof, every wave alone on its SIMD: their time is the dependent chain of
@@ -322,17 +258,9 @@ __global__ __launch_bounds__(64) void k_opened_hash_pair(OpenedHashArgs a)
 template <int K>
 static void launch_opened_hash_k(const OpenedHashArgs &a, bool view, int nproofs, hipStream_t st)
 {
-    // KOSK_OPENED_HASH_PAIR=0 (per process): one state per lane, as in rounds 1-4
-    static const bool pair = !(getenv("KOSK_OPENED_HASH_PAIR") && atoi(getenv("KOSK_OPENED_HASH_PAIR")) == 0);
-    if (pair) {
-        dim3 grid((2 * NOPEN + 63) / 64, nproofs);
-        if (view) hipLaunchKernelGGL((k_opened_hash_pair<K, true>), grid, dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_opened_hash_pair<K, false>), grid, dim3(64), 0, st, a);
-        return;
-    }
-    dim3 grid((NOPEN + 63) / 64, nproofs);
-    if (view) hipLaunchKernelGGL((k_opened_hash<K, true>), grid, dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_opened_hash<K, false>), grid, dim3(64), 0, st, a);
+    dim3 grid((2 * NOPEN + 63) / 64, nproofs);
+    if (view) hipLaunchKernelGGL((k_opened_hash_pair<K, true>), grid, dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_opened_hash_pair<K, false>), grid, dim3(64), 0, st, a);
 }
 hipError_t launch_opened_hash(const OpenedHashArgs &a, int K, bool view, int nproofs, hipStream_t st)
 {

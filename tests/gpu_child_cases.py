@@ -9,13 +9,16 @@ import os
 from tests import oracle_lib as oracle
 
 
-def _kosk(k, max_batch, **env):
-    """a handle created under the given environment knobs (read by kosk_create, per handle)"""
+def _kosk(k, max_batch, **kw):
+    """a handle created with the given kosk_options fields (lower-case names: streams, combine, fs_mode, ...) and, for the few
+    DEBUG knobs the library still reads from the environment at kosk_create (upper-case names: KOSK_REGISTER, KOSK_GRAPHS), under them"""
     from mpcith_kyber_kosk_amd import api
+    opts = {n: v for n, v in kw.items() if n.islower()}
+    env = {n: v for n, v in kw.items() if not n.islower()}
     old = {name: os.environ.get(name) for name in env}
     os.environ.update({name: str(v) for name, v in env.items()})
     try:
-        return api.Kosk(kyber_k=k, max_batch=max_batch)
+        return api.Kosk(kyber_k=k, max_batch=max_batch, **opts)
     finally:
         for name, v in old.items():
             if v is None:
@@ -25,7 +28,7 @@ def _kosk(k, max_batch, **env):
 
 
 def streamed_chunks(k):
-    """KOSK_STREAMS=3: a call longer than one sub-context is cut into chunks that run on three sub-contexts concurrently; n = 7
+    """streams=3: a call longer than one sub-context is cut into chunks that run on three sub-contexts concurrently; n = 7
     over sub-batches of 2 leaves a ragged last chunk.  Same bytes as the single-context path and the oracle.  The library never
     page-locks the caller's (pageable) buffers -- KOSK_REGISTER=2 of rounds 2-4 is gone and is read as 1 -- so every chunk is staged."""
     from mpcith_kyber_kosk_amd import api
@@ -34,7 +37,7 @@ def streamed_chunks(k):
     plain = api.Kosk(kyber_k=k, max_batch=n)
     pks0, sks0, pis0 = plain.verifiable_keygen(tapes)
     assert plain.path_counts()["copy_direct"] == 0
-    st = _kosk(k, 6, KOSK_STREAMS=3, KOSK_REGISTER=2)  # the retired value: behaves like the default
+    st = _kosk(k, 6, streams=3, KOSK_REGISTER=2)  # the retired value: behaves like the default
     assert st.streams == 3 and st.host_threads >= 1
     pks, sks, pis = st.verifiable_keygen(tapes)
     assert pks == pks0 and sks == sks0 and pis == pis0
@@ -56,7 +59,7 @@ def streamed_chunks(k):
     assert plain.verify(bad, keys) == want
     assert plain.fail_masks(n) == m_st
     assert all((m != 0) == (not w) for m, w in zip(m_st, want))
-    st2 = _kosk(k, 6, KOSK_STREAMS=3)
+    st2 = _kosk(k, 6, streams=3)
     pks2, sks2, pis2 = st2.verifiable_keygen(tapes)
     assert pks2 == pks0 and sks2 == sks0 and pis2 == pis0
     assert st2.verify(bad, keys) == want
@@ -75,7 +78,7 @@ def streamed_loop(k, iters):
     tapes = [oracle.tape_bytes_for(k, 40 + b) for b in range(n)]
     plain = api.Kosk(kyber_k=k, max_batch=n)
     ref = plain.verifiable_keygen(tapes)
-    hs = [_kosk(k, 6, KOSK_STREAMS=3), _kosk(k, 4, KOSK_STREAMS=2), _kosk(k, 6, KOSK_STREAMS=3, KOSK_REGISTER=0), _kosk(k, 3)]
+    hs = [_kosk(k, 6, streams=3), _kosk(k, 4, streams=2), _kosk(k, 6, streams=3, KOSK_REGISTER=0), _kosk(k, 3)]
     for it in range(iters):
         h = hs[it % len(hs)]
         got = h.verifiable_keygen(tapes)
@@ -83,7 +86,7 @@ def streamed_loop(k, iters):
         assert h.verify(got[2], got[0]) == [True] * n, it
         if it % 16 == 5:  # handles come and go while the others stay alive
             hs[1].close()
-            hs[1] = _kosk(k, 4, KOSK_STREAMS=2)
+            hs[1] = _kosk(k, 4, streams=2)
     for h in hs + [plain]:
         h.close()
     print("streamed_loop ok", k, iters)
@@ -99,7 +102,7 @@ def errors_do_not_kill(k):
     assert lib.kosk_create(C.byref(h), 0, 7, 4) != 0 and b"kyber_k" in lib.kosk_last_error(None)
     assert lib.kosk_create(C.byref(h), 0, k, 0) != 0 and b"max_batch" in lib.kosk_last_error(None)
     assert lib.kosk_create(C.byref(h), 99, k, 1) != 0 and lib.kosk_last_error(None) != b""
-    st = _kosk(k, 4, KOSK_STREAMS=2)
+    st = _kosk(k, 4, streams=2)
     tapes = [oracle.tape_bytes_for(k, 90 + b) for b in range(5)]
     guard = C.create_string_buffer(64)
     assert lib.kosk_verifiable_keygen_batch(st.handle, 5, None, 0, None, guard, guard) != 0
@@ -137,7 +140,7 @@ def pinned_buffers(k):
     ref = plain.verifiable_keygen(tapes)
     blob = b"".join(tapes)
     for streams, cap, reg in ((1, n, 1), (2, 4, 1), (2, 4, 0)):
-        h = _kosk(k, cap, KOSK_STREAMS=streams, KOSK_REGISTER=reg)
+        h = _kosk(k, cap, streams=streams, KOSK_REGISTER=reg)
         nbytes = h.proof_bytes * n
         ptr = lib.kosk_host_alloc(nbytes)
         assert ptr
@@ -189,27 +192,8 @@ def big_batches():
     print("big_batches ok")
 
 
-def process_wide_knobs(n):
-    """The per-PROCESS kernel knobs (read once by the first launch, so they need a process of their own; the caller sets them in
-    this child's environment): KOSK_TG_WIDE=1 -- 64 data rows per workgroup in the expansion product where that takes fewer rounds,
-    which is the case at 138 proofs = 29 946 rows per launch -- and KOSK_TG_STORE16=0 -- 8-byte stores only.  Same bytes as the
-    oracle, every proof verifies."""
-    from mpcith_kyber_kosk_amd import api
-    k = 3
-    ctx = api.Kosk(kyber_k=k, max_batch=n)
-    tapes = [oracle.tape_bytes_for(k, 7000 + b) for b in range(n)]
-    pks, sks, pis = ctx.verifiable_keygen(tapes)
-    for b in sorted({0, n // 2, n - 1}):
-        opk, osk, opi, _, _ = oracle.verifiable_keygen(k, tapes[b])
-        assert (pks[b], sks[b], pis[b]) == (opk, osk, opi), b
-    assert ctx.verify(pis, pks) == [True] * n
-    assert ctx.path_counts()["table_gemm"] > 0
-    ctx.close()
-    print("process_wide_knobs ok", n, os.environ.get("KOSK_TG_WIDE"), os.environ.get("KOSK_TG_STORE16"))
-
-
 def combined_calls(k, threads=6, rounds=4, min_merge=0.5):
-    """KOSK_COMBINE=3: six caller threads, each with its own handle and its own small resident calls.  The calls of a cohort's
+    """combine=3: six caller threads, each with its own handle and its own small resident calls.  The calls of a cohort's
     members are served by merged pipeline runs; every caller must get exactly what an uncombined handle gives it -- pk, sk, proof
     images, resident digest tables, verify bits and fail masks byte for byte -- with host tapes, device tapes read by a merged
     run, a short (ragged) batch on one member, and given / resident public keys.  The oracle pins three of the proofs."""
@@ -220,7 +204,7 @@ def combined_calls(k, threads=6, rounds=4, min_merge=0.5):
     lib = api.lib
     per = 3
     plain = api.Kosk(kyber_k=k, max_batch=per)
-    hs = [_kosk(k, per, KOSK_COMBINE=3, KOSK_COMBINE_WAIT_US=200000, KOSK_COMBINE_IDLE_US=100000) for _ in range(threads)]
+    hs = [_kosk(k, per, combine=3, combine_wait_us=200000, combine_idle_us=100000) for _ in range(threads)]
     stride = (plain.tape_bytes + 63) // 64 * 64
     # what every (thread, round) must produce: from the uncombined handle
     want = {}
@@ -308,7 +292,7 @@ def combined_calls(k, threads=6, rounds=4, min_merge=0.5):
     assert hs[1].verify(got[2], got[0]) == [True] * per
     assert hs[0].fetch_proofs(per) == want[0, rounds - 1][2]  # neighbour's resident proofs untouched
     # pk == NULL without resident keys on a member: an error for that caller alone
-    fresh = _kosk(k, per, KOSK_COMBINE=3)
+    fresh = _kosk(k, per, combine=3)
     okb = C.create_string_buffer(per)
     assert lib.kosk_verify_resident_pk(fresh.handle, per, None, okb) != 0 and b"resident public keys" in lib.kosk_last_error(fresh.handle)
     for h in hs + [plain, fresh]:
@@ -316,9 +300,9 @@ def combined_calls(k, threads=6, rounds=4, min_merge=0.5):
     print("combined_calls ok", k, "mean callers per run %.2f" % (members / calls))
 
 
-def line_of_record_shape(k=3, per=46, callers=3, rounds=3, table_chunks=1, fs_device=0):
+def line_of_record_shape(k=3, per=46, callers=3, rounds=3, fs_device=0):
     """The shape bench.py's line of record runs (bench.py: Slot.step), checked byte for byte: `callers` caller threads of ONE cohort
-    (KOSK_COMBINE=callers: 6 is the bench's default since round 5, 4 and 3 its side runs), each with 46 Kyber-768 proofs per call on DEVICE tapes with a 64-byte-aligned stride that a merged run reads in
+    (combine=callers: 6 is the bench's default since round 5, 4 and 3 its side runs), each with 46 Kyber-768 proofs per call on DEVICE tapes with a 64-byte-aligned stride that a merged run reads in
     place (the tape pointer table of the first kernel), the raw resident entry points with the key generation's pk / sk staying
     resident for the verifier (pk == NULL) -- so every launch covers 138 proofs: the single-buffer instantiation of the commitment
     hash (3 174 waves), three rounds of row blocks in the expansion product.  Every caller's pk / sk / proof images / both digest
@@ -331,10 +315,10 @@ def line_of_record_shape(k=3, per=46, callers=3, rounds=3, table_chunks=1, fs_de
     from mpcith_kyber_kosk_amd import api
     lib = api.lib
     plain = api.Kosk(kyber_k=k, max_batch=per)
-    # fs_device=1: the cohort runs its Fiat-Shamir rounds on the GPU (kosk_options::fs_mode through the environment twin KOSK_FS_DEVICE);
+    # fs_device=1: the cohort runs its Fiat-Shamir rounds on the GPU (kosk_options::fs_mode);
     # `plain`, the handle everything is compared with, hashes on the host
-    hs = [_kosk(k, per, KOSK_COMBINE=callers, KOSK_COMBINE_WAIT_US=5000000, KOSK_COMBINE_IDLE_US=2000000, KOSK_TABLE_CHUNKS=table_chunks,
-                KOSK_FS_DEVICE=fs_device) for _ in range(callers)]
+    hs = [_kosk(k, per, combine=callers, combine_wait_us=5000000, combine_idle_us=2000000,
+                fs_mode=fs_device) for _ in range(callers)]
     stride = (plain.tape_bytes + 63) // 64 * 64
     nsets = rounds
     tapes = {(t, r): [oracle.tape_bytes_for(k, 20000 + ((t * nsets) + r) * per + b) for b in range(per)] for t in range(callers) for r in range(nsets)}
@@ -406,9 +390,6 @@ def line_of_record_shape(k=3, per=46, callers=3, rounds=3, table_chunks=1, fs_de
     assert members == callers * calls, (calls, members)  # every checked call ran in a merged run of all the cohort's callers
     pc = hs[0].path_counts()
     assert sum(h.path_counts()["hash_dma"] for h in hs) > 0 and all(h.path_counts()["hash_plain"] == 0 for h in hs), pc
-    # one copy per round by default; KOSK_TABLE_CHUNKS=n: every merged run's four tables reached the host in pieces
-    nchunked = sum(h.path_counts()["table_chunks"] for h in hs)
-    assert (nchunked == 0) if (table_chunks < 2 or fs_device) else (nchunked >= 4 * nsets), nchunked
     nfs_dev, nfs_host, ncopy = (sum(h.path_counts()[nm] for h in hs) for nm in ("fs_device", "fs_host", "digest_copy"))
     assert (nfs_dev >= 4 * nsets and nfs_host == 0 and ncopy == 0) if fs_device else (nfs_dev == 0 and nfs_host >= 4 * nsets), (nfs_dev, nfs_host, ncopy)
     assert plain.path_counts()["fs_device"] == 0
@@ -425,7 +406,7 @@ def member_big_batch_stays_in_its_block(k=3, per=3):
     import threading
     from mpcith_kyber_kosk_amd import api
     plain = api.Kosk(kyber_k=k, max_batch=per)
-    hs = [_kosk(k, per, KOSK_COMBINE=3, KOSK_COMBINE_WAIT_US=2000, KOSK_COMBINE_IDLE_US=500) for _ in range(3)]
+    hs = [_kosk(k, per, combine=3, combine_wait_us=2000, combine_idle_us=500) for _ in range(3)]
     n_big = 2 * per + 1
     big_tapes = [oracle.tape_bytes_for(k, 7000 + b) for b in range(n_big)]
     want_big = plain.verifiable_keygen(big_tapes)
@@ -484,7 +465,7 @@ def combined_members_come_and_go(k):
     from mpcith_kyber_kosk_amd import api
     per = 2
     plain = api.Kosk(kyber_k=k, max_batch=per)
-    mk = lambda: _kosk(k, per, KOSK_COMBINE=3, KOSK_COMBINE_WAIT_US=100000, KOSK_COMBINE_IDLE_US=50000)
+    mk = lambda: _kosk(k, per, combine=3, combine_wait_us=100000, combine_idle_us=50000)
     tapes = [[oracle.tape_bytes_for(k, 9000 + t * per + b) for b in range(per)] for t in range(5)]
     want = []
     for tp in tapes:

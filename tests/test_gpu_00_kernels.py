@@ -108,33 +108,6 @@ def test_ntt256_matches_oracle(torch, ctx, oracle):
     assert out.min() >= -1664 and out.max() <= 1664
 
 
-def test_ntt256_packed_fp32_variant(torch, oracle, monkeypatch):
-    """KOSK_NTT_FP32=1 selects the packed-fp32 butterflies (operands pinned to VGPRs, see the HAZARD note at k_ntt256_fp32):
-    same outputs as poly_ntt, bit for bit, on the kernel entry point and through a whole prove + verify."""
-    from mpcith_kyber_kosk_amd import api
-    monkeypatch.setenv("KOSK_NTT_FP32", "1")
-    c = api.Kosk(kyber_k=3, max_batch=2)
-    rng = np.random.default_rng(8)
-    n = 2000 + 5
-    a = rng.integers(-3328, 3329, size=(n, 256), dtype=np.int16)
-    a[0] = 3328; a[1] = -3328; a[2] = 0; a[3] = np.arange(256) % 3329
-    d_in = _dev(torch, a)
-    d_out = torch.zeros_like(d_in)
-    torch.cuda.synchronize()  # torch fills / copies run on the null stream; the library streams are not ordered against it
-    c.ntt256_batch(d_in.data_ptr(), d_out.data_ptr(), n)
-    c.synchronize()
-    out = d_out.cpu().numpy()
-    for i in list(range(0, n, 29)) + [0, 1, 2, 3, n - 1]:
-        assert np.array_equal(out[i], oracle.poly_ntt(a[i])), i
-    assert out.min() >= -1664 and out.max() <= 1664
-    tapes = [oracle.tape_bytes_for(3, 70 + b) for b in range(2)]
-    c.verifiable_keygen_resident(tapes)
-    pis = c.fetch_proofs(2)
-    for b in range(2):
-        assert pis[b] == oracle.verifiable_keygen(3, tapes[b])[2]
-    assert c.verify_resident_pk(2) == [True, True]
-    c.close()
-
 
 @pytest.mark.parametrize("n", [300, 9982])  # 9 982 rows = 46 proofs: every wave walks 10-11 table chunks (the pipelined epilogue's steady state)
 def test_lagrange_expand_and_recon_match_oracle(n, torch, ctx, oracle):

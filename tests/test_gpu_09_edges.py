@@ -1,4 +1,4 @@
-"""GPU edge cases of the batch ABI: empty and ragged batches, the chunk-parallel host-buffer path (KOSK_STREAMS > 1), and
+"""GPU edge cases of the batch ABI: empty and ragged batches, the chunk-parallel host-buffer path (kosk_options::streams > 1), and
 batches larger than the context (chunking), all against the single-context path and the CPU oracle, bit for bit."""
 import ctypes as C
 
@@ -63,13 +63,6 @@ def test_host_paths_under_glibc_heap_checking(torch_cuda, gpu_child):
     assert "heap-checked ok" in out
 
 
-@pytest.mark.parametrize("env,n", [({"KOSK_TG_WIDE": "1"}, 138), ({"KOSK_TG_STORE16": "0"}, 5)])
-def test_per_process_table_product_knobs_do_not_change_results(env, n, torch_cuda, gpu_child):
-    """tests/gpu_child_cases.py: process_wide_knobs -- the two table-product knobs that are read once per process."""
-    out = gpu_child("from tests.gpu_child_cases import process_wide_knobs; process_wide_knobs(%d)" % n, env=env)
-    assert "process_wide_knobs ok %d" % n in out
-
-
 def test_abi_errors_are_return_codes(torch_cuda, gpu_child):
     out = gpu_child("from tests.gpu_child_cases import errors_do_not_kill; errors_do_not_kill(2)")
     assert "errors_do_not_kill ok" in out
@@ -112,93 +105,21 @@ def test_degenerate_randomness_tapes(k, oracle, torch_cuda):
     ctx.close()
 
 
-def test_split_commitment_launches_give_identical_proofs(oracle, torch_cuda, monkeypatch):
-    """KOSK_HASH_SPLIT=1 + KOSK_HASH_PRIMER=1 (opt-in): 46 proofs are hashed as 44 + 2 behind a placement primer.  Same bytes as
-    the default single launch; the two proofs of the second launch also against the oracle."""
-    from mpcith_kyber_kosk_amd import api
-    k, n = 3, 46
-    tapes = [oracle.tape_bytes_for(k, 300 + b) for b in range(n)]
-    plain = api.Kosk(kyber_k=k, max_batch=n)
-    assert plain.commit_launch_groups(n) == n
-    ref = plain.verifiable_keygen(tapes)
-    plain.close()
-    monkeypatch.setenv("KOSK_HASH_SPLIT", "1")
-    monkeypatch.setenv("KOSK_HASH_PRIMER", "1")
-    ctx = api.Kosk(kyber_k=k, max_batch=n)
-    assert ctx.commit_launch_groups(n) == 44 and ctx.commit_launch_groups(44) == 44 and ctx.commit_launch_groups(3) == 3
-    got = ctx.verifiable_keygen(tapes)
-    assert got == ref
-    pc = ctx.path_counts()
-    assert pc["hash_primer"] >= 2 and pc["hash_dma"] >= 4, pc   # two rounds x (44-proof launch behind a primer + 2-proof launch)
-    for b in (44, 45):
-        opk, osk, opi, _, _ = oracle.verifiable_keygen(k, tapes[b])
-        assert (got[0][b], got[1][b], got[2][b]) == (opk, osk, opi)
-    assert ctx.verify(got[2], got[0]) == [True] * n
-    ctx.close()
-
-
-@pytest.mark.parametrize("n", [49, 64])
-def test_digest_tables_copied_in_pieces_give_identical_results(n, oracle, torch_cuda, monkeypatch):
-    """KOSK_TABLE_CHUNKS=n (opt-in): batches of >= 48 proofs send each round's digest table to the host in n pieces of whole 8-proof
-    groups and the host's workers wait for the piece they reach (csrc/kosk_ctx.cpp: copy_round_table, table_gate_wait).  A ragged
-    batch (49 = 24 + 24 + 1) and an even one, prover and resident verifier: same keys, proof images, digest tables and verify bits
-    as the default's one copy per round, in three and in four pieces; first / last proof of each piece against the oracle; a corrupted
-    proof in the LAST piece is still rejected (its table reached the host)."""
-    import torch
-    from mpcith_kyber_kosk_amd import api
-    k = 2
-    tapes = [oracle.tape_bytes_for(k, 7000 + b) for b in range(n)]
-    one = api.Kosk(kyber_k=k, max_batch=n)
-
-    def run(ctx):
-        ctx.verifiable_keygen_resident(tapes)
-        pk, sk = ctx.keys(n)
-        bits = ctx.verify_resident_pk(n)
-        return pk, sk, ctx.fetch_proofs(n), bits, [torch.as_tensor(ctx.resident_digests(i, n), device="cuda").cpu().numpy().tobytes() for i in (0, 1)]
-    ref = run(one)
-    assert one.path_counts()["table_chunks"] == 0 and ref[3] == [True] * n
-    for b in (0, 23, 24, 47, 48, n - 1):
-        opk, osk, opi, _, _ = oracle.verifiable_keygen(k, tapes[b])
-        assert (ref[0][b], ref[1][b], ref[2][b]) == (opk, osk, opi), b
-    for chunks in ("3", "4"):
-        monkeypatch.setenv("KOSK_TABLE_CHUNKS", chunks)
-        ctx = api.Kosk(kyber_k=k, max_batch=n)
-        monkeypatch.delenv("KOSK_TABLE_CHUNKS")
-        assert run(ctx) == ref, chunks
-        assert ctx.path_counts()["table_chunks"] == 4, ctx.path_counts()  # two rounds of the prover, two of the verifier
-        # host-buffer verify of the same proofs takes the split tables (150 recomputed digests per proof: one small copy)
-        bad = bytearray(ref[2][n - 1]); bad[oracle.params(k).off[0] + 9] ^= 2
-        pis = list(ref[2][:n - 1]) + [bytes(bad)]
-        assert ctx.verify(pis, ref[0]) == [True] * (n - 1) + [False]
-        # ... and the resident verifier with pieces, on a batch whose last proof is corrupted in HBM
-        ctx.stage_verifier_inputs(pis, ref[0])
-        assert ctx.verify_resident(n) == [True] * (n - 1) + [False]
-        assert ctx.path_counts()["table_chunks"] == 6
-        ctx.close()
-    one.close()
-
-
-KNOBS = {  # knob -> (path counter that must be > 0 on the knob's handle, counter that must stay 0 there)
-    "KOSK_TABLE_GEMM=0": ("limb_gemm", "table_gemm"),
-    "KOSK_HASH_DMA=0": ("hash_plain", "hash_dma"),
-    "KOSK_LINCOMB_FUSED=0": ("limb_gemm", "lincomb_stream"),
-    "KOSK_LINCOMB_FUSED=2": ("lincomb_oneshot", "lincomb_stream"),
-    "KOSK_ASSEMBLE_GROUPS=0": ("assemble_fields", "assemble_groups"),
-    "KOSK_WAIT_NAP=0": (None, None),
-    "KOSK_NTT_FP32=1": ("ntt_fp32", "ntt_int"),
-    "KOSK_BLOCKING_SYNC=1": (None, None),
-    "KOSK_GRAPHS=1": ("graph_replay", None),
-    "KOSK_DIGEST_DIRECT=1": ("digest_direct", "digest_copy"),
-    "KOSK_COPY_WAVES=256": ("copy_kernel", None),
-    "KOSK_SMALL_COPY_KERNEL=0": (None, "small_copy_kernel"),
+KNOBS = {  # handle setting -> (path counter that must be > 0 on that handle, counter that must stay 0 there)
+    "KOSK_WAIT_NAP=0": (None, None),        # debug knob (environment): waits spin throughout
+    "KOSK_GRAPHS=1": ("graph_replay", None),  # debug knob: the segments between host rounds as replayed hipGraphs
+    "blocking_sync=1": (None, None),          # option: the handle's host waits sleep on events
+    "host_threads=2": (None, None),           # option: two Fiat-Shamir workers
+    "fs_mode=1": ("fs_device", "fs_host"),    # option: the Fiat-Shamir hashes on the device
 }
 
 
 @pytest.mark.parametrize("knob", list(KNOBS))
-def test_documented_knobs_do_not_change_results(knob, oracle, torch_cuda, monkeypatch):
-    """Every runtime knob of INTEGRATION.md 5 selects another kernel or another way of waiting, never other bytes: proofs, keys
-    and verify bits equal the default context's (which the other tests pin to the oracle), for K = 3 and a K = 4 spot check.
-    The knobs are per handle (read by kosk_create); kosk_path_count proves that the alternative path is the one that ran."""
+def test_handle_settings_do_not_change_results(knob, oracle, torch_cuda, monkeypatch):
+    """The handle options (kosk_options, lower case) and the two debug knobs that remain in the environment (upper case)
+    select another way of waiting, of launching or another place for the Fiat-Shamir hashes, never other bytes: proofs, keys and verify
+    bits equal the default handle's (which the other tests pin to the oracle), for K = 3 and a K = 4 spot check.  kosk_path_count proves
+    which path ran.  (The losing kernel variants that rounds 2-5 kept behind knobs are gone: DESIGN.md 16.5.)"""
     from mpcith_kyber_kosk_amd import api
     name, val = knob.split("=")
     must, must_not = KNOBS[knob]
@@ -207,12 +128,15 @@ def test_documented_knobs_do_not_change_results(knob, oracle, torch_cuda, monkey
         base = api.Kosk(kyber_k=k, max_batch=n)
         ref = base.verifiable_keygen(tapes)
         pc0 = base.path_counts()
-        assert pc0["table_gemm"] > 0 and pc0["hash_dma"] > 0 and pc0["ntt_int"] > 0 and pc0["graph_replay"] == 0 and pc0["hash_plain"] == 0
-        assert pc0["lincomb_stream"] > 0 and pc0["lincomb_oneshot"] == 0  # the default beta / gamma kernel
-        assert pc0["small_copy_kernel"] > 0  # the default: challenge vectors, opened lists, key records and fail masks move by kernel
-        monkeypatch.setenv(name, val)
-        ctx = api.Kosk(kyber_k=k, max_batch=n)
-        monkeypatch.delenv(name)
+        assert pc0["table_gemm"] > 0 and pc0["hash_dma"] > 0 and pc0["graph_replay"] == 0 and pc0["hash_plain"] == 0
+        assert pc0["fs_host"] > 0 and pc0["fs_device"] == 0 and pc0["digest_copy"] > 0  # the default: the host hashes the digest tables
+        assert pc0["small_copy_kernel"] > 0  # challenge vectors, opened lists, key records and fail masks move by kernel
+        if name.islower():
+            ctx = api.Kosk(kyber_k=k, max_batch=n, **{name: int(val)})
+        else:
+            monkeypatch.setenv(name, val)
+            ctx = api.Kosk(kyber_k=k, max_batch=n)
+            monkeypatch.delenv(name)
         # GRAPHS captures at the resident split (the keygen-in-front call never captures its first segment, but P1B.. do)
         got = ctx.verifiable_keygen(tapes)
         assert got == ref
@@ -220,17 +144,34 @@ def test_documented_knobs_do_not_change_results(knob, oracle, torch_cuda, monkey
         if knob == "KOSK_GRAPHS=1":
             got2 = ctx.verifiable_keygen(tapes)   # second call replays the captured segments
             assert got2 == ref
+        if knob == "host_threads=2":
+            assert ctx.host_threads == 2
         pc = ctx.path_counts()
         if must:
             assert pc[must] > 0, (knob, pc)
         if must_not:
             assert pc[must_not] == 0, (knob, pc)
-        # the default handle created earlier is unaffected by the knob (per handle, not per process)
+        # the default handle created earlier is unaffected (per handle, not per process)
         assert base.verifiable_keygen(tapes) == ref and base.path_counts()["hash_plain"] == 0
         base.close()
         bad = bytearray(got[2][0]); bad[oracle.params(k).off[0] + 7] ^= 4  # an f share of an opened party: always read
         assert ctx.verify([bytes(bad)], [got[0][0]]) == [False]
         ctx.close()
+
+
+def test_retired_environment_knobs_are_ignored(oracle, torch_cuda, monkeypatch):
+    """what a host decides per handle is in kosk_options since round 6: the variables rounds 2-5 read at kosk_create no longer change anything"""
+    from mpcith_kyber_kosk_amd import api
+    for name, val in (("KOSK_STREAMS", "3"), ("KOSK_COMBINE", "3"), ("KOSK_STRICT_ENCODING", "0"), ("KOSK_FS_DEVICE", "1"), ("KOSK_HOST_THREADS", "1"),
+                      ("KOSK_LINCOMB_FUSED", "2"), ("KOSK_ASSEMBLE_GROUPS", "0"), ("KOSK_DIGEST_DIRECT", "1"), ("KOSK_NTT_FP32", "1")):
+        monkeypatch.setenv(name, val)
+    ctx = api.Kosk(kyber_k=2, max_batch=2)
+    tapes = [oracle.tape_bytes_for(2, 0)]
+    pks, sks, pis = ctx.verifiable_keygen(tapes)
+    assert oracle.verifiable_keygen(2, tapes[0])[:3] == (pks[0], sks[0], pis[0])
+    pc = ctx.path_counts()
+    assert ctx.streams == 1 and ctx.combine_stats() == (0, 0) and pc["fs_host"] > 0 and pc["fs_device"] == 0, pc
+    ctx.close()
 
 
 def test_graphs_with_alternating_device_tape_buffers(oracle, torch_cuda, monkeypatch):

@@ -1,4 +1,4 @@
-"""GPU tests of call combining (KOSK_COMBINE, include/kosk_mi355x.h): several caller threads, one handle each, their resident
+"""GPU tests of call combining (kosk_options::combine, include/kosk_mi355x.h): several caller threads, one handle each, their resident
 calls served by merged pipeline runs.  In a fresh child process like every multi-threaded / multi-handle case."""
 import pytest
 
@@ -33,14 +33,13 @@ def test_cohort_members_come_and_go(torch_cuda, gpu_child):
     assert "combined_members_come_and_go ok 3" in out
 
 
-@pytest.mark.parametrize("callers,chunks", [(6, 1), (4, 1), (3, 1), (4, 3)])
-def test_line_of_record_shape(callers, chunks, torch_cuda, gpu_child):
-    """tests/gpu_child_cases.py: line_of_record_shape -- bench.py's arrangement (KOSK_COMBINE=6 by default, 4 and 3 for the side runs:
-    that many caller threads x 46 Kyber-768 proofs on device tapes read in place by merged 276- / 184- / 138-proof runs, raw
-    resident entry points, resident public keys) against an uncombined handle byte for
-    byte and against the oracle (proof images, keys, both digest tables); once with the merged runs' digest tables going to the host
-    in three pieces (KOSK_TABLE_CHUNKS=3, opt-in)."""
-    out = gpu_child("from tests.gpu_child_cases import line_of_record_shape; line_of_record_shape(callers=%d, table_chunks=%d)" % (callers, chunks))
+@pytest.mark.parametrize("callers", [6, 4, 3])
+def test_line_of_record_shape(callers, torch_cuda, gpu_child):
+    """tests/gpu_child_cases.py: line_of_record_shape -- bench.py's arrangement (kosk_options::combine = 6 by default, 4 and 3 for the side
+    runs: that many caller threads x 46 Kyber-768 proofs on device tapes read in place by merged 276- / 184- / 138-proof runs, raw
+    resident entry points, resident public keys) against an uncombined handle byte for byte and against the oracle (proof images, keys,
+    both digest tables)."""
+    out = gpu_child("from tests.gpu_child_cases import line_of_record_shape; line_of_record_shape(callers=%d)" % callers)
     assert "line_of_record_shape ok 3 46 %d callers per run %d.00" % (callers, callers) in out
 
 

@@ -82,14 +82,15 @@ def test_host_budget_per_rank():
     import bench
     assert bench.host_budget(256, 1, 6, 6) == (6, False)
     assert bench.host_budget(256, 8, 4, 6) == (6, False)      # 32 cores per rank >= 4 x 7
-    assert bench.host_budget(128, 8, 6, 6) == (5, True)       # 16 cores per rank, 6 slots: 2 * 16 // 6 = 5
+    assert bench.host_budget(128, 8, 6, 6) == (5, False)      # 16 cores per rank, 6 slots: 2 * 16 // 6 = 5; napping waits from 12 cores up
     assert bench.host_budget(64, 8, 6, 6) == (3, True)        # 8 cores per rank: the floor of three
     assert bench.host_budget(8, 8, 4, 8) == (2, True)         # one core per rank: the floor of two
     assert bench.host_budget(1, 1, 1, 6) == (2, True)
     # the default configuration since round 5: three cohorts of six callers with three workers each (18 per merged run)
     assert bench.CONFIGS[3]["slots"] == 18 and bench.CONFIGS[3]["combine"] == 6 and bench.CONFIGS[3]["threads"] == 3
     assert bench.host_budget(256, 1, 3, 18) == (18, False)    # one rank on a whole host: 3 per caller, spinning waits
-    assert bench.host_budget(256, 8, 3, 18) == (18, True)     # a rank of eight on 32 cores: sleeping waits, still 18 // 6 = 3 per caller
+    assert bench.host_budget(256, 8, 3, 18) == (18, False)    # a rank of eight on 32 cores: 18 // 6 = 3 per caller, the default waits
+    assert bench.host_budget(16, 1, 3, 18) == (10, False)     # ONE rank on a 16-core quota (the driver's N = 1 run): as round 5's line
     assert bench.host_budget(64, 8, 3, 18) == (5, True)       # 8 cores per rank: 2 * 8 // 3 = 5 per cohort -> the floor of three per caller
     assert bench.threads_per_caller(5, True, 6, 8) == 3
     # the driver's container (round 5): 256 hardware threads visible, a CPU quota of 16 cores, eight ranks -> two cores per rank:
@@ -98,6 +99,7 @@ def test_host_budget_per_rank():
     assert bench.threads_per_caller(2, True, 6, 16 // 8) == 2
     assert bench.threads_per_caller(18, False, 6, 256) == 3
     assert bench.threads_per_caller(18, True, 6, 32) == 3
+    assert bench.threads_per_caller(10, False, 6, 16) == 3
 
 
 def test_usable_host_cores_honours_the_cgroup_quota(monkeypatch):

@@ -1,14 +1,11 @@
-"""Diagnostic: which calls of barrier-aligned caller threads end up merged (KOSK_COMBINE=3).  Prints, per thread and call, the size
+"""Diagnostic: which calls of barrier-aligned caller threads end up merged (kosk_options::combine = 3).  Prints, per thread and call, the size
 of the run that served it and the time since the previous combiner call of that thread."""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["KOSK_COMBINE"] = "3"
-os.environ.setdefault("KOSK_COMBINE_WAIT_US", "200000")
-os.environ.setdefault("KOSK_COMBINE_IDLE_US", "100000")
 from mpcith_kyber_kosk_amd import api
 from tests import oracle_lib as oracle
 k, per, threads, rounds = 2, 3, 6, 4
-hs = [api.Kosk(kyber_k=k, max_batch=per) for _ in range(threads)]
+hs = [api.Kosk(kyber_k=k, max_batch=per, combine=3, combine_wait_us=200000, combine_idle_us=100000) for _ in range(threads)]
 tapes = [[oracle.tape_bytes_for(k, 100 + t * per + b) for b in range(per)] for t in range(threads)]
 barrier = threading.Barrier(threads)
 log = [[] for _ in range(threads)]

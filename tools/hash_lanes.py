@@ -1,12 +1,11 @@
 #!/usr/bin/env python3
-"""View-hash kernel time vs lane count, both load paths (KOSK_HASH_DMA=0: two-byte gathers, default: LDS-DMA staging).
+"""View-hash kernel time vs lane count, LDS-DMA staged load path (the gather path of rounds 1-2 is what unaligned rows still get: profiles/r02_hash_lanes.txt).
 Not product code.  usage: hash_lanes.py [lanes ...]"""
 import os, sys, torch
 sys.path.insert(0, ".")
 from mpcith_kyber_kosk_amd import api
 ctx = api.Kosk(kyber_k=3, max_batch=46, device=0)
 g = torch.Generator(device="cuda"); g.manual_seed(1)
-print("path", "dma" if os.environ.get("KOSK_HASH_DMA", "1") != "0" else "gather")
 for lanes in [int(x) for x in sys.argv[1:]] or [32768, 65536, 66880, 131072, 262144, 1048576]:
     rows = torch.randint(0, 3329, (220, lanes), dtype=torch.int16, device="cuda", generator=g)
     pre = torch.randint(0, 256, (lanes, 32), dtype=torch.uint8, device="cuda", generator=g)

@@ -1,12 +1,12 @@
 """Workload for the PMC passes: one merged run of the bench configuration -- 276 proofs, what a cohort of six 46-proof callers sends
-through every launch (KOSK_COMBINE=6; PMC_PROOFS=184 / 138: the cohorts of four / three of the side runs) -- plus a known-bytes calibration copy."""
+through every launch (kosk_options::combine = 6; PMC_PROOFS=184 / 138: the cohorts of four / three of the side runs) -- plus a known-bytes calibration copy."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hashlib
 import torch
 from mpcith_kyber_kosk_amd import api
 k, B = 3, int(os.environ.get("PMC_PROOFS", "276"))
-ctx = api.Kosk(kyber_k=k, max_batch=B)
+ctx = api.Kosk(kyber_k=k, max_batch=B, fs_mode=1 if os.environ.get("PMC_FS", "host") == "device" else 0)  # PMC_FS=device: the chain kernels in the trace
 tapes = [hashlib.shake_256(("kosk-tape-v1:%d" % b).encode()).digest(ctx.tape_bytes) for b in range(B)]
 for _ in range(2):
     ctx.verifiable_keygen_resident(tapes)

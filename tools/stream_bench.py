@@ -1,13 +1,12 @@
 #!/usr/bin/env python3
-"""PCIe-inclusive rate of the two host-buffer calls from ONE caller thread, by number of sub-contexts (KOSK_STREAMS) and host
+"""PCIe-inclusive rate of the two host-buffer calls from ONE caller thread, by number of sub-contexts (kosk_options::streams) and host
 threads per sub-context. Not product code.  usage: stream_bench.py [streams ...]"""
 import ctypes as C, hashlib, os, sys, time
 sys.path.insert(0, ".")
 k, B = 3, 46
 for S in [int(x) for x in sys.argv[1:]] or [1, 3, 4, 6]:
-    os.environ["KOSK_STREAMS"] = str(S)
     from mpcith_kyber_kosk_amd import api
-    c = api.Kosk(kyber_k=k, max_batch=S * B)
+    c = api.Kosk(kyber_k=k, max_batch=S * B, streams=S, host_threads=int(os.environ.get("STREAM_BENCH_THREADS", "0")))
     n = 2 * S * B
     tapes = [hashlib.shake_256(("kosk-tape-v1:%d" % b).encode()).digest(c.tape_bytes) for b in range(B)]
     blob = C.create_string_buffer(b"".join(tapes) * (2 * S), c.tape_bytes * n)
@@ -23,6 +22,6 @@ for S in [int(x) for x in sys.argv[1:]] or [1, 3, 4, 6]:
     t0 = time.perf_counter()
     for _ in range(3): verify()
     tv = (time.perf_counter() - t0) / 3
-    print("KOSK_STREAMS=%d threads/sub=%s: %d proofs per call: keygen+prove+fetch %.1f ms (%.0f/s), stage+verify %.1f ms (%.0f/s), both %.0f proofs/s"
-          % (S, os.environ.get("KOSK_HOST_THREADS", "default"), n, tp * 1e3, n / tp, tv * 1e3, n / tv, n / (tp + tv)))
+    print("streams=%d threads/sub=%s: %d proofs per call: keygen+prove+fetch %.1f ms (%.0f/s), stage+verify %.1f ms (%.0f/s), both %.0f proofs/s"
+          % (S, os.environ.get("STREAM_BENCH_THREADS", "default"), n, tp * 1e3, n / tp, tv * 1e3, n / tv, n / (tp + tv)))
     c.close()

@@ -1,19 +1,19 @@
 #!/usr/bin/env python3
-"""Soak of the combined path (KOSK_COMBINE=$STRESS_COMBINE, default 6 = bench.py's default since round 5): S caller threads, one handle each, N x (kosk_verifiable_keygen_resident on device tapes +
+"""Soak of the combined path (kosk_options::combine = $STRESS_COMBINE, default 6 = bench.py's default since round 5): S caller threads, one handle each, N x (kosk_verifiable_keygen_resident on device tapes +
 kosk_verify_resident_pk).  Every verify bit is checked; every 50th step the proofs and keys of the step are compared with the ones an
 uncombined handle produced for the same tapes.  Not product code.     python tools/stress_combine.py 18 3000 [check interval]"""
 import os, sys, threading, hashlib, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-os.environ["KOSK_COMBINE"] = os.environ.get("STRESS_COMBINE", "6")
+CMB = int(os.environ.get("STRESS_COMBINE", "6"))
+FS = 1 if os.environ.get("STRESS_FS", "host") == "device" else 0  # STRESS_FS=device: the cohorts hash on the GPU
 from mpcith_kyber_kosk_amd import api
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 18
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 EVERY = int(sys.argv[3]) if len(sys.argv) > 3 else 50  # byte comparison every EVERY-th step (0: never; it stalls the caller for ~60 ms)
 B, k = 46, 3
-slots = [api.Kosk(kyber_k=k, max_batch=B, device=0) for _ in range(S)]
-del os.environ["KOSK_COMBINE"]
+slots = [api.Kosk(kyber_k=k, max_batch=B, device=0, combine=CMB, fs_mode=FS) for _ in range(S)]
 plain = api.Kosk(kyber_k=k, max_batch=B, device=0)
 stride = (plain.tape_bytes + 63) // 64 * 64
 banks, want = [], []
