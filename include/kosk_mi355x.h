@@ -49,7 +49,7 @@ enum { KOSK_FS_HOST = 0, KOSK_FS_DEVICE = 1 };
 typedef struct kosk_options {
     uint32_t size;              /* sizeof(kosk_options) as the caller compiled it (set by kosk_options_init) */
     int32_t streams;            /* sub-batches of a batch call in flight on separate HIP streams, 1..8; 0: not given = 1 */
-    int32_t combine;            /* handles per cohort whose resident calls are merged, 2..8 (call combining, see below); 0: not given, 1: off */
+    int32_t combine;            /* handles per cohort whose resident calls are merged, 2..16 (call combining, see below); 0: not given, 1: off */
     int32_t combine_wait_us;    /* longest wait of a call for the cohort's other members (default 5000); < 0: not given */
     int32_t combine_idle_us;    /* a member that left a call longer ago than this is not waited for (default 1000); < 0: not given */
     int32_t combine_prewake_us; /* how long the sleeping callers of a merged run may spin for its return (default 400); < 0: not given */
@@ -192,7 +192,7 @@ int kosk_profile_read(const kosk_ctx *ctx, int id, double *total_ms, long *launc
 int kosk_profile_read_units(const kosk_ctx *ctx, int id, double *total_ms, long *launches, long *proofs);
 
 /* ---- Call combining (no reference counterpart: the reference is one call, one proof, one thread -- kosk.hpp:18-24).
- * With kosk_options::combine = C (2..8, needs streams = 1), handles created with equal (device, kyber_k,
+ * With kosk_options::combine = C (2..16, needs streams = 1), handles created with equal (device, kyber_k,
  * max_batch) are grouped into cohorts of C that share one workspace, and the resident calls kosk_verifiable_keygen_resident /
  * kosk_verify_resident_pk that neighbouring members of a cohort make at about the same time -- each from its own thread --
  * are served by ONE pipeline run over all their proofs: every launch then covers 2..C callers' batches, which is what the

@@ -273,7 +273,7 @@ int kosk_create_ex(kosk_ctx **ctx, int device, int kyber_k, int max_batch, const
         h->max_batch = max_batch;
         h->hooks_unmerged = o.hooks_unmerged > 0;
         int W = 1; // combine: handles per cohort (needs streams = 1)
-        if (o.combine > 0) W = o.combine > 8 ? 8 : o.combine;
+        if (o.combine > 0) W = o.combine > Combiner::MAX_WIDTH ? Combiner::MAX_WIDTH : o.combine;
         if (W > 1 && S == 1 && max_batch >= 1) {
             std::lock_guard<std::mutex> lk(g_cohort_mu);
             Cohort *co = nullptr;

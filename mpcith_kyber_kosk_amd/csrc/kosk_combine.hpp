@@ -44,7 +44,7 @@ public:
     // on the calling thread -- member `first`'s thread; the return value is handed to every member of the run
     using Exec = std::function<int(int first, int count, const CombineReq *const *reqs)>;
 
-    static constexpr int MAX_WIDTH = 8;
+    static constexpr int MAX_WIDTH = 16;
     Combiner(int width, int wait_us, int idle_us, int prewake_us = 0)
         : C_(width < 1 ? 1 : (width > MAX_WIDTH ? MAX_WIDTH : width)), wait_us_(wait_us), idle_us_(idle_us), prewake_us_(prewake_us), m_((size_t)C_) {}
     int width() const { return C_; }

@@ -643,7 +643,7 @@ static int upload_tapes_segs(Ctx &c, int n, const KeygenIn &kg)
         bool ok = per > 0;
         for (const KeygenIn *s = &kg; s && ok; s = s->next, j++) {
             const int cnt = s->count ? s->count : n - total;
-            ok = j < 8 && s->tapes && s->tape_stride == kg.tape_stride && s->tape_stride >= c.P.tape_bytes && s->tape_stride % 8 == 0 &&
+            ok = j < 16 && s->tapes && s->tape_stride == kg.tape_stride && s->tape_stride >= c.P.tape_bytes && s->tape_stride % 8 == 0 &&
                  (reinterpret_cast<uintptr_t>(s->tapes) & 7) == 0 && cnt >= 1 && (cnt == per || (!s->next && cnt < per)) && is_device_pointer(s->tapes);
             if (ok) c.tape_segs.ptr[j] = s->tapes;
             total += cnt;

@@ -327,7 +327,7 @@ hipError_t launch_rows_copy(const uint16_t *src, size_t src_stride, uint16_t *ds
 // the randomness tapes of a merged call whose callers keep theirs in HBM: caller j's tapes start at ptr[j], `per` proofs each
 // (the last one may hold fewer), all tape_stride apart -- read in place, no copy into one buffer (count == 0: one buffer)
 struct TapeSegs {
-    const uint8_t *ptr[8];
+    const uint8_t *ptr[16]; // Combiner::MAX_WIDTH callers of a merged run
     int per, count;
 };
 struct KeygenFront {

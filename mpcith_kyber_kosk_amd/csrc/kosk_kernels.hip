@@ -398,7 +398,7 @@ __device__ __forceinline__ const uint8_t *pre_tape(const PreArgs &a, int b)
     // static indices only: a run-time index into the by-value argument block would make the compiler copy all of it to scratch
     const uint8_t *base = a.segs.ptr[0];
 #pragma unroll
-    for (int k = 1; k < 8; k++) base = j == k ? a.segs.ptr[k] : base;
+    for (int k = 1; k < 16; k++) base = j == k ? a.segs.ptr[k] : base;
     return base + (size_t)(b - j * a.segs.per) * a.tape_stride;
 }
 

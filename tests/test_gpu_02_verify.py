@@ -259,7 +259,7 @@ def test_default_verifier_is_strict_about_encodings(oracle, torch_cuda):
     """The production default (rounds 1-4, and again since round 6: kosk_options::strict_encoding = 1): a u16 >= q in any record the
     reference reads marks the proof malformed (fail bit 0), whatever the reference would do with it -- no honest prover emits one, and
     accepting them makes proofs malleable; records the reference never reads stay unchecked.  The reference-following mode is opt-in
-    (strict_encoding = 0 / KOSK_STRICT_ENCODING=0): it accepts the same five proofs the oracle accepts."""
+    (strict_encoding = 0): it accepts the same five proofs the oracle accepts."""
     import os
     from mpcith_kyber_kosk_amd import api
     k = 3
@@ -284,14 +284,14 @@ def test_default_verifier_is_strict_about_encodings(oracle, torch_cuda):
     for t in cases:  # the reference (oracle) accepts all five
         assert oracle.kosk_verify(k, t, pks[0])[0]
     ctx.close()
-    os.environ["KOSK_STRICT_ENCODING"] = "0"  # the environment twin of the option, read by kosk_create
-    try:
-        lax = api.Kosk(kyber_k=k, max_batch=8)
-    finally:
-        os.environ.pop("KOSK_STRICT_ENCODING", None)
+    lax = api.Kosk(kyber_k=k, max_batch=8, strict_encoding=0)  # the reference-following mode is an option of the handle, never the environment
     assert lax.verify(cases, [pks[0]] * 5) == [True] * 5 and lax.fail_masks(5) == [0] * 5
     lax.close()
-    strict = api.Kosk(kyber_k=k, max_batch=8, strict_encoding=1)  # the option wins over the environment either way
+    os.environ["KOSK_STRICT_ENCODING"] = "0"  # what round 5 read at kosk_create: ignored now
+    try:
+        strict = api.Kosk(kyber_k=k, max_batch=8)
+    finally:
+        os.environ.pop("KOSK_STRICT_ENCODING", None)
     assert strict.verify(cases, [pks[0]] * 5) == [False, False, False, True, True]
     strict.close()
 

@@ -31,8 +31,8 @@ for n in (1, 8, 46, 138, 276, 552, 1024, 2048, 4096):
     d_out = torch.zeros((n, 32), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     res = []
-    for fn in (c.sha3_256_batch_wave, c.sha3_256_batch, c.sha3_256_batch_pair):
-        if fn is not c.sha3_256_batch_wave and n > 1024:
+    for idx, fn in enumerate((c.sha3_256_batch_wave, c.sha3_256_batch, c.sha3_256_batch_pair)):
+        if idx and n > 1024:  # the per-lane sponges take 16 ms per launch: not beyond 1 024 tables
             res.append(float("nan"))
             continue
         best = 1e9
