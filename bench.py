@@ -1008,11 +1008,11 @@ def main():
             # the same arrangement driven by a NATIVE caller loop (examples/throughput.cpp: std::thread callers on the C ABI, the same
             # tape banks, every verify bit asserted) as a child process: what a C++ host -- the reference is one -- would run; proofs/s
             # and busy host cores without the interpreter lock.  Reported next to `value`, never instead of it.
-            def native_run(fs_):
+            def native_run(fs_, callers_=None, combine_=None):
                 exe = os.path.join(ROOT, "examples", "throughput")
                 if not os.path.exists(exe):
                     return {"error": "examples/throughput is not built (__graft_entry__.build() builds it)"}
-                cmd = [exe, "--k", str(k), "--batch", str(B), "--callers", str(S), "--combine", str(CMB), "--fs", fs_, "--threads", str(threads),
+                cmd = [exe, "--k", str(k), "--batch", str(B), "--callers", str(callers_ or S), "--combine", str(combine_ or CMB), "--fs", fs_, "--threads", str(threads),
                        "--steps", str(max(K, 20)), "--warmup", str(W), "--tape-sets", str(args.tape_sets), "--device", str(local_rank)]
                 try:
                     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
@@ -1025,6 +1025,9 @@ def main():
             line["native_callers"] = native_run(FS)
             other_ = "host" if FS == "device" else "device"
             line["native_callers_fs_" + other_] = native_run(other_)
+            # device mode's fixed cost per round (a 0.78 ms chain) does not grow with the launch: sixteen callers per cohort (736 proofs per
+            # launch; the combiner's limit) is where it reaches the host mode's rate, at under five busy cores and 12 ms per call pair
+            line["native_callers_fs_device_cohorts_of_16"] = native_run("device", callers_=48, combine_=16)
             line["fiat_shamir_" + other_] = side_run(S, CMB, threads_=0, fs_=other_, note="python bench.py --fs %s: the line of record's arrangement with the Fiat-Shamir "
                                                      "hashes on the %s; not the line of record" % (other_, other_))
             line["uncombined"] = side_run(6, 1, "python bench.py --combine 1 --slots 6: six independent handles, every launch serves one 46-proof call "
