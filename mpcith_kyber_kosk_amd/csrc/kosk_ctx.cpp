@@ -166,22 +166,31 @@ hipError_t stream_sync(Ctx &c)
 hipError_t wait_event(Ctx &c, hipEvent_t ev, int site, int n)
 {
     if (c.blocking_sync || !c.wait_nap || site < 0 || site >= Ctx::WAIT_SITES) return hipEventSynchronize(ev);
-    double *hist = c.wait_hist_us[site];
-    if (c.wait_ema_n[site] != n) { // another batch size: learn again
-        c.wait_ema_n[site] = n;
-        for (int i = 0; i < Ctx::WAIT_HIST; i++) hist[i] = 0;
+    // this site's history at this batch size (or the least recently used one, started afresh)
+    Ctx::WaitHist *h = nullptr, *lru = &c.wait_hist[site][0];
+    for (auto &w : c.wait_hist[site]) {
+        if (w.n == n) h = &w;
+        if (w.stamp < lru->stamp) lru = &w;
     }
+    if (!h) {
+        h = lru;
+        *h = Ctx::WaitHist{};
+        h->n = n;
+    }
+    h->stamp = ++c.wait_stamp;
     int filled = 0;
     double est = 0;
     for (int i = 0; i < Ctx::WAIT_HIST; i++)
-        if (hist[i] > 0) { est = filled ? (hist[i] < est ? hist[i] : est) : hist[i]; filled++; }
+        if (h->us[i] > 0) { est = filled ? (h->us[i] < est ? h->us[i] : est) : h->us[i]; filled++; }
     const double t0 = now_sec();
     bool overslept = false;
     if (filled >= 4 && est > 250.0) { // (no nap before the site has been seen four times at this batch size)
         const double keep = est * 0.3 > 100.0 ? est * 0.3 : 100.0; // spin through the last 30 % (at least 100 us: the sleep's own wake-up jitter)
+        double nap_us = est - keep;
+        if (nap_us > 200000.0) nap_us = 200000.0; // never more than 0.2 s at a time (tv_nsec must stay below 1e9; a phase that long is an anomaly)
         struct timespec ts;
         ts.tv_sec = 0;
-        ts.tv_nsec = (long)((est - keep) * 1e3);
+        ts.tv_nsec = (long)(nap_us * 1e3);
         nanosleep(&ts, nullptr);
         const hipError_t q = hipEventQuery(ev);
         if (q == hipSuccess) overslept = true;
@@ -189,11 +198,14 @@ hipError_t wait_event(Ctx &c, hipEvent_t ev, int site, int n)
     }
     const hipError_t e = overslept ? hipSuccess : hipEventSynchronize(ev);
     const double took = (now_sec() - t0) * 1e6;
-    if (overslept) { // the phase was shorter than the nap: everything the site remembers is too long
-        for (int i = 0; i < Ctx::WAIT_HIST; i++) hist[i] = est * 0.5;
+    if (overslept) {
+        // the phase was shorter than the nap: what the site remembers is too long (a history seeded by cold-start waits of several ms would
+        // otherwise oversleep call after call while it halves).  Forget it: the next four waits spin and measure afresh
+        for (int i = 0; i < Ctx::WAIT_HIST; i++) h->us[i] = 0;
+        h->at = 0;
     } else {
-        hist[c.wait_hist_at[site]] = took > 1.0 ? took : 1.0;
-        c.wait_hist_at[site] = (c.wait_hist_at[site] + 1) % Ctx::WAIT_HIST;
+        h->us[h->at] = took > 1.0 ? took : 1.0;
+        h->at = (h->at + 1) % Ctx::WAIT_HIST;
     }
     return e;
 }

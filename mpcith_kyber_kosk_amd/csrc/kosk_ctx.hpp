@@ -230,9 +230,18 @@ struct Ctx {
     bool wait_nap = true;
     enum { WAIT_SITES = 8 };
     enum { WAIT_HIST = 8 };
-    double wait_hist_us[WAIT_SITES][WAIT_HIST] = {{0}}; // the site's last measured waits (0 = empty): the nap is sized by their MINIMUM
-    int wait_hist_at[WAIT_SITES] = {0};
-    int wait_ema_n[WAIT_SITES] = {0};
+    // (round 6) a site keeps WAIT_SIZES histories, one per batch size it has recently seen (a cohort whose merged runs alternate
+    // between two sizes -- 276 and 230 proofs when one member is late -- no longer forgets what it learnt at every change), least
+    // recently used first out
+    enum { WAIT_SIZES = 2 };
+    struct WaitHist {
+        int n = 0;                    // batch size this history belongs to (0: unused)
+        int at = 0;                   // next entry to overwrite
+        unsigned long stamp = 0;      // last use (for the replacement)
+        double us[WAIT_HIST] = {0};   // the last measured waits (0 = empty): the nap is sized by their MINIMUM
+    };
+    WaitHist wait_hist[WAIT_SITES][WAIT_SIZES];
+    unsigned long wait_stamp = 0;
     hipEvent_t ev_sync = nullptr; // KOSK_BLOCKING_SYNC=1: every host wait sleeps on an event instead of spinning (few host cores per GPU)
     bool blocking_sync = false;
     int n_simd = 1024;      // SIMDs of the device (4 per CU)
