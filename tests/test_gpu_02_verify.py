@@ -12,11 +12,12 @@ def torch_cuda():
     return torch
 
 
+@pytest.mark.parametrize("fs", [0, 1])  # Fiat-Shamir hashes on the host / on the device (kosk_options::fs_mode)
 @pytest.mark.parametrize("k", [2, 3, 4])
-def test_verify_honest_and_tampered(k, oracle, torch_cuda):
+def test_verify_honest_and_tampered(k, fs, oracle, torch_cuda):
     from mpcith_kyber_kosk_amd import api
     p = oracle.params(k)
-    ctx = api.Kosk(kyber_k=k, max_batch=13)
+    ctx = api.Kosk(kyber_k=k, max_batch=13, fs_mode=fs)
     tapes = [oracle.tape_bytes_for(k, b) for b in range(2)]
     pks, sks, pis = ctx.verifiable_keygen(tapes)
     assert ctx.verify(pis, pks) == [True, True]
@@ -76,8 +77,9 @@ def test_verify_malformed_opened_list(oracle, torch_cuda):
 BYTE_FIELDS = (4, 23)  # Tcomm, comm digests; field 5 is the list I; every other field holds u16 elements of GF(3329)
 
 
+@pytest.mark.parametrize("fs", [0, 1])
 @pytest.mark.parametrize("k", [2, 3, 4])
-def test_verify_random_corruptions_match_oracle(k, oracle, torch_cuda):
+def test_verify_random_corruptions_match_oracle(k, fs, oracle, torch_cuda):
     """Differential test at random positions: single-bit flips and substitutions of whole elements, anywhere in the proof
     image, always leaving CANONICAL field elements (< q) behind.  Whatever the reference's verifier does not read (see
     test_verify_honest_and_tampered) must be accepted here too, everything else rejected -- the oracle decides, proof by proof;
@@ -86,7 +88,7 @@ def test_verify_random_corruptions_match_oracle(k, oracle, torch_cuda):
     from mpcith_kyber_kosk_amd import api
     p = oracle.params(k)
     rnd = random.Random(20260 + k)
-    ctx = api.Kosk(kyber_k=k, max_batch=16)
+    ctx = api.Kosk(kyber_k=k, max_batch=16, fs_mode=fs)
     tape = [oracle.tape_bytes_for(k, 90 + k)]
     pks, sks, pis = ctx.verifiable_keygen(tape)
     pi = pis[0]

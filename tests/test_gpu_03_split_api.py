@@ -26,15 +26,16 @@ def _keygen_inst(api, k, seed64):
     return A.tobytes() + t.tobytes() + s.tobytes() + e.tobytes(), pk.raw
 
 
+@pytest.mark.parametrize("fs", [0, 1])  # Fiat-Shamir hashes on the host / on the device (kosk_options::fs_mode)
 @pytest.mark.parametrize("k", [2, 3, 4])
-def test_main_cpp_order_matches_oracle(oracle, torch_cuda, k):
+def test_main_cpp_order_matches_oracle(oracle, torch_cuda, k, fs):
     """main.cpp:21-47: prepare_randomness, prepare_range_proof, kyber_keygen, prove, verify on ONE tape."""
     from mpcith_kyber_kosk_amd import api
     tape = oracle.tape_bytes_for(k, 31)
     ref = oracle.main_order(k, tape)
     assert ref["verify"]
     u = ref["used"]
-    ctx = api.Kosk(kyber_k=k, max_batch=2)
+    ctx = api.Kosk(kyber_k=k, max_batch=2, fs_mode=fs)
     assert api.lib.kosk_randomness_bytes(k) == len(ref["rand"])
     assert api.lib.kosk_range_proof_bytes(k) == len(ref["range"])
     assert api.lib.kosk_mlwe_inst_bytes(k) == len(ref["inst"])

@@ -73,13 +73,14 @@ def _spot_check(ctx, oracle, k, tapes, n, spots):
         yield b, pis[b], tr, p
 
 
-def test_config4_kyber1024_91_proofs_and_digest_tables(oracle, torch_cuda):
+@pytest.mark.parametrize("fs", [0, 1])  # Fiat-Shamir hashes on the host / on the device (kosk_options::fs_mode)
+def test_config4_kyber1024_91_proofs_and_digest_tables(fs, oracle, torch_cuda):
     """configs[3] per-GPU share: K=4, 91 proofs = 132 314 party lanes in one batch.  The digest tables a multi-GPU job
     all-gathers after each commitment round are reachable in HBM and hold exactly Tcomm[0..1454) / the view commitments."""
     torch = torch_cuda
     from mpcith_kyber_kosk_amd import api
     k, n = 4, 91
-    ctx = api.Kosk(kyber_k=k, max_batch=n)
+    ctx = api.Kosk(kyber_k=k, max_batch=n, fs_mode=fs)
     tapes = [oracle.tape_bytes_for(k, 2000 + b) for b in range(n)]
     seen = []
 
@@ -108,11 +109,12 @@ def test_config4_kyber1024_91_proofs_and_digest_tables(oracle, torch_cuda):
     ctx.close()
 
 
-def test_config5_kyber768_512_keygens(oracle, torch_cuda):
+@pytest.mark.parametrize("fs", [0, 1])
+def test_config5_kyber768_512_keygens(fs, oracle, torch_cuda):
     """configs[4] per-GPU share: 512 independent Kyber-768 verifiable keygens in one batch."""
     from mpcith_kyber_kosk_amd import api
     k, n = 3, 512
-    ctx = api.Kosk(kyber_k=k, max_batch=n)
+    ctx = api.Kosk(kyber_k=k, max_batch=n, fs_mode=fs)
     tapes = [oracle.tape_bytes_for(k, b) for b in range(n)]   # seeds "kosk-tape-v1:0" .. ":511" (SURVEY 8(d) config 5)
     ctx.verifiable_keygen_resident(tapes)
     for _ in _spot_check(ctx, oracle, k, tapes, n, (0, 255, 511)):
@@ -126,4 +128,5 @@ def test_config5_kyber768_512_keygens(oracle, torch_cuda):
     pis[300] = bytes(bad)
     ok = ctx.verify(pis, pks)
     assert ok == [i != 300 for i in range(n)]
+    assert (ctx.path_counts()["fs_device"] > 0) == bool(fs) and (ctx.path_counts()["fs_host"] > 0) == (not fs)
     ctx.close()

@@ -64,7 +64,7 @@ def test_compact_host_buffer_calls_chunked(k, oracle, torch_cuda):
     ref = api.Kosk(kyber_k=k, max_batch=n)
     pks, sks, pis = ref.verifiable_keygen(tapes)
     cb = lib.kosk_compact_proof_bytes(k)
-    ctx = api.Kosk(kyber_k=k, max_batch=2)
+    ctx = api.Kosk(kyber_k=k, max_batch=2, fs_mode=k & 1)  # K = 3 with the Fiat-Shamir hashes on the device (`ref` above hashes on the host)
     pk = C.create_string_buffer(ctx.pk_bytes * n); sk = C.create_string_buffer(ctx.sk_bytes * n)
     out = C.create_string_buffer(cb * n); ok = C.create_string_buffer(n)
     assert lib.kosk_verifiable_keygen_batch_compact(ctx.handle, n, C.c_char_p(b"".join(tapes)), ctx.tape_bytes, pk, sk, out) == 0

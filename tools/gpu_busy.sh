@@ -14,6 +14,6 @@ rows=list(csv.DictReader(open(sys.argv[1])))
 tot=sum(float(r["TotalDurationNs"]) for r in rows)
 steps=[int(r["Calls"]) for r in rows if "k_opened_setup" in r["Name"]][0]  # one k_opened_setup launch per verify = per step
 for r in rows[:int("${2:-16}")]:
-    print("%-40s calls/step %5.1f  avg %7.1f us  per-step %6.1f us"%(r["Name"].split("(")[0].replace("void ","").replace("kosk::","")[:40], int(r["Calls"])/steps, float(r["AverageNs"])/1e3, float(r["TotalDurationNs"])/1e3/steps))
+    print("%-40s calls/step %5.1f  avg %7.1f us  per-step %6.1f us"%(r["Name"].replace("void ","").replace("kosk::","").replace("(anonymous namespace)::","").split("(")[0][:44], int(r["Calls"])/steps, float(r["AverageNs"])/1e3, float(r["TotalDurationNs"])/1e3/steps))
 print("GPU busy per step: %.0f us over %d steps"%(tot/1e3/steps, steps))
 PY
