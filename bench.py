@@ -901,6 +901,10 @@ def main():
             "combining": {"calls": sum(c_[0] for c_ in cstats), "mean_callers_per_run": (sum(c_[1] for c_ in cstats) / max(1, sum(c_[0] for c_ in cstats))),
                           "note": "resident calls that went through the combiner since the handles were created, and the mean number of "
                                   "callers served by the run a call ended up in"} if CMB > 1 else None,
+            # what the rate was bought with: the proofs in flight per GPU, the latency of one caller's call pair, and what the harness
+            # does with its interpreter during the timed run -- next to `value`, not only inside `config` / `harness`
+            "proofs_in_flight_per_gpu": S * B, "call_pair_latency_ms_median": lats[len(lats) // 2] * 1e3,
+            "python_gc_in_timed_run": os.environ.get("KOSK_BENCH_GC", "0") == "1",
             "host_cpu_cores_busy": round(host_cpu_s / max(dt_drained, 1e-9), 2),
             "host_cpus_usable": usable_cores, "host_cpus_affinity": len(os.sched_getaffinity(0)), "host_cores_per_rank": cores_per_rank,
             "harness": {"python_gc_in_timed_run": os.environ.get("KOSK_BENCH_GC", "0") == "1",

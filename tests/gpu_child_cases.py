@@ -457,6 +457,75 @@ def member_big_batch_stays_in_its_block(k=3, per=3):
     print("member_big_batch_stays_in_its_block ok", k)
 
 
+def cohort_round_hooks(k=2, per=3, rounds=4):
+    """Round hooks inside a cohort: member 0 has no hook and leads the merged runs; member 1 has a hook and merges (the default): its
+    hook fires from the merged run, on the LEADER's thread, with member 1's own block of the table; member 2 has a hook and
+    kosk_options::hooks_unmerged = 1: its calls never merge and its hook always fires on its own thread.  Member 2 also sends a shorter
+    batch.  Every caller's bytes equal an uncombined handle's."""
+    import hashlib
+    import threading
+    import torch
+    from mpcith_kyber_kosk_amd import api
+    plain = api.Kosk(kyber_k=k, max_batch=per)
+    ns = [per, per, per - 1]
+    tapes = [[oracle.tape_bytes_for(k, 9500 + t * per + b) for b in range(ns[t])] for t in range(3)]
+    want = []
+    for t in range(3):
+        plain.verifiable_keygen_resident(tapes[t])
+        want.append((plain.keys(ns[t]), plain.fetch_proofs(ns[t]),
+                     [hashlib.sha3_256(torch.as_tensor(plain.resident_digests(r, ns[t]), device="cuda").cpu().numpy().tobytes()).hexdigest() for r in (0, 1)]))
+    hs = [_kosk(k, per, combine=3, combine_wait_us=2000000, combine_idle_us=1000000),
+          _kosk(k, per, combine=3, combine_wait_us=2000000, combine_idle_us=1000000),
+          _kosk(k, per, combine=3, combine_wait_us=2000000, combine_idle_us=1000000, hooks_unmerged=1)]
+    seen = {1: [], 2: []}
+    idents = {}
+
+    def mk_hook(t):
+        def hook(role, rnd, ptr, nbytes):
+            tab = torch.as_tensor(api.DeviceView(ptr, (ns[t], 1454, 32)), device="cuda")
+            seen[t].append((threading.get_ident(), role, rnd, nbytes, hashlib.sha3_256(tab.cpu().numpy().tobytes()).hexdigest()))
+        return hook
+    hs[1].set_round_hook(mk_hook(1))
+    hs[2].set_round_hook(mk_hook(2))
+    errs = []
+    barrier = threading.Barrier(3)
+
+    def worker(t):
+        try:
+            idents[t] = threading.get_ident()
+            h = hs[t]
+            for r in range(rounds):
+                barrier.wait()
+                h.verifiable_keygen_resident(tapes[t])
+                assert h.keys(ns[t]) == want[t][0], ("keys", t, r)
+                assert h.verify_resident_pk(ns[t]) == [True] * ns[t], ("bits", t, r)
+                assert h.fetch_proofs(ns[t]) == want[t][1], ("proofs", t, r)
+        except Exception as e:  # noqa: BLE001
+            errs.append((t, repr(e)))
+            try:
+                barrier.abort()
+            except Exception:
+                pass
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    [x.start() for x in th]; [x.join() for x in th]
+    assert not errs, errs
+    for t in (1, 2):
+        assert len(seen[t]) == 4 * rounds, (t, len(seen[t]))
+        for ident, role, rnd, nbytes, dig in seen[t]:
+            assert nbytes == ns[t] * 1454 * 32 and role in (0, 1) and rnd in (0, 1), (t, role, rnd, nbytes)
+            if role == 0:
+                assert dig == want[t][2][rnd], (t, role, rnd)  # the member's OWN block of the prover's round table
+    assert all(s_[0] == idents[2] for s_ in seen[2])                  # unmerged: always the handle's own thread
+    assert any(s_[0] == idents[0] for s_ in seen[1]), "member 1's hook never fired from a merged run led by member 0"
+    c2, m2 = hs[2].combine_stats()
+    assert c2 > 0 and m2 == c2                                         # every call of member 2 ran alone
+    c1, m1 = hs[1].combine_stats()
+    assert m1 > c1                                                     # member 1 did merge (with member 0)
+    for h in hs + [plain]:
+        h.close()
+    print("cohort_round_hooks ok", k)
+
+
 def combined_members_come_and_go(k):
     """A cohort whose members are destroyed and re-created while the others keep calling: the freed block is reused by the next
     handle, members that are no neighbours any more run on their own, the workspace lives until the last member is gone, a

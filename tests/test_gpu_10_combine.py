@@ -43,6 +43,13 @@ def test_line_of_record_shape(callers, torch_cuda, gpu_child):
     assert "line_of_record_shape ok 3 46 %d callers per run %d.00" % (callers, callers) in out
 
 
+def test_round_hooks_inside_a_cohort(torch_cuda, gpu_child):
+    """tests/gpu_child_cases.py: cohort_round_hooks -- a merged member's hook fires on the run leader's thread with the member's own block;
+    kosk_options::hooks_unmerged keeps a hooked handle's calls (and its hook) on its own thread; unequal batch sizes (ADVICE r5)."""
+    out = gpu_child("from tests.gpu_child_cases import cohort_round_hooks; cohort_round_hooks()")
+    assert "cohort_round_hooks ok 2" in out
+
+
 def test_member_calls_larger_than_its_block_stay_in_its_block(torch_cuda, gpu_child):
     """tests/gpu_child_cases.py: member_big_batch_stays_in_its_block -- a cohort member's host-buffer calls of 2 * per + 1 proofs are
     chunked by its own batch size and never touch the neighbouring members' blocks of the shared workspace."""
