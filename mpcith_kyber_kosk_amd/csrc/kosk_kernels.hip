@@ -1436,14 +1436,14 @@ __global__ __launch_bounds__(256, 2) void k_lincomb_stream(const uint16_t *P, si
     auto gload = [&](int fb) {
         const int g = fb / MB, m0 = (fb - g * MB) * 128;
         // No predicates: a point pair behind the row's last point (only in a group's last block) reads the row's first pair instead,
-        // and rows M .. 79 of chunk 4 are whatever rows follow the f rows in the row matrix (always inside the proof's block: f and
-        // NTT f sit in its first quarter).  Neither reaches an output: MFMA rows are independent and those points are never
-        // stored; the coefficient columns k >= M are zero (k_coef_limbs).
+        // and the slots of rows M .. 79 of chunk 4 read row M - 1 again (a line this wave has just asked for: no HBM bytes; round 5
+        // read the three rows that follow the f rows there: 1.9 % of the launch's traffic).  Neither reaches an output: MFMA rows are
+        // independent and those points are never stored; the coefficient columns k >= M are zero (k_coef_limbs).
         const uint16_t *src = P + (size_t)(g >> 1) * proof_stride + (size_t)((g & 1) ? row_tf : row_f) * RS + (m0 + xl < NPTS ? m0 + xl : 0);
 #pragma unroll
         for (int q = 0; q < 16; q++) raw[q] = *reinterpret_cast<const uint32_t *>(src + (size_t)(c4 * 16 + q) * RS);
 #pragma unroll
-        for (int q = 0; q < 4; q++) raw[16 + q] = *reinterpret_cast<const uint32_t *>(src + (size_t)(64 + c4 * 4 + q) * RS);
+        for (int q = 0; q < 4; q++) raw[16 + q] = *reinterpret_cast<const uint32_t *>(src + (size_t)min(64 + c4 * 4 + q, M - 1) * RS);
     };
     // LDS position of point x of the block: MFMA row tile 2 (x >> 5) + ((x >> 2) & 1), row 4 ((x >> 3) & 3) + (x & 3) -- an output lane
     // (row group lane >> 4) then holds eight CONSECUTIVE points across the two tiles of a pair: one 16-byte store per output row
@@ -1507,7 +1507,8 @@ __global__ __launch_bounds__(256, 2) void k_lincomb_stream(const uint16_t *P, si
         stage();
         lds_barrier();
         if (fb + 1 < fb1) gload(fb + 1);
-        __builtin_amdgcn_sched_barrier(0); // the prefetch goes out before the arithmetic below, not behind it
+        __builtin_amdgcn_sched_barrier(0); // the prefetch goes out before the arithmetic below, not behind it (issued ahead of the LDS writes of
+                                           // stage() instead -- tried in round 6 -- the launch is 4 % slower: 86.0 against 82.8 us per 276 proofs)
         v4i s0[2][LS_JT], s1[2][LS_JT], s2[2][LS_JT];
         const v4i zero4 = {0, 0, 0, 0};
 #pragma unroll

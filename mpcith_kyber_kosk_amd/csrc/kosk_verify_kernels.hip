@@ -97,6 +97,15 @@ __global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const F
     }
     if (cnt <= 0) return;
     const FieldDesc fd = fields[f];
+    if (kind && fd.limit) {
+        // Records the reference's verify() never reads (FieldDesc::limit: beta / gamma shares of parties >= 407, t / eta shares behind the
+        // 407th and u shares behind the 813th unopened party) are not range-checked and no kernel of the verifier reads their place in the
+        // row matrix (recon_secrets_*: party columns 0 .. 406 / 812; the interpolations: the first 407 / 813 entries of `rest`): a window
+        // that holds only such records has nothing to do -- 43 % of the image's bytes and 44 % of the launch's stores (round 6; rounds
+        // 2-5 scattered them all).  Every party of window w is >= 64 w, every record index >= i0.
+        if ((fd.limit_by_party ? 64 * (x % NWIN) : i0) >= fd.limit) return;
+        if (!fd.limit_by_party) cnt = min(cnt, fd.limit - i0); // the window's tail behind the last record that is read
+    }
     const uint16_t *in = reinterpret_cast<const uint16_t *>(proof + (size_t)b * image_stride + fd.off) + (size_t)i0 * fd.width;
     const int n16 = cnt * fd.width;
     const int head = (int)((reinterpret_cast<uintptr_t>(in) >> 1) & 1);
@@ -138,9 +147,10 @@ __global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const F
         if (kind) {
             const int party = sel[i0 + lane];
             uint16_t *dst = v.P + (size_t)b * v.proof_stride + NSEC + party;
+            if (!(fd.limit && fd.limit_by_party && party >= fd.limit)) { // (a record behind a limit by index is not in cnt any more)
 #pragma unroll 8
-            for (int e = 0; e < fd.width; e++) { const uint32_t x_ = t[e]; big |= x_ >= (uint32_t)Q; dst[(size_t)rt[e] * RS] = (uint16_t)gf_fold(x_); }
-            if (fd.limit && (fd.limit_by_party ? party : i0 + lane) >= fd.limit) big = false; // never read by the reference
+                for (int e = 0; e < fd.width; e++) { const uint32_t x_ = t[e]; big |= x_ >= (uint32_t)Q; dst[(size_t)rt[e] * RS] = (uint16_t)gf_fold(x_); }
+            }
         } else {
             // records of the opened parties: into the opened matrix, consecutive lanes = consecutive entries of a row
             uint16_t *dst = v.O + (size_t)b * v.o_stride + i0 + lane;
