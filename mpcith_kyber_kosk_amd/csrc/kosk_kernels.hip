@@ -1566,9 +1566,15 @@ __global__ __launch_bounds__(256, 2) void k_lincomb_stream(const uint16_t *P, si
 __global__ __launch_bounds__(1024) void k_coef_limbs(const uint16_t *__restrict__ alpha, int J, int M, uint8_t *__restrict__ B, int BRT)
 {
     const int j = threadIdx.x & 127, ch = threadIdx.x >> 7, b = blockIdx.x;
+    // the challenge vector is read ONCE per proof (host mode: from the page-locked host table, across PCIe; rounds 2-5: every one of the
+    // eight k-chunks asked for it itself -- the same 13-14 us per 276 proofs either way: the launch is one PCIe read plus a chain of <= 30 products)
+    __shared__ uint16_t al_s[128];
+    if (threadIdx.x < 128) al_s[threadIdx.x] = threadIdx.x < J ? alpha[(size_t)b * LC_JPAD + threadIdx.x] : (uint16_t)0;
+    __syncthreads();
+    auto gf_mul = [](uint32_t x, uint32_t y) { return gf_reduce_u32(__umul24(x, y)); }; // x, y < q: seven full-rate instructions
     uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
     if (j < J) {
-        const uint32_t al = alpha[(size_t)b * LC_JPAD + j] % (uint32_t)Q;
+        const uint32_t al = (uint32_t)al_s[j] % (uint32_t)Q;
         uint32_t p = 1, base = al;
         for (int e = ch * 16; e; e >>= 1) { // alpha^(16 ch)
             if (e & 1) p = gf_mul(p, base);
@@ -1646,9 +1652,18 @@ __global__ __launch_bounds__(256) void k_lincomb(LincombArgs a)
     // The verifier's inputs are the image's RAW u16 (a crafted proof may hold elements >= q): every term k >= 1 goes through
     // gf3329_mul in the reference (mlwe_verifier.cpp:76, :85, :157, :166) and is folded here; the k == 0 term does not, see below.
     // two terms per instruction: acc_j += c_j[k] v[k] + c_j[k + 1] v[k + 1] (v_dot2_i32_i16; centred operands, |sum| < 79 * 1665^2 < 2^31);
-    // the pair (0, 1) carries coefficient 0 for k == 0, a row at or beyond M is not read
+    // the pair (0, 1) carries coefficient 0 for k == 0, a row at or beyond M reads row M - 1 again under a zero coefficient
     const int M = a.rm.M;
-    for (int k0 = 0; k0 < M; k0 += 8) { // eight independent loads in flight, then four pairs
+    // two raw u16 -> their centred representatives as one packed pair: (v + 1664) mod q by one packed unsigned minimum, minus 1664.
+    // An element >= q (a crafted proof) is folded first, behind a branch the whole wave takes or skips (round 6; rounds 2-5 folded and
+    // centred every value on its own: 24 instructions per pair under 20 products, a third of them quarter-rate multiplies).
+    auto centre_pair = [](uint32_t x0, uint32_t x1) -> uint32_t {
+        if (__any((int)(max(x0, x1) >= (uint32_t)Q))) { x0 = gf_fold(x0); x1 = gf_fold(x1); }
+        const us2 x = __builtin_bit_cast(us2, x0 | (x1 << 16));
+        const us2 m = __builtin_elementwise_min(x + (us2){1664, 1664}, x - (us2){1665, 1665});
+        return __builtin_bit_cast(uint32_t, __builtin_bit_cast(ss2, m) - (ss2){1664, 1664});
+    };
+    for (int k0 = 0; k0 < M; k0 += 8) { // eight independent loads in flight, then four pairs (all 80 at once: 52 against 43 us per 276 proofs)
         uint32_t raw[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) raw[i] = in0[(size_t)(k0 + i < M ? k0 + i : M - 1) * istride];
@@ -1656,9 +1671,7 @@ __global__ __launch_bounds__(256) void k_lincomb(LincombArgs a)
         for (int i = 0; i < 4; i++) {
             const int k = k0 + 2 * i;
             if (k >= M) break; // uniform
-            const int32_t v0 = gf_center(gf_fold(raw[2 * i]));
-            const int32_t v1 = k + 1 < M ? gf_center(gf_fold(raw[2 * i + 1])) : 0;
-            const uint32_t vv = ((uint32_t)v0 & 0xFFFFu) | ((uint32_t)v1 << 16);
+            const uint32_t vv = centre_pair(raw[2 * i], raw[2 * i + 1]); // (a second half at M: its coefficient is 0, k_pow_table)
             const int32_t *pk = pw + (size_t)(k >> 1) * LC_JPAD;
 #pragma unroll
             for (int j = 0; j < LC_JC; j++) asm("v_dot2_i32_i16 %0, %1, %2, %0" : "+v"(acc[j]) : "s"(pk[j]), "v"(vv));

@@ -283,6 +283,10 @@ hipError_t launch_opened_hash(const OpenedHashArgs &a, int K, bool view, int npr
 
 // ---- interpolation operators over the nodes x_j = 256 + rest[j] (see InterpArgs) ---------------
 __device__ __forceinline__ uint32_t gf_neg_if(uint32_t v, int odd) { return (odd & 1) && v ? (uint32_t)Q - v : v; }
+// a b mod q for a, b < 2^16 with a b < 2^32 in seven full-rate instructions (24-bit multiply + gf_reduce_u32) where `a * b % Q` costs three
+// quarter-rate 32-bit multiplies; the canonical representative of a difference |d| < q
+__device__ __forceinline__ uint32_t gf_mul_fast(uint32_t a, uint32_t b) { return gf_reduce_u32(__umul24(a, b)); }
+__device__ __forceinline__ uint32_t gf_diff(int d) { return (uint32_t)(d < 0 ? d + Q : d); }
 
 // weights of both sets, l(k) and the node map of set 0
 __device__ __forceinline__ void interp_setup_block(const InterpArgs &a, const int bx, const int b, const int set, uint16_t *is)
@@ -301,7 +305,7 @@ __device__ __forceinline__ void interp_setup_block(const InterpArgs &a, const in
         if (t < n) {
             const int xj = rest[t];
             uint32_t pr = 1;
-            for (int h = h0; h < h1; h++) pr = gf_mul(pr, gf_from_i32(xj - (int)is[h]));
+            for (int h = h0; h < h1; h++) pr = gf_mul_fast(pr, gf_diff(xj - (int)is[h])); // |x_j - h| < 1 454 (the launch is bound by these products: round 6)
             w = gf_mul(pr, gf_mul(a.invfact[xj - lo], a.invfact[hi - xj]));
             w = gf_neg_if(w, hi - xj);
         }
@@ -318,7 +322,7 @@ __device__ __forceinline__ void interp_setup_block(const InterpArgs &a, const in
             for (int h = h0; h < h1; h++) {
                 const int d = kp - (int)is[h];
                 if (d == 0) is_hole = true;
-                else den = gf_mul(den, gf_from_i32(d));
+                else den = gf_mul_fast(den, gf_diff(d)); // d in [-1 709, 150]
                 below += (int)is[h] < kp;
             }
             if (kp < lo) { // (-1)^cnt (hi - kp)! / (lo - 1 - kp)!
@@ -365,7 +369,11 @@ __global__ __launch_bounds__(256) void k_gather_frags(const uint16_t *__restrict
     if (set) t -= T1;
     const int KS = set ? IA_KS2 : IA_KS1, NT = set ? IA_NT2 : IA_NT1;
     if (t >= NT * 16 * KS * 4) return;
-    const int r = t % (NT * 16), kc16 = t / (NT * 16); // consecutive threads: consecutive columns of one chunk -> one tile
+    // consecutive threads: consecutive 16-node chunks of ONE row (round 6).  A wave's sixteen gather instructions then walk two or three
+    // rows' node columns side by side -- about 25 different 128-byte lines per instruction; with consecutive threads on consecutive rows
+    // (rounds 3-5: the coalesced order of the two stores below) every lane of every gather had a line of its own, and the launch ran at
+    // the texture path's line rate: 25 us per 276 proofs for 30 MB.
+    const int kc16 = t % (KS * 4), r = t / (KS * 4);
     const int ncols = set ? DEG2 + 1 : DEG + 1, nrows = set ? nrows2 : nrows1;
     uint4 x0 = make_uint4(0, 0, 0, 0), x1 = x0;
     if (r < nrows && kc16 * 16 < ncols) {
@@ -381,7 +389,7 @@ __global__ __launch_bounds__(256) void k_gather_frags(const uint16_t *__restrict
         uint32_t o[8];
 #pragma unroll
         for (int q = 0; q < 16; q += 2) {
-            const uint32_t lo = gf_mul(ww[q >> 1] & 0xFFFFu, v[q]), hi = gf_mul(ww[q >> 1] >> 16, v[q + 1]);
+            const uint32_t lo = gf_mul_fast(ww[q >> 1] & 0xFFFFu, v[q]), hi = gf_mul_fast(ww[q >> 1] >> 16, v[q + 1]); // w < q, v any u16
             o[q >> 1] = lo | (hi << 16);
         }
         x0 = make_uint4(o[0], o[1], o[2], o[3]);
@@ -540,9 +548,11 @@ __global__ __launch_bounds__(256) void k_interp_apply(InterpApplyArgs g, int npr
 // recomputed s+r / e+r shares against the unopened ones in the proof   mlwe_verifier.cpp:232-246
 
 // relation checks on the opened columns   mlwe_verifier.cpp:273-284, :304-312, :365-376, :447-466
+// One workgroup per (proof, i < K); every operand of the thread is in flight before the first comparison (round 6: one block per proof
+// walked i and m with the loads of one step at a time -- a chain of ~10 round trips on a grid of one workgroup per CU, 16 us per 276 proofs).
 __global__ __launch_bounds__(192) void k_check_opened(VerifyArgs v)
 {
-    const int t = threadIdx.x, b = blockIdx.x;
+    const int t = threadIdx.x, b = blockIdx.x, i = blockIdx.y;
     if (t >= NOPEN) return;
     const RowMap &rm = v.rm;
     // recomputed sharings (every party) come from the row matrix, what the proof holds for the opened parties and what the
@@ -553,16 +563,27 @@ __global__ __launch_bounds__(192) void k_check_opened(VerifyArgs v)
     auto op = [&](int row) { return (uint32_t)Ob[(size_t)row * OS]; };
     // op() values are the image's RAW u16 (and the raw NTT_r of k_lincomb): the reference compares and combines them with its
     // non-reducing gf3329_add / gf3329_sub, reproduced by ref_add_u16 / ref_sub_u16 (identical to gf_add / gf_sub on canonical values)
+    constexpr int MAXE = 7; // 2 eta1 + 1, eta1 <= 3
+    const int E = rm.E;
+    const uint32_t p_nttsr = at(rm.nttsr + i), p_ntter = at(rm.ntter + i), p_nttasr = at(rm.nttasr + i), p_t = at(rm.t + i);
+    const uint32_t o_ntts = op(rm.ntts + i), o_ntte = op(rm.ntte + i), o_nttr_s = op(rm.nttr + i), o_nttr_e = op(rm.nttr + rm.K + i);
+    const uint32_t o_nttas = op(rm.nttas + i), o_nttar = op(rm.nttar + i), o_s = op(rm.s + i), o_e = op(rm.e + i);
+    uint32_t p_seta[MAXE], p_eeta[MAXE], o_ssub[MAXE], o_esub[MAXE];
+#pragma unroll
+    for (int m = 0; m < MAXE; m++) { // (a slot at or beyond E reads the last gate's operands again and is not compared)
+        const int mm = i * E + min(m, E - 1);
+        p_seta[m] = at(rm.seta + mm); p_eeta[m] = at(rm.eeta + mm);
+        o_ssub[m] = op(rm.ssub + mm); o_esub[m] = op(rm.esub + mm);
+    }
     uint32_t bits = 0;
-    for (int i = 0; i < rm.K; i++) {
-        if (op(rm.ntts + i) != ref_sub_u16(at(rm.nttsr + i), op(rm.nttr + i))) bits |= 1u << FB_NTT_S_E;          // :275
-        if (op(rm.ntte + i) != ref_sub_u16(at(rm.ntter + i), op(rm.nttr + rm.K + i))) bits |= 1u << FB_NTT_S_E;   // :279
-        if (at(rm.nttasr + i) != ref_add_u16(op(rm.nttas + i), op(rm.nttar + i))) bits |= 1u << FB_A_SR;          // :306
-        if (at(rm.t + i) != ref_add_u16(op(rm.nttas + i), op(rm.ntte + i))) bits |= 1u << FB_T_RELATION;          // :370
-        for (int m = 0; m < rm.E; m++) {
-            if (op(rm.ssub + i * rm.E + m) != ref_sub_u16(op(rm.s + i), at(rm.seta + i * rm.E + m))) bits |= 1u << FB_SUB_ETA; // :451
-            if (op(rm.esub + i * rm.E + m) != ref_sub_u16(op(rm.e + i), at(rm.eeta + i * rm.E + m))) bits |= 1u << FB_SUB_ETA; // :459
-        }
+    if (o_ntts != ref_sub_u16(p_nttsr, o_nttr_s)) bits |= 1u << FB_NTT_S_E;          // :275
+    if (o_ntte != ref_sub_u16(p_ntter, o_nttr_e)) bits |= 1u << FB_NTT_S_E;          // :279
+    if (p_nttasr != ref_add_u16(o_nttas, o_nttar)) bits |= 1u << FB_A_SR;            // :306
+    if (p_t != ref_add_u16(o_nttas, o_ntte)) bits |= 1u << FB_T_RELATION;            // :370
+#pragma unroll
+    for (int m = 0; m < MAXE; m++) {
+        if (m < E && o_ssub[m] != ref_sub_u16(o_s, p_seta[m])) bits |= 1u << FB_SUB_ETA; // :451
+        if (m < E && o_esub[m] != ref_sub_u16(o_e, p_eeta[m])) bits |= 1u << FB_SUB_ETA; // :459
     }
     if (bits) atomicOr(&v.fail[b], bits);
 }
@@ -661,21 +682,44 @@ __global__ __launch_bounds__(256) void k_check_batch(VerifyArgs v, const uint16_
         if (i >= NREST) return;
         const uint16_t *Pb = v.P + (size_t)b * v.proof_stride + NSEC + v.rest[(size_t)b * v.sel_stride + i];
         bool bad = false;
-        for (int r = 0; r < rm.K; r++) {
-            bad |= Pb[(size_t)(rm.sr + r) * RS] != Pb[(size_t)(rm.sr_in + r) * RS];
-            bad |= Pb[(size_t)(rm.er + r) * RS] != Pb[(size_t)(rm.er_in + r) * RS];
+        uint32_t x[4 * MAXK]; // every operand in flight before the first comparison (a slot at or beyond K repeats row K - 1)
+#pragma unroll
+        for (int r = 0; r < MAXK; r++) {
+            const int rr = min(r, rm.K - 1);
+            x[4 * r] = Pb[(size_t)(rm.sr + rr) * RS]; x[4 * r + 1] = Pb[(size_t)(rm.sr_in + rr) * RS];
+            x[4 * r + 2] = Pb[(size_t)(rm.er + rr) * RS]; x[4 * r + 3] = Pb[(size_t)(rm.er_in + rr) * RS];
         }
+#pragma unroll
+        for (int r = 0; r < MAXK; r++) bad |= x[4 * r] != x[4 * r + 1] || x[4 * r + 2] != x[4 * r + 3];
         if (bad) atomicOr(&v.fail[b], 1u << FB_SR_ER_SHARES);
     } else if (role == NB_REST) {
         const uint16_t *Pb = v.P + (size_t)b * v.proof_stride + t;
         uint32_t bits = 0;
-        for (int i = 0; i < rm.K; i++) {
-            if (Pb[(size_t)(rm.t + i) * RS] != t_pk[((size_t)b * rm.K + i) * 256 + t]) bits |= 1u << FB_T_PK;
-            for (int m = 0; m < rm.E; m++) {
-                const uint32_t c = gf_encode(m - v.eta1);
-                if (Pb[(size_t)(rm.seta + i * rm.E + m) * RS] != c) bits |= 1u << FB_ETA_CONST;
-                if (Pb[(size_t)(rm.eeta + i * rm.E + m) * RS] != c) bits |= 1u << FB_ETA_CONST;
+        constexpr int MAXE = 7;
+        const int K = rm.K, E = rm.E;
+        uint32_t pt[MAXK], tk[MAXK];
+#pragma unroll
+        for (int i = 0; i < MAXK; i++) {
+            const int ii = min(i, K - 1);
+            pt[i] = Pb[(size_t)(rm.t + ii) * RS];
+            tk[i] = t_pk[((size_t)b * K + ii) * 256 + t];
+        }
+#pragma unroll
+        for (int i = 0; i < MAXK; i++) bits |= pt[i] != tk[i] ? 1u << FB_T_PK : 0u;
+        // the 2 K E range constants: one gate index m at a time with all 2 K rows of it in flight
+#pragma unroll
+        for (int m = 0; m < MAXE; m++) {
+            const int mm = min(m, E - 1);
+            const uint32_t c = gf_encode(mm - v.eta1);
+            uint32_t y[2 * MAXK];
+#pragma unroll
+            for (int i = 0; i < MAXK; i++) {
+                const int ii = min(i, K - 1);
+                y[2 * i] = Pb[(size_t)(rm.seta + ii * E + mm) * RS];
+                y[2 * i + 1] = Pb[(size_t)(rm.eeta + ii * E + mm) * RS];
             }
+#pragma unroll
+            for (int i = 0; i < 2 * MAXK; i++) bits |= y[i] != c ? 1u << FB_ETA_CONST : 0u;
         }
         if (bits) atomicOr(&v.fail[b], bits);
     } else {
@@ -744,7 +788,7 @@ hipError_t launch_interp_apply(const InterpArgs &a, uint16_t *P, size_t proof_st
 }
 hipError_t launch_check_opened(const VerifyArgs &v, int nproofs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_check_opened, dim3(nproofs), dim3(192), 0, st, v);
+    hipLaunchKernelGGL(k_check_opened, dim3(nproofs, v.rm.K), dim3(192), 0, st, v);
     return hipGetLastError();
 }
 

@@ -4,9 +4,9 @@
 set -o pipefail
 cd "$(dirname "$0")/.."
 O=gpurun_out/r6; mkdir -p $O
-python -m pytest tests/test_gpu_02_verify.py tests/test_gpu_04_configs.py tests/test_gpu_10_combine.py -m gpu -x -q 2>&1 | tail -3 || exit 1
+python -m pytest tests/test_gpu_00_kernels.py tests/test_gpu_02_verify.py tests/test_gpu_04_configs.py tests/test_gpu_07_api_paths.py -m gpu -x -q 2>&1 | tail -3 || exit 1
 BUSY_STEPS=60 BUSY_ARGS="--slots 6 --combine 6" tools/gpu_busy.sh gpurun_out/prof/busy6 40 > $O/dis_busy.txt 2>&1 || exit 1
-grep -E "lincomb|assemble|GPU busy" $O/dis_busy.txt
+grep -E "lincomb|assemble|gather_frags|check_|interp_setup|coef_limbs|pow_table|GPU busy" $O/dis_busy.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/lc_f -- python3 tools/pmc_workload.py > /dev/null 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/lc_w -- python3 tools/pmc_workload.py > /dev/null 2>&1 || exit 1
