@@ -21,6 +21,7 @@
 #include "kosk_keccak_dev.hpp"
 #include "kosk_keccak_split_dev.hpp"
 #include "kosk_keygen_dev.hpp"
+#include "kosk_keygen_wave_dev.hpp"
 #include "kosk_math.hpp"
 #include "kosk_limb_dev.hpp"
 
@@ -476,15 +477,14 @@ __device__ __forceinline__ void pre_expand_f_pair(const PreArgs &a, int pr, bool
         }
     }
 }
-__device__ __forceinline__ void pre_gen_matrix_pair(const PreArgs &a, int pr, bool hi)
+// role G on the WAVE sponge (kosk_keygen_wave_dev.hpp): block t of the role = matrix entry t, the whole wave on its chain
+// (sha3_512(d || K), then SHAKE128(rho || j || i) block by block with a one-step rejection parse)
+__device__ __forceinline__ void pre_gen_matrix_wave(const PreArgs &a, int t, uint32_t *st, uint8_t *sq)
 {
-    const int KK = a.K * a.K, n = a.nproofs * KK;
-    const bool live = pr < n;
-    const int t = live ? pr : n - 1;
+    const int KK = a.K * a.K;
     const int b = t / KK, ij = t - b * KK, i = ij / a.K, j = ij - i * a.K;
-    uint32_t pub[8], noise[8];
-    kp_seed_hash(pre_tape(a, b), a.K, hi, pub, noise);
-    kp_gen_matrix(pub, i, j, hi, live, a.kg_A + (size_t)b * a.kg_A_stride + (size_t)ij * 256, a.xof);
+    __builtin_amdgcn_s_setprio(3);
+    kw_gen_matrix(pre_tape(a, b), true, a.K, i, j, a.kg_A + (size_t)b * a.kg_A_stride + (size_t)ij * 256, a.xof, st, sq);
 }
 __device__ __forceinline__ void pre_noise_pair(const PreArgs &a, int pr, bool hi)
 {
@@ -504,15 +504,16 @@ __device__ __forceinline__ void pre_noise_pair(const PreArgs &a, int pr, bool hi
 
 __global__ __launch_bounds__(64) void k_prover_pre(PreArgs a)
 {
-    // Workgroups are dispatched in index order, so the roles come longest chain first: G (a matrix entry: six or more dependent
-    // Keccak permutations and a rejection parse per lane, ~60 us for a lone wave), N, A (four permutations per lane) start at once
-    // and the thousands of short role-B workgroups stream through beside them.  With B in front of G (rounds 1-3) the launch took
-    // B's streaming time PLUS G's chain: 100 us at 138 proofs, 73 us at 46.
+    // Workgroups are dispatched in index order, so the roles come chains first: G (a matrix entry: four or more dependent Keccak
+    // permutations; a wave per entry since round 6 -- on one lane pair the chain was ~60 us and set the launch's time), N, A (four
+    // permutations per lane pair) start at once and the thousands of short role-B workgroups stream through beside them.  With B in
+    // front of G (rounds 1-3) the launch took B's streaming time PLUS G's chain: 100 us at 138 proofs, 73 us at 46.
     int blk = blockIdx.x;
-    // roles G, N, A run on the lane-pair sponge (kosk_keygen_dev.hpp: kp_*): 32 sponges per 64-thread block
-    const int pr = blk * 32 + ((int)threadIdx.x >> 1); // sponge index inside the role's range
+    // role G: one matrix entry per block on the wave sponge (round 6); roles N, A on the lane-pair sponge (kosk_keygen_dev.hpp: kp_*): 32 sponges per 64-thread block
+    __shared__ __attribute__((aligned(16))) uint32_t kw_st[KW_ST_WORDS];
+    __shared__ __attribute__((aligned(16))) uint8_t kw_sq[KW_SQ_BYTES];
     const bool hi = threadIdx.x & 1;
-    if (blk < a.nbG) return pre_gen_matrix_pair(a, pr, hi);
+    if (blk < a.nbG) return pre_gen_matrix_wave(a, blk, kw_st, kw_sq);
     blk -= a.nbG;
     if (blk < a.nbN) return pre_noise_pair(a, blk * 32 + ((int)threadIdx.x >> 1), hi);
     blk -= a.nbN;
@@ -2091,7 +2092,7 @@ hipError_t launch_prover_pre(const uint8_t *tape, size_t tape_stride, uint16_t *
         // the witness secrets (role C) read s and e, which role N of this launch produces: they follow in a launch of their own
         a.kg_seeds = kg->seeds; a.kg_seed_stride = kg->seed_stride; a.kg_A = kg->A; a.kg_A_stride = kg->A_stride; a.kg_se = kg->se; a.kg_se_stride = kg->se_stride;
         a.xof = kg->xof;
-        a.nbG = (nproofs * rm.K * rm.K + per - 1) / per;
+        a.nbG = nproofs * rm.K * rm.K; // one block (wave) per matrix entry
         a.nbN = (nproofs * 2 * rm.K + per - 1) / per;
         hipLaunchKernelGGL(k_prover_pre, dim3(a.nbA + a.nbB + a.nbG + a.nbN), dim3(64), 0, st, a);
         if (nbC) {
@@ -2115,7 +2116,7 @@ hipError_t launch_keygen(const uint8_t *tape, size_t tape_stride, uint8_t *seeds
     a.tape = tape; a.tape_stride = tape_stride; a.nproofs = n; a.eta1 = eta1; a.K = K;
     a.kg_seeds = seeds; a.kg_seed_stride = seed_stride; a.kg_A = A; a.kg_A_stride = A_stride; a.kg_se = se; a.kg_se_stride = se_stride;
     const int per = 32;
-    a.nbG = (n * K * K + per - 1) / per;
+    a.nbG = n * K * K; // one block (wave) per matrix entry
     a.nbN = (n * 2 * K + per - 1) / per;
     hipLaunchKernelGGL(k_prover_pre, dim3(a.nbG + a.nbN), dim3(64), 0, st, a);
     return hipGetLastError();

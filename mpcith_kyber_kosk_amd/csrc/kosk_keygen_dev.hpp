@@ -3,7 +3,7 @@
 // The squeezed blocks are parsed straight from the state registers (static lane indices after unrolling): no per-thread
 // LDS byte buffer, no dependent LDS reads inside the rejection loop.
 //   kg_seed_hash     sha3_512(d || K) -> public seed || noise seed               kosk.cpp:12-14
-//   kg_gen_matrix    SHAKE128(seed || j || i) + rej_uniform                       indcpa.c:124-145, :168-193
+//   (gen_matrix)     SHAKE128(seed || j || i) + rej_uniform: kosk_keygen_wave_dev.hpp     indcpa.c:124-145, :168-193
 //   kg_noise         SHAKE256(noise seed || nonce) + cbd2 / cbd3                  poly.c:225-230, cbd.c:58-107
 #pragma once
 #include <hip/hip_runtime.h>
@@ -125,37 +125,7 @@ __device__ __forceinline__ void kp_seed_hash(const uint8_t *d32, int K, bool hi,
 #pragma unroll
     for (int l = 0; l < 4; l++) { pub[2 * l] = f.lo[l]; pub[2 * l + 1] = f.hi[l]; noise[2 * l] = f.lo[4 + l]; noise[2 * l + 1] = f.hi[4 + l]; }
 }
-// gen_matrix entry (i, j): both lanes run the rejection parse on the whole squeezed block (the running count is sequential), the
-// even lane stores
-__device__ __forceinline__ void kp_gen_matrix(const uint32_t (&pub)[8], int i, int j, bool hi, bool store, int16_t *__restrict__ r, const XofGuard &xof)
-{
-    KHalf s;
-    kp_absorb(s, hi, pub, (uint32_t)j | ((uint32_t)i << 8), 2, 168, 0x1F);
-    int ctr = 0;
-    const bool st = store && !hi;
-#pragma unroll 1
-    for (int blk = 0; blk < xof.max_blocks && ctr < 256; blk++) { // uniform over the pair: both lanes see the same count
-        keccak_f1600_split(s, hi);
-        KState f;
-        kp_full(s, hi, 21, f);
-        auto parse = [&]<int... Ts>(std::integer_sequence<int, Ts...>) {
-            (([&] {
-                 const uint32_t x = kg_triple<Ts>(f);
-                 const uint32_t v0 = x & 0xFFFu, v1 = x >> 12;
-                 if (v0 < (uint32_t)Q && ctr < 256) { if (st) r[ctr] = (int16_t)v0; ctr++; }
-                 if (v1 < (uint32_t)Q && ctr < 256) { if (st) r[ctr] = (int16_t)v1; ctr++; }
-             }()),
-             ...);
-        };
-        parse(std::make_integer_sequence<int, 56>{});
-    }
-    if (ctr < 256) {
-        if (st) {
-            for (; ctr < 256; ctr++) r[ctr] = 0;
-            if (xof.err) *reinterpret_cast<volatile uint32_t *>(xof.err) = DEVERR_XOF_BLOCKS;
-        }
-    }
-}
+// (gen_matrix runs on the wave sponge since round 6: kosk_keygen_wave_dev.hpp)
 // poly_getnoise_eta1: eta1 == 2: every lane turns its own dwords of the block into coefficients (dword W = 2 l + half -> eight
 // coefficients, no exchange); eta1 == 3: 3-byte groups straddle dwords, so both lanes rebuild the block and the even lane runs the
 // one-lane parse

@@ -3,7 +3,7 @@
 // straight from the state registers.
 //   (seed hash, gen_matrix and noise sampling of the PROVER are roles of k_prover_pre, kosk_kernels.hip; their device
 //    functions live in kosk_keygen_dev.hpp)
-//   k_gen_matrix_pair SHAKE128(seed || j || i) + rej_uniform (verifier)             indcpa.c:124-145, :168-193
+//   k_gen_matrix_wave SHAKE128(seed || j || i) + rej_uniform (verifier), one entry per wave  indcpa.c:124-145, :168-193
 //   k_keygen_pack    t = A o NTT(s) * R^-1 * R + NTT(e), Barrett; pk / sk bytes    kosk.cpp:39-69, poly.c:124-139
 //   k_decode_pk      polyvec_frombytes + seed extraction                           kosk.cpp:94-97, poly.c:151-158
 #include <hip/hip_runtime.h>
@@ -14,6 +14,7 @@
 
 #include "kosk_keccak_dev.hpp"
 #include "kosk_keygen_dev.hpp"
+#include "kosk_keygen_wave_dev.hpp"
 #include "kosk_math.hpp"
 
 namespace kosk {
@@ -21,17 +22,17 @@ namespace kosk {
 __constant__ static const ZetaTable kZetasKg = ZetaTable();
 
 // A[b][i][j][256] canonical from the 32-byte public seed found at seeds + b * seed_stride (the verifier's gen_matrix, kosk.cpp:98-99;
-// the prover's runs as a role of k_prover_pre, kosk_kernels.hip), on the lane-pair sponge (kp_gen_matrix): 32 entries per 64-thread block
-__global__ __launch_bounds__(64) void k_gen_matrix_pair(const uint8_t *__restrict__ seeds, size_t seed_stride, int16_t *__restrict__ A,
+// the prover's runs as a role of k_prover_pre, kosk_kernels.hip), on the wave sponge (kw_gen_matrix): one entry per 64-thread block
+// (rounds 5-6a: the lane-pair sponge, 32 entries per block: 56 us per 276 proofs, the length of one lane's chain)
+__global__ __launch_bounds__(64) void k_gen_matrix_wave(const uint8_t *__restrict__ seeds, size_t seed_stride, int16_t *__restrict__ A,
                                                         size_t A_stride, int K, int n, XofGuard xof)
 {
-    const int pr = (blockIdx.x * 64 + threadIdx.x) >> 1, total = n * K * K;
-    const bool hi = threadIdx.x & 1, live = pr < total;
-    const int t = live ? pr : total - 1;
+    __shared__ __attribute__((aligned(16))) uint32_t st[KW_ST_WORDS];
+    __shared__ __attribute__((aligned(16))) uint8_t sq[KW_SQ_BYTES];
+    const int t = blockIdx.x; // one wave per matrix entry (kosk_keygen_wave_dev.hpp); the grid is exactly n K K blocks
     const int b = t / (K * K), ij = t - b * K * K, i = ij / K, j = ij - i * K;
-    uint32_t pub[8];
-    kg_load_seed(pub, seeds + (size_t)b * seed_stride);
-    kp_gen_matrix(pub, i, j, hi, live, A + (size_t)b * A_stride + (size_t)ij * 256, xof);
+    __builtin_amdgcn_s_setprio(3);
+    kw_gen_matrix(seeds + (size_t)b * seed_stride, false, K, i, j, A + (size_t)b * A_stride + (size_t)ij * 256, xof, st, sq);
 }
 
 // poly.c:124-139 on a pair of centred coefficients
@@ -94,7 +95,7 @@ hipError_t launch_decode_pk(const uint8_t *pk, size_t pk_stride, uint16_t *t_out
 {
     hipLaunchKernelGGL(k_decode_pk, dim3(K, n), dim3(128), 0, st, pk, pk_stride, t_out, K);
     // gen_matrix from the seed stored behind the packed t (kosk.cpp:96-99)
-    hipLaunchKernelGGL(k_gen_matrix_pair, dim3((n * K * K + 31) / 32), dim3(64), 0, st, pk + 384 * K, pk_stride, A, A_stride, K, n, xof);
+    hipLaunchKernelGGL(k_gen_matrix_wave, dim3(n * K * K), dim3(64), 0, st, pk + 384 * K, pk_stride, A, A_stride, K, n, xof);
     return hipGetLastError();
 }
 
