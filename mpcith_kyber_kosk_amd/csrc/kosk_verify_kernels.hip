@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const F
 {
     { // last blocks: multiplication-gate outputs u = z_2d - z_d of the OPENED parties (mlwe_verifier.cpp:468-502), read from
       // the party-major image records (30 + 24 contiguous bytes per party) instead of 54 scattered matrix columns
-        const int nfb = plan.nrest * NWIN + plan.nopen * ((NOPEN + 63) / 64) + (NREST * 16 + 63) / 64;
+        const int nfb = plan.nrest * NWIN + plan.nopen * ((NOPEN + 63) / 64) + (NREST * 4 + 63) / 64;
         if ((int)blockIdx.x >= nfb) {
             const int t = ((int)blockIdx.x - nfb) * 64 + threadIdx.x, b = blockIdx.y;
             if (t >= NOPEN) return;
@@ -69,13 +69,24 @@ __global__ __launch_bounds__(64) void k_disassemble_fields(VerifyArgs v, const F
     { // blocks past the field tiles: Tcomm / comm of the unopened parties into the two digest tables  mlwe_verifier.cpp:36-38, :645-647
         const int nfield_blocks = plan.nrest * NWIN + plan.nopen * ((NOPEN + 63) / 64);
         if ((int)blockIdx.x >= nfield_blocks) {
+            // one thread per (unopened party, table, 16-byte half of its digest); the image side is read with 4-byte loads (its digest
+            // fields are 4-byte aligned for every Kyber parameter set; 2-byte loads otherwise), the table side written with one
+            // 16-byte store.  Rounds 1-6a: two bytes per thread and table, 326 workgroups per proof (see k_assemble_groups).
             const int q = ((int)blockIdx.x - nfield_blocks) * 64 + threadIdx.x, b = blockIdx.y;
-            if (q >= NREST * 16) return;
+            if (q >= NREST * 4) return;
             const uint8_t *img = proof + (size_t)b * image_stride;
-            const int i = q >> 4, w = q & 15;
-            const size_t dst = ((size_t)b * NPARTY + v.rest[(size_t)b * v.sel_stride + i]) * 32 + 2 * w;
-            *reinterpret_cast<uint16_t *>(dig1 + dst) = reinterpret_cast<const uint16_t *>(img + off_tcomm)[q];
-            *reinterpret_cast<uint16_t *>(dig2 + dst) = reinterpret_cast<const uint16_t *>(img + off_comm)[q];
+            const int i = q >> 2, tab = (q >> 1) & 1, half = q & 1;
+            const uint8_t *src = img + (tab ? off_comm : off_tcomm) + (size_t)i * 32 + 16 * half;
+            uint32_t w[4];
+            if ((reinterpret_cast<uintptr_t>(src) & 3) == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) w[k] = reinterpret_cast<const uint32_t *>(src)[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) w[k] = (uint32_t)reinterpret_cast<const uint16_t *>(src)[2 * k] | ((uint32_t)reinterpret_cast<const uint16_t *>(src)[2 * k + 1] << 16);
+            }
+            const size_t dst = ((size_t)b * NPARTY + v.rest[(size_t)b * v.sel_stride + i]) * 32 + 16 * half;
+            *reinterpret_cast<uint4 *>((tab ? dig2 : dig1) + dst) = make_uint4(w[0], w[1], w[2], w[3]);
             return;
         }
     }
@@ -759,7 +770,7 @@ hipError_t launch_disassemble(const VerifyArgs &v, const FieldDesc *fields, cons
                               const uint8_t *proof, size_t image_stride, size_t off_tcomm, size_t off_comm,
                               uint8_t *dig1, uint8_t *dig2, const GateOffsets &go, int nproofs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_disassemble_fields, dim3(plan.nrest * NWIN + plan.nopen * ((NOPEN + 63) / 64) + (NREST * 16 + 63) / 64 + (NOPEN + 63) / 64, nproofs), dim3(64), 0,
+    hipLaunchKernelGGL(k_disassemble_fields, dim3(plan.nrest * NWIN + plan.nopen * ((NOPEN + 63) / 64) + (NREST * 4 + 63) / 64 + (NOPEN + 63) / 64, nproofs), dim3(64), 0,
                        st, v, fields, plan, rowtab, proof, image_stride, (uint32_t)off_tcomm, (uint32_t)off_comm, dig1, dig2, go);
     return hipGetLastError();
 }
