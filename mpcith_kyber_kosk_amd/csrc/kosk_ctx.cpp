@@ -74,10 +74,10 @@ Ctx::~Ctx()
             if (e) (void)hipEventDestroy(e);
         return; // the stream is the arena's
     }
-    void *dev[] = {t_expand.d, t_recon_d.d, t_recon_2d.d, t_expand.dpoint, t_expand.dfrag, t_recon_d.dfrag, t_recon_2d.dfrag, d_fresh_rows, d_gemm1_rows, d_gemm2_rows, d_off, d_fields, d_asm_groups, d_asm_elems,
+    void *dev[] = {t_expand.d, t_recon_d.d, t_recon_2d.d, t_expand.dfrag, t_recon_d.dfrag, t_recon_2d.dfrag, d_fresh_rows, d_gemm1_rows, d_gemm2_rows, d_off, d_fields, d_asm_groups, d_asm_elems,
                    d_rowtab, d_P, d_tape, d_dig1, d_dig2, d_proof, d_A, d_se, d_kg, d_sehat, d_t, d_alpha, d_I, d_pwT, d_limbs, d_coef, d_lin_rows,
                    d_gather, d_gather2, d_O, d_w, d_ell, d_sec, d_sec_u1, d_sec_u2, d_fail, d_inv, d_invlimb, d_vfields,
-                   d_vrowtab, d_rows_bg, d_rows_isrc, d_rows_idst, d_rows_u, d_fact, d_invfact, d_node_of, d_isort, d_hrange, d_odig, d_orec_rows, d_orec};
+                   d_vrowtab, d_rows_bg, d_rows_isrc, d_rows_idst, d_rows_u, d_fact, d_invfact, d_node_of, d_isort, d_hrange, d_odig};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     void *host[] = {h_err, h_tape, h_dig, h_dig2, h_proof, h_alpha, h_I, h_fail, h_Iimg, h_kg, h_odig};
@@ -281,9 +281,6 @@ static int build_tables(Ctx &c)
             else if (x < NPTS) lagrange_row(&A[(size_t)m * XLEN], XLEN, 0, x); // ss.cpp:26-27
         }
         if (upload_table(c, c.t_expand, A, EXP_M, XLEN)) return -1;
-        std::vector<uint8_t> pt;
-        pack_point_table(A, EXP_M, XLEN, c.t_expand.KS, pt);
-        if (upload_vec(c, &c.t_expand.dpoint, pt)) return -1;
     }
     { // reconstruction of the packed secrets from parties 0..406 / 0..812   ss.cpp:47, :66
         std::vector<uint16_t> A((size_t)NSEC * XLEN), A2((size_t)NSEC * (DEG2 + 1));
@@ -373,17 +370,10 @@ static int build_tables(Ctx &c)
     {
         std::vector<AsmGroup> groups;
         std::vector<AsmElem> elems;
-        std::vector<int16_t> orec_rows; // rows of the opened-kind groups, group after group: the rows of k_opened_gemm's compact matrix
         for (int sel = 1; sel >= 0; sel--) {
             AsmGroup g{};
             auto flush = [&]() {
-                if (g.nsub) {
-                    if (!g.sel) {
-                        g.orec_row0 = (int)orec_rows.size();
-                        for (int k = 0; k < g.nrows; k++) orec_rows.push_back(c.h_rowtab[g.rowtab_off + k]);
-                    }
-                    groups.push_back(g);
-                }
+                if (g.nsub) groups.push_back(g);
                 g = AsmGroup{};
             };
             for (int f = 0; f < c.nfields; f++) {
@@ -407,10 +397,6 @@ static int build_tables(Ctx &c)
         c.n_asm_groups = (int)groups.size();
         if (upload_vec(c, &c.d_asm_groups, groups)) return -1;
         if (upload_vec(c, &c.d_asm_elems, elems)) return -1;
-        if (orec_rows.empty()) { c.err = "internal: no opened-kind rows"; return -1; }
-        while (orec_rows.size() % 48) orec_rows.push_back(orec_rows.back()); // whole row blocks (the padding recomputes the last row)
-        c.n_orec_pad = (int)orec_rows.size();
-        if (upload_vec(c, &c.d_orec_rows, orec_rows)) return -1;
     }
     if (upload_vec(c, &c.d_fields, c.h_fields)) return -1;
     if (upload_vec(c, &c.d_rowtab, c.h_rowtab)) return -1;
@@ -521,7 +507,6 @@ int ctx_create(Ctx **out, int device, int kyber_k, int max_batch, std::string &e
         c.limb_cap = ((B * 256 + 63) / 64 * 64 / 16) * (size_t)13 * 2048;
         HIPCHK(dev(&c.d_limbs, (size_t)(256 / 16) * 13 * 2048));
         HIPCHK(dev(&c.d_coef, 2 * (size_t)8 * 2 * 2048));
-        HIPCHK(dev(&c.d_orec, (size_t)c.n_orec_pad * 160));
         HIPCHK(dev(&c.d_fail, 1));
         HIPCHK(host(&c.h_tape, c.tape_stride));
         HIPCHK(host(&c.h_dig, (size_t)NPARTY * 32));
@@ -999,13 +984,7 @@ int prove_resident(Ctx &c, int n, bool online_only, const KeygenIn *keygen)
         aa.groups = c.d_asm_groups;
         aa.elems = c.d_asm_elems;
         aa.ngroups = c.n_asm_groups;
-        static const bool orec_on = !(getenv("KOSK_OREC") && atoi(getenv("KOSK_OREC")) == 0); // (temporary: A/B of review item 4)
-        aa.orec = orec_on ? c.d_orec : nullptr;
-        aa.orec_rows = c.n_orec_pad;
-        aa.orec_stride = 160;
         c.prof_begin(PR_ASSEMBLE, n);
-        // the opened parties' shares of the opened-kind rows: recomputed from the rows' first 407 points (k_opened_gemm), not gathered
-        if (orec_on) HIPCHK(launch_opened_gemm(c.d_P, c.proof_stride, c.d_orec_rows, c.n_orec_pad, c.t_expand.dpoint, c.t_expand.M, c.d_I, c.sel_stride, c.d_orec, n, st));
         HIPCHK(launch_assemble(aa, P.off[F_TCOMM], P.off[F_COMM], P.off[F_I], n, st));
         c.prof_end(PR_ASSEMBLE);
         if (c.near_end_hook) c.near_end_hook(); // the last kernel is queued: a merged run's sleeping callers get ready for the return

@@ -73,7 +73,6 @@ enum PathId { PATH_HASH_DMA = 0, PATH_HASH_PLAIN, PATH_TABLE_GEMM, PATH_LIMB_GEM
 struct GemmTable {
     uint8_t *d = nullptr; // limb matrix (kosk_device.hpp)
     uint8_t *dfrag = nullptr; // the same in fragment-linear tile order (k_table_gemm), tables with Kdim <= 448 only
-    uint8_t *dpoint = nullptr; // the same point-major (k_opened_gemm's gathered rows): the expansion table only
     int M = 0, Mpad = 0, KS = 0, Kdim = 0;
 };
 
@@ -154,11 +153,6 @@ struct Ctx {
     AsmGroup *d_asm_groups = nullptr; // the grouped image kernel's tables (build_tables)
     AsmElem *d_asm_elems = nullptr;
     int n_asm_groups = 0;
-    // the opened parties' records by recomputation (k_opened_gemm): the opened-kind rows in group order, padded to whole 48-row blocks,
-    // and the compact matrix [proof][n_orec_pad][160] they are computed into
-    int16_t *d_orec_rows = nullptr;
-    uint16_t *d_orec = nullptr;
-    int n_orec_pad = 0;
     int nfields = 0;
     std::vector<FieldDesc> h_fields;
     std::vector<int16_t> h_rowtab;

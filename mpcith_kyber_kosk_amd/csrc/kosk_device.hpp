@@ -172,7 +172,6 @@ struct AsmGroup {
     int nsub;
     uint32_t sub_off[12]; // image byte offset, width and first tile column of the group's fields (unopened kind: the write-out runs)
     int16_t sub_width[12], sub_col[12];
-    int orec_row0;  // opened kind: the group's first row in the compact matrix of k_opened_gemm
 };
 constexpr int ASM_MAX_GROUPS = 8;
 
@@ -188,11 +187,6 @@ struct AssembleArgs {
     const uint8_t *dig1, *dig2; // [proof][NPARTY][32]
     uint8_t *proof;
     size_t image_stride;
-    // the opened parties' shares of the opened-kind rows, recomputed (k_opened_gemm): [proof][orec_rows][orec_stride], columns = the
-    // opened parties ascending; null: gather them from the row matrix (rounds 5-6a)
-    const uint16_t *orec;
-    int orec_rows, orec_stride;
-    int dbg;
     int img_align; // filled in by the launcher: 16, 8, 4 or 2 -- the widest store the digest blocks may use on the image
 };
 
@@ -372,8 +366,6 @@ hipError_t launch_post_gates(uint16_t *P, size_t proof_stride, const RowMap &rm,
 hipError_t launch_copy_tails(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st);
 hipError_t launch_post_relation(uint16_t *P, size_t proof_stride, const RowMap &rm, int nproofs, hipStream_t st);
 // the proof wire image (k_assemble_groups: opened-party records from dense window gathers)
-hipError_t launch_opened_gemm(const uint16_t *P, size_t proof_stride, const int16_t *rows, int npad, const uint8_t *Apt, int Mtab,
-                              const uint16_t *sel, int sel_stride, uint16_t *C, int nproofs, hipStream_t st);
 hipError_t launch_assemble(const AssembleArgs &a, size_t off_tcomm, size_t off_comm, size_t off_I, int nproofs, hipStream_t st);
 
 } // namespace kosk

@@ -614,22 +614,6 @@ void pack_frag_table(const std::vector<uint16_t> &A, int M, int Kdim, int Mpad, 
         }
 }
 
-// The limb split "point-major" for the product over GATHERED table rows (k_opened_gemm): row m's KS * 64 low limbs, then its KS * 64 high
-// limbs, contiguous (KS * 128 bytes per row) -- a lane that needs 16 bytes of an arbitrary row then shares its 64-byte segment with the three
-// lanes of the row's other k-chunks and walks the row's lines k-step by k-step; in the fragment-linear order 16 rows share every line, and a
-// gather over scattered rows pulls a 128-byte line through L1 for each 16 bytes it uses.
-void pack_point_table(const std::vector<uint16_t> &A, int M, int Kdim, int KS, std::vector<uint8_t> &out)
-{
-    out.assign((size_t)M * KS * 128, 0);
-    for (int m = 0; m < M; m++)
-        for (int k = 0; k < Kdim; k++) {
-            const int32_t c = gf_center(A[(size_t)m * Kdim + k]);
-            const int c0 = ((c + 32) & 63) - 32, c1 = (c - c0) >> 6;
-            out[(size_t)m * KS * 128 + k] = (uint8_t)(int8_t)c0;
-            out[(size_t)m * KS * 128 + KS * 64 + k] = (uint8_t)(int8_t)c1;
-        }
-}
-
 // -------------------------------------------------------------------- misc --
 // Persistent worker pool: Fiat-Shamir rounds arrive in short bursts between GPU phases, so the
 // workers spin briefly on a generation counter before they block.

@@ -44,7 +44,6 @@ uint16_t gf_inv_host(uint16_t a);
 void pack_limb_table(const std::vector<uint16_t> &A, int M, int Kdim, int Mpad, int KS, std::vector<uint8_t> &out);
 // the same limbs with each 1 KiB tile in MFMA-fragment order (lane l's 16 bytes at offset 16 l): operands loaded from global memory
 void pack_frag_table(const std::vector<uint16_t> &A, int M, int Kdim, int Mpad, int KS, std::vector<uint8_t> &out);
-void pack_point_table(const std::vector<uint16_t> &A, int M, int Kdim, int KS, std::vector<uint8_t> &out);
 
 // Persistent worker pool.  One per library context: several contexts (pipeline slots) run their
 // Fiat-Shamir rounds concurrently, each on its own few threads.

@@ -1393,117 +1393,6 @@ __global__ __launch_bounds__(512, 1) void k_table_gemm_p(GemmArgs a, int nchunks
     }
 }
 
-// ---- the OPENED parties' records by recomputation (round 6; review item 4; mlwe_prover.cpp:480-537, ss.cpp:23-32) ------------------
-// The wire image carries, for each of the 150 opened parties, its shares of the 214-254 input sharings (f, NTT f, s, e, ... : the
-// fields with FieldDesc::sel == 0).  Gathered from the row matrix they cost every 128-byte line of those rows (each holds an opened
-// party with probability 0.999): 675 KB read per proof for 70 KB used.  Every one of those rows is a degree-d sharing -- fresh, or a
-// pointwise linear combination of such (k_post_gates, k_post_relation, k_lincomb_stream) -- so its share at party p is the expansion
-// product T[p][.] * (its values at points 0..406), the product k_table_gemm_p computes for ALL 1 344 columns, restricted here to the
-// proof's 150 opened columns: 11 % of the expansion's matrix work, reading 448 of a row's 1 728 values and writing a compact
-// [row][160] matrix per proof (the opened parties in ascending order, SEL_OSORT) that k_assemble_groups turns into records.
-// A workgroup = (proof, 48 of its rows): rows -> int8 limbs in LDS as in k_table_gemm; a wave takes table chunks of 16 opened
-// parties: lane (k-chunk lane >> 4, party lane & 15) finds its 16-byte table fragment in a POINT-MAJOR copy of the table (row m =
-// party - 128: the table's first row is point 384) -- in the fragment-linear copy every 16 bytes of a scattered row cost a 128-byte
-// line through L1 (60 us per 276 proofs).  Parties < 128 have no table row (their shares ARE inputs): their slots compute row 0 and
-// k_assemble_groups reads those few from the row matrix instead.  Four waves, two workgroups per CU.
-constexpr int OG_NB = 48, OG_KS = 7, OG_WAVES = 4, OG_PTS = 160, OG_CHUNKS = OG_PTS / 16;
-__global__ __launch_bounds__(256, 3) void k_opened_gemm(const uint16_t *__restrict__ P, size_t proof_stride, const int16_t *__restrict__ rows, int npad,
-                                                        const uint8_t *__restrict__ Apt, int Mtab, const uint16_t *__restrict__ sel, int sel_stride,
-                                                        uint16_t *__restrict__ C, int nproofs)
-{
-    constexpr int KS = OG_KS, NBT = OG_NB / 16;
-    __shared__ __attribute__((aligned(16))) uint8_t ldsB[KS * NBT * 2048];
-    __shared__ uint16_t m_s[OG_PTS];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int bpp = npad / OG_NB;
-    const int b = (int)blockIdx.x / bpp, rb = (int)blockIdx.x - b * bpp;
-    if (b >= nproofs) return;
-    // ---- this block's 48 rows, points 0 .. 447, u16 -> limbs (points 407 .. 447 meet zero table columns)
-    constexpr int ITEMS = OG_NB * KS * 4, PER = (ITEMS + 255) / 256;
-    uint4 x0[PER], x1[PER];
-#pragma unroll
-    for (int q = 0; q < PER; q++) {
-        const int item = tid + q * 256;
-        x0[q] = make_uint4(0, 0, 0, 0);
-        x1[q] = x0[q];
-        if (item < ITEMS) {
-            const int row_l = item / (KS * 4), kc16 = item - row_l * (KS * 4);
-            const uint16_t *src = P + (size_t)b * proof_stride + (size_t)rows[rb * OG_NB + row_l] * RS + kc16 * 16;
-            x0[q] = *reinterpret_cast<const uint4 *>(src);
-            x1[q] = *reinterpret_cast<const uint4 *>(src + 8);
-        }
-    }
-    if (tid < OG_PTS) { // the opened parties ascending (the list's tail repeats its last entry), as table rows
-        const int p = sel[(size_t)b * sel_stride + SEL_OSORT + min(tid, NOPEN - 1)];
-        m_s[tid] = (uint16_t)min(max(p - (EXP_OFF - NSEC), 0), Mtab - 1);
-    }
-#pragma unroll
-    for (int q = 0; q < PER; q++) {
-        const int item = tid + q * 256;
-        if (item < ITEMS) {
-            const int row_l = item / (KS * 4), kc16 = item - row_l * (KS * 4);
-            uint4 lo, hi;
-            gm_split16_pk(x0[q], x1[q], lo, hi); // the prover's rows are canonical
-            uint8_t *d = ldsB + ((kc16 >> 2) * NBT + (row_l >> 4)) * 2048 + (row_l & 15) * 64 + (((kc16 & 3) ^ limb_swz(row_l & 15)) << 4);
-            *reinterpret_cast<uint4 *>(d) = lo;
-            *reinterpret_cast<uint4 *>(d + 1024) = hi;
-        }
-    }
-    __syncthreads();
-    const int frag = (lane & 15) * 64 + (((lane >> 4) ^ limb_swz(lane & 15)) << 4);
-    v4i fa[KS][2];
-    auto load_chunk_ks = [&](int c, int ks, v4i (&dst)[2]) { // gathered: every lane its own table row, in the point-major copy of the table
-        const int m = m_s[c * 16 + (lane & 15)];
-        const uint8_t *src = Apt + (size_t)m * (KS * 128) + ks * 64 + (lane >> 4) * 16;
-        dst[0] = *reinterpret_cast<const v4i *>(src);
-        dst[1] = *reinterpret_cast<const v4i *>(src + KS * 64);
-    };
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) load_chunk_ks(w, ks, fa[ks]);
-    uint16_t *crow[NBT]; // compact matrix [proof][npad][OG_PTS]: this lane's row of tile j, its four consecutive columns
-#pragma unroll
-    for (int j = 0; j < NBT; j++) crow[j] = C + ((size_t)b * npad + rb * OG_NB + j * 16 + (lane & 15)) * OG_PTS + (lane >> 4) * 4;
-    const v4i zero4 = {0, 0, 0, 0}, bias4 = {LIMB_BIAS, LIMB_BIAS, LIMB_BIAS, LIMB_BIAS};
-    v4i fb[2][2 * NBT], fb0[2 * NBT];
-    auto load_b = [&](int ks, v4i (&dst)[2 * NBT]) {
-        const uint8_t *lb = ldsB + ks * NBT * 2048 + frag;
-#pragma unroll
-        for (int j = 0; j < NBT; j++) {
-            dst[2 * j] = *reinterpret_cast<const v4i *>(lb + j * 2048);
-            dst[2 * j + 1] = *reinterpret_cast<const v4i *>(lb + j * 2048 + 1024);
-        }
-    };
-    load_b(0, fb0);
-    for (int c = w; c < OG_CHUNKS; c += OG_WAVES) {
-        const int cn = c + OG_WAVES < OG_CHUNKS ? c + OG_WAVES : c; // the chunk to prefetch (the last one re-loads itself: harmless)
-        v4i s0[NBT], s1[NBT], s2[NBT];
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            v4i(&bc)[2 * NBT] = ks == 0 ? fb0 : fb[ks & 1];
-            v4i(&bn)[2 * NBT] = ks + 1 == KS ? fb0 : fb[(ks & 1) ^ 1];
-            load_b(ks + 1 < KS ? ks + 1 : 0, bn);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < NBT; j++) s0[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][0], bc[2 * j], ks == 0 ? bias4 : s0[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NBT; j++) s1[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][0], bc[2 * j + 1], ks == 0 ? zero4 : s1[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NBT; j++) s1[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][1], bc[2 * j], s1[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NBT; j++) s2[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[ks][1], bc[2 * j + 1], ks == 0 ? zero4 : s2[j], 0, 0, 0);
-            load_chunk_ks(cn, ks, fa[ks]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int j = 0; j < NBT; j++) { // D[row = party 4 (lane >> 4) + r of the chunk][col = data row lane & 15 of tile j]
-            uint32_t v[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) v[r] = gf_reduce_limbs_biased_lazy(s0[j][r], s1[j][r], s2[j][r]);
-            *reinterpret_cast<uint2 *>(crow[j] + c * 16) = make_uint2(gf_canon_pair(v[0], v[1]), gf_canon_pair(v[2], v[3]));
-        }
-    }
-}
-
 // ---- K3 (prover) on the matrix cores: out_j[x] = sum_k Coef[j][k] * in_k[x], per proof a [76 x 77] x [77 x 1710] product.
 // (Rounds 2-4 ran it as a transposition pass + the generic GEMM, then as the one-shot kernel k_lincomb_fused -- one workgroup per
 // (proof, f | NTT f, 128 points); both are gone since round 6, their measurements are in profiles/r05_* and DESIGN.md 15.2.)
@@ -1997,7 +1886,7 @@ __device__ __forceinline__ void asm_group_block(const AssembleArgs &a, const Asm
     uint2 v[NQ];
     const uint16_t *src = Pb + NSEC + lo + 4 * cq;
 #pragma unroll
-    for (int q = 0; q < NQ; q++) v[q] = (a.dbg & 16) ? make_uint2(q, lane) : *reinterpret_cast<const uint2 *>(src + (size_t)rr[q] * RS);
+    for (int q = 0; q < NQ; q++) v[q] = *reinterpret_cast<const uint2 *>(src + (size_t)rr[q] * RS);
     __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the rank table is written
     __builtin_amdgcn_wave_barrier();
     int rk[4];
@@ -2022,7 +1911,6 @@ __device__ __forceinline__ void asm_group_block(const AssembleArgs &a, const Asm
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
-    if (g.sel && (a.dbg & 8)) return;
     if (g.sel) {
         for (int s = 0; s < g.nsub; s++) { // one contiguous run per field; its start is only 2-byte aligned in general
             const int width = g.sub_width[s];
@@ -2046,56 +1934,12 @@ __device__ __forceinline__ void asm_group_block(const AssembleArgs &a, const Asm
     }
 }
 
-// Records of the OPENED parties from the compact matrix of k_opened_gemm (a.orec: [proof][row of the opened kind][160], the opened parties
-// ascending): block = (group, 16 consecutive entries of the sorted list) -- ten blocks per group.  Lane = (row slot lane >> 4, entry
-// lane & 15): a load instruction brings four rows' 32-byte pieces; an opened party below 128 (its shares are inputs of the expansion,
-// not outputs) is read from the row matrix instead.  The tile holds [entry][rows]; the write-out is the one of the gathering form: the
-// record of sorted entry k goes to position SEL_OPOS[k] of the image's field.
-constexpr int ASM_OCH = 16, ASM_OBLOCKS = (NOPEN + ASM_OCH - 1) / ASM_OCH;
-__device__ __forceinline__ void asm_opened_block(const AssembleArgs &a, const AsmGroup &g, const int b, const int ch, uint16_t *tile, AsmElem *el_s)
-{
-    const int lane = threadIdx.x, e = lane & 15, slot = lane >> 4;
-    const int k0 = ASM_OCH * ch, nk = min(ASM_OCH, NOPEN - k0);
-    if (nk <= 0) return;
-    const uint16_t *orow = a.opened + (size_t)b * a.sel_stride;
-    const int nrows = g.nrows;
-    const int k = k0 + min(e, nk - 1);
-    const int party = orow[SEL_OSORT + k], my_pos = orow[SEL_OPOS + k];
-    const AsmElem *el = a.elems + g.elem_off;
-    el_s[lane] = el[lane];
-    el_s[lane + 64] = el[lane + 64];
-    const uint16_t *src = a.orec + ((size_t)b * a.orec_rows + g.orec_row0) * a.orec_stride + k;
-    const bool direct = party < EXP_OFF - NSEC; // no table row: the share is an input point of the row
-    const uint16_t *Pc = a.P + (size_t)b * a.proof_stride + NSEC + party;
-    const int16_t *rt = a.rowtab + g.rowtab_off;
-    constexpr int NQ = 20; // 4 NQ >= the largest group (80 rows)
-    uint32_t v[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-        const int r = min(4 * q + slot, nrows - 1);
-        v[q] = direct ? Pc[(size_t)rt[r] * RS] : src[(size_t)r * a.orec_stride];
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; q++)
-        if (4 * q + slot < nrows && e < nk) tile[e * nrows + 4 * q + slot] = (uint16_t)v[q];
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-    uint16_t *img16 = reinterpret_cast<uint16_t *>(a.proof + (size_t)b * a.image_stride);
-    const AsmElem e0 = el_s[lane], e1 = el_s[lane + 64];
-    for (int j = 0; j < nk; j++) {
-        const int i = __builtin_amdgcn_readlane(my_pos, j); // lane j: slot 0, entry j
-        if (lane < nrows) img16[e0.dst + i * (int)e0.width] = tile[j * nrows + lane];
-        if (lane + 64 < nrows) img16[e1.dst + i * (int)e1.width] = tile[j * nrows + lane + 64];
-    }
-}
-
 __global__ __launch_bounds__(64) void k_assemble_groups(AssembleArgs a, uint32_t off_tcomm, uint32_t off_comm, uint32_t off_I, int blocks_per_proof, int nproofs)
 {
     const int vid = xcd_virtual_id(); // the windows of a group read adjacent lines of the same rows: one XCD, one L2
     const int b = vid / blocks_per_proof, bx = vid - b * blocks_per_proof;
     if (b >= nproofs) return;
     const int ngb = a.ngroups * NWIN;
-    if (bx >= ngb && (a.dbg & 4)) return;
     if (bx >= ngb) { // Tcomm / comm of the unopened parties and the list I itself
         // one thread per (unopened party, table, 16-byte half of its digest): 16-byte loads (the digests are 32-byte aligned in both
         // tables), stores as wide as the image's field offsets allow (the launcher's img_align).  Rounds 1-6a moved two bytes per
@@ -2129,12 +1973,6 @@ __global__ __launch_bounds__(64) void k_assemble_groups(AssembleArgs a, uint32_t
     __shared__ AsmElem el_s[128];
     const int gi = bx / NWIN, w = bx - gi * NWIN;
     const AsmGroup &g = a.groups[gi];
-    if ((a.dbg & 1) && !g.sel) return;
-    if ((a.dbg & 2) && g.sel) return;
-    if (!g.sel && a.orec) { // the opened kind from the recomputed compact matrix: ten blocks of 16 sorted entries, the group's other blocks idle
-        if (w < ASM_OBLOCKS) asm_opened_block(a, g, b, w, tile, el_s);
-        return;
-    }
     if (g.nrows <= 16) asm_group_block<4>(a, g, b, w, tile, rank_s, el_s);
     else if (g.nrows <= 64) asm_group_block<16>(a, g, b, w, tile, rank_s, el_s);
     else asm_group_block<20>(a, g, b, w, tile, rank_s, el_s);
@@ -2449,20 +2287,9 @@ hipError_t launch_post_relation(uint16_t *P, size_t proof_stride, const RowMap &
     return hipGetLastError();
 }
 
-hipError_t launch_opened_gemm(const uint16_t *P, size_t proof_stride, const int16_t *rows, int npad, const uint8_t *Apt, int Mtab,
-                              const uint16_t *sel, int sel_stride, uint16_t *C, int nproofs, hipStream_t st)
-{
-    if (npad <= 0 || npad % OG_NB || !Apt) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_opened_gemm, dim3((unsigned)(npad / OG_NB * nproofs)), dim3(256), 0, st, P, proof_stride, rows, npad, Apt, Mtab, sel,
-                       sel_stride, C, nproofs);
-    return hipGetLastError();
-}
-
 hipError_t launch_assemble(const AssembleArgs &a, size_t off_tcomm, size_t off_comm, size_t off_I, int nproofs, hipStream_t st)
 {
     if (!a.groups || a.ngroups <= 0) return hipErrorInvalidValue;
-    static const int dbg = getenv("KOSK_ASM_DBG") ? atoi(getenv("KOSK_ASM_DBG")) : 0;
-    const_cast<AssembleArgs &>(a).dbg = dbg;
     // widest store the image's digest fields allow (field offsets, image stride and base all multiples of it)
     auto ok = [&](size_t m) { return off_tcomm % m == 0 && off_comm % m == 0 && a.image_stride % m == 0 && (reinterpret_cast<uintptr_t>(a.proof) % m) == 0; };
     const_cast<AssembleArgs &>(a).img_align = ok(16) ? 16 : ok(8) ? 8 : ok(4) ? 4 : 2;
