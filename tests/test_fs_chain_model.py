@@ -35,6 +35,14 @@ def test_lane_model_of_the_bpermute_variant_matches_hashlib():
             assert len({m.lane_b(x, y, h) >> 4 for y in range(5)}) == 1
 
 
+def test_lane_model_of_gen_matrix_on_the_wave_sponge():
+    """csrc/kosk_keygen_wave_dev.hpp (kw_gen_matrix) lane by lane: the seed hash whose digest words stay in their lanes as the XOF's first
+    words, the padding words of SHAKE128's 168-byte rate, and the one-step rejection parse (56 lanes x one 3-byte group, two ballots)
+    against hashlib + the scalar rej_uniform of kyber/indcpa.c:124-145 -- K = 2, 3, 4, several (i, j), and the block guard"""
+    import fs_chain_model as m
+    assert m.self_check_gen_matrix()
+
+
 def test_lane_tables_match_the_device_header():
     """the LDS map constants of csrc/kosk_fs_dev.hpp are the model's"""
     import fs_chain_model as m

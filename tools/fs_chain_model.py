@@ -267,7 +267,81 @@ def self_check_b():
     return True
 
 
+# ---- gen_matrix on the wave sponge (csrc/kosk_keygen_wave_dev.hpp: kw_gen_matrix), lane by lane -------------------------------------
+def gen_matrix_wave(seed32, i, j, K=3, hash_d=False, max_blocks=32):
+    """(coefficients, blocks squeezed).  The state stays in the wave's lanes between the seed hash and the XOF (rho = words 0..3 as they
+    stand); a squeezed block is parsed in ONE step: lane t takes the 3-byte group t, two ballots place every accepted candidate."""
+    w = WaveB()
+    seed32 = bytes(seed32)
+    words = [int.from_bytes(seed32[8 * q:8 * q + 8], "little") for q in range(4)]
+    if hash_d:  # sha3_512(d || K): rate 72
+        w.absorb_words(words + [K | (0x06 << 8), 0, 0, 0, 0x80 << 56])
+        w.permute()
+        keep = [lane_b(q % 5, q // 5, h) for q in range(4) for h in range(2)]
+        a = np.zeros(64, np.uint64)
+        a[keep] = w.a[keep]
+        w.a = a
+        w.absorb_words([0, 0, 0, 0, j | (i << 8) | (0x1F << 16)] + [0] * 15 + [0x80 << 56])
+    else:
+        w.absorb_words(words + [j | (i << 8) | (0x1F << 16)] + [0] * 15 + [0x80 << 56])
+    r = [0] * 256
+    ctr = blocks = 0
+    while blocks < max_blocks and ctr < 256:
+        w.permute()
+        blocks += 1
+        sq = b"".join(w.word(q).to_bytes(8, "little") for q in range(21))
+        v0 = [0xFFFF] * 64
+        v1 = [0xFFFF] * 64
+        for lane in range(56):
+            x = sq[3 * lane] | (sq[3 * lane + 1] << 8) | (sq[3 * lane + 2] << 16)
+            v0[lane], v1[lane] = x & 0xFFF, x >> 12
+        ok0 = [v < 3329 for v in v0]
+        ok1 = [v < 3329 for v in v1]
+        for lane in range(64):  # every lane on its own, from the two ballot masks
+            at0 = ctr + sum(ok0[:lane]) + sum(ok1[:lane])
+            at1 = at0 + (1 if ok0[lane] else 0)
+            if ok0[lane] and at0 < 256:
+                r[at0] = v0[lane]
+            if ok1[lane] and at1 < 256:
+                r[at1] = v1[lane]
+        ctr += sum(ok0) + sum(ok1)
+    return r, blocks, min(ctr, 256)
+
+
+def gen_matrix_scalar(rho, i, j):
+    """kyber/indcpa.c:124-145, :168-193 (not transposed: xof_absorb(rho, j, i)) with hashlib"""
+    buf = hashlib.shake_128(bytes(rho) + bytes([j, i])).digest(168 * 32)
+    r, pos = [], 0
+    while len(r) < 256:
+        v0 = (buf[pos] | (buf[pos + 1] << 8)) & 0xFFF
+        v1 = ((buf[pos + 1] >> 4) | (buf[pos + 2] << 4)) & 0xFFF
+        pos += 3
+        if v0 < 3329:
+            r.append(v0)
+        if len(r) < 256 and v1 < 3329:
+            r.append(v1)
+    return r
+
+
+def self_check_gen_matrix():
+    rng = np.random.default_rng(7)
+    for K in (2, 3, 4):
+        d = rng.integers(0, 256, 32, dtype=np.uint8).tobytes()
+        rho = hashlib.sha3_512(d + bytes([K])).digest()[:32]
+        for (i, j) in ((0, 0), (1, 2 % K), (K - 1, K - 1)):
+            want = gen_matrix_scalar(rho, i, j)
+            got, blocks, ctr = gen_matrix_wave(d, i, j, K, hash_d=True)
+            assert got == want and ctr == 256 and 3 <= blocks <= 5, (K, i, j)
+            got2, _, _ = gen_matrix_wave(rho, i, j, K, hash_d=False)
+            assert got2 == want, (K, i, j)
+    # the block guard: one block holds at most 112 candidates
+    got, blocks, ctr = gen_matrix_wave(rho, 0, 0, 3, max_blocks=1)
+    assert blocks == 1 and ctr < 256 and got[:ctr] == gen_matrix_scalar(rho, 0, 0)[:ctr]
+    return True
+
+
 if __name__ == "__main__":
     self_check()
     self_check_b()
+    self_check_gen_matrix()
     print("fs_chain_model: both lane models (LDS exchanges; DPP + ds_bpermute) == hashlib (sha3_256 of a 46 528-byte table, shake256, edge lengths)")
