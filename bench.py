@@ -579,11 +579,22 @@ def main():
     threads, blocking = host_budget(usable_cores, local_world, -(-S // CMB), cfg["threads"] * CMB)
     threads = threads_per_caller(threads, blocking, CMB, cores_per_rank)  # per handle; a merged run led by a cohort's first member uses CMB times as many
     # Where the Fiat-Shamir hashes run.  On the host they cost four to five busy cores per GPU and four PCIe copies of 46.5 KB per proof,
-    # and give the higher rate when the cores exist (177-180 k against 115 k proofs/s on one GPU, profiles/r06_fs_device.txt); on the
-    # device a rank needs two to four cores with this Python harness.  The host's hashing costs ~0.06 busy cores per k proofs/s (10.7 at 180 k),
-    # so below ~8 cores per rank host mode would be CPU-bound under what device mode delivers (115-120 k).  Not given: the device below eight
+    # and give the higher rate when the cores exist (189-191 k proofs/s at 10-11 busy cores on one GPU); on the device a rank needs two to
+    # three cores with this Python harness and makes 166-176 k with sixteen callers per cohort (below).  Host mode costs ~0.06 busy cores per
+    # k proofs/s, so below a dozen cores per rank it would be CPU-bound under what device mode delivers.  Not given: the device below twelve
     # usable cores per rank (eight ranks on a 16-core quota could not even start the host's hashing), else the host.
-    FS = args.fs or cfg.get("fs") or ("device" if cores_per_rank < 8 else "host")
+    FS = args.fs or cfg.get("fs") or ("device" if cores_per_rank < 12 else "host")
+    if FS == "device":
+        # Nothing to hash on the host: ONE worker per caller (it only finishes the key records).  Three of them -- host mode's figure --
+        # cost 1.9 busy cores per GPU in wake-ups for nothing (profiles/r06b_device_arrangements.txt: 48 callers 4.76 -> 2.88 cores).
+        threads = 1
+        # A cohort's stream waits 4 x 0.79 ms per step for its chains whatever the launch size, so device mode wants LARGE cohorts: sixteen
+        # callers per merged run (736 proofs per launch) make 179 k proofs/s at 2.9 busy cores where six make 124 k at 1.8 (native callers;
+        # this harness: 166-176 k at 2.8-3.2 cores, profiles/r06b_device_arrangements.txt).  Taken when neither --slots nor --combine is
+        # given, at 46 proofs per call, where the rank has four cores for the 48 caller threads (with three, 36 callers made 86 k: the
+        # interpreter's threads starve each other; two or three cores keep eighteen callers: 94 k at 1.9 cores).
+        if args.slots <= 0 and args.combine <= 0 and not args.batch and cfg.get("combine", 1) == 6 and cores_per_rank >= 4:
+            S, CMB = 48, 16
     if args.threads > 0:
         threads = args.threads
     if os.environ.get("KOSK_BENCH_BLOCKING") in ("0", "1"):
@@ -1019,7 +1030,7 @@ def main():
                 exe = os.path.join(ROOT, "examples", "throughput")
                 if not os.path.exists(exe):
                     return {"error": "examples/throughput is not built (__graft_entry__.build() builds it)"}
-                cmd = [exe, "--k", str(k), "--batch", str(B), "--callers", str(callers_ or S), "--combine", str(combine_ or CMB), "--fs", fs_, "--threads", str(threads),
+                cmd = [exe, "--k", str(k), "--batch", str(B), "--callers", str(callers_ or S), "--combine", str(combine_ or CMB), "--fs", fs_, "--threads", str(1 if fs_ == "device" else threads),
                        "--steps", str(max(K, 20)), "--warmup", str(W), "--tape-sets", str(args.tape_sets), "--device", str(local_rank)]
                 try:
                     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
