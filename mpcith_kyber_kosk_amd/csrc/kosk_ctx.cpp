@@ -703,7 +703,10 @@ int issue_keygen(Ctx &c, int n, bool sampled)
 static void finish_keygen_part(Ctx &c, int first, int n, uint8_t *pk, uint8_t *sk)
 {
     const Params &P = c.P;
-    parallel_for(c.pool, n, c.nthreads, [&](int i) { // sk = NTT(s) bytes || pk || H(pk) || z, z = noise seed   kosk.cpp:62-69
+    // device Fiat-Shamir: this is the only host job of a step and the GPU is far from waiting for it -- on the caller's own thread, without
+    // waking the workers of every member of a merged run for 46 records of ~4 us each (native callers, sixteen per cohort: 4.8 busy host
+    // cores with three workers per caller, 2.9 with this)
+    parallel_for(c.pool, n, c.fs_device ? 1 : c.nthreads, [&](int i) { // sk = NTT(s) bytes || pk || H(pk) || z, z = noise seed   kosk.cpp:62-69
         const int b = first + i;
         uint8_t *pkb = pk + (size_t)i * P.pk_bytes, *skb = sk + (size_t)i * P.sk_bytes;
         memcpy(pkb, c.h_pk + (size_t)b * c.pk_stride, P.pk_bytes);
