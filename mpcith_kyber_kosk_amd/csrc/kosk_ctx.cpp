@@ -724,12 +724,35 @@ void finish_keygen_host(Ctx &c, int n, uint8_t *pk, uint8_t *sk)
 
 static void finish_keygen_segs(Ctx &c, int n, const KeygenIn &kg)
 {
-    int first = 0;
-    for (const KeygenIn *s = &kg; s && first < n; s = s->next) {
+    // ONE job over the proofs of all callers of a merged run (round 6; a job per caller woke the run's workers once per member)
+    struct Seg { int first, cnt; uint8_t *pk, *sk; };
+    constexpr int MAXSEG = 16; // kosk_combine.hpp: Combiner::MAX_WIDTH
+    Seg segs[MAXSEG];
+    int nseg = 0, first = 0;
+    const KeygenIn *s = &kg;
+    for (; s && first < n && nseg < MAXSEG; s = s->next) {
         const int cnt = s->count ? s->count : n - first;
-        finish_keygen_part(c, first, cnt, s->pk, s->sk);
+        segs[nseg++] = Seg{first, cnt, s->pk, s->sk};
         first += cnt;
     }
+    for (int rest = first; s && rest < n; s = s->next) { // (more members than a cohort can have: one by one)
+        const int cnt = s->count ? s->count : n - rest;
+        finish_keygen_part(c, rest, cnt, s->pk, s->sk);
+        rest += cnt;
+    }
+    if (nseg == 1) { finish_keygen_part(c, segs[0].first, segs[0].cnt, segs[0].pk, segs[0].sk); return; }
+    const Params &P = c.P;
+    parallel_for(c.pool, first, c.fs_device ? 1 : c.nthreads, [&](int b) {
+        int k = 0;
+        while (k + 1 < nseg && b >= segs[k + 1].first) k++;
+        const int i = b - segs[k].first;
+        uint8_t *pkb = segs[k].pk + (size_t)i * P.pk_bytes, *skb = segs[k].sk + (size_t)i * P.sk_bytes;
+        memcpy(pkb, c.h_pk + (size_t)b * c.pk_stride, P.pk_bytes);
+        memcpy(skb, c.h_sb + (size_t)b * c.sb_stride, c.sb_bytes);
+        memcpy(skb + c.sb_bytes, pkb, P.pk_bytes);
+        sha3_256(skb + P.sk_bytes - 64, pkb, P.pk_bytes);
+        memcpy(skb + P.sk_bytes - 32, c.h_seeds + (size_t)b * c.kg_rec + 32, 32);
+    });
 }
 
 int stage_prover_inputs(Ctx &c, int n, const uint8_t *tapes, size_t tape_stride, uint8_t *pk, uint8_t *sk)
