@@ -195,3 +195,11 @@ def test_line_of_record_shape_with_device_fiat_shamir(callers, torch, gpu_child)
     pk / sk / images / digest tables equal a HOST-mode handle's and the oracle's"""
     out = gpu_child("from tests.gpu_child_cases import line_of_record_shape; line_of_record_shape(callers=%d, fs_device=1)" % callers)
     assert "line_of_record_shape ok 3 46 %d callers per run %d.00 fs_device" % (callers, callers) in out
+
+
+def test_sixteen_callers_per_cohort_in_device_mode(torch, gpu_child):
+    """the arrangement bench.py runs in device mode since round 6 (three cohorts of sixteen): ONE cohort of sixteen callers, 736 proofs per
+    launch -- every caller's pk / sk (assembled in one host job over the whole run) / images / digest tables equal a host-mode handle's and
+    the oracle's"""
+    out = gpu_child("from tests.gpu_child_cases import line_of_record_shape; line_of_record_shape(callers=16, fs_device=1, rounds=2)", timeout=900)
+    assert "line_of_record_shape ok 3 46 16 callers per run 16.00 fs_device" in out
